@@ -1,0 +1,159 @@
+/*
+ * uu3d.h -- C ABI of the MI355X-native uplift/upsample 3D-HPE transformer forward path.
+ *
+ * This is the drop-in boundary of the hot path.  The reference has
+ * no FFI of its own: the path sits behind a Keras model object,
+ *
+ *     model = build_uplift_upsample_transformer(config)
+ *         (/root/reference/common/net/uplift_upsample_transformer_constructor.py:14-50)
+ *     full, central = model([x, stride_mask], training=False)
+ *         (/root/reference/common/net/uplift_upsample_transformer.py:388-421)
+ *
+ * so every entry point below cites the reference call it replaces.  The host-side mirror
+ * of the Keras interface (uplift-upsample-3dhpe_amd/net/...) binds exactly these symbols
+ * through ctypes; INTEGRATION.md shows the stub.
+ *
+ * Conventions: plain C, no exceptions cross the ABI, every function returns a uu3d_status
+ * (0 = ok).  Pointers named *_dev are device (HBM) pointers on the model's device; all
+ * other pointers are host pointers.  `stream` is a hipStream_t passed as void* (NULL =
+ * the null stream).  Calls are stream-ordered and perform no host synchronisation unless
+ * stated.  The caller owns every buffer it passes in; the model owns its weights.
+ */
+#ifndef UU3D_H_
+#define UU3D_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define UU3D_MAX_STRIDED 8
+
+typedef enum uu3d_status {
+    UU3D_OK = 0,
+    UU3D_ERR_INVALID_ARGUMENT = 1, /* NULL pointer, bad size, unknown weight name ...        */
+    UU3D_ERR_UNSUPPORTED = 2,      /* config is schema-legal but outside the compiled kernels */
+    UU3D_ERR_SHAPE = 3,            /* tensor element count does not match the model           */
+    UU3D_ERR_NOT_READY = 4,        /* forward before every weight was set and committed       */
+    UU3D_ERR_WORKSPACE = 5,        /* workspace too small / misaligned                        */
+    UU3D_ERR_HIP = 6,              /* a HIP runtime call failed (see uu3d_last_error)          */
+    UU3D_ERR_NO_DEVICE = 7         /* no usable gfx950 device                                 */
+} uu3d_status;
+
+/* Arithmetic the GEMM-shaped work is carried out in. */
+typedef enum uu3d_precision {
+    UU3D_PREC_F32 = 0      /* f32-input MFMA (v_mfma_f32_32x32x2_f32 / 16x16x4_f32), exact f32 */
+} uu3d_precision;
+
+/*
+ * Architecture hyper-parameters: the keyword arguments the reference constructor derives
+ * from the config (uplift_upsample_transformer_constructor.py:15-43) and hands to
+ * UpliftUpsampleTransformer.__init__ (uplift_upsample_transformer.py:165-177).
+ */
+typedef struct uu3d_config {
+    int32_t num_frames;          /* SEQUENCE_LENGTH (token count N)                     */
+    int32_t num_keypoints;       /* NUM_KEYPOINTS (J)                                   */
+    int32_t d_spatial;           /* SPATIAL_EMBED_DIM                                   */
+    int32_t d_temporal;          /* TEMPORAL_EMBED_DIM                                  */
+    int32_t h_spatial;           /* int(d_spatial  * MLP_RATIO)                         */
+    int32_t h_temporal;          /* int(d_temporal * MLP_RATIO)                         */
+    int32_t spatial_depth;       /* SPATIAL_TRANSFORMER_BLOCKS                          */
+    int32_t temporal_depth;      /* TEMPORAL_TRANSFORMER_BLOCKS                         */
+    int32_t num_strided;         /* len(STRIDES)                                        */
+    int32_t strides[UU3D_MAX_STRIDED];
+    int32_t pad_left[UU3D_MAX_STRIDED];   /* PADDINGS[i][0] ([1,1] when PADDINGS is null) */
+    int32_t pad_right[UU3D_MAX_STRIDED];  /* PADDINGS[i][1]                               */
+    int32_t num_heads;           /* NUM_HEADS                                           */
+    int32_t qkv_bias;            /* QKV_BIAS                                            */
+    int32_t has_strided_input;   /* constructor.py:16-21                                */
+    int32_t first_strided_token_attention_layer; /* FIRST_STRIDED_TOKEN_ATTENTION_LAYER */
+    int32_t full_output;         /* not USE_REFINE                                      */
+    int32_t precision;           /* uu3d_precision                                      */
+} uu3d_config;
+
+typedef struct uu3d_model uu3d_model;
+
+/* Library / build information: "uu3d <version> gfx950 ...". Never NULL. */
+const char* uu3d_version(void);
+const char* uu3d_status_string(int status);
+/* Human-readable detail of the last failure on this model (or of the last failed
+ * uu3d_create when model == NULL).  Never NULL. */
+const char* uu3d_last_error(const uu3d_model* model);
+
+/*
+ * Replaces: build_uplift_upsample_transformer(config) -> model
+ * (uplift_upsample_transformer_constructor.py:14-50).  Creates the model on HIP device
+ * `device` with all weight storage allocated but unset.
+ */
+int uu3d_create(const uu3d_config* config, int device, uu3d_model** out_model);
+void uu3d_destroy(uu3d_model* model);
+
+/*
+ * Weight inventory in the reference's creation order, Keras layouts
+ * (Dense kernel (in,out), Conv1D kernel (k,in,out)); names follow the Keras layer names
+ * given at uplift_upsample_transformer.py:198-285, e.g.
+ * "temporal_block_1/attn/wq/kernel".  Replaces model.weights / get_weights / set_weights
+ * (train.py:400,503) and the by-name h5 loader's target (common/utils/weight_io.py:172-235).
+ */
+int uu3d_num_weights(const uu3d_model* model);
+int uu3d_weight_info(const uu3d_model* model, int index, const char** out_name,
+                     int32_t* out_ndim, int64_t out_dims[4]);
+/* Copy `numel` host floats into the named weight.  Stages on the host; nothing reaches
+ * the device until uu3d_commit_weights. */
+int uu3d_set_weight(uu3d_model* model, const char* name, const float* host_data, int64_t numel);
+int uu3d_get_weight(const uu3d_model* model, const char* name, float* host_out, int64_t numel);
+/* Repack every weight into the device layouts the kernels read ([N][K]-transposed,
+ * padded GEMM operands, fused QKV) and upload.  Fails with UU3D_ERR_NOT_READY (and names
+ * the first missing tensor in uu3d_last_error) if any weight was never set.
+ * Synchronises `stream` before returning. */
+int uu3d_commit_weights(uu3d_model* model, void* stream);
+
+/* Bytes of device scratch uu3d_forward needs for `batch` sequences (256-byte aligned). */
+size_t uu3d_workspace_bytes(const uu3d_model* model, int32_t batch);
+
+/*
+ * Replaces: model([x, stride_mask], training=False) -> (full_output, central_output)
+ * (uplift_upsample_transformer.py:388-421; called at eval.py:70, train.py:520).
+ *   kp2d_dev        (B, N, J, 2) f32.  The CALLER zeroes masked frames (eval.py:67).
+ *   stride_mask_dev (B, N) uint8, 1 = real 2D input present; must be NULL iff the model
+ *                   has no strided input.
+ *   full_out_dev    (B, N, J, 3) f32, or NULL to skip head1 (must be NULL-able only when
+ *                   full_output == 0 / temporal_depth == 0, where the reference returns None).
+ *   central_out_dev (B, J, 3) f32.
+ */
+int uu3d_forward(uu3d_model* model, const float* kp2d_dev, const uint8_t* stride_mask_dev,
+                 int32_t batch, float* full_out_dev, float* central_out_dev,
+                 void* workspace_dev, size_t workspace_bytes, void* stream);
+
+/*
+ * Replaces: metrics.mpjpe(pred, gt, root_index, normalize=False)
+ * (common/dataset/metrics.py:13-37) on device, float64 like the reference's numpy call:
+ * root-align pred and gt, per-joint L2 distance; -1 where gt valid flag <= 0.
+ *   pred_dev (B, J, 3) f32; gt_dev (B, J, 4) f32 (x, y, z, valid); out_dev (B, J) f64.
+ * This (B_local, J) block is the payload of the multi-GPU all-gather.
+ */
+int uu3d_mpjpe(const float* pred_dev, const float* gt_dev, int32_t batch, int32_t num_keypoints,
+               int32_t root_index, double* out_dev, void* stream);
+
+/*
+ * Per-kernel timing of the next uu3d_forward calls with HIP events on the launch stream.
+ * When enabled, uu3d_forward records an event pair around every launch; uu3d_profile_read
+ * synchronises those events and returns the per-launch records of the LAST forward.
+ */
+typedef struct uu3d_profile_entry {
+    char name[48];        /* launch label, e.g. "t1.ln_qkv"              */
+    char kernel[32];      /* kernel family, e.g. "gemm_f32"              */
+    float ms;             /* event-measured duration                      */
+    double flops;         /* algorithmic FLOPs (2*MAC) of this launch     */
+    double bytes;         /* algorithmic HBM bytes (operands in + out)    */
+} uu3d_profile_entry;
+int uu3d_set_profiling(uu3d_model* model, int32_t enabled);
+int uu3d_profile_read(uu3d_model* model, uu3d_profile_entry* out_entries, int32_t capacity,
+                      int32_t* out_count);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* UU3D_H_ */

@@ -1,0 +1,261 @@
+"""CPU ORACLE (test infrastructure, NOT the product path) -- PyTorch-CPU restatement.
+
+A plain restatement, op for op, of the reference's uplifting-transformer forward
+(``common/net/vision_transformer.py``, ``common/net/uplift_upsample_transformer.py``) and of
+the harness arithmetic around it (``eval.py:63-71,154-193``, ``common/dataset/metrics.py:13-37``,
+``common/dataset/uplifiting_dataset.py:377-394``).  Only ``tests/``,
+``__graft_entry__.smoke()`` and ``bench.py``'s ``cpu_baseline`` leg may import it; the
+shipped path (``uplift-upsample-3dhpe_amd/``) never does.
+
+PARITY UNPINNED: the reference ships no tests, golden vectors or fixtures, and its
+arithmetic lives in TensorFlow 2.4.3 (``requirements.txt:3``), which is neither vendored
+under ``/root/reference`` nor installable here.  This file therefore restates the
+*published semantics* of the TF/Keras ops at the reference's call sites:
+
+* ``Dense``: kernel ``(in, out)``, ``y = x @ W + b``.
+* ``LayerNormalization`` (eps 1e-5 / 1e-6 < 1.001e-5 -> Keras' non-fused path):
+  ``mean, var = moments(x, -1)`` (biased), ``inv = rsqrt(var + eps) * gamma``,
+  ``y = x * inv + (beta - mean * inv)``.
+* ``keras.activations.gelu`` (approximate=False): ``0.5 * x * (1 + erf(x / sqrt(2)))``.
+* ``Conv1D`` ``valid``: kernel ``(k, in, out)``, ``y[t] = sum_j xpad[t*s + j] @ W[j] + b``.
+* ``MaxPool1D(pool_size=1, strides=s)``: rows ``0, s, 2s, ...``.
+* ``tf.nn.softmax`` over the last axis after adding ``mask * -1e9`` (finite, not -inf).
+
+It is cross-checked against an independently written numpy restatement
+(``oracle/uplift_oracle_np.py``) and against semantic invariants in ``tests/``.
+
+The oracle is deliberately self-contained: hyper-parameters arrive as a plain dict and
+weights as a ``{name: ndarray}`` dict in Keras layouts (names: see ``weight_names`` below).
+"""
+import math
+
+import numpy as np
+import torch
+
+
+# --------------------------------------------------------------------------------------
+# primitive ops
+# --------------------------------------------------------------------------------------
+def _t(a, dtype):
+    return torch.as_tensor(np.asarray(a)).to(dtype)
+
+
+def dense(x, w, b=None):
+    y = torch.matmul(x, w)
+    if b is not None:
+        y = y + b
+    return y
+
+
+def layer_norm(x, gamma, beta, eps):
+    # Keras non-fused path: tf.nn.moments + tf.nn.batch_normalization
+    mean = x.mean(dim=-1, keepdim=True)
+    var = ((x - mean) ** 2).mean(dim=-1, keepdim=True)
+    inv = torch.rsqrt(var + eps) * gamma
+    return x * inv + (beta - mean * inv)
+
+
+def gelu_exact(x):
+    return 0.5 * x * (1.0 + torch.erf(x / math.sqrt(2.0)))
+
+
+def mha(p, prefix, x, num_heads, mask=None):
+    """vision_transformer.py:132-156 (self-attention: v = k = q = x)."""
+    b, L, d = x.shape
+    depth = d // num_heads
+    q = dense(x, p[f"{prefix}/wq/kernel"], p.get(f"{prefix}/wq/bias"))
+    k = dense(x, p[f"{prefix}/wk/kernel"], p.get(f"{prefix}/wk/bias"))
+    v = dense(x, p[f"{prefix}/wv/kernel"], p.get(f"{prefix}/wv/bias"))
+
+    def split(t):  # :92-97
+        return t.reshape(b, L, num_heads, depth).permute(0, 2, 1, 3)
+
+    q, k, v = split(q), split(k), split(v)
+    logits = torch.matmul(q, k.transpose(-1, -2))                       # :117
+    logits = logits / torch.sqrt(torch.tensor(float(depth), dtype=x.dtype))  # :119-120
+    if mask is not None:
+        logits = logits + mask * torch.tensor(-1e9, dtype=x.dtype)      # :122-123
+    attn = torch.softmax(logits, dim=-1)                                # :126
+    out = torch.matmul(attn, v)                                         # :129
+    out = out.permute(0, 2, 1, 3).reshape(b, L, d)                      # :147-150
+    out = dense(out, p[f"{prefix}/projection/kernel"], p[f"{prefix}/projection/bias"])  # :151
+    return out, attn
+
+
+def transformer_block(p, prefix, x, num_heads, activation, mask=None):
+    """vision_transformer.py:176-195, inference (DropPath identity)."""
+    y = layer_norm(x, p[f"{prefix}/norm1/gamma"], p[f"{prefix}/norm1/beta"], 1e-5)
+    y, attn = mha(p, f"{prefix}/attn", y, num_heads, mask)
+    x = x + y
+    z = layer_norm(x, p[f"{prefix}/norm2/gamma"], p[f"{prefix}/norm2/beta"], 1e-5)
+    z = dense(z, p[f"{prefix}/mlp/fc1/kernel"], p[f"{prefix}/mlp/fc1/bias"])
+    z = activation(z)
+    z = dense(z, p[f"{prefix}/mlp/fc2/kernel"], p[f"{prefix}/mlp/fc2/bias"])
+    x = x + z
+    return x, attn
+
+
+def strided_transformer_block(p, prefix, x, pe, num_heads, stride, pad):
+    """uplift_upsample_transformer.py:122-160 with StridedMLP :81-90."""
+    assert x.shape[1] == pe.shape[0]                                    # :127
+    x = x + pe                                                          # :128
+    y = layer_norm(x, p[f"{prefix}/norm1/gamma"], p[f"{prefix}/norm1/beta"], 1e-5)
+    y, attn = mha(p, f"{prefix}/attn", y, num_heads, None)
+    x = x + y
+    z = layer_norm(x, p[f"{prefix}/norm2/gamma"], p[f"{prefix}/norm2/beta"], 1e-5)
+    # fc1: Conv1D k=1
+    z = dense(z, p[f"{prefix}/mlp/fc1/kernel"][0], p[f"{prefix}/mlp/fc1/bias"])
+    z = torch.relu(z)
+    # ZeroPadding1D(pad) + Conv1D(k=3, stride, 'valid')
+    b, L, h = z.shape
+    zp = torch.zeros(b, L + pad[0] + pad[1], h, dtype=z.dtype)
+    zp[:, pad[0]:pad[0] + L] = z
+    wk = p[f"{prefix}/mlp/strided_conv/kernel"]                         # (3, h, d)
+    Lout = (L + pad[0] + pad[1] - 3) // stride + 1
+    taps = []
+    for j in range(3):
+        rows = zp[:, j:j + (Lout - 1) * stride + 1:stride]              # (b, Lout, h)
+        taps.append(torch.matmul(rows, wk[j]))
+    z = taps[0] + taps[1] + taps[2] + p[f"{prefix}/mlp/strided_conv/bias"]
+    # residual path :138-156
+    if stride > 1:
+        identity = x
+        if pad[0] == 0:
+            identity = identity[:, 1:]
+        if pad[1] == 0:
+            identity = identity[:, :-1]
+        identity = identity[:, ::stride]                                # MaxPool1D(pool 1, strides s)
+    else:
+        identity = x
+    return identity + z, attn
+
+
+# --------------------------------------------------------------------------------------
+# the model forward
+# --------------------------------------------------------------------------------------
+def forward(hp, weights, x, stride_mask=None, dtype=torch.float32, return_attention=False):
+    """``UpliftUpsampleTransformer.call`` (u_u_t.py:388-421), ``training=False``.
+
+    hp: dict with num_frames, num_keypoints, d_spatial, d_temporal, spatial_depth,
+        temporal_depth, strides, paddings, num_heads, has_strided_input,
+        first_strided_token_attention_layer, full_output.
+    x: (B, N, J, 2); stride_mask: (B, N) bool, 1 = real input present.
+    Returns (full (B,N,J,3) or None, central (B,J,3)) as numpy arrays of ``dtype``.
+    """
+    p = {k: _t(v, dtype) for k, v in weights.items()}
+    x = _t(x, dtype)
+    B, N, J, _ = x.shape
+    H = hp["num_heads"]
+    att_list = []
+
+    # spatial_transformation :313-333
+    if hp["spatial_depth"] == 0:
+        x = x.reshape(B, N, J * 2)
+    else:
+        x = x.reshape(B * N, J, 2)
+        x = dense(x, p["keypoint_embedding/kernel"], p["keypoint_embedding/bias"])
+        x = x + p["spatial_pe/positional_encoding_weights"]
+        for i in range(hp["spatial_depth"]):
+            x, _ = transformer_block(p, f"spatial_block_{i + 1}", x, H, gelu_exact)
+        x = layer_norm(x, p["spatial_norm/gamma"], p["spatial_norm/beta"], 1e-6)
+        x = x.reshape(B, N, J * hp["d_spatial"])                        # "(b n) p c -> b n (p c)"
+    x = dense(x, p["spatial_to_temporal_fc/kernel"], p["spatial_to_temporal_fc/bias"])
+
+    # temporal_transformation :335-367 (TOKEN_MASK_RATE path is training-only)
+    pe = p["temporal_pe/positional_encoding_weights"]
+    inv = None
+    if hp["has_strided_input"]:
+        m = _t(np.asarray(stride_mask).astype(np.float32), dtype)
+        inv = 1.0 - m
+        tok = p["strided_input_token_layer/learnable_masked_token"]
+        x = m[..., None] * x + inv[..., None] * tok                     # :350
+    x = x + pe                                                          # :352
+    for i in range(hp["temporal_depth"]):
+        mask = None
+        if hp["has_strided_input"] and i < hp["first_strided_token_attention_layer"]:
+            mask = inv[:, None, None, :]                                # :361
+        x, att = transformer_block(p, f"temporal_block_{i + 1}", x, H, torch.relu, mask)
+        att_list.append(att)
+
+    full = None
+    if hp["full_output"] and hp["temporal_depth"] > 0:
+        full = dense(x, p["temporal_fc/kernel"], p["temporal_fc/bias"])
+        full = full.reshape(B, N, J, 3)                                 # "b n (p c) -> b n p c"
+
+    # strided_temporal_transformation :369-386
+    if len(hp["strides"]) > 0:
+        for i, s in enumerate(hp["strides"]):
+            if hp["temporal_depth"] == 0 and hp["has_strided_input"] and \
+                    i < hp["first_strided_token_attention_layer"]:
+                raise NotImplementedError("temporal_depth == 0 masked strided attention (dead for shipped configs)")
+            pe_i = p[f"strided_temporal_pe_{i + 1}/positional_encoding_weights"]
+            x, _ = strided_transformer_block(p, f"strided_temporal_block_{i + 1}", x, pe_i, H,
+                                             s, hp["paddings"][i])
+        central = x
+    else:
+        central = x[:, N // 2: N // 2 + 1, :]
+    central = dense(central, p["strided_temporal_fc/kernel"], p["strided_temporal_fc/bias"])
+    assert central.shape[1] == 1                                        # einops n=1 at :416
+    central = central.reshape(B, J, 3)
+
+    full_np = None if full is None else full.numpy()
+    if return_attention:
+        return full_np, central.numpy(), [a.numpy() for a in att_list]
+    return full_np, central.numpy()
+
+
+# --------------------------------------------------------------------------------------
+# harness arithmetic around the model call
+# --------------------------------------------------------------------------------------
+def stride_mask_eval(num_frames, seq_stride, mask_stride, frame_index):
+    """Global-aligned stride mask (uplifiting_dataset.py:377-384,394). 1 = real input."""
+    mid = num_frames // 2
+    idx = (np.arange(num_frames) - mid) * seq_stride + frame_index
+    return np.equal(idx % mask_stride, 0)
+
+
+def test_step(hp, weights, keypoints2d, stride_masks, dtype=torch.float32):
+    """eval.py:63-71: the CALLER zeroes masked frames, then calls the model."""
+    if hp["has_strided_input"]:
+        masked = np.asarray(keypoints2d, np.float32) * \
+            np.asarray(stride_masks).astype(np.float32)[:, :, None, None]
+        return forward(hp, weights, masked, stride_masks, dtype)
+    return forward(hp, weights, keypoints2d, None, dtype)
+
+
+def eval_step_with_flip(hp, weights, keypoints2d, stride_masks, flip_order, dtype=torch.float32):
+    """eval.py:152-180: test-time flip augmentation, averaged."""
+    seq, cen = test_step(hp, weights, keypoints2d, stride_masks, dtype)
+    kp = np.asarray(keypoints2d, np.float32)
+    fl = np.concatenate([kp[..., :1] * -1.0, kp[..., 1:]], axis=-1)[:, :, flip_order]
+    fseq, fcen = test_step(hp, weights, fl, stride_masks, dtype)
+    fcen = np.concatenate([fcen[..., :1] * -1.0, fcen[..., 1:]], axis=-1)[:, flip_order]
+    cen = (cen + fcen) / 2.0
+    if seq is not None:
+        fseq = np.concatenate([fseq[..., :1] * -1.0, fseq[..., 1:]], axis=-1)[:, :, flip_order]
+        seq = (seq + fseq) / 2.0
+    return seq, cen
+
+
+def mpjpe(pred, gt, root_index, normalize=True):
+    """metrics.py:13-37. pred (B,K,3), gt (B,K,4) with valid flag; float64 like the caller."""
+    pred = np.asarray(pred, np.float64)
+    gt = np.asarray(gt, np.float64)
+    gt3d = gt[:, :, :3]
+    valid = gt[:, :, 3] > 0
+    gt3d = gt3d - gt3d[:, root_index, None, :]
+    pred3d = pred - pred[:, root_index, None, :]
+    dist = np.linalg.norm(pred3d - gt3d, ord=2, axis=-1)
+    if normalize is False:
+        return np.where(valid, dist, -1.0)
+    dist = np.where(valid, dist, 0.0)
+    return np.sum(dist) / float(np.sum(valid > 0.0))
+
+
+def frame_mpjpe_mm(pred, gt3, root_index):
+    """action_wise_eval.py:25-26,43 on root-shifted GT with the dummy valid flag (eval.py:185-196)."""
+    gt3 = np.asarray(gt3, np.float64)
+    gt3 = gt3 - gt3[:, root_index:root_index + 1, :]
+    gt4 = np.concatenate([gt3, np.ones(gt3.shape[:-1] + (1,))], axis=-1)
+    per_joint = mpjpe(pred, gt4, root_index, normalize=False) * 1000.0
+    return per_joint, float(np.mean(per_joint[per_joint >= 0]))

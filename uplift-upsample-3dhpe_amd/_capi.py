@@ -1,0 +1,115 @@
+"""ctypes binding of ``include/uu3d.h`` (the C-ABI shared library ``csrc/libuu3d.so``).
+
+There is NO fallback: if the HIP library is missing or fails to load, importing a symbol
+raises ``Uu3dLibraryError`` -- the product path never computes on the CPU.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libuu3d.so")
+
+UU3D_MAX_STRIDED = 8
+UU3D_PREC_F32 = 0
+
+(UU3D_OK, UU3D_ERR_INVALID_ARGUMENT, UU3D_ERR_UNSUPPORTED, UU3D_ERR_SHAPE, UU3D_ERR_NOT_READY,
+ UU3D_ERR_WORKSPACE, UU3D_ERR_HIP, UU3D_ERR_NO_DEVICE) = range(8)
+
+# every symbol include/uu3d.h declares
+EXPORTED_SYMBOLS = (
+    "uu3d_version", "uu3d_status_string", "uu3d_last_error", "uu3d_create", "uu3d_destroy",
+    "uu3d_num_weights", "uu3d_weight_info", "uu3d_set_weight", "uu3d_get_weight",
+    "uu3d_commit_weights", "uu3d_workspace_bytes", "uu3d_forward", "uu3d_mpjpe",
+    "uu3d_set_profiling", "uu3d_profile_read",
+)
+
+
+class Uu3dLibraryError(RuntimeError):
+    pass
+
+
+class Uu3dError(RuntimeError):
+    def __init__(self, status, message):
+        super().__init__(f"uu3d status {status}: {message}")
+        self.status = status
+
+
+class Uu3dConfig(C.Structure):
+    _fields_ = [
+        ("num_frames", C.c_int32), ("num_keypoints", C.c_int32),
+        ("d_spatial", C.c_int32), ("d_temporal", C.c_int32),
+        ("h_spatial", C.c_int32), ("h_temporal", C.c_int32),
+        ("spatial_depth", C.c_int32), ("temporal_depth", C.c_int32),
+        ("num_strided", C.c_int32),
+        ("strides", C.c_int32 * UU3D_MAX_STRIDED),
+        ("pad_left", C.c_int32 * UU3D_MAX_STRIDED),
+        ("pad_right", C.c_int32 * UU3D_MAX_STRIDED),
+        ("num_heads", C.c_int32), ("qkv_bias", C.c_int32), ("has_strided_input", C.c_int32),
+        ("first_strided_token_attention_layer", C.c_int32), ("full_output", C.c_int32),
+        ("precision", C.c_int32),
+    ]
+
+
+class Uu3dProfileEntry(C.Structure):
+    _fields_ = [("name", C.c_char * 48), ("kernel", C.c_char * 32), ("ms", C.c_float),
+                ("flops", C.c_double), ("bytes", C.c_double)]
+
+
+_lib = None
+
+
+def load_library(path=None):
+    """dlopen the HIP library and declare every prototype.  Raises if it is not built."""
+    global _lib
+    if _lib is not None and path is None:
+        return _lib
+    p = path or LIB_PATH
+    if not os.path.exists(p):
+        raise Uu3dLibraryError(
+            f"{p} not found: build it with `python __graft_entry__.py build` "
+            f"(hipcc --offload-arch=gfx950); there is no CPU fallback")
+    try:
+        lib = C.CDLL(p)
+    except OSError as e:  # pragma: no cover
+        raise Uu3dLibraryError(f"cannot load {p}: {e}") from e
+    vp, i32, i64, sz = C.c_void_p, C.c_int32, C.c_int64, C.c_size_t
+    lib.uu3d_version.restype = C.c_char_p
+    lib.uu3d_version.argtypes = []
+    lib.uu3d_status_string.restype = C.c_char_p
+    lib.uu3d_status_string.argtypes = [C.c_int]
+    lib.uu3d_last_error.restype = C.c_char_p
+    lib.uu3d_last_error.argtypes = [vp]
+    lib.uu3d_create.restype = C.c_int
+    lib.uu3d_create.argtypes = [C.POINTER(Uu3dConfig), C.c_int, C.POINTER(vp)]
+    lib.uu3d_destroy.restype = None
+    lib.uu3d_destroy.argtypes = [vp]
+    lib.uu3d_num_weights.restype = C.c_int
+    lib.uu3d_num_weights.argtypes = [vp]
+    lib.uu3d_weight_info.restype = C.c_int
+    lib.uu3d_weight_info.argtypes = [vp, C.c_int, C.POINTER(C.c_char_p), C.POINTER(i32), C.POINTER(i64 * 4)]
+    lib.uu3d_set_weight.restype = C.c_int
+    lib.uu3d_set_weight.argtypes = [vp, C.c_char_p, vp, i64]
+    lib.uu3d_get_weight.restype = C.c_int
+    lib.uu3d_get_weight.argtypes = [vp, C.c_char_p, vp, i64]
+    lib.uu3d_commit_weights.restype = C.c_int
+    lib.uu3d_commit_weights.argtypes = [vp, vp]
+    lib.uu3d_workspace_bytes.restype = sz
+    lib.uu3d_workspace_bytes.argtypes = [vp, i32]
+    lib.uu3d_forward.restype = C.c_int
+    lib.uu3d_forward.argtypes = [vp, vp, vp, i32, vp, vp, vp, sz, vp]
+    lib.uu3d_mpjpe.restype = C.c_int
+    lib.uu3d_mpjpe.argtypes = [vp, vp, i32, i32, i32, vp, vp]
+    lib.uu3d_set_profiling.restype = C.c_int
+    lib.uu3d_set_profiling.argtypes = [vp, i32]
+    lib.uu3d_profile_read.restype = C.c_int
+    lib.uu3d_profile_read.argtypes = [vp, C.POINTER(Uu3dProfileEntry), i32, C.POINTER(i32)]
+    if path is None:
+        _lib = lib
+    return lib
+
+
+def check(lib, status, handle=None):
+    if status != UU3D_OK:
+        detail = lib.uu3d_last_error(handle).decode() if True else ""
+        base = lib.uu3d_status_string(status).decode()
+        raise Uu3dError(status, f"{base}: {detail}" if detail else base)

@@ -1,0 +1,691 @@
+// uu3d_api.hip -- C ABI (include/uu3d.h) over the gfx950 kernels: model object, weight
+// inventory / repacking, workspace carving and the forward launch schedule.
+//
+// Forward schedule (reference: UpliftUpsampleTransformer.call, u_u_t.py:388-421):
+//   spatial_stack                       kp2d -> S (B*N, J*d_s)                [u_u_t.py:313-330]
+//   gemm  S x W_s2t  (+token blend +PE) -> X (B*N, d_t)                       [:332,344-352]
+//   temporal block i (x temporal_depth)                                       [vit.py:176-195]
+//     row_stats(X); gemm LN1(X) x Wqkv -> QKV; attn -> O; gemm O x Wp (+res) -> X
+//     row_stats(X); gemm LN2(X) x W1 (+relu) -> Hb; gemm Hb x W2 (+res) -> X
+//       (last block also writes XA = X + strided_pe_1)
+//   gemm X x W_head1 -> full_out                                              [:400-404]
+//   strided block i (x len(STRIDES)) on XA (B*L_i, d_t)                       [:122-160]
+//     row_stats; gemm LN1 x Wqkv; attn; gemm proj (+res); row_stats; gemm LN2 x W1 (+relu);
+//     gemm conv3(Hb) x Wc (+identity gather +bias +strided_pe_{i+1}) -> XB ; swap
+//   gemm XA x W_head2 -> central_out                                          [:414-416]
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "../../include/uu3d.h"
+#include "uu3d_gemm.h"
+#include "uu3d_attn.h"
+#include "uu3d_spatial.h"
+#include "uu3d_misc.h"
+
+using namespace uu3d;
+
+namespace {
+
+constexpr int kJ = 17, kDS = 32, kHS = 64, kHeads = 8, kDH = 48;
+using SLY = SpatialBlockLayout<kDS, kHS>;
+
+std::string g_create_error;
+
+inline int round_up(int v, int m) { return (v + m - 1) / m * m; }
+inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+struct WeightRec {
+    std::string name;
+    std::vector<int64_t> dims;
+    int64_t numel = 0;
+    std::vector<float> host;
+    bool set = false;
+};
+
+// Device views of one packed transformer block (temporal or strided).
+struct BlockDev {
+    const float *ln1_g, *ln1_b, *wqkv_t, *bqkv, *wp_t, *bp, *ln2_g, *ln2_b, *w1_t, *b1, *w2_t, *b2;
+    const float* pe;   // strided blocks: (L_i, d_t)
+};
+
+struct ProfRec {
+    std::string name, kernel;
+    double flops, bytes;
+    hipEvent_t e0, e1;
+};
+
+}  // namespace
+
+struct uu3d_model {
+    uu3d_config cfg;
+    int device = 0;
+    std::vector<WeightRec> weights;
+    std::map<std::string, int> index;
+    std::vector<int> L;            // strided lengths L_0 .. L_ns
+    bool committed = false;
+    float* arena = nullptr;        // packed device weights
+    size_t arena_floats = 0;
+    // packed views
+    SpatialParams sp{};
+    const float *s2t_wt = nullptr, *s2t_b = nullptr, *token = nullptr, *pe_t = nullptr;
+    std::vector<BlockDev> tblocks, sblocks;
+    const float *h1_wt = nullptr, *h1_b = nullptr, *h2_wt = nullptr, *h2_b = nullptr;
+    // profiling
+    bool profiling = false;
+    std::vector<ProfRec> prof;
+    size_t prof_used = 0;
+    std::string err;
+};
+
+namespace {
+
+int fail(uu3d_model* m, int code, const std::string& msg) {
+    if (m) m->err = msg; else g_create_error = msg;
+    return code;
+}
+
+#define HIPCHK(m, expr)                                                                         \
+    do {                                                                                        \
+        hipError_t e__ = (expr);                                                                \
+        if (e__ != hipSuccess)                                                                  \
+            return fail(m, UU3D_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e__));   \
+    } while (0)
+
+void add_weight(uu3d_model* m, const std::string& name, std::vector<int64_t> dims) {
+    WeightRec r;
+    r.name = name;
+    r.dims = dims;
+    r.numel = 1;
+    for (auto d : dims) r.numel *= d;
+    m->index[name] = (int)m->weights.size();
+    m->weights.push_back(std::move(r));
+}
+
+void add_block(uu3d_model* m, const std::string& p, int d, int h, bool strided, bool qkv_bias) {
+    add_weight(m, p + "/norm1/gamma", {d});
+    add_weight(m, p + "/norm1/beta", {d});
+    for (const char* nm : {"wq", "wk", "wv"}) {
+        add_weight(m, p + "/attn/" + nm + "/kernel", {d, d});
+        if (qkv_bias) add_weight(m, p + "/attn/" + nm + "/bias", {d});
+    }
+    add_weight(m, p + "/attn/projection/kernel", {d, d});
+    add_weight(m, p + "/attn/projection/bias", {d});
+    add_weight(m, p + "/norm2/gamma", {d});
+    add_weight(m, p + "/norm2/beta", {d});
+    if (strided) {
+        add_weight(m, p + "/mlp/fc1/kernel", {1, d, h});
+        add_weight(m, p + "/mlp/fc1/bias", {h});
+        add_weight(m, p + "/mlp/strided_conv/kernel", {3, h, d});
+        add_weight(m, p + "/mlp/strided_conv/bias", {d});
+    } else {
+        add_weight(m, p + "/mlp/fc1/kernel", {d, h});
+        add_weight(m, p + "/mlp/fc1/bias", {h});
+        add_weight(m, p + "/mlp/fc2/kernel", {h, d});
+        add_weight(m, p + "/mlp/fc2/bias", {d});
+    }
+}
+
+// Creation order of the reference's __init__ (u_u_t.py:196-285) = model.weights order.
+void build_inventory(uu3d_model* m) {
+    const uu3d_config& c = m->cfg;
+    const int J = c.num_keypoints, N = c.num_frames, ds = c.d_spatial, dt = c.d_temporal;
+    if (c.spatial_depth > 0) {
+        add_weight(m, "keypoint_embedding/kernel", {2, ds});
+        add_weight(m, "keypoint_embedding/bias", {ds});
+        add_weight(m, "spatial_pe/positional_encoding_weights", {J, ds});
+    }
+    add_weight(m, "temporal_pe/positional_encoding_weights", {N, dt});
+    for (int i = 0; i < c.num_strided; ++i)
+        add_weight(m, "strided_temporal_pe_" + std::to_string(i + 1) + "/positional_encoding_weights", {m->L[i], dt});
+    if (c.has_strided_input) add_weight(m, "strided_input_token_layer/learnable_masked_token", {dt});
+    if (c.spatial_depth > 0) {
+        for (int i = 0; i < c.spatial_depth; ++i)
+            add_block(m, "spatial_block_" + std::to_string(i + 1), ds, c.h_spatial, false, c.qkv_bias != 0);
+        add_weight(m, "spatial_norm/gamma", {ds});
+        add_weight(m, "spatial_norm/beta", {ds});
+    }
+    add_weight(m, "spatial_to_temporal_fc/kernel", {(int64_t)J * ds, dt});
+    add_weight(m, "spatial_to_temporal_fc/bias", {dt});
+    for (int i = 0; i < c.temporal_depth; ++i)
+        add_block(m, "temporal_block_" + std::to_string(i + 1), dt, c.h_temporal, false, c.qkv_bias != 0);
+    for (int i = 0; i < c.num_strided; ++i)
+        add_block(m, "strided_temporal_block_" + std::to_string(i + 1), dt, c.h_temporal, true, c.qkv_bias != 0);
+    if (c.full_output && c.temporal_depth > 0) {
+        add_weight(m, "temporal_fc/kernel", {dt, 3 * J});
+        add_weight(m, "temporal_fc/bias", {3 * J});
+    }
+    add_weight(m, "strided_temporal_fc/kernel", {dt, 3 * J});
+    add_weight(m, "strided_temporal_fc/bias", {3 * J});
+}
+
+// ---- host-side packing ------------------------------------------------------------------
+struct Packer {
+    std::vector<float> buf;
+    size_t alloc(size_t n) {                       // 256-byte aligned segments
+        size_t off = align_up(buf.size(), 64);
+        buf.resize(off + n, 0.f);
+        return off;
+    }
+};
+
+const float* W(const uu3d_model* m, const std::string& name) {
+    auto it = m->index.find(name);
+    return it == m->index.end() ? nullptr : m->weights[it->second].host.data();
+}
+
+// Keras Dense kernel (K, N) -> Bt[Np][Kp], Np = round_up(N,128), Kp = round_up(K,32); row offset n0.
+void pack_dense_t(std::vector<float>& buf, size_t off, const float* w, int K, int N, int Kp, int n0) {
+    for (int k = 0; k < K; ++k)
+        for (int n = 0; n < N; ++n) buf[off + (size_t)(n0 + n) * Kp + k] = w[(size_t)k * N + n];
+}
+
+}  // namespace
+
+// =========================================================================================
+// Definitions below take C linkage from their extern "C" declarations in include/uu3d.h.
+
+const char* uu3d_version(void) { return "uu3d 0.1.0 gfx950 f32-mfma"; }
+
+const char* uu3d_status_string(int s) {
+    switch (s) {
+        case UU3D_OK: return "ok";
+        case UU3D_ERR_INVALID_ARGUMENT: return "invalid argument";
+        case UU3D_ERR_UNSUPPORTED: return "configuration not supported by the compiled kernels";
+        case UU3D_ERR_SHAPE: return "shape mismatch";
+        case UU3D_ERR_NOT_READY: return "weights not set/committed";
+        case UU3D_ERR_WORKSPACE: return "workspace too small or misaligned";
+        case UU3D_ERR_HIP: return "HIP runtime error";
+        case UU3D_ERR_NO_DEVICE: return "no usable device";
+        default: return "unknown status";
+    }
+}
+
+const char* uu3d_last_error(const uu3d_model* model) {
+    return model ? model->err.c_str() : g_create_error.c_str();
+}
+
+int uu3d_create(const uu3d_config* c, int device, uu3d_model** out) {
+    if (!c || !out) return fail(nullptr, UU3D_ERR_INVALID_ARGUMENT, "null config/out pointer");
+    *out = nullptr;
+    if (c->num_frames < 1 || c->num_keypoints < 1 || c->num_strided < 0 || c->num_strided > UU3D_MAX_STRIDED)
+        return fail(nullptr, UU3D_ERR_INVALID_ARGUMENT, "bad num_frames/num_keypoints/num_strided");
+    if (c->precision != UU3D_PREC_F32) return fail(nullptr, UU3D_ERR_UNSUPPORTED, "only UU3D_PREC_F32 is built");
+    // limits of the compiled kernels (all shipped configs satisfy them)
+    if (c->spatial_depth < 1 || c->num_keypoints != kJ || c->d_spatial != kDS || c->h_spatial != kHS ||
+        c->num_heads != kHeads)
+        return fail(nullptr, UU3D_ERR_UNSUPPORTED,
+                    "spatial stack is compiled for J=17, d_s=32, h_s=64, 8 heads, depth>=1");
+    if (c->d_temporal != kDH * kHeads)
+        return fail(nullptr, UU3D_ERR_UNSUPPORTED, "temporal attention is compiled for head dim 48 (d_t = 384)");
+    if (c->h_temporal % 4 != 0 || c->h_temporal < 4)
+        return fail(nullptr, UU3D_ERR_UNSUPPORTED, "h_temporal must be a positive multiple of 4");
+    if (c->temporal_depth < 1) return fail(nullptr, UU3D_ERR_UNSUPPORTED, "temporal_depth >= 1 required");
+    if (c->num_strided < 1) return fail(nullptr, UU3D_ERR_UNSUPPORTED, "at least one strided block required");
+    if (c->d_temporal > 64 * 4 * 4)
+        return fail(nullptr, UU3D_ERR_UNSUPPORTED, "d_temporal > 1024");
+
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || device < 0 || device >= ndev)
+        return fail(nullptr, UU3D_ERR_NO_DEVICE, "HIP device not available");
+
+    auto* m = new uu3d_model();
+    m->cfg = *c;
+    m->device = device;
+    m->L.push_back(c->num_frames);
+    for (int i = 0; i < c->num_strided; ++i) {
+        if (c->strides[i] < 1 || c->pad_left[i] < 0 || c->pad_right[i] < 0) {
+            delete m;
+            return fail(nullptr, UU3D_ERR_INVALID_ARGUMENT, "bad stride/padding");
+        }
+        const int Lin = m->L.back();
+        const int Lout = (Lin + c->pad_left[i] + c->pad_right[i] - 3) / c->strides[i] + 1;
+        if (Lin + c->pad_left[i] + c->pad_right[i] < 3 || Lout < 1) {
+            delete m;
+            return fail(nullptr, UU3D_ERR_INVALID_ARGUMENT, "strided block reduces the sequence below one token");
+        }
+        if (Lin > 128) {
+            delete m;
+            return fail(nullptr, UU3D_ERR_UNSUPPORTED, "sequence length > 128 tokens");
+        }
+        m->L.push_back(Lout);
+    }
+    if (m->L.back() != 1) {
+        delete m;   // einops "b n (p c) -> (b n) p c", n=1 fails in the reference (u_u_t.py:416)
+        return fail(nullptr, UU3D_ERR_INVALID_ARGUMENT, "STRIDES/PADDINGS must reduce the sequence to one token");
+    }
+    build_inventory(m);
+    *out = m;
+    return UU3D_OK;
+}
+
+void uu3d_destroy(uu3d_model* m) {
+    if (!m) return;
+    (void)hipSetDevice(m->device);
+    if (m->arena) (void)hipFree(m->arena);
+    for (auto& r : m->prof) { (void)hipEventDestroy(r.e0); (void)hipEventDestroy(r.e1); }
+    delete m;
+}
+
+int uu3d_num_weights(const uu3d_model* m) { return m ? (int)m->weights.size() : 0; }
+
+int uu3d_weight_info(const uu3d_model* m, int i, const char** name, int32_t* ndim, int64_t dims[4]) {
+    if (!m || i < 0 || i >= (int)m->weights.size()) return UU3D_ERR_INVALID_ARGUMENT;
+    const WeightRec& r = m->weights[i];
+    if (name) *name = r.name.c_str();
+    if (ndim) *ndim = (int32_t)r.dims.size();
+    if (dims) for (size_t k = 0; k < 4; ++k) dims[k] = k < r.dims.size() ? r.dims[k] : 1;
+    return UU3D_OK;
+}
+
+int uu3d_set_weight(uu3d_model* m, const char* name, const float* data, int64_t numel) {
+    if (!m || !name || !data) return fail(m, UU3D_ERR_INVALID_ARGUMENT, "null argument to uu3d_set_weight");
+    auto it = m->index.find(name);
+    if (it == m->index.end()) return fail(m, UU3D_ERR_INVALID_ARGUMENT, std::string("unknown weight: ") + name);
+    WeightRec& r = m->weights[it->second];
+    if (numel != r.numel)
+        return fail(m, UU3D_ERR_SHAPE, std::string("element count mismatch for ") + name + ": got " +
+                                           std::to_string(numel) + ", expected " + std::to_string(r.numel));
+    r.host.assign(data, data + numel);
+    r.set = true;
+    m->committed = false;
+    return UU3D_OK;
+}
+
+int uu3d_get_weight(const uu3d_model* mc, const char* name, float* out, int64_t numel) {
+    auto* m = const_cast<uu3d_model*>(mc);
+    if (!m || !name || !out) return fail(m, UU3D_ERR_INVALID_ARGUMENT, "null argument to uu3d_get_weight");
+    auto it = m->index.find(name);
+    if (it == m->index.end()) return fail(m, UU3D_ERR_INVALID_ARGUMENT, std::string("unknown weight: ") + name);
+    const WeightRec& r = m->weights[it->second];
+    if (!r.set) return fail(m, UU3D_ERR_NOT_READY, std::string("weight never set: ") + name);
+    if (numel != r.numel) return fail(m, UU3D_ERR_SHAPE, std::string("element count mismatch for ") + name);
+    std::memcpy(out, r.host.data(), sizeof(float) * (size_t)numel);
+    return UU3D_OK;
+}
+
+int uu3d_commit_weights(uu3d_model* m, void* stream_) {
+    if (!m) return UU3D_ERR_INVALID_ARGUMENT;
+    for (auto& r : m->weights)
+        if (!r.set) return fail(m, UU3D_ERR_NOT_READY, "weight never set: " + r.name);
+    hipStream_t stream = (hipStream_t)stream_;
+    HIPCHK(m, hipSetDevice(m->device));
+    const uu3d_config& c = m->cfg;
+    const int J = c.num_keypoints, N = c.num_frames, ds = c.d_spatial, dt = c.d_temporal, ht = c.h_temporal;
+    const int Kdt = round_up(dt, 32), Kht = round_up(ht, 32), Ks2t = round_up(J * ds, 32);
+    Packer P;
+
+    // ---- spatial ----
+    const size_t o_ew = P.alloc(2 * ds), o_eb = P.alloc(ds), o_spe = P.alloc((size_t)J * ds);
+    std::copy_n(W(m, "keypoint_embedding/kernel"), 2 * ds, P.buf.begin() + o_ew);
+    std::copy_n(W(m, "keypoint_embedding/bias"), ds, P.buf.begin() + o_eb);
+    std::copy_n(W(m, "spatial_pe/positional_encoding_weights"), J * ds, P.buf.begin() + o_spe);
+    const size_t o_sblk = P.alloc((size_t)c.spatial_depth * SLY::size);
+    for (int i = 0; i < c.spatial_depth; ++i) {
+        const std::string p = "spatial_block_" + std::to_string(i + 1);
+        float* d = P.buf.data() + o_sblk + (size_t)i * SLY::size;
+        auto vec = [&](int off, const std::string& nm, int n) {
+            const float* s = W(m, p + nm);
+            if (s) std::copy_n(s, n, d + off);   // absent (qkv_bias false) stays zero
+        };
+        auto tr = [&](int off, const std::string& nm, int K, int Nn) {   // (K,N) -> [N][K]
+            const float* s = W(m, p + nm);
+            for (int k = 0; k < K; ++k) for (int n = 0; n < Nn; ++n) d[off + n * K + k] = s[k * Nn + n];
+        };
+        vec(SLY::ln1_g, "/norm1/gamma", ds); vec(SLY::ln1_b, "/norm1/beta", ds);
+        tr(SLY::wq_t, "/attn/wq/kernel", ds, ds); vec(SLY::bq, "/attn/wq/bias", ds);
+        tr(SLY::wk_t, "/attn/wk/kernel", ds, ds); vec(SLY::bk, "/attn/wk/bias", ds);
+        tr(SLY::wv_t, "/attn/wv/kernel", ds, ds); vec(SLY::bv, "/attn/wv/bias", ds);
+        vec(SLY::wp, "/attn/projection/kernel", ds * ds); vec(SLY::bp, "/attn/projection/bias", ds);
+        vec(SLY::ln2_g, "/norm2/gamma", ds); vec(SLY::ln2_b, "/norm2/beta", ds);
+        tr(SLY::w1_t, "/mlp/fc1/kernel", ds, kHS); vec(SLY::b1, "/mlp/fc1/bias", kHS);
+        vec(SLY::w2, "/mlp/fc2/kernel", kHS * ds); vec(SLY::b2, "/mlp/fc2/bias", ds);
+    }
+    const size_t o_sng = P.alloc(ds), o_snb = P.alloc(ds);
+    std::copy_n(W(m, "spatial_norm/gamma"), ds, P.buf.begin() + o_sng);
+    std::copy_n(W(m, "spatial_norm/beta"), ds, P.buf.begin() + o_snb);
+
+    // ---- spatial_to_temporal_fc, token, temporal PE ----
+    const int Npdt = round_up(dt, 128);
+    const size_t o_s2t = P.alloc((size_t)Npdt * Ks2t), o_s2tb = P.alloc(Npdt);
+    pack_dense_t(P.buf, o_s2t, W(m, "spatial_to_temporal_fc/kernel"), J * ds, dt, Ks2t, 0);
+    std::copy_n(W(m, "spatial_to_temporal_fc/bias"), dt, P.buf.begin() + o_s2tb);
+    const size_t o_tok = P.alloc(dt);
+    if (c.has_strided_input)
+        std::copy_n(W(m, "strided_input_token_layer/learnable_masked_token"), dt, P.buf.begin() + o_tok);
+    const size_t o_pet = P.alloc((size_t)N * dt);
+    std::copy_n(W(m, "temporal_pe/positional_encoding_weights"), (size_t)N * dt, P.buf.begin() + o_pet);
+
+    // ---- transformer blocks ----
+    struct BlockOff { size_t ln1_g, ln1_b, wqkv, bqkv, wp, bp, ln2_g, ln2_b, w1, b1, w2, b2, pe; };
+    auto pack_block = [&](const std::string& p, bool strided, int peL, const std::string& pe_name) {
+        BlockOff o{};
+        o.ln1_g = P.alloc(dt); o.ln1_b = P.alloc(dt);
+        std::copy_n(W(m, p + "/norm1/gamma"), dt, P.buf.begin() + o.ln1_g);
+        std::copy_n(W(m, p + "/norm1/beta"), dt, P.buf.begin() + o.ln1_b);
+        const int Npq = round_up(3 * dt, 128);
+        o.wqkv = P.alloc((size_t)Npq * Kdt); o.bqkv = P.alloc(Npq);
+        int part = 0;
+        for (const char* nm : {"wq", "wk", "wv"}) {
+            pack_dense_t(P.buf, o.wqkv, W(m, p + "/attn/" + nm + "/kernel"), dt, dt, Kdt, part * dt);
+            const float* b = W(m, p + "/attn/" + nm + "/bias");
+            if (b) std::copy_n(b, dt, P.buf.begin() + o.bqkv + part * dt);
+            ++part;
+        }
+        o.wp = P.alloc((size_t)Npdt * Kdt); o.bp = P.alloc(Npdt);
+        pack_dense_t(P.buf, o.wp, W(m, p + "/attn/projection/kernel"), dt, dt, Kdt, 0);
+        std::copy_n(W(m, p + "/attn/projection/bias"), dt, P.buf.begin() + o.bp);
+        o.ln2_g = P.alloc(dt); o.ln2_b = P.alloc(dt);
+        std::copy_n(W(m, p + "/norm2/gamma"), dt, P.buf.begin() + o.ln2_g);
+        std::copy_n(W(m, p + "/norm2/beta"), dt, P.buf.begin() + o.ln2_b);
+        const int Nph = round_up(ht, 128);
+        o.w1 = P.alloc((size_t)Nph * Kdt); o.b1 = P.alloc(Nph);
+        pack_dense_t(P.buf, o.w1, W(m, p + "/mlp/fc1/kernel"), dt, ht, Kdt, 0);   // Conv1D k=1 (1,dt,ht) has the same flat layout
+        std::copy_n(W(m, p + "/mlp/fc1/bias"), ht, P.buf.begin() + o.b1);
+        if (strided) {
+            const int Kc = round_up(3 * ht, 32);
+            o.w2 = P.alloc((size_t)Npdt * Kc); o.b2 = P.alloc(Npdt);
+            // Conv1D kernel (3, ht, dt): flat (j*ht + c, n) is exactly a Dense kernel of K = 3*ht
+            pack_dense_t(P.buf, o.w2, W(m, p + "/mlp/strided_conv/kernel"), 3 * ht, dt, Kc, 0);
+            std::copy_n(W(m, p + "/mlp/strided_conv/bias"), dt, P.buf.begin() + o.b2);
+            o.pe = P.alloc((size_t)peL * dt);
+            std::copy_n(W(m, pe_name), (size_t)peL * dt, P.buf.begin() + o.pe);
+        } else {
+            o.w2 = P.alloc((size_t)Npdt * Kht); o.b2 = P.alloc(Npdt);
+            pack_dense_t(P.buf, o.w2, W(m, p + "/mlp/fc2/kernel"), ht, dt, Kht, 0);
+            std::copy_n(W(m, p + "/mlp/fc2/bias"), dt, P.buf.begin() + o.b2);
+        }
+        return o;
+    };
+    std::vector<BlockOff> toff, soff;
+    for (int i = 0; i < c.temporal_depth; ++i)
+        toff.push_back(pack_block("temporal_block_" + std::to_string(i + 1), false, 0, ""));
+    for (int i = 0; i < c.num_strided; ++i)
+        soff.push_back(pack_block("strided_temporal_block_" + std::to_string(i + 1), true, m->L[i],
+                                  "strided_temporal_pe_" + std::to_string(i + 1) + "/positional_encoding_weights"));
+
+    // ---- heads ----
+    const int Nph = round_up(3 * J, 128);
+    size_t o_h1 = 0, o_h1b = 0;
+    const bool has_h1 = c.full_output && c.temporal_depth > 0;
+    if (has_h1) {
+        o_h1 = P.alloc((size_t)Nph * Kdt); o_h1b = P.alloc(Nph);
+        pack_dense_t(P.buf, o_h1, W(m, "temporal_fc/kernel"), dt, 3 * J, Kdt, 0);
+        std::copy_n(W(m, "temporal_fc/bias"), 3 * J, P.buf.begin() + o_h1b);
+    }
+    const size_t o_h2 = P.alloc((size_t)Nph * Kdt), o_h2b = P.alloc(Nph);
+    pack_dense_t(P.buf, o_h2, W(m, "strided_temporal_fc/kernel"), dt, 3 * J, Kdt, 0);
+    std::copy_n(W(m, "strided_temporal_fc/bias"), 3 * J, P.buf.begin() + o_h2b);
+
+    // ---- upload ----
+    if (m->arena_floats < P.buf.size()) {
+        if (m->arena) HIPCHK(m, hipFree(m->arena));
+        m->arena = nullptr;
+        HIPCHK(m, hipMalloc((void**)&m->arena, P.buf.size() * sizeof(float)));
+        m->arena_floats = P.buf.size();
+    }
+    HIPCHK(m, hipMemcpyAsync(m->arena, P.buf.data(), P.buf.size() * sizeof(float), hipMemcpyHostToDevice, stream));
+    HIPCHK(m, hipStreamSynchronize(stream));
+
+    const float* A = m->arena;
+    m->sp.embed_w = A + o_ew; m->sp.embed_b = A + o_eb; m->sp.pe = A + o_spe; m->sp.blocks = A + o_sblk;
+    m->sp.norm_g = A + o_sng; m->sp.norm_b = A + o_snb; m->sp.depth = c.spatial_depth; m->sp.total_frames = 0;
+    m->s2t_wt = A + o_s2t; m->s2t_b = A + o_s2tb; m->token = A + o_tok; m->pe_t = A + o_pet;
+    auto view = [&](const BlockOff& o, bool strided) {
+        BlockDev b{};
+        b.ln1_g = A + o.ln1_g; b.ln1_b = A + o.ln1_b; b.wqkv_t = A + o.wqkv; b.bqkv = A + o.bqkv;
+        b.wp_t = A + o.wp; b.bp = A + o.bp; b.ln2_g = A + o.ln2_g; b.ln2_b = A + o.ln2_b;
+        b.w1_t = A + o.w1; b.b1 = A + o.b1; b.w2_t = A + o.w2; b.b2 = A + o.b2;
+        b.pe = strided ? A + o.pe : nullptr;
+        return b;
+    };
+    m->tblocks.clear(); m->sblocks.clear();
+    for (auto& o : toff) m->tblocks.push_back(view(o, false));
+    for (auto& o : soff) m->sblocks.push_back(view(o, true));
+    m->h1_wt = has_h1 ? A + o_h1 : nullptr; m->h1_b = has_h1 ? A + o_h1b : nullptr;
+    m->h2_wt = A + o_h2; m->h2_b = A + o_h2b;
+    m->committed = true;
+    return UU3D_OK;
+}
+
+// ---- workspace --------------------------------------------------------------------------
+namespace {
+struct Workspace {
+    float *S, *X, *QKV, *O, *Hb, *XA, *XB;
+    float2* stats;
+    size_t bytes;
+};
+Workspace carve(const uu3d_model* m, int B, char* base) {
+    const uu3d_config& c = m->cfg;
+    const size_t rows = (size_t)B * c.num_frames;
+    const size_t rows_s = (size_t)B * (c.num_strided > 1 ? std::max(m->L[1], 1) : 1);
+    size_t off = 0;
+    auto take = [&](size_t n) { size_t o = off; off = align_up(off + n, 256); return o; };
+    Workspace w{};
+    const size_t oS = take(rows * c.num_keypoints * c.d_spatial * 4);
+    const size_t oX = take(rows * c.d_temporal * 4);
+    const size_t oQ = take(rows * 3 * c.d_temporal * 4);
+    const size_t oO = take(rows * c.d_temporal * 4);
+    const size_t oH = take(rows * c.h_temporal * 4);
+    const size_t oA = take(rows * c.d_temporal * 4);
+    const size_t oB = take(rows_s * c.d_temporal * 4);
+    const size_t oT = take(rows * sizeof(float2));
+    w.bytes = off;
+    if (base) {
+        w.S = (float*)(base + oS); w.X = (float*)(base + oX); w.QKV = (float*)(base + oQ);
+        w.O = (float*)(base + oO); w.Hb = (float*)(base + oH); w.XA = (float*)(base + oA);
+        w.XB = (float*)(base + oB); w.stats = (float2*)(base + oT);
+    }
+    return w;
+}
+}  // namespace
+
+size_t uu3d_workspace_bytes(const uu3d_model* m, int32_t batch) {
+    if (!m || batch < 1) return 0;
+    return carve(m, batch, nullptr).bytes;
+}
+
+// ---- launch helpers ---------------------------------------------------------------------
+namespace {
+
+struct Launcher {
+    uu3d_model* m;
+    hipStream_t stream;
+    int status = UU3D_OK;
+
+    void begin(const char* name, const char* kernel, double flops, double bytes) {
+        if (!m->profiling) return;
+        if (m->prof_used == m->prof.size()) {
+            ProfRec r;
+            if (hipEventCreate(&r.e0) != hipSuccess || hipEventCreate(&r.e1) != hipSuccess) { status = UU3D_ERR_HIP; return; }
+            m->prof.push_back(r);
+        }
+        ProfRec& r = m->prof[m->prof_used];
+        r.name = name; r.kernel = kernel; r.flops = flops; r.bytes = bytes;
+        (void)hipEventRecord(r.e0, stream);
+    }
+    void end() {
+        if (m->profiling && m->prof_used < m->prof.size()) { (void)hipEventRecord(m->prof[m->prof_used].e1, stream); ++m->prof_used; }
+        hipError_t e = hipGetLastError();
+        if (e != hipSuccess && status == UU3D_OK) { status = UU3D_ERR_HIP; m->err = std::string("kernel launch failed: ") + hipGetErrorString(e); }
+    }
+
+    template <int BM, int BN, class AL, class EP>
+    void gemm_tile(const AL& al, const float* Bt, int M, int N, int Kp, const EP& ep) {
+        auto kern = gemm_f32_kernel<BM, BN, AL, EP>;
+        constexpr size_t lds = gemm_lds_bytes(BM, BN);
+        static bool attr_done = false;   // one attribute call per instantiation
+        if (!attr_done) { (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr_done = true; }
+        const int mt = (M + BM - 1) / BM, nt = (N + BN - 1) / BN;
+        const int grid = round_up(mt, 8) * nt;
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, stream, al, Bt, M, N, Kp, mt, nt, ep);
+    }
+
+    // C[M][N] = A[M][K] * W ; tile shape picked per problem (see DESIGN.md "GEMM tiling").
+    template <class AL, class EP>
+    void gemm(const char* name, const AL& al, const float* Bt, int M, int N, int K, const EP& ep, double extra_bytes = 0) {
+        const int Kp = round_up(K, 32);
+        begin(name, "gemm_f32", 2.0 * M * (double)N * K, 4.0 * ((double)M * K + (double)N * K + (double)M * N) + extra_bytes);
+        const long t128 = (long)((M + 127) / 128) * ((N + 127) / 128);
+        if (N >= 512 && t128 >= 256) gemm_tile<128, 128>(al, Bt, M, N, Kp, ep);
+        else if (N > 64 && (long)((M + 127) / 128) * ((N + 63) / 64) >= 256) gemm_tile<128, 64>(al, Bt, M, N, Kp, ep);
+        else gemm_tile<64, 64>(al, Bt, M, N, Kp, ep);
+        end();
+    }
+
+    void row_stats(const char* name, const float* x, int D, int M, float2* stats) {
+        begin(name, "row_stats", 0.0, 4.0 * (double)M * D + 8.0 * M);
+        hipLaunchKernelGGL(row_stats_kernel<4>, dim3((M + 3) / 4), dim3(256), 0, stream, x, D, D, M, 1e-5f, stats);
+        end();
+    }
+
+    void attn(const char* name, const float* qkv, int B, int L, const uint8_t* mask, float* out) {
+        const int D = m->cfg.d_temporal, H = m->cfg.num_heads;
+        const int NT = (L + 15) / 16;
+        begin(name, "attn_f32", 4.0 * B * (double)H * L * L * kDH, 4.0 * 4.0 * B * (double)L * D);
+        const dim3 grid(B * H);
+#define UU3D_ATTN_CASE(nt) case nt: hipLaunchKernelGGL((attn_f32_kernel<nt, kDH>), grid, dim3(64 * nt), 0, stream, qkv, 3 * D, D, L, H, mask, out, D); break;
+        switch (NT) {
+            UU3D_ATTN_CASE(1) UU3D_ATTN_CASE(2) UU3D_ATTN_CASE(3) UU3D_ATTN_CASE(4)
+            UU3D_ATTN_CASE(5) UU3D_ATTN_CASE(6) UU3D_ATTN_CASE(7) UU3D_ATTN_CASE(8)
+            default: status = UU3D_ERR_UNSUPPORTED; m->err = "attention length > 128"; break;
+        }
+#undef UU3D_ATTN_CASE
+        end();
+    }
+};
+
+}  // namespace
+
+int uu3d_forward(uu3d_model* m, const float* kp2d, const uint8_t* mask, int32_t B, float* full_out,
+                 float* central_out, void* workspace, size_t workspace_bytes, void* stream_) {
+    if (!m) return UU3D_ERR_INVALID_ARGUMENT;
+    if (!m->committed) return fail(m, UU3D_ERR_NOT_READY, "uu3d_commit_weights has not been called");
+    if (!kp2d || !central_out || !workspace || B < 1) return fail(m, UU3D_ERR_INVALID_ARGUMENT, "null buffer or batch < 1");
+    const uu3d_config& c = m->cfg;
+    if ((c.has_strided_input != 0) != (mask != nullptr))
+        return fail(m, UU3D_ERR_INVALID_ARGUMENT, "stride_mask must be given iff the model has strided input");
+    const bool has_h1 = c.full_output && c.temporal_depth > 0;
+    if (has_h1 && !full_out) return fail(m, UU3D_ERR_INVALID_ARGUMENT, "full_out_dev is required for this model");
+    if (((uintptr_t)workspace & 255) != 0) return fail(m, UU3D_ERR_WORKSPACE, "workspace must be 256-byte aligned");
+    Workspace w = carve(m, B, (char*)workspace);
+    if (workspace_bytes < w.bytes) return fail(m, UU3D_ERR_WORKSPACE, "workspace smaller than uu3d_workspace_bytes(batch)");
+    if ((long)B * c.num_frames * c.num_keypoints > (1L << 30)) return fail(m, UU3D_ERR_INVALID_ARGUMENT, "batch too large");
+
+    HIPCHK(m, hipSetDevice(m->device));
+    Launcher Lh{m, (hipStream_t)stream_};
+    m->prof_used = 0;
+    const int N = c.num_frames, J = c.num_keypoints, ds = c.d_spatial, dt = c.d_temporal, ht = c.h_temporal;
+    const int M = B * N;
+    char nm[48];
+
+    // 1. spatial stack
+    {
+        SpatialParams sp = m->sp;
+        sp.total_frames = M;
+        constexpr int FPW = 256 / kJ;
+        auto kern = spatial_stack_kernel<kJ, kDS, kHS, kHeads>;
+        static bool attr_done = false;
+        if (!attr_done) { (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)spatial_lds_bytes(kDS)); attr_done = true; }
+        const double fl = (double)M * (2.0 * J * 2 * ds + c.spatial_depth * (4.0 * 2 * J * ds * ds + 8.0 * 4 * J * J * (ds / 8) + 2.0 * 2 * J * ds * kHS));
+        Lh.begin("spatial_stack", "spatial_stack", fl, 4.0 * M * J * (2.0 + ds));
+        hipLaunchKernelGGL(kern, dim3((M + FPW - 1) / FPW), dim3(256), spatial_lds_bytes(kDS), Lh.stream, kp2d, sp, w.S);
+        Lh.end();
+    }
+    // 2. spatial_to_temporal_fc + token blend + temporal PE
+    {
+        ALoadPlain al{w.S, J * ds, M, J * ds};
+        EpSpatialToTemporal ep{w.X, m->s2t_b, dt, mask, m->token, m->pe_t, N, nullptr, nullptr};
+        Lh.gemm("s2t", al, m->s2t_wt, M, dt, J * ds, ep);
+    }
+    // 3. temporal blocks
+    for (int i = 0; i < c.temporal_depth; ++i) {
+        const BlockDev& b = m->tblocks[i];
+        const bool masked = c.has_strided_input && i < c.first_strided_token_attention_layer;
+        const bool last = (i + 1 == c.temporal_depth);
+        snprintf(nm, sizeof nm, "t%d.stats1", i + 1); Lh.row_stats(nm, w.X, dt, M, w.stats);
+        { ALoadLayerNorm al{w.X, w.stats, b.ln1_g, b.ln1_b, dt, M, dt}; EpBias ep{w.QKV, b.bqkv, 3 * dt};
+          snprintf(nm, sizeof nm, "t%d.ln_qkv", i + 1); Lh.gemm(nm, al, b.wqkv_t, M, 3 * dt, dt, ep); }
+        snprintf(nm, sizeof nm, "t%d.attn", i + 1); Lh.attn(nm, w.QKV, B, N, masked ? mask : nullptr, w.O);
+        { ALoadPlain al{w.O, dt, M, dt}; EpBiasResidual ep{w.X, b.bp, dt, nullptr, nullptr, 1};
+          snprintf(nm, sizeof nm, "t%d.proj_res", i + 1); Lh.gemm(nm, al, b.wp_t, M, dt, dt, ep, 4.0 * M * dt); }
+        snprintf(nm, sizeof nm, "t%d.stats2", i + 1); Lh.row_stats(nm, w.X, dt, M, w.stats);
+        { ALoadLayerNorm al{w.X, w.stats, b.ln2_g, b.ln2_b, dt, M, dt}; EpBiasRelu ep{w.Hb, b.b1, ht};
+          snprintf(nm, sizeof nm, "t%d.ln_fc1", i + 1); Lh.gemm(nm, al, b.w1_t, M, ht, dt, ep); }
+        { ALoadPlain al{w.Hb, ht, M, ht};
+          EpBiasResidual ep{w.X, b.b2, dt, last ? w.XA : nullptr, last ? m->sblocks[0].pe : nullptr, N};
+          snprintf(nm, sizeof nm, "t%d.fc2_res", i + 1); Lh.gemm(nm, al, b.w2_t, M, dt, ht, ep, 4.0 * M * dt); }
+    }
+    // 4. head1
+    if (has_h1) {
+        ALoadPlain al{w.X, dt, M, dt}; EpBias ep{full_out, m->h1_b, 3 * J};
+        Lh.gemm("head1", al, m->h1_wt, M, 3 * J, dt, ep);
+    }
+    // 5. strided blocks
+    float* xa = w.XA; float* xb = w.XB;
+    for (int i = 0; i < c.num_strided; ++i) {
+        const BlockDev& b = m->sblocks[i];
+        const int Li = m->L[i], Lo = m->L[i + 1], Mi = B * Li, Mo = B * Lo;
+        snprintf(nm, sizeof nm, "s%d.stats1", i + 1); Lh.row_stats(nm, xa, dt, Mi, w.stats);
+        { ALoadLayerNorm al{xa, w.stats, b.ln1_g, b.ln1_b, dt, Mi, dt}; EpBias ep{w.QKV, b.bqkv, 3 * dt};
+          snprintf(nm, sizeof nm, "s%d.ln_qkv", i + 1); Lh.gemm(nm, al, b.wqkv_t, Mi, 3 * dt, dt, ep); }
+        snprintf(nm, sizeof nm, "s%d.attn", i + 1); Lh.attn(nm, w.QKV, B, Li, nullptr, w.O);
+        { ALoadPlain al{w.O, dt, Mi, dt}; EpBiasResidual ep{xa, b.bp, dt, nullptr, nullptr, 1};
+          snprintf(nm, sizeof nm, "s%d.proj_res", i + 1); Lh.gemm(nm, al, b.wp_t, Mi, dt, dt, ep, 4.0 * Mi * dt); }
+        snprintf(nm, sizeof nm, "s%d.stats2", i + 1); Lh.row_stats(nm, xa, dt, Mi, w.stats);
+        { ALoadLayerNorm al{xa, w.stats, b.ln2_g, b.ln2_b, dt, Mi, dt}; EpBiasRelu ep{w.Hb, b.b1, ht};
+          snprintf(nm, sizeof nm, "s%d.ln_fc1", i + 1); Lh.gemm(nm, al, b.w1_t, Mi, ht, dt, ep); }
+        { ALoadConv3 al{w.Hb, ht, Li, Lo, c.strides[i], c.pad_left[i], Mo, 3 * ht};
+          // MaxPool1D(pool 1, stride s) on the trimmed sequence; stride 1 keeps x untrimmed (u_u_t.py:138-154)
+          const int lo = (c.strides[i] > 1 && c.pad_left[i] == 0) ? 1 : 0;
+          EpConvResidual ep{xb, b.b2, dt, xa, Li, Lo, c.strides[i], lo,
+                            (i + 1 < c.num_strided) ? m->sblocks[i + 1].pe : nullptr};
+          snprintf(nm, sizeof nm, "s%d.conv_res", i + 1); Lh.gemm(nm, al, b.w2_t, Mo, dt, 3 * ht, ep, 4.0 * Mo * dt); }
+        std::swap(xa, xb);
+        if (i == 0) xb = w.XA;   // XA (B*N rows) is free again; XB only needs B*L_1 rows
+    }
+    // 6. head2
+    {
+        ALoadPlain al{xa, dt, B, dt}; EpBias ep{central_out, m->h2_b, 3 * J};
+        Lh.gemm("head2", al, m->h2_wt, B, 3 * J, dt, ep);
+    }
+    if (Lh.status != UU3D_OK) return Lh.status;
+    return UU3D_OK;
+}
+
+int uu3d_mpjpe(const float* pred, const float* gt, int32_t B, int32_t J, int32_t root, double* out, void* stream) {
+    if (!pred || !gt || !out || B < 1 || J < 1 || root < 0 || root >= J) return UU3D_ERR_INVALID_ARGUMENT;
+    hipLaunchKernelGGL(mpjpe_kernel, dim3((B * J + 255) / 256), dim3(256), 0, (hipStream_t)stream, pred, gt, B, J, root, out);
+    return hipGetLastError() == hipSuccess ? UU3D_OK : UU3D_ERR_HIP;
+}
+
+int uu3d_set_profiling(uu3d_model* m, int32_t enabled) {
+    if (!m) return UU3D_ERR_INVALID_ARGUMENT;
+    m->profiling = enabled != 0;
+    m->prof_used = 0;
+    return UU3D_OK;
+}
+
+int uu3d_profile_read(uu3d_model* m, uu3d_profile_entry* out, int32_t capacity, int32_t* count) {
+    if (!m || !count) return UU3D_ERR_INVALID_ARGUMENT;
+    *count = (int32_t)m->prof_used;
+    if (!out) return UU3D_OK;
+    for (size_t i = 0; i < m->prof_used && (int32_t)i < capacity; ++i) {
+        ProfRec& r = m->prof[i];
+        HIPCHK(m, hipEventSynchronize(r.e1));
+        float ms = 0.f;
+        HIPCHK(m, hipEventElapsedTime(&ms, r.e0, r.e1));
+        uu3d_profile_entry& e = out[i];
+        std::memset(&e, 0, sizeof e);
+        std::snprintf(e.name, sizeof e.name, "%s", r.name.c_str());
+        std::snprintf(e.kernel, sizeof e.kernel, "%s", r.kernel.c_str());
+        e.ms = ms; e.flops = r.flops; e.bytes = r.bytes;
+    }
+    return UU3D_OK;
+}
+

@@ -1,0 +1,138 @@
+// uu3d_attn.h -- temporal / strided self-attention for one (sequence, head) per workgroup.
+//
+// Replaces vit.MHA.scaled_dot_product_attention (vision_transformer.py:99-130) for the
+// temporal stacks: logits = Q K^T / sqrt(d_h) (+ mask * -1e9), softmax over keys, P V.
+// The probabilities are never written to memory (the reference materialises and returns them).
+//
+// Layout: qkv rows are [q(D) | k(D) | v(D)], head h owns channels [h*DH, (h+1)*DH).
+// One workgroup = one (b, h); wave w owns query tile w (16 queries); NT = ceil(L / 16) waves.
+// K and V of the head are staged once in LDS (zero padded to NT*16 rows, row stride DH+4).
+//
+// MFMA: v_mfma_f32_16x16x4_f32 (exact f32).  The wave computes the TRANSPOSED logit tile
+// S^T = K Q^T (A = K rows, B = Q^T), so that in the C/D map (col = lane & 15 -> query,
+// row = 4 * (lane >> 4) + reg -> key) every lane holds, for its query, the keys
+// 16j + 4g + r.  The softmax over keys is then in-lane plus two cross-lane steps
+// (xor 16, 32), and the probability registers are ALREADY the A operand of the P V product:
+// A[i = query = lane & 15][k-slot g, step (j, s)] = P[query][key 16j + 4g + s] -- the
+// k-slot order of an MFMA is free as long as B uses the same one, so V is read as
+// V[16j + 4g + s][d].  No LDS round trip and no shuffle for P.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <math.h>
+#include "uu3d_gemm.h"
+
+namespace uu3d {
+
+template <int NT, int DH>
+__global__ void __launch_bounds__(64 * NT)
+attn_f32_kernel(const float* __restrict__ qkv, const int ld, const int D, const int L, const int H,
+                const uint8_t* __restrict__ key_mask,   // (B, L) 1 = attend; nullptr = no mask
+                float* __restrict__ out, const int ldo)
+{
+    static_assert(DH % 16 == 0, "head dim must be a multiple of 16");
+    constexpr int LD = DH + 4;
+    constexpr int F4 = DH / 4;
+    constexpr int KT = DH / 16;             // float4 k-groups per lane
+    __shared__ __attribute__((aligned(16))) float Ks[NT * 16 * LD];
+    __shared__ __attribute__((aligned(16))) float Vs[NT * 16 * LD];
+
+    const int bh = blockIdx.x;
+    const int b = bh / H, h = bh - b * H;
+    const int tid = threadIdx.x;
+    const float* base = qkv + (size_t)b * L * ld + h * DH;
+
+    for (int idx = tid; idx < NT * 16 * F4; idx += 64 * NT) {
+        const int row = idx / F4, c4 = (idx - row * F4) * 4;
+        float4 kv = make_float4(0.f, 0.f, 0.f, 0.f), vv = kv;
+        if (row < L) {
+            const float* p = base + (size_t)row * ld + c4;
+            kv = *reinterpret_cast<const float4*>(p + D);
+            vv = *reinterpret_cast<const float4*>(p + 2 * D);
+        }
+        *reinterpret_cast<float4*>(&Ks[row * LD + c4]) = kv;
+        *reinterpret_cast<float4*>(&Vs[row * LD + c4]) = vv;
+    }
+
+    const int lane = tid & 63, w = tid >> 6;
+    const int qi = lane & 15, g = lane >> 4;
+    const int qrow = 16 * w + qi;
+    f32x4 qf[KT];
+#pragma unroll
+    for (int t = 0; t < KT; ++t) {
+        qf[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        if (qrow < L) qf[t] = *reinterpret_cast<const f32x4*>(base + (size_t)qrow * ld + 16 * t + 4 * g);
+    }
+    __syncthreads();
+
+    // S^T tiles: st[j][r] = <Q[qrow], K[16j + 4g + r]>
+    f32x4 st[NT];
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+        f32x4 a = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int t = 0; t < KT; ++t) {
+            const f32x4 kf = *reinterpret_cast<const f32x4*>(&Ks[(16 * j + qi) * LD + 16 * t + 4 * g]);
+#pragma unroll
+            for (int s = 0; s < 4; ++s)
+                a = __builtin_amdgcn_mfma_f32_16x16x4f32(kf[s], qf[t][s], a, 0, 0, 0);
+        }
+        st[j] = a;
+    }
+
+    // logits / sqrt(d_h) (+ mask * -1e9), softmax over keys
+    const float scale_div = sqrtf((float)DH);
+    float mx = -INFINITY;
+#pragma unroll
+    for (int j = 0; j < NT; ++j)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int key = 16 * j + 4 * g + r;
+            float v = st[j][r] / scale_div;
+            if (key < L) {
+                if (key_mask != nullptr) v += (key_mask[(size_t)b * L + key] ? 0.0f : 1.0f) * -1e9f;
+            } else {
+                v = -INFINITY;
+            }
+            st[j][r] = v;
+            mx = fmaxf(mx, v);
+        }
+    mx = fmaxf(mx, __shfl_xor(mx, 16));
+    mx = fmaxf(mx, __shfl_xor(mx, 32));
+    float sum = 0.f;
+#pragma unroll
+    for (int j = 0; j < NT; ++j)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const float e = expf(st[j][r] - mx);
+            st[j][r] = e;
+            sum += e;
+        }
+    sum += __shfl_xor(sum, 16);
+    sum += __shfl_xor(sum, 32);
+#pragma unroll
+    for (int j = 0; j < NT; ++j)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) st[j][r] = st[j][r] / sum;
+
+    // O = P V : tile t covers head channels 16t .. 16t+15
+#pragma unroll
+    for (int t = 0; t < KT; ++t) {
+        f32x4 o = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                const float vv = Vs[(16 * j + 4 * g + s) * LD + 16 * t + qi];
+                o = __builtin_amdgcn_mfma_f32_16x16x4f32(st[j][s], vv, o, 0, 0, 0);
+            }
+        // C/D map: col = lane & 15 -> channel, row = 4g + r -> query
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int q = 16 * w + 4 * g + r;
+            if (q < L) out[((size_t)b * L + q) * ldo + h * DH + 16 * t + qi] = o[r];
+        }
+    }
+}
+
+}  // namespace uu3d

@@ -1,0 +1,286 @@
+// uu3d_gemm.h -- exact-f32 MFMA GEMM for gfx950 with fused A-operand loaders and epilogues.
+//
+// C[M][N] = Aop[M][K] * W[K][N] (+ epilogue).  W is stored TRANSPOSED and padded in HBM as
+// Bt[Np][Kp] (Np multiple of 128, Kp multiple of 32, zero filled) so that both operands are
+// read as 16-byte, k-contiguous fragments.
+//
+// Arithmetic: v_mfma_f32_32x32x2_f32 (f32 in, f32 accumulate: bit-for-bit an fmaf chain).
+// A wave owns TM x TN tiles of 32x32.  Per 8-deep k-slice a lane reads ONE float4 per
+// operand tile: lane (r = lane&31, h = lane>>5) takes k = 8*kk + 4*h + s for MFMA step
+// s = 0..3.  The MFMA contracts over "k slots", so any permutation of k that is the same
+// for A and B is legal; this one makes every LDS fragment read a ds_read_b128.
+//
+// LDS tiles are [rows][32] floats with a row stride of 36 floats: the 16 lanes of every
+// ds_read_b128 group then hit 16 distinct 16-byte slots (36 = 4 * 9, 9 odd) -- no bank
+// conflicts, and the staging ds_write_b128 of 8 lanes covers one contiguous 128-byte row.
+//
+// Workgroup = 256 threads = 4 waves as 2 (M) x 2 (N); LDS double buffered, next k-tile's
+// global loads are issued before the MFMAs of the current one and written after them.
+//
+// Block -> tile mapping is XCD aware: block ids are dealt round-robin over the 8 XCDs, so
+// id % 8 selects the XCD; all N-tiles of one M-tile go to the same XCD so the A rows are
+// fetched into ONE L2 (weights are read by every XCD regardless).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace uu3d {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+static constexpr int GEMM_BK = 32;
+static constexpr int GEMM_LD = 36;
+
+__host__ __device__ inline constexpr size_t gemm_lds_bytes(int BM, int BN) {
+    return (size_t)2 * (BM + BN) * GEMM_LD * sizeof(float);
+}
+
+// ------------------------------------------------------------------------------------
+// A-operand loaders.  prep(row) builds a per-row context once; load(ctx, k) returns
+// A[row][k .. k+3] (k multiple of 4); rows >= M and k >= K read as zero.
+// ------------------------------------------------------------------------------------
+struct ALoadPlain {
+    const float* __restrict__ A;
+    int lda, M, K;
+    struct Ctx { const float* p; };
+    __device__ __forceinline__ Ctx prep(int row) const {
+        Ctx c; c.p = (row < M) ? A + (size_t)row * lda : nullptr; return c;
+    }
+    __device__ __forceinline__ f32x4 load(const Ctx& c, int k) const {
+        if (c.p == nullptr || k >= K) return (f32x4){0.f, 0.f, 0.f, 0.f};
+        return *reinterpret_cast<const f32x4*>(c.p + k);
+    }
+};
+
+// LayerNorm fused into the load: Keras' non-fused formula
+//   inv = rsqrt(var + eps) * gamma ;  y = x * inv + (beta - mean * inv)
+// with (mean, rstd) per row precomputed by row_stats_kernel.
+struct ALoadLayerNorm {
+    const float* __restrict__ A;
+    const float2* __restrict__ stats;   // (mean, rstd) per row
+    const float* __restrict__ gamma;
+    const float* __restrict__ beta;
+    int lda, M, K;
+    struct Ctx { const float* p; float mean, rstd; };
+    __device__ __forceinline__ Ctx prep(int row) const {
+        Ctx c; c.p = nullptr; c.mean = 0.f; c.rstd = 0.f;
+        if (row < M) { c.p = A + (size_t)row * lda; float2 s = stats[row]; c.mean = s.x; c.rstd = s.y; }
+        return c;
+    }
+    __device__ __forceinline__ f32x4 load(const Ctx& c, int k) const {
+        if (c.p == nullptr || k >= K) return (f32x4){0.f, 0.f, 0.f, 0.f};
+        const f32x4 x = *reinterpret_cast<const f32x4*>(c.p + k);
+        const f32x4 g = *reinterpret_cast<const f32x4*>(gamma + k);
+        const f32x4 b = *reinterpret_cast<const f32x4*>(beta + k);
+        f32x4 y;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float inv = c.rstd * g[e];
+            y[e] = x[e] * inv + (b[e] - c.mean * inv);
+        }
+        return y;
+    }
+};
+
+// Strided k=3 convolution as a 3-tap GEMM over gathered rows (ZeroPadding1D + Conv1D
+// 'valid'): output row (b, t) contracts over k = j*C + c with source row t*stride + j - pad_left
+// of sequence b (zero outside [0, L_in)).
+struct ALoadConv3 {
+    const float* __restrict__ Hin;      // (B * L_in, C)
+    int C, L_in, L_out, stride, pad_left, M, K;   // M = B * L_out, K = 3 * C
+    struct Ctx { int base_row; int t0; };          // base_row = b * L_in ; t0 = t*stride - pad_left
+    __device__ __forceinline__ Ctx prep(int row) const {
+        Ctx c; c.base_row = -1; c.t0 = 0;
+        if (row < M) { int b = row / L_out; int t = row - b * L_out; c.base_row = b * L_in; c.t0 = t * stride - pad_left; }
+        return c;
+    }
+    __device__ __forceinline__ f32x4 load(const Ctx& c, int k) const {
+        if (c.base_row < 0 || k >= K) return (f32x4){0.f, 0.f, 0.f, 0.f};
+        const int j = k / C;
+        const int cc = k - j * C;
+        const int src = c.t0 + j;
+        if (src < 0 || src >= L_in) return (f32x4){0.f, 0.f, 0.f, 0.f};
+        return *reinterpret_cast<const f32x4*>(Hin + (size_t)(c.base_row + src) * C + cc);
+    }
+};
+
+// ------------------------------------------------------------------------------------
+// Epilogues: operator()(row, col, acc) for row < M, col < N.
+// ------------------------------------------------------------------------------------
+struct EpBias {            // out = acc + bias
+    float* __restrict__ out; const float* __restrict__ bias; int ldo;
+    __device__ __forceinline__ void operator()(int row, int col, float v) const {
+        out[(size_t)row * ldo + col] = v + bias[col];
+    }
+};
+struct EpBiasRelu {        // out = max(acc + bias, 0)
+    float* __restrict__ out; const float* __restrict__ bias; int ldo;
+    __device__ __forceinline__ void operator()(int row, int col, float v) const {
+        out[(size_t)row * ldo + col] = fmaxf(v + bias[col], 0.f);
+    }
+};
+// x = x + (acc + bias), in place; optionally a second stream out2 = x_new + pe2[row % period]
+// (the next strided block's positional encoding, folded in here).
+struct EpBiasResidual {
+    float* x; const float* __restrict__ bias; int ld;
+    float* out2; const float* __restrict__ pe2; int period;
+    __device__ __forceinline__ void operator()(int row, int col, float v) const {
+        const size_t o = (size_t)row * ld + col;
+        const float y = x[o] + (v + bias[col]);
+        x[o] = y;
+        if (out2 != nullptr) out2[o] = y + pe2[(size_t)(row % period) * ld + col];
+    }
+};
+// spatial_to_temporal_fc + strided-input token blend + temporal PE (u_u_t.py:332,344-352):
+//   t = acc + bias ; x = m ? t : token ; x += pe[row % N]
+struct EpSpatialToTemporal {
+    float* __restrict__ x; const float* __restrict__ bias; int ld;
+    const uint8_t* __restrict__ mask;     // per row (B*N), nullptr when no strided input
+    const float* __restrict__ token; const float* __restrict__ pe; int period;
+    float* out2; const float* __restrict__ pe2;   // used when temporal_depth == 0
+    __device__ __forceinline__ void operator()(int row, int col, float v) const {
+        float t = v + bias[col];
+        if (mask != nullptr && mask[row] == 0) t = token[col];
+        const size_t o = (size_t)row * ld + col;
+        const float y = t + pe[(size_t)(row % period) * ld + col];
+        x[o] = y;
+        if (out2 != nullptr) out2[o] = y + pe2[(size_t)(row % period) * ld + col];
+    }
+};
+// strided block tail (u_u_t.py:138-156): out = identity + (acc + bias) (+ next block's PE)
+// identity row of output (b, t) is row  b*L_in + t*stride + lo  of the block's input stream.
+struct EpConvResidual {
+    float* __restrict__ out; const float* __restrict__ bias; int ld;
+    const float* __restrict__ xin; int L_in, L_out, stride, lo;
+    const float* __restrict__ pe_next;    // (L_out, ld) or nullptr
+    __device__ __forceinline__ void operator()(int row, int col, float v) const {
+        const int b = row / L_out; const int t = row - b * L_out;
+        const float id = xin[(size_t)(b * L_in + t * stride + lo) * ld + col];
+        float y = id + (v + bias[col]);
+        if (pe_next != nullptr) y += pe_next[(size_t)t * ld + col];
+        out[(size_t)row * ld + col] = y;
+    }
+};
+
+// ------------------------------------------------------------------------------------
+// kernel
+// ------------------------------------------------------------------------------------
+template <int BM, int BN, class AL, class EP>
+__global__ void __launch_bounds__(256)
+gemm_f32_kernel(const AL al, const float* __restrict__ Bt, const int M, const int N, const int Kp,
+                const int m_tiles, const int n_tiles, const EP ep)
+{
+    constexpr int LD = GEMM_LD;
+    constexpr int TM = BM / 64, TN = BN / 64;     // 32x32 MFMA tiles per wave
+    constexpr int AI = BM / 32, BI = BN / 32;     // float4 staging loads per thread per k-tile
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* As = smem;                    // [2][BM][LD]
+    float* Bs = smem + 2 * BM * LD;      // [2][BN][LD]
+
+    // XCD-aware tile mapping (see header).
+    const int id = blockIdx.x;
+    const int xcd = id & 7;
+    const int slot = id >> 3;
+    const int bn = slot % n_tiles;
+    const int bm = (slot / n_tiles) * 8 + xcd;
+    if (bm >= m_tiles) return;
+    const int bm0 = bm * BM, bn0 = bn * BN;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int srow = tid >> 3;           // staging row 0..31
+    const int scol = (tid & 7) * 4;      // staging k offset
+
+    typename AL::Ctx actx[AI];
+#pragma unroll
+    for (int i = 0; i < AI; ++i) actx[i] = al.prep(bm0 + srow + 32 * i);
+    const float* bptr[BI];
+#pragma unroll
+    for (int i = 0; i < BI; ++i) bptr[i] = Bt + (size_t)(bn0 + srow + 32 * i) * Kp + scol;
+
+    f32x4 ra[AI], rb[BI];
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    const int KT = Kp / GEMM_BK;
+
+    // prologue: tile 0 -> LDS buffer 0
+#pragma unroll
+    for (int i = 0; i < AI; ++i) ra[i] = al.load(actx[i], scol);
+#pragma unroll
+    for (int i = 0; i < BI; ++i) rb[i] = *reinterpret_cast<const f32x4*>(bptr[i]);
+#pragma unroll
+    for (int i = 0; i < AI; ++i) *reinterpret_cast<f32x4*>(&As[(srow + 32 * i) * LD + scol]) = ra[i];
+#pragma unroll
+    for (int i = 0; i < BI; ++i) *reinterpret_cast<f32x4*>(&Bs[(srow + 32 * i) * LD + scol]) = rb[i];
+    __syncthreads();
+
+    const int fr = lane & 31;            // fragment row
+    const int fk = (lane >> 5) * 4;      // fragment k offset inside an 8-slice
+
+    for (int kt = 0; kt < KT; ++kt) {
+        const int cur = kt & 1;
+        const bool more = (kt + 1 < KT);
+        if (more) {
+            const int k0 = (kt + 1) * GEMM_BK;
+#pragma unroll
+            for (int i = 0; i < AI; ++i) ra[i] = al.load(actx[i], k0 + scol);
+#pragma unroll
+            for (int i = 0; i < BI; ++i) rb[i] = *reinterpret_cast<const f32x4*>(bptr[i] + k0);
+        }
+        const float* Ac = As + cur * BM * LD + (wm * (BM / 2) + fr) * LD + fk;
+        const float* Bc = Bs + cur * BN * LD + (wn * (BN / 2) + fr) * LD + fk;
+#pragma unroll
+        for (int kk = 0; kk < GEMM_BK / 8; ++kk) {
+            f32x4 af[TM], bf[TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) af[i] = *reinterpret_cast<const f32x4*>(Ac + i * 32 * LD + kk * 8);
+#pragma unroll
+            for (int j = 0; j < TN; ++j) bf[j] = *reinterpret_cast<const f32x4*>(Bc + j * 32 * LD + kk * 8);
+#pragma unroll
+            for (int s = 0; s < 4; ++s)
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][s], bf[j][s], acc[i][j], 0, 0, 0);
+        }
+        if (more) {
+            const int nxt = cur ^ 1;
+#pragma unroll
+            for (int i = 0; i < AI; ++i)
+                *reinterpret_cast<f32x4*>(&As[nxt * BM * LD + (srow + 32 * i) * LD + scol]) = ra[i];
+#pragma unroll
+            for (int i = 0; i < BI; ++i)
+                *reinterpret_cast<f32x4*>(&Bs[nxt * BN * LD + (srow + 32 * i) * LD + scol]) = rb[i];
+        }
+        __syncthreads();
+    }
+
+    // epilogue: C/D map of the 32x32 MFMA: col = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)
+    const int crow0 = bm0 + wm * (BM / 2) + 4 * (lane >> 5);
+    const int ccol0 = bn0 + wn * (BN / 2) + (lane & 31);
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int col = ccol0 + j * 32;
+            if (col < N) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = crow0 + i * 32 + (r & 3) + 8 * (r >> 2);
+                    if (row < M) ep(row, col, acc[i][j][r]);
+                }
+            }
+        }
+}
+
+}  // namespace uu3d

@@ -1,0 +1,69 @@
+// uu3d_misc.h -- small row-wise kernels: LayerNorm statistics and per-joint MPJPE.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <math.h>
+
+namespace uu3d {
+
+// (mean, 1/sqrt(var + eps)) per row, biased variance, two passes over registers:
+// the statistics half of Keras' non-fused LayerNormalization (tf.nn.moments), consumed by
+// ALoadLayerNorm.  One wave per row, 4 rows per workgroup.  D % 4 == 0, D <= 64 * 4 * MAXV.
+template <int MAXV>
+__global__ void __launch_bounds__(256)
+row_stats_kernel(const float* __restrict__ x, const int ld, const int D, const int M, const float eps,
+                 float2* __restrict__ stats)
+{
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= M) return;
+    const float* p = x + (size_t)row * ld;
+    float4 v[MAXV];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) {
+        const int c = (i * 64 + lane) * 4;
+        v[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (c < D) v[i] = *reinterpret_cast<const float4*>(p + c);
+        s += (v[i].x + v[i].y) + (v[i].z + v[i].w);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+    const float mean = s / (float)D;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) {
+        const int c = (i * 64 + lane) * 4;
+        if (c < D) {
+            const float a = v[i].x - mean, b = v[i].y - mean, cc = v[i].z - mean, d = v[i].w - mean;
+            q += (a * a + b * b) + (cc * cc + d * d);
+        }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) q += __shfl_xor(q, o);
+    if (lane == 0) stats[row] = make_float2(mean, 1.0f / sqrtf(q / (float)D + eps));
+}
+
+// metrics.mpjpe(normalize=False) (common/dataset/metrics.py:13-37), float64 arithmetic on
+// f32 inputs exactly as the reference's numpy call after its astype(np.float64).
+__global__ void __launch_bounds__(256)
+mpjpe_kernel(const float* __restrict__ pred, const float* __restrict__ gt, const int B, const int J,
+             const int root, double* __restrict__ out)
+{
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= B * J) return;
+    const int b = idx / J;
+    const float* pp = pred + (size_t)idx * 3;
+    const float* pr = pred + ((size_t)b * J + root) * 3;
+    const float* gp = gt + (size_t)idx * 4;
+    const float* gr = gt + ((size_t)b * J + root) * 4;
+    double acc = 0.0;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        const double d = ((double)pp[c] - (double)pr[c]) - ((double)gp[c] - (double)gr[c]);
+        acc += d * d;
+    }
+    out[idx] = (gp[3] > 0.f) ? sqrt(acc) : -1.0;
+}
+
+}  // namespace uu3d

@@ -1,0 +1,207 @@
+// uu3d_spatial.h -- the whole per-frame spatial stack in ONE launch.
+//
+// Replaces UpliftUpsampleTransformer.spatial_transformation up to (not including)
+// spatial_to_temporal_fc (uplift_upsample_transformer.py:313-330): keypoint_embedding
+// Dense(2 -> d_s) + spatial_pe, `depth` vit.TransformerBlock (vision_transformer.py:176-195,
+// pre-LN, 8 heads of d_h = d_s / 8, GELU(erf) MLP), spatial_norm (eps 1e-6), and the
+// "(b n) p c -> b n (p c)" flatten.
+//
+// Mapping: one thread = one (frame, joint) token row; its d_s-wide activation stays in
+// registers for the whole stack.  A 256-thread workgroup holds floor(256 / J) frames
+// (15 for J = 17).  Only K and V cross threads: they are exchanged through an LDS tile
+// (row stride 2*DS + 4 floats), read back as 16-byte, frame-broadcast fragments.
+//
+// The d_s x d_s / d_s x 2d_s products are tiny (K = 32..64) and every weight address is
+// wave-uniform, so weights are read through the scalar cache (s_load) straight into the
+// SGPR operand of v_fma_f32.  Each product is written either in "dot" form (loop over
+// the OUTPUT index, reduce over a statically indexed register row) or in "axpy" form
+// (loop over the INPUT index, update a statically indexed accumulator row), so no
+// register array is ever indexed by a run-time value.  fc1 -> GELU -> fc2 and
+// q -> attention -> projection are chained element by element without staging.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <math.h>
+
+namespace uu3d {
+
+// Packed per-block weights (floats), see pack_spatial_block() in uu3d_api.hip.
+template <int DS, int HS>
+struct SpatialBlockLayout {
+    static constexpr int ln1_g = 0;
+    static constexpr int ln1_b = ln1_g + DS;
+    static constexpr int wq_t = ln1_b + DS;          // [DS out][DS in]
+    static constexpr int bq = wq_t + DS * DS;
+    static constexpr int wk_t = bq + DS;
+    static constexpr int bk = wk_t + DS * DS;
+    static constexpr int wv_t = bk + DS;
+    static constexpr int bv = wv_t + DS * DS;
+    static constexpr int wp = bv + DS;               // [DS in][DS out]  (Keras layout)
+    static constexpr int bp = wp + DS * DS;
+    static constexpr int ln2_g = bp + DS;
+    static constexpr int ln2_b = ln2_g + DS;
+    static constexpr int w1_t = ln2_b + DS;          // [HS out][DS in]
+    static constexpr int b1 = w1_t + HS * DS;
+    static constexpr int w2 = b1 + HS;               // [HS in][DS out]  (Keras layout)
+    static constexpr int b2 = w2 + HS * DS;
+    static constexpr int size = b2 + DS;
+};
+
+__host__ __device__ inline constexpr size_t spatial_lds_bytes(int DS) { return (size_t)256 * (2 * DS + 4) * sizeof(float); }
+
+struct SpatialParams {
+    const float* __restrict__ embed_w;   // (2, DS)
+    const float* __restrict__ embed_b;   // (DS)
+    const float* __restrict__ pe;        // (J, DS)
+    const float* __restrict__ blocks;    // depth * SpatialBlockLayout::size
+    const float* __restrict__ norm_g;    // (DS)
+    const float* __restrict__ norm_b;    // (DS)
+    int depth;
+    int total_frames;                    // B * N
+};
+
+template <int DS>
+__device__ __forceinline__ void ln_row(const float (&x)[DS], const float* __restrict__ g,
+                                       const float* __restrict__ b, const float eps, float (&y)[DS])
+{
+    float mean = 0.f;
+#pragma unroll
+    for (int c = 0; c < DS; ++c) mean += x[c];
+    mean *= (1.0f / DS);
+    float var = 0.f;
+#pragma unroll
+    for (int c = 0; c < DS; ++c) { const float d = x[c] - mean; var = fmaf(d, d, var); }
+    var *= (1.0f / DS);
+    const float rstd = 1.0f / sqrtf(var + eps);
+#pragma unroll
+    for (int c = 0; c < DS; ++c) {
+        const float inv = rstd * g[c];
+        y[c] = x[c] * inv + (b[c] - mean * inv);
+    }
+}
+
+template <int DS>
+__device__ __forceinline__ float dot_row(const float (&y)[DS], const float* __restrict__ w)
+{
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+#pragma unroll
+    for (int k = 0; k < DS; k += 4) {
+        a0 = fmaf(y[k + 0], w[k + 0], a0);
+        a1 = fmaf(y[k + 1], w[k + 1], a1);
+        a2 = fmaf(y[k + 2], w[k + 2], a2);
+        a3 = fmaf(y[k + 3], w[k + 3], a3);
+    }
+    return (a0 + a1) + (a2 + a3);
+}
+
+template <int J, int DS, int HS, int HEADS>
+__global__ void __launch_bounds__(256)
+spatial_stack_kernel(const float* __restrict__ kp2d, const SpatialParams p, float* __restrict__ out)
+{
+    using LY = SpatialBlockLayout<DS, HS>;
+    constexpr int DH = DS / HEADS;
+    static_assert(DH == 4, "spatial head dim must be 4 (d_s = 32, 8 heads)");
+    constexpr int FPW = 256 / J;                 // frames per workgroup
+    constexpr int LDR = 2 * DS + 4;              // K|V row stride in LDS
+    extern __shared__ __attribute__((aligned(16))) float KV[];   // [256][LDR], 69,632 B (dynamic: > 64 KiB)
+
+    const int tid = threadIdx.x;
+    const int fl = tid / J;                      // local frame
+    const int joint = tid - fl * J;
+    const int frame = blockIdx.x * FPW + fl;
+    const bool valid = (fl < FPW) && (frame < p.total_frames);
+    const int fbase = fl * J;                    // first LDS row of this thread's frame
+
+    float x[DS];
+    {
+        float kx = 0.f, ky = 0.f;
+        if (valid) { const float2 k2 = *reinterpret_cast<const float2*>(kp2d + ((size_t)frame * J + joint) * 2); kx = k2.x; ky = k2.y; }
+        const float* pe = p.pe + (valid ? joint : 0) * DS;
+#pragma unroll
+        for (int c = 0; c < DS; ++c)
+            x[c] = (fmaf(ky, p.embed_w[DS + c], kx * p.embed_w[c]) + p.embed_b[c]) + pe[c];
+    }
+
+    const float sqrt_dh = sqrtf((float)DH);
+    for (int blk = 0; blk < p.depth; ++blk) {
+        const float* __restrict__ W = p.blocks + (size_t)blk * LY::size;
+        float y[DS];
+        ln_row<DS>(x, W + LY::ln1_g, W + LY::ln1_b, 1e-5f, y);
+
+        // K, V rows -> LDS (dot form)
+#pragma unroll 2
+        for (int j = 0; j < DS; ++j) {
+            KV[tid * LDR + j] = dot_row<DS>(y, W + LY::wk_t + j * DS) + W[LY::bk + j];
+            KV[tid * LDR + DS + j] = dot_row<DS>(y, W + LY::wv_t + j * DS) + W[LY::bv + j];
+        }
+        __syncthreads();
+
+        float acc[DS];
+#pragma unroll
+        for (int c = 0; c < DS; ++c) acc[c] = W[LY::bp + c];
+
+        for (int h = 0; h < HEADS; ++h) {
+            float q[DH];
+#pragma unroll
+            for (int cc = 0; cc < DH; ++cc)
+                q[cc] = dot_row<DS>(y, W + LY::wq_t + (h * DH + cc) * DS) + W[LY::bq + h * DH + cc];
+            float s[J];
+            float mx = -INFINITY;
+#pragma unroll
+            for (int j = 0; j < J; ++j) {
+                const float4 k4 = *reinterpret_cast<const float4*>(&KV[(fbase + j) * LDR + h * DH]);
+                float d = q[0] * k4.x;
+                d = fmaf(q[1], k4.y, d); d = fmaf(q[2], k4.z, d); d = fmaf(q[3], k4.w, d);
+                s[j] = d / sqrt_dh;
+                mx = fmaxf(mx, s[j]);
+            }
+            float sum = 0.f;
+#pragma unroll
+            for (int j = 0; j < J; ++j) { s[j] = expf(s[j] - mx); sum += s[j]; }
+            float o[DH] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int j = 0; j < J; ++j) {
+                const float pj = s[j] / sum;
+                const float4 v4 = *reinterpret_cast<const float4*>(&KV[(fbase + j) * LDR + DS + h * DH]);
+                o[0] = fmaf(pj, v4.x, o[0]); o[1] = fmaf(pj, v4.y, o[1]);
+                o[2] = fmaf(pj, v4.z, o[2]); o[3] = fmaf(pj, v4.w, o[3]);
+            }
+            // projection, axpy form: acc += o[cc] * Wp[h*DH + cc][:]
+#pragma unroll
+            for (int cc = 0; cc < DH; ++cc) {
+                const float* __restrict__ wr = W + LY::wp + (h * DH + cc) * DS;
+#pragma unroll
+                for (int c = 0; c < DS; ++c) acc[c] = fmaf(o[cc], wr[c], acc[c]);
+            }
+        }
+#pragma unroll
+        for (int c = 0; c < DS; ++c) x[c] += acc[c];
+        __syncthreads();   // K/V tile is rewritten by the next block
+
+        // MLP: fc1 (dot) -> GELU(erf) -> fc2 (axpy)
+        ln_row<DS>(x, W + LY::ln2_g, W + LY::ln2_b, 1e-5f, y);
+#pragma unroll
+        for (int c = 0; c < DS; ++c) acc[c] = W[LY::b2 + c];
+#pragma unroll 2
+        for (int j = 0; j < HS; ++j) {
+            float hj = dot_row<DS>(y, W + LY::w1_t + j * DS) + W[LY::b1 + j];
+            hj = 0.5f * hj * (1.0f + erff(hj * 0.70710678118654752440f));
+            const float* __restrict__ wr = W + LY::w2 + j * DS;
+#pragma unroll
+            for (int c = 0; c < DS; ++c) acc[c] = fmaf(hj, wr[c], acc[c]);
+        }
+#pragma unroll
+        for (int c = 0; c < DS; ++c) x[c] += acc[c];
+    }
+
+    float y[DS];
+    ln_row<DS>(x, p.norm_g, p.norm_b, 1e-6f, y);
+    if (valid) {
+        float* o = out + ((size_t)frame * J + joint) * DS;
+#pragma unroll
+        for (int c = 0; c < DS; c += 4)
+            *reinterpret_cast<float4*>(o + c) = make_float4(y[c], y[c + 1], y[c + 2], y[c + 3]);
+    }
+}
+
+}  // namespace uu3d

@@ -1,0 +1,180 @@
+"""Host-side mirror of the reference's Keras model object
+(``common/net/uplift_upsample_transformer.py:163-421``) over the C-ABI HIP library.
+
+    full, central = model([x, stride_mask], training=False)      # has_strided_input
+    full, central = model(x, training=False)                     # otherwise
+
+``x``: (B, N, J, 2) float32 torch tensor on the model's ROCm device (the caller zeroes
+masked frames, eval.py:67); ``stride_mask``: (B, N) bool/uint8, 1 = real input present.
+Returns ``full`` (B, N, J, 3) (``None`` when the reference would return None, :399-404)
+and ``central`` (B, J, 3).  PyTorch is used for device memory and streams only; every
+FLOP runs in ``csrc/libuu3d.so``.  There is no CPU fallback.
+"""
+import ctypes as C
+
+import numpy as np
+
+from .. import _capi
+from ..arch import UpliftArch
+from ..weights import init_weights, weight_spec
+
+
+class UpliftUpsampleTransformer(object):
+
+    def __init__(self, arch: UpliftArch, device=None, seed=0, weights=None, return_attention=False):
+        import torch
+        if return_attention:
+            # never used by the reference's scripts (eval.py:70, train.py:478,520)
+            raise NotImplementedError("return_attention=True: attention maps are never materialised")
+        if not torch.cuda.is_available():
+            raise _capi.Uu3dLibraryError("no ROCm device visible: the uplift path has no CPU fallback")
+        self._torch = torch
+        self.arch = arch
+        self.device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+        self._lib = _capi.load_library()
+        # attributes the reference's callers read (eval.py:66,171)
+        self.full_output = arch.full_output
+        self.has_strided_input = arch.has_strided_input
+        self.num_frames = arch.num_frames
+        self._returns_full = arch.full_output and arch.temporal_depth > 0
+
+        cfg = _capi.Uu3dConfig()
+        cfg.num_frames, cfg.num_keypoints = arch.num_frames, arch.num_keypoints
+        cfg.d_spatial, cfg.d_temporal = arch.d_spatial, arch.d_temporal
+        cfg.h_spatial, cfg.h_temporal = arch.h_spatial, arch.h_temporal
+        cfg.spatial_depth, cfg.temporal_depth = arch.spatial_depth, arch.temporal_depth
+        if len(arch.strides) > _capi.UU3D_MAX_STRIDED:
+            raise ValueError("too many strided blocks")
+        cfg.num_strided = len(arch.strides)
+        for i, (s, p) in enumerate(zip(arch.strides, arch.paddings)):
+            cfg.strides[i], cfg.pad_left[i], cfg.pad_right[i] = s, p[0], p[1]
+        cfg.num_heads = arch.num_heads
+        cfg.qkv_bias = int(arch.qkv_bias)
+        cfg.has_strided_input = int(arch.has_strided_input)
+        cfg.first_strided_token_attention_layer = arch.first_strided_token_attention_layer
+        cfg.full_output = int(arch.full_output)
+        cfg.precision = _capi.UU3D_PREC_F32
+        handle = C.c_void_p()
+        st = self._lib.uu3d_create(C.byref(cfg), self.device.index or 0, C.byref(handle))
+        _capi.check(self._lib, st, None)
+        self._h = handle
+        self._ws = None
+        self._ws_batch = 0
+        self._spec = self._query_spec()
+        expected = [(n, tuple(s)) for n, s in weight_spec(arch)]
+        if self._spec != expected:
+            raise RuntimeError("weight inventory of libuu3d.so disagrees with weights.weight_spec")
+        self.set_weights_dict(weights if weights is not None else init_weights(arch, seed=seed))
+
+    # ---- weights (model.weights / get_weights / set_weights analogues) ----------------------
+    def _query_spec(self):
+        n = self._lib.uu3d_num_weights(self._h)
+        out = []
+        for i in range(n):
+            name = C.c_char_p()
+            ndim = C.c_int32()
+            dims = (C.c_int64 * 4)()
+            _capi.check(self._lib, self._lib.uu3d_weight_info(self._h, i, C.byref(name), C.byref(ndim), C.byref(dims)), self._h)
+            out.append((name.value.decode(), tuple(int(dims[k]) for k in range(ndim.value))))
+        return out
+
+    @property
+    def weight_names(self):
+        return [n for n, _ in self._spec]
+
+    def set_weights_dict(self, weights):
+        for name, shape in self._spec:
+            if name not in weights:
+                raise ValueError(f"missing weight {name}")
+            a = np.ascontiguousarray(np.asarray(weights[name], dtype=np.float32))
+            if tuple(a.shape) != shape:
+                raise ValueError(f"weight {name}: shape {a.shape} != {shape}")
+            st = self._lib.uu3d_set_weight(self._h, name.encode(), a.ctypes.data_as(C.c_void_p), a.size)
+            _capi.check(self._lib, st, self._h)
+        self._commit()
+
+    def set_weights(self, weight_list):
+        if len(weight_list) != len(self._spec):
+            raise ValueError(f"expected {len(self._spec)} arrays, got {len(weight_list)}")
+        self.set_weights_dict({n: w for (n, _), w in zip(self._spec, weight_list)})
+
+    def get_weights_dict(self):
+        out = {}
+        for name, shape in self._spec:
+            a = np.empty(shape, np.float32)
+            st = self._lib.uu3d_get_weight(self._h, name.encode(), a.ctypes.data_as(C.c_void_p), a.size)
+            _capi.check(self._lib, st, self._h)
+            out[name] = a
+        return out
+
+    def get_weights(self):
+        d = self.get_weights_dict()
+        return [d[n] for n, _ in self._spec]
+
+    def _commit(self):
+        torch = self._torch
+        with torch.cuda.device(self.device):
+            stream = torch.cuda.current_stream().cuda_stream
+            _capi.check(self._lib, self._lib.uu3d_commit_weights(self._h, C.c_void_p(stream)), self._h)
+
+    # ---- forward -----------------------------------------------------------------------------
+    def _workspace(self, batch):
+        if self._ws is None or batch > self._ws_batch:
+            nbytes = int(self._lib.uu3d_workspace_bytes(self._h, batch))
+            self._ws = self._torch.empty(nbytes, dtype=self._torch.uint8, device=self.device)
+            self._ws_bytes = nbytes
+            self._ws_batch = batch
+        return self._ws
+
+    def __call__(self, inputs, training=None, mask=None):
+        torch = self._torch
+        if training:
+            raise NotImplementedError("training=True (DropPath + backward) is not part of this round's path")
+        if self.has_strided_input:
+            x, stride_mask = inputs[0], inputs[1]
+        else:
+            x, stride_mask = inputs, None
+        a = self.arch
+        if x.dim() != 4 or tuple(x.shape[1:]) != (a.num_frames, a.num_keypoints, 2):
+            raise ValueError(f"x must be (B, {a.num_frames}, {a.num_keypoints}, 2), got {tuple(x.shape)}")
+        if x.device != self.device:
+            raise ValueError(f"x is on {x.device}, model is on {self.device}")
+        B = x.shape[0]
+        x = x.to(torch.float32).contiguous()
+        m_ptr = None
+        if stride_mask is not None:
+            if tuple(stride_mask.shape) != (B, a.num_frames):
+                raise ValueError(f"stride_mask must be (B, {a.num_frames})")
+            stride_mask = stride_mask.to(device=self.device, dtype=torch.uint8).contiguous()
+            m_ptr = C.c_void_p(stride_mask.data_ptr())
+        full = torch.empty((B, a.num_frames, a.num_keypoints, 3), dtype=torch.float32, device=self.device) \
+            if self._returns_full else None
+        central = torch.empty((B, a.num_keypoints, 3), dtype=torch.float32, device=self.device)
+        ws = self._workspace(B)
+        stream = torch.cuda.current_stream(self.device).cuda_stream
+        st = self._lib.uu3d_forward(self._h, C.c_void_p(x.data_ptr()), m_ptr, B,
+                                    C.c_void_p(full.data_ptr()) if full is not None else None,
+                                    C.c_void_p(central.data_ptr()), C.c_void_p(ws.data_ptr()),
+                                    self._ws_bytes, C.c_void_p(stream))
+        _capi.check(self._lib, st, self._h)
+        return full, central
+
+    # ---- profiling -------------------------------------------------------------------------
+    def set_profiling(self, enabled):
+        _capi.check(self._lib, self._lib.uu3d_set_profiling(self._h, int(bool(enabled))), self._h)
+
+    def read_profile(self):
+        n = C.c_int32()
+        _capi.check(self._lib, self._lib.uu3d_profile_read(self._h, None, 0, C.byref(n)), self._h)
+        arr = (_capi.Uu3dProfileEntry * max(n.value, 1))()
+        _capi.check(self._lib, self._lib.uu3d_profile_read(self._h, arr, n.value, C.byref(n)), self._h)
+        return [dict(name=e.name.decode(), kernel=e.kernel.decode(), ms=float(e.ms), flops=float(e.flops),
+                     bytes=float(e.bytes)) for e in arr[:n.value]]
+
+    def __del__(self):
+        try:
+            if getattr(self, "_h", None):
+                self._lib.uu3d_destroy(self._h)
+                self._h = None
+        except Exception:
+            pass
