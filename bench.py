@@ -1,0 +1,184 @@
+"""Throughput of the uplift/upsample transformer forward on synthetic (B, N, 17, 2) windows.
+
+    python bench.py --gpus 1 --steps 50 --warmup 10
+    python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
+
+One step = one forward of `--batch` sequences per rank (inputs resident in HBM) + the
+per-joint MPJPE kernel; with N > 1 ranks the batch is sharded (weak scaling: every rank
+runs `--batch` sequences) and each step all-gathers the (B_local, 17) f64 error block over
+RCCL.  Prints ONE JSON line on rank 0 (see DESIGN.md "Measurement").
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+PEAK_F32_MFMA_TFLOPS = 157.3   # /opt/skills/guides/MI355X_MICROARCH.md "Peak FP32 (matrix)"
+
+
+def cpu_baseline(cfg, arch, weights, x, m, budget_s=12.0):
+    """Oracle ("port": PyTorch-CPU fp32 restatement) timed on the host cores on a bounded sample."""
+    import numpy as np
+    import torch
+    from oracle import uplift_oracle as O
+    from tests import util
+    hp = util.hp_from_arch(arch)
+    nb = min(8, x.shape[0])
+    xs, ms = x[:nb], m[:nb]
+    O.forward(hp, weights, xs, ms, torch.float32)    # warm-up
+    t0 = time.time()
+    n = 0
+    while True:
+        O.forward(hp, weights, xs, ms, torch.float32)
+        n += 1
+        if time.time() - t0 > budget_s or n >= 20:
+            break
+    dt = time.time() - t0
+    return {"value": round(nb * n / dt, 2), "unit": "pose-sequences/s", "cores": int(torch.get_num_threads()),
+            "kind": "port", "sample": f"{n} forwards of {nb} sequences, PyTorch-CPU fp32 oracle (oracle/uplift_oracle.py)"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--batch", type=int, default=128, help="sequences per GPU per step")
+    ap.add_argument("--config", default="h36m_351")
+    ap.add_argument("--mask-stride", type=int, default=None, help="s_in; default = first MASK_STRIDE")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-graph", action="store_true", help="launch eagerly instead of replaying a hipGraph")
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+    import uplift_upsample_3dhpe_amd as pkg
+    from tests import util
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    cfg = util.load_config(args.config)
+    arch = pkg.arch_from_config(cfg)
+    weights = pkg.init_weights(arch, seed=0)                 # replicated: same seed on every rank
+    model = pkg.build_uplift_upsample_transformer(cfg, weights=weights, device=f"cuda:{local_rank}")
+    s_in = args.mask_stride or (cfg.MASK_STRIDE[0] if isinstance(cfg.MASK_STRIDE, list) else cfg.MASK_STRIDE)
+    B, N, J = args.batch, arch.num_frames, arch.num_keypoints
+    x_np, m_np = util.synthetic_batch(cfg, B, seed=1000 + rank, mask_specs=[(s_in, 0)])
+    x_np = x_np * m_np[:, :, None, None].astype(np.float32)
+    rng = np.random.default_rng(2000 + rank)
+    gt_np = np.concatenate([rng.normal(0, 0.3, size=(B, J, 3)), np.ones((B, J, 1))], -1).astype(np.float32)
+    x = torch.from_numpy(x_np).cuda()
+    m = torch.from_numpy(m_np).cuda()
+    gt = torch.from_numpy(gt_np).cuda()
+    err = torch.empty((B, J), dtype=torch.float64, device="cuda")
+    gathered = torch.empty((world * B, J), dtype=torch.float64, device="cuda") if world > 1 else None
+    from uplift_upsample_3dhpe_amd.harness import per_joint_error
+
+    def step():
+        full, central = model([x, m], training=False)
+        per_joint_error(central, gt, cfg.ROOT_KEYTPOINT, out=err)
+        if world > 1:
+            dist.all_gather_into_tensor(gathered, err)
+        return central
+
+    def sync_all():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    use_graph = not args.no_graph and world == 1
+    run = step
+    if use_graph:
+        try:
+            for _ in range(2):
+                step()
+            torch.cuda.synchronize()
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                step()
+            run = g.replay
+        except Exception as e:  # pragma: no cover
+            print(f"[bench] graph capture failed ({e}); running eagerly", file=sys.stderr)
+            use_graph = False
+            run = step
+
+    for _ in range(args.warmup):
+        run()
+    sync_all()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        run()
+    sync_all()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    # ---- per-kernel timing with HIP events on the launch stream (outside the timed region) ----
+    model.set_profiling(True)
+    agg = {}
+    reps = 5
+    for _ in range(reps):
+        model([x, m], training=False)
+        for e in model.read_profile():
+            key = e["name"].split(".", 1)[-1] if "." in e["name"] else e["name"]
+            a = agg.setdefault(key, dict(ms=0.0, flops=0.0, bytes=0.0, n=0, kernel=e["kernel"]))
+            a["ms"] += e["ms"]; a["flops"] += e["flops"]; a["bytes"] += e["bytes"]; a["n"] += 1
+    model.set_profiling(False)
+
+    if rank == 0:
+        fl = pkg.flops_per_sequence(arch)
+        total_ms = sum(a["ms"] for a in agg.values()) / reps
+        dom_key = max((k for k in agg if agg[k]["kernel"] == "gemm_f32"), key=lambda k: agg[k]["ms"])
+        dom = agg[dom_key]
+        ach = dom["flops"] / (dom["ms"] * 1e-3) / 1e12
+        gemm_fl = sum(a["flops"] for a in agg.values() if a["kernel"] == "gemm_f32")
+        gemm_ms = sum(a["ms"] for a in agg.values() if a["kernel"] == "gemm_f32")
+        seqs = world * B * args.steps
+        out = {
+            "metric": "pose-sequences/sec",
+            "value": round(seqs / elapsed, 2),
+            "unit": "pose-sequences/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(elapsed / args.steps * 1e3, 4),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"config/{args.config}.json forward, N={N} tokens (receptive field "
+                                   f"{(N - 1) * cfg.SEQUENCE_STRIDE + 1}), J={J}, batch {B}/GPU, s_in={s_in}, "
+                                   f"seeded Keras-default weights", "global_batch": world * B,
+                       "parallelism": f"batch-sharded x{world}", "hipgraph": bool(use_graph)},
+            "roofline": {"bound": "mfma", "kernel": f"gemm_f32 [{dom_key}]",
+                         "achieved": round(ach, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                         "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 4), "traffic": None,
+                         "avg_launch_ms": round(dom["ms"] / dom["n"], 5),
+                         "all_gemm_tflops": round(gemm_fl / (gemm_ms * 1e-3) / 1e12, 2),
+                         "model_tflops": round(fl["total"] * seqs / world / elapsed / 1e12, 2)},
+            "kernel_ms_per_forward": {k: round(a["ms"] / reps, 4) for k, a in sorted(agg.items(), key=lambda kv: -kv[1]["ms"])},
+            "sum_kernel_ms": round(total_ms, 4),
+        }
+        if not args.no_cpu_baseline and world == 1:
+            out["cpu_baseline"] = cpu_baseline(cfg, arch, weights, x_np, m_np)
+        else:
+            out["cpu_baseline"] = None
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -33,7 +33,11 @@ def test_forward_matches_oracle(cfgname, seed):
     f64, c64 = O.forward(hp, w, xm, m, torch.float64)
     assert np.isfinite(full).all() and np.isfinite(central).all()
     err32 = max(np.abs(full - f32).max(), np.abs(central - c32).max())
-    err64 = max(np.abs(full - f64).max(), np.abs(central - c64).max())
+    # The float64 twin only bounds rounding where it is meaningful: for an ALL-masked row the
+    # reference's fp32 `logits + mask * -1e9` rounds every logit of temporal block 1 to exactly
+    # -1e9 (uniform attention), which float64 does not reproduce.  fp32 is the reference.
+    rows = m.any(axis=1)
+    err64 = max(np.abs(full - f64)[rows].max(), np.abs(central - c64)[rows].max())
     print(f"{cfgname} seed {seed}: max-abs vs oracle f32 {err32:.3e}, vs f64 {err64:.3e}")
     assert err32 <= util.TOL_MAX_ABS
     assert err64 <= util.TOL_MAX_ABS
