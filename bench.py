@@ -136,7 +136,9 @@ def main():
     for _ in range(reps):
         model([x, m], training=False)
         for e in model.read_profile():
-            key = e["name"].split(".", 1)[-1] if "." in e["name"] else e["name"]
+            # temporal blocks share one shape class ("t.<op>"); strided blocks keep their index
+            nm = e["name"]
+            key = ("t." + nm.split(".", 1)[1]) if (nm[0] == "t" and "." in nm) else nm
             a = agg.setdefault(key, dict(ms=0.0, flops=0.0, bytes=0.0, n=0, kernel=e["kernel"]))
             a["ms"] += e["ms"]; a["flops"] += e["flops"]; a["bytes"] += e["bytes"]; a["n"] += 1
     model.set_profiling(False)

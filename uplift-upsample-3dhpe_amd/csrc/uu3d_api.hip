@@ -600,7 +600,7 @@ int uu3d_forward(uu3d_model* m, const float* kp2d, const uint8_t* mask, int32_t 
     // 2. spatial_to_temporal_fc + token blend + temporal PE
     {
         ALoadPlain al{w.S, J * ds, M, J * ds};
-        EpSpatialToTemporal ep{w.X, m->s2t_b, dt, mask, m->token, m->pe_t, N, nullptr, nullptr};
+        EpSpatialToTemporal ep{w.X, m->s2t_b, dt, mask, m->token, m->pe_t, N};
         Lh.gemm("s2t", al, m->s2t_wt, M, dt, J * ds, ep);
     }
     // 3. temporal blocks

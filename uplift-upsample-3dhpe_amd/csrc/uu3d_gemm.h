@@ -37,19 +37,25 @@ __host__ __device__ inline constexpr size_t gemm_lds_bytes(int BM, int BN) {
 }
 
 // ------------------------------------------------------------------------------------
-// A-operand loaders.  prep(row) builds a per-row context once; load(ctx, k) returns
-// A[row][k .. k+3] (k multiple of 4); rows >= M and k >= K read as zero.
+// A-operand loaders.  prep(row) builds a per-row context once.  Staging is split in two so
+// that nothing waits on a global load before the MFMAs of the current k-tile have issued:
+//   issue(ctx, k)        -> Raw : only address arithmetic + global loads (no use of the data)
+//   finish(ctx, k, raw)  -> A[row][k .. k+3] ready for LDS (transforms run AFTER the MFMAs)
+// Rows >= M are clamped to row M-1 (their products are never stored); k >= K reads as zero.
 // ------------------------------------------------------------------------------------
 struct ALoadPlain {
     const float* __restrict__ A;
     int lda, M, K;
     struct Ctx { const float* p; };
+    struct Raw { f32x4 x; };
     __device__ __forceinline__ Ctx prep(int row) const {
-        Ctx c; c.p = (row < M) ? A + (size_t)row * lda : nullptr; return c;
+        Ctx c; c.p = A + (size_t)min(row, M - 1) * lda; return c;
     }
-    __device__ __forceinline__ f32x4 load(const Ctx& c, int k) const {
-        if (c.p == nullptr || k >= K) return (f32x4){0.f, 0.f, 0.f, 0.f};
-        return *reinterpret_cast<const f32x4*>(c.p + k);
+    __device__ __forceinline__ Raw issue(const Ctx& c, int k) const {
+        Raw r; r.x = *reinterpret_cast<const f32x4*>(c.p + min(k, K - 4)); return r;
+    }
+    __device__ __forceinline__ f32x4 finish(const Ctx&, int k, const Raw& r) const {
+        return (k < K) ? r.x : (f32x4){0.f, 0.f, 0.f, 0.f};
     }
 };
 
@@ -63,23 +69,28 @@ struct ALoadLayerNorm {
     const float* __restrict__ beta;
     int lda, M, K;
     struct Ctx { const float* p; float mean, rstd; };
+    struct Raw { f32x4 x, g, b; };
     __device__ __forceinline__ Ctx prep(int row) const {
-        Ctx c; c.p = nullptr; c.mean = 0.f; c.rstd = 0.f;
-        if (row < M) { c.p = A + (size_t)row * lda; float2 s = stats[row]; c.mean = s.x; c.rstd = s.y; }
+        const int rc = min(row, M - 1);
+        Ctx c; c.p = A + (size_t)rc * lda; const float2 s = stats[rc]; c.mean = s.x; c.rstd = s.y;
         return c;
     }
-    __device__ __forceinline__ f32x4 load(const Ctx& c, int k) const {
-        if (c.p == nullptr || k >= K) return (f32x4){0.f, 0.f, 0.f, 0.f};
-        const f32x4 x = *reinterpret_cast<const f32x4*>(c.p + k);
-        const f32x4 g = *reinterpret_cast<const f32x4*>(gamma + k);
-        const f32x4 b = *reinterpret_cast<const f32x4*>(beta + k);
+    __device__ __forceinline__ Raw issue(const Ctx& c, int k) const {
+        const int kc = min(k, K - 4);
+        Raw r;
+        r.x = *reinterpret_cast<const f32x4*>(c.p + kc);
+        r.g = *reinterpret_cast<const f32x4*>(gamma + kc);
+        r.b = *reinterpret_cast<const f32x4*>(beta + kc);
+        return r;
+    }
+    __device__ __forceinline__ f32x4 finish(const Ctx& c, int k, const Raw& r) const {
         f32x4 y;
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-            const float inv = c.rstd * g[e];
-            y[e] = x[e] * inv + (b[e] - c.mean * inv);
+            const float inv = c.rstd * r.g[e];
+            y[e] = r.x[e] * inv + (r.b[e] - c.mean * inv);
         }
-        return y;
+        return (k < K) ? y : (f32x4){0.f, 0.f, 0.f, 0.f};
     }
 };
 
@@ -90,34 +101,52 @@ struct ALoadConv3 {
     const float* __restrict__ Hin;      // (B * L_in, C)
     int C, L_in, L_out, stride, pad_left, M, K;   // M = B * L_out, K = 3 * C
     struct Ctx { int base_row; int t0; };          // base_row = b * L_in ; t0 = t*stride - pad_left
+    struct Raw { f32x4 x; int ok; };
     __device__ __forceinline__ Ctx prep(int row) const {
-        Ctx c; c.base_row = -1; c.t0 = 0;
-        if (row < M) { int b = row / L_out; int t = row - b * L_out; c.base_row = b * L_in; c.t0 = t * stride - pad_left; }
+        const int rc = min(row, M - 1);
+        Ctx c; const int b = rc / L_out; const int t = rc - b * L_out;
+        c.base_row = b * L_in; c.t0 = t * stride - pad_left;
         return c;
     }
-    __device__ __forceinline__ f32x4 load(const Ctx& c, int k) const {
-        if (c.base_row < 0 || k >= K) return (f32x4){0.f, 0.f, 0.f, 0.f};
-        const int j = k / C;
-        const int cc = k - j * C;
+    __device__ __forceinline__ Raw issue(const Ctx& c, int k) const {
+        const int kc = min(k, K - 4);
+        const int j = kc / C;
+        const int cc = kc - j * C;
         const int src = c.t0 + j;
-        if (src < 0 || src >= L_in) return (f32x4){0.f, 0.f, 0.f, 0.f};
-        return *reinterpret_cast<const f32x4*>(Hin + (size_t)(c.base_row + src) * C + cc);
+        Raw r;
+        r.ok = (src >= 0) & (src < L_in) & (k < K);
+        const int srcc = min(max(src, 0), L_in - 1);
+        r.x = *reinterpret_cast<const f32x4*>(Hin + (size_t)(c.base_row + srcc) * C + cc);
+        return r;
+    }
+    __device__ __forceinline__ f32x4 finish(const Ctx&, int, const Raw& r) const {
+        return r.ok ? r.x : (f32x4){0.f, 0.f, 0.f, 0.f};
     }
 };
 
 // ------------------------------------------------------------------------------------
-// Epilogues: operator()(row, col, acc) for row < M, col < N.
+// Epilogues.  To keep the 16 accumulator rows of a lane from turning into 16 dependent
+// load->wait->store round trips, an epilogue is split into loads that do not depend on the
+// accumulator and the final store:
+//   colv(col)            -> float2 : per-column constants (bias, ...), once per tile column
+//   pre(rowc, col)       -> float2 : per-element inputs (residual, PE, mask ...); rowc is a
+//                                    CLAMPED (always valid) row, all 16 issued together
+//   store(row, col, acc, colv, pre) : only called for row < M
 // ------------------------------------------------------------------------------------
 struct EpBias {            // out = acc + bias
     float* __restrict__ out; const float* __restrict__ bias; int ldo;
-    __device__ __forceinline__ void operator()(int row, int col, float v) const {
-        out[(size_t)row * ldo + col] = v + bias[col];
+    __device__ __forceinline__ float2 colv(int col) const { return make_float2(bias[col], 0.f); }
+    __device__ __forceinline__ float2 pre(int, int) const { return make_float2(0.f, 0.f); }
+    __device__ __forceinline__ void store(int row, int col, float v, float2 cv, float2) const {
+        out[(size_t)row * ldo + col] = v + cv.x;
     }
 };
 struct EpBiasRelu {        // out = max(acc + bias, 0)
     float* __restrict__ out; const float* __restrict__ bias; int ldo;
-    __device__ __forceinline__ void operator()(int row, int col, float v) const {
-        out[(size_t)row * ldo + col] = fmaxf(v + bias[col], 0.f);
+    __device__ __forceinline__ float2 colv(int col) const { return make_float2(bias[col], 0.f); }
+    __device__ __forceinline__ float2 pre(int, int) const { return make_float2(0.f, 0.f); }
+    __device__ __forceinline__ void store(int row, int col, float v, float2 cv, float2) const {
+        out[(size_t)row * ldo + col] = fmaxf(v + cv.x, 0.f);
     }
 };
 // x = x + (acc + bias), in place; optionally a second stream out2 = x_new + pe2[row % period]
@@ -125,11 +154,17 @@ struct EpBiasRelu {        // out = max(acc + bias, 0)
 struct EpBiasResidual {
     float* x; const float* __restrict__ bias; int ld;
     float* out2; const float* __restrict__ pe2; int period;
-    __device__ __forceinline__ void operator()(int row, int col, float v) const {
+    __device__ __forceinline__ float2 colv(int col) const { return make_float2(bias[col], 0.f); }
+    __device__ __forceinline__ float2 pre(int rowc, int col) const {
+        float2 p; p.x = x[(size_t)rowc * ld + col];
+        p.y = (out2 != nullptr) ? pe2[(size_t)(rowc % period) * ld + col] : 0.f;
+        return p;
+    }
+    __device__ __forceinline__ void store(int row, int col, float v, float2 cv, float2 p) const {
         const size_t o = (size_t)row * ld + col;
-        const float y = x[o] + (v + bias[col]);
+        const float y = p.x + (v + cv.x);
         x[o] = y;
-        if (out2 != nullptr) out2[o] = y + pe2[(size_t)(row % period) * ld + col];
+        if (out2 != nullptr) out2[o] = y + p.y;
     }
 };
 // spatial_to_temporal_fc + strided-input token blend + temporal PE (u_u_t.py:332,344-352):
@@ -138,14 +173,17 @@ struct EpSpatialToTemporal {
     float* __restrict__ x; const float* __restrict__ bias; int ld;
     const uint8_t* __restrict__ mask;     // per row (B*N), nullptr when no strided input
     const float* __restrict__ token; const float* __restrict__ pe; int period;
-    float* out2; const float* __restrict__ pe2;   // used when temporal_depth == 0
-    __device__ __forceinline__ void operator()(int row, int col, float v) const {
-        float t = v + bias[col];
-        if (mask != nullptr && mask[row] == 0) t = token[col];
-        const size_t o = (size_t)row * ld + col;
-        const float y = t + pe[(size_t)(row % period) * ld + col];
-        x[o] = y;
-        if (out2 != nullptr) out2[o] = y + pe2[(size_t)(row % period) * ld + col];
+    __device__ __forceinline__ float2 colv(int col) const {
+        return make_float2(bias[col], mask != nullptr ? token[col] : 0.f);
+    }
+    __device__ __forceinline__ float2 pre(int rowc, int col) const {
+        float2 p; p.x = pe[(size_t)(rowc % period) * ld + col];
+        p.y = (mask != nullptr && mask[rowc] == 0) ? 0.f : 1.f;
+        return p;
+    }
+    __device__ __forceinline__ void store(int row, int col, float v, float2 cv, float2 p) const {
+        const float t = (p.y != 0.f) ? (v + cv.x) : cv.y;
+        x[(size_t)row * ld + col] = t + p.x;
     }
 };
 // strided block tail (u_u_t.py:138-156): out = identity + (acc + bias) (+ next block's PE)
@@ -154,11 +192,16 @@ struct EpConvResidual {
     float* __restrict__ out; const float* __restrict__ bias; int ld;
     const float* __restrict__ xin; int L_in, L_out, stride, lo;
     const float* __restrict__ pe_next;    // (L_out, ld) or nullptr
-    __device__ __forceinline__ void operator()(int row, int col, float v) const {
-        const int b = row / L_out; const int t = row - b * L_out;
-        const float id = xin[(size_t)(b * L_in + t * stride + lo) * ld + col];
-        float y = id + (v + bias[col]);
-        if (pe_next != nullptr) y += pe_next[(size_t)t * ld + col];
+    __device__ __forceinline__ float2 colv(int col) const { return make_float2(bias[col], 0.f); }
+    __device__ __forceinline__ float2 pre(int rowc, int col) const {
+        const int b = rowc / L_out; const int t = rowc - b * L_out;
+        float2 p; p.x = xin[(size_t)(b * L_in + t * stride + lo) * ld + col];
+        p.y = (pe_next != nullptr) ? pe_next[(size_t)t * ld + col] : 0.f;
+        return p;
+    }
+    __device__ __forceinline__ void store(int row, int col, float v, float2 cv, float2 p) const {
+        float y = p.x + (v + cv.x);
+        if (pe_next != nullptr) y += p.y;
         out[(size_t)row * ld + col] = y;
     }
 };
@@ -173,7 +216,7 @@ gemm_f32_kernel(const AL al, const float* __restrict__ Bt, const int M, const in
 {
     constexpr int LD = GEMM_LD;
     constexpr int TM = BM / 64, TN = BN / 64;     // 32x32 MFMA tiles per wave
-    constexpr int AI = BM / 32, BI = BN / 32;     // float4 staging loads per thread per k-tile
+    constexpr int AI = BM / 32, BI = BN / 32;     // 16-byte staging loads per thread per k-tile
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* As = smem;                    // [2][BM][LD]
     float* Bs = smem + 2 * BM * LD;      // [2][BN][LD]
@@ -201,7 +244,8 @@ gemm_f32_kernel(const AL al, const float* __restrict__ Bt, const int M, const in
 #pragma unroll
     for (int i = 0; i < BI; ++i) bptr[i] = Bt + (size_t)(bn0 + srow + 32 * i) * Kp + scol;
 
-    f32x4 ra[AI], rb[BI];
+    typename AL::Raw ra[AI];
+    f32x4 rb[BI];
     f32x16 acc[TM][TN];
 #pragma unroll
     for (int i = 0; i < TM; ++i)
@@ -214,11 +258,12 @@ gemm_f32_kernel(const AL al, const float* __restrict__ Bt, const int M, const in
 
     // prologue: tile 0 -> LDS buffer 0
 #pragma unroll
-    for (int i = 0; i < AI; ++i) ra[i] = al.load(actx[i], scol);
+    for (int i = 0; i < AI; ++i) ra[i] = al.issue(actx[i], scol);
 #pragma unroll
     for (int i = 0; i < BI; ++i) rb[i] = *reinterpret_cast<const f32x4*>(bptr[i]);
 #pragma unroll
-    for (int i = 0; i < AI; ++i) *reinterpret_cast<f32x4*>(&As[(srow + 32 * i) * LD + scol]) = ra[i];
+    for (int i = 0; i < AI; ++i)
+        *reinterpret_cast<f32x4*>(&As[(srow + 32 * i) * LD + scol]) = al.finish(actx[i], scol, ra[i]);
 #pragma unroll
     for (int i = 0; i < BI; ++i) *reinterpret_cast<f32x4*>(&Bs[(srow + 32 * i) * LD + scol]) = rb[i];
     __syncthreads();
@@ -228,14 +273,14 @@ gemm_f32_kernel(const AL al, const float* __restrict__ Bt, const int M, const in
 
     for (int kt = 0; kt < KT; ++kt) {
         const int cur = kt & 1;
-        const bool more = (kt + 1 < KT);
-        if (more) {
-            const int k0 = (kt + 1) * GEMM_BK;
+        // Next k-tile's global loads are issued first; the last iteration re-loads its own
+        // tile (cheap, L1/L2 hit) so the loop body stays branch-free.
+        const int k0 = min(kt + 1, KT - 1) * GEMM_BK;
 #pragma unroll
-            for (int i = 0; i < AI; ++i) ra[i] = al.load(actx[i], k0 + scol);
+        for (int i = 0; i < AI; ++i) ra[i] = al.issue(actx[i], k0 + scol);
 #pragma unroll
-            for (int i = 0; i < BI; ++i) rb[i] = *reinterpret_cast<const f32x4*>(bptr[i] + k0);
-        }
+        for (int i = 0; i < BI; ++i) rb[i] = *reinterpret_cast<const f32x4*>(bptr[i] + k0);
+
         const float* Ac = As + cur * BM * LD + (wm * (BM / 2) + fr) * LD + fk;
         const float* Bc = Bs + cur * BN * LD + (wn * (BN / 2) + fr) * LD + fk;
 #pragma unroll
@@ -253,34 +298,58 @@ gemm_f32_kernel(const AL al, const float* __restrict__ Bt, const int M, const in
                     for (int j = 0; j < TN; ++j)
                         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][s], bf[j][s], acc[i][j], 0, 0, 0);
         }
-        if (more) {
-            const int nxt = cur ^ 1;
+        // stage the prefetched tile into the other buffer (harmless rewrite on the last pass:
+        // nobody reads that buffer again)
+        const int nxt = cur ^ 1;
 #pragma unroll
-            for (int i = 0; i < AI; ++i)
-                *reinterpret_cast<f32x4*>(&As[nxt * BM * LD + (srow + 32 * i) * LD + scol]) = ra[i];
+        for (int i = 0; i < AI; ++i)
+            *reinterpret_cast<f32x4*>(&As[nxt * BM * LD + (srow + 32 * i) * LD + scol]) =
+                al.finish(actx[i], k0 + scol, ra[i]);
 #pragma unroll
-            for (int i = 0; i < BI; ++i)
-                *reinterpret_cast<f32x4*>(&Bs[nxt * BN * LD + (srow + 32 * i) * LD + scol]) = rb[i];
-        }
+        for (int i = 0; i < BI; ++i)
+            *reinterpret_cast<f32x4*>(&Bs[nxt * BN * LD + (srow + 32 * i) * LD + scol]) = rb[i];
         __syncthreads();
     }
 
-    // epilogue: C/D map of the 32x32 MFMA: col = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)
+    // epilogue: C/D map of the 32x32 MFMA: col = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5).
+    // Interior tiles (the common case) take a branch-free path: per-lane predicates would make
+    // the compiler fence every store with s_waitcnt vmcnt(0).
     const int crow0 = bm0 + wm * (BM / 2) + 4 * (lane >> 5);
     const int ccol0 = bn0 + wn * (BN / 2) + (lane & 31);
+    if (bm0 + BM <= M && bn0 + BN <= N) {
 #pragma unroll
-    for (int i = 0; i < TM; ++i)
+        for (int i = 0; i < TM; ++i)
 #pragma unroll
-        for (int j = 0; j < TN; ++j) {
-            const int col = ccol0 + j * 32;
-            if (col < N) {
+            for (int j = 0; j < TN; ++j) {
+                const int col = ccol0 + j * 32;
+                const float2 cv = ep.colv(col);
+                float2 pr[16];
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int row = crow0 + i * 32 + (r & 3) + 8 * (r >> 2);
-                    if (row < M) ep(row, col, acc[i][j][r]);
+                for (int r = 0; r < 16; ++r) pr[r] = ep.pre(crow0 + i * 32 + (r & 3) + 8 * (r >> 2), col);
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    ep.store(crow0 + i * 32 + (r & 3) + 8 * (r >> 2), col, acc[i][j][r], cv, pr[r]);
+            }
+    } else {
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                const int col = ccol0 + j * 32;
+                if (col < N) {
+                    const float2 cv = ep.colv(col);
+                    float2 pr[16];
+#pragma unroll
+                    for (int r = 0; r < 16; ++r)
+                        pr[r] = ep.pre(min(crow0 + i * 32 + (r & 3) + 8 * (r >> 2), M - 1), col);
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int row = crow0 + i * 32 + (r & 3) + 8 * (r >> 2);
+                        if (row < M) ep.store(row, col, acc[i][j][r], cv, pr[r]);
+                    }
                 }
             }
-        }
+    }
 }
 
 }  // namespace uu3d
