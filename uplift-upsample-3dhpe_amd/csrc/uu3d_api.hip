@@ -17,6 +17,7 @@
 
 #include <algorithm>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <string>
@@ -34,6 +35,8 @@ namespace {
 
 constexpr int kJ = 17, kDS = 32, kHS = 64, kHeads = 8, kDH = 48;
 using SLY = SpatialBlockLayout<kDS, kHS>;
+using SLY2 = SpatialBlockLayoutV2<kDS, kHS>;
+constexpr int kFR = 3;   // frames per wave in the MFMA spatial kernel (3 * 17 = 51 rows)
 
 std::string g_create_error;
 
@@ -73,6 +76,9 @@ struct uu3d_model {
     size_t arena_floats = 0;
     // packed views
     SpatialParams sp{};
+    const float* sp_blocks_v1 = nullptr;   // VALU kernel layout (kept for A/B runs: UU3D_SPATIAL=valu)
+    const float* sp_blocks_v2 = nullptr;   // MFMA kernel layout
+    bool spatial_valu = false;
     const float *s2t_wt = nullptr, *s2t_b = nullptr, *token = nullptr, *pe_t = nullptr;
     std::vector<BlockDev> tblocks, sblocks;
     const float *h1_wt = nullptr, *h1_b = nullptr, *h2_wt = nullptr, *h2_b = nullptr;
@@ -260,6 +266,7 @@ int uu3d_create(const uu3d_config* c, int device, uu3d_model** out) {
         return fail(nullptr, UU3D_ERR_INVALID_ARGUMENT, "STRIDES/PADDINGS must reduce the sequence to one token");
     }
     build_inventory(m);
+    { const char* e = getenv("UU3D_SPATIAL"); m->spatial_valu = (e != nullptr && std::string(e) == "valu"); }
     *out = m;
     return UU3D_OK;
 }
@@ -345,6 +352,32 @@ int uu3d_commit_weights(uu3d_model* m, void* stream_) {
         vec(SLY::ln2_g, "/norm2/gamma", ds); vec(SLY::ln2_b, "/norm2/beta", ds);
         tr(SLY::w1_t, "/mlp/fc1/kernel", ds, kHS); vec(SLY::b1, "/mlp/fc1/bias", kHS);
         vec(SLY::w2, "/mlp/fc2/kernel", kHS * ds); vec(SLY::b2, "/mlp/fc2/bias", ds);
+    }
+    const size_t o_sblk2 = P.alloc((size_t)c.spatial_depth * SLY2::size);
+    for (int i = 0; i < c.spatial_depth; ++i) {
+        const std::string p = "spatial_block_" + std::to_string(i + 1);
+        float* d = P.buf.data() + o_sblk2 + (size_t)i * SLY2::size;
+        auto vec = [&](int off, const std::string& nm, int n) {
+            const float* s = W(m, p + nm);
+            if (s) std::copy_n(s, n, d + off);
+        };
+        // fragment order of the 32x32x2 MFMA B operand: [n-tile][kk][lane][s] = W[8kk + 4(lane>>5) + s][32nt + (lane&31)]
+        auto frag = [&](int off, const std::string& nm, int K, int Nn) {
+            const float* s = W(m, p + nm);
+            for (int nt = 0; nt < Nn / 32; ++nt)
+                for (int kk = 0; kk < K / 8; ++kk)
+                    for (int lane = 0; lane < 64; ++lane)
+                        for (int e = 0; e < 4; ++e)
+                            d[off + ((nt * (K / 8) + kk) * 64 + lane) * 4 + e] =
+                                s[(size_t)(8 * kk + 4 * (lane >> 5) + e) * Nn + 32 * nt + (lane & 31)];
+        };
+        vec(SLY2::ln1_g, "/norm1/gamma", ds); vec(SLY2::ln1_b, "/norm1/beta", ds);
+        vec(SLY2::ln2_g, "/norm2/gamma", ds); vec(SLY2::ln2_b, "/norm2/beta", ds);
+        vec(SLY2::bq, "/attn/wq/bias", ds); vec(SLY2::bk, "/attn/wk/bias", ds); vec(SLY2::bv, "/attn/wv/bias", ds);
+        vec(SLY2::bp, "/attn/projection/bias", ds); vec(SLY2::b1, "/mlp/fc1/bias", kHS); vec(SLY2::b2, "/mlp/fc2/bias", ds);
+        frag(SLY2::fq, "/attn/wq/kernel", ds, ds); frag(SLY2::fk, "/attn/wk/kernel", ds, ds);
+        frag(SLY2::fv, "/attn/wv/kernel", ds, ds); frag(SLY2::fp, "/attn/projection/kernel", ds, ds);
+        frag(SLY2::f1, "/mlp/fc1/kernel", ds, kHS); frag(SLY2::f2, "/mlp/fc2/kernel", kHS, ds);
     }
     const size_t o_sng = P.alloc(ds), o_snb = P.alloc(ds);
     std::copy_n(W(m, "spatial_norm/gamma"), ds, P.buf.begin() + o_sng);
@@ -434,6 +467,7 @@ int uu3d_commit_weights(uu3d_model* m, void* stream_) {
 
     const float* A = m->arena;
     m->sp.embed_w = A + o_ew; m->sp.embed_b = A + o_eb; m->sp.pe = A + o_spe; m->sp.blocks = A + o_sblk;
+    m->sp_blocks_v1 = A + o_sblk; m->sp_blocks_v2 = A + o_sblk2;
     m->sp.norm_g = A + o_sng; m->sp.norm_b = A + o_snb; m->sp.depth = c.spatial_depth; m->sp.total_frames = 0;
     m->s2t_wt = A + o_s2t; m->s2t_b = A + o_s2tb; m->token = A + o_tok; m->pe_t = A + o_pet;
     auto view = [&](const BlockOff& o, bool strided) {
@@ -588,14 +622,23 @@ int uu3d_forward(uu3d_model* m, const float* kp2d, const uint8_t* mask, int32_t 
     {
         SpatialParams sp = m->sp;
         sp.total_frames = M;
-        constexpr int FPW = 256 / kJ;
-        auto kern = spatial_stack_kernel<kJ, kDS, kHS, kHeads>;
-        static bool attr_done = false;
-        if (!attr_done) { (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)spatial_lds_bytes(kDS)); attr_done = true; }
         const double fl = (double)M * (2.0 * J * 2 * ds + c.spatial_depth * (4.0 * 2 * J * ds * ds + 8.0 * 4 * J * J * (ds / 8) + 2.0 * 2 * J * ds * kHS));
-        Lh.begin("spatial_stack", "spatial_stack", fl, 4.0 * M * J * (2.0 + ds));
-        hipLaunchKernelGGL(kern, dim3((M + FPW - 1) / FPW), dim3(256), spatial_lds_bytes(kDS), Lh.stream, kp2d, sp, w.S);
-        Lh.end();
+        if (m->spatial_valu) {
+            constexpr int FPW = 256 / kJ;
+            sp.blocks = m->sp_blocks_v1;
+            auto kern = spatial_stack_kernel<kJ, kDS, kHS, kHeads>;
+            static bool attr_done = false;
+            if (!attr_done) { (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)spatial_lds_bytes(kDS)); attr_done = true; }
+            Lh.begin("spatial_stack", "spatial_valu", fl, 4.0 * M * J * (2.0 + ds));
+            hipLaunchKernelGGL(kern, dim3((M + FPW - 1) / FPW), dim3(256), spatial_lds_bytes(kDS), Lh.stream, kp2d, sp, w.S);
+            Lh.end();
+        } else {
+            sp.blocks = m->sp_blocks_v2;
+            auto kern = spatial_stack_mfma_kernel<kJ, kFR>;
+            Lh.begin("spatial_stack", "spatial_mfma", fl, 4.0 * M * J * (2.0 + ds));
+            hipLaunchKernelGGL(kern, dim3((M + kFR - 1) / kFR), dim3(64), spatial_v2_lds_bytes(), Lh.stream, kp2d, sp, w.S);
+            Lh.end();
+        }
     }
     // 2. spatial_to_temporal_fc + token blend + temporal PE
     {

@@ -22,6 +22,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <math.h>
+#include "uu3d_gemm.h"
 
 namespace uu3d {
 
@@ -192,6 +193,236 @@ spatial_stack_kernel(const float* __restrict__ kp2d, const SpatialParams p, floa
         }
 #pragma unroll
         for (int c = 0; c < DS; ++c) x[c] += acc[c];
+    }
+
+    float y[DS];
+    ln_row<DS>(x, p.norm_g, p.norm_b, 1e-6f, y);
+    if (valid) {
+        float* o = out + ((size_t)frame * J + joint) * DS;
+#pragma unroll
+        for (int c = 0; c < DS; c += 4)
+            *reinterpret_cast<float4*>(o + c) = make_float4(y[c], y[c + 1], y[c + 2], y[c + 3]);
+    }
+}
+
+// =========================================================================================
+// v2: MFMA spatial stack.  One WAVE (= one 64-thread workgroup) owns FR whole frames
+// (FR * J <= 64 token rows), so nothing ever crosses a wave: no __syncthreads between
+// workgroup waves, and co-resident waves overlap each other's MFMA, VALU and LDS phases.
+//
+//   home layout : thread = token row, x[d_s] in registers (LayerNorm, softmax, residual in-lane)
+//   linear maps : v_mfma_f32_32x32x2_f32 on 2 row tiles of 32; the A operand is the wave's
+//                 [64][36] LDS tile (ds_read_b128 fragments, k-slot order 8kk + 4h + s), the
+//                 B operand is read from HBM/L2 in FRAGMENT ORDER ([kk][lane][4], packed by
+//                 uu3d_commit_weights) - one coalesced 1 KiB load per k-slice, no LDS.
+//   C/D tiles   : bias (+GELU) applied in the accumulator layout (column on the lane), then
+//                 written [row][col] to LDS where the row-owning thread (or the next MFMA's
+//                 A fragments) picks them up.
+//   attention   : per thread, 8 heads x J keys, K/V rows read as 16-byte LDS fragments.
+// LDS per wave: T0 [64][36] (y / q / o / projection / fc2 staging), TK,TV [52][36] aliased
+// with H [64][68] (fc1 output) = 26,624 B -> 6 waves per CU.
+// =========================================================================================
+template <int DS, int HS>
+struct SpatialBlockLayoutV2 {
+    static constexpr int ln1_g = 0, ln1_b = ln1_g + DS, ln2_g = ln1_b + DS, ln2_b = ln2_g + DS;
+    static constexpr int bq = ln2_b + DS, bk = bq + DS, bv = bk + DS, bp = bv + DS, b1 = bp + DS, b2 = b1 + HS;
+    static constexpr int fq = b2 + DS;                 // fragment-ordered weights, 16-byte aligned
+    static constexpr int fk = fq + DS * DS, fv = fk + DS * DS, fp = fv + DS * DS;
+    static constexpr int f1 = fp + DS * DS;            // [2 n-tiles][4 kk][64][4]
+    static constexpr int f2 = f1 + DS * HS;            // [8 kk][64][4]
+    static constexpr int size = f2 + HS * DS;
+    static_assert(fq % 4 == 0, "fragment arrays must be 16-byte aligned");
+};
+
+__host__ __device__ inline constexpr size_t spatial_v2_lds_bytes() {
+    return (size_t)(64 * 36 + (64 * 68 > 2 * 52 * 36 ? 64 * 68 : 2 * 52 * 36)) * sizeof(float);
+}
+
+namespace sv2 {
+template <int KK>
+__device__ __forceinline__ void load_afrags(const float* T, const int ld, const int lane, f32x4 (&a)[2][KK]) {
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int kk = 0; kk < KK; ++kk)
+            a[mt][kk] = *reinterpret_cast<const f32x4*>(&T[(32 * mt + (lane & 31)) * ld + 8 * kk + 4 * (lane >> 5)]);
+}
+template <int KK>
+__device__ __forceinline__ void load_bfrags(const float* __restrict__ wfrag, const int lane, f32x4 (&b)[KK]) {
+#pragma unroll
+    for (int kk = 0; kk < KK; ++kk) b[kk] = reinterpret_cast<const f32x4*>(wfrag)[kk * 64 + lane];
+}
+template <int KK>
+__device__ __forceinline__ void mma(const f32x4 (&a)[2][KK], const f32x4 (&b)[KK], f32x16 (&acc)[2]) {
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[mt][r] = 0.f;
+#pragma unroll
+    for (int kk = 0; kk < KK; ++kk)
+#pragma unroll
+        for (int s = 0; s < 4; ++s)
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt)
+                acc[mt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mt][kk][s], b[kk][s], acc[mt], 0, 0, 0);
+}
+// accumulator tile (+bias) -> LDS [row][coloff + col]; rows above maxrow land on row maxrow (dummy)
+__device__ __forceinline__ void store_ctile(float* T, const int ld, const int coloff, const int lane,
+                                            const f32x16 (&acc)[2], const float bias, const int maxrow) {
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = min(32 * mt + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5), maxrow);
+            T[row * ld + coloff + (lane & 31)] = acc[mt][r] + bias;
+        }
+}
+template <int DS>
+__device__ __forceinline__ void write_row(float* T, const int lane, const float (&y)[DS]) {
+#pragma unroll
+    for (int c = 0; c < DS; c += 4)
+        *reinterpret_cast<f32x4*>(&T[lane * 36 + c]) = (f32x4){y[c], y[c + 1], y[c + 2], y[c + 3]};
+}
+template <int DS>
+__device__ __forceinline__ void read_row(const float* T, const int lane, float (&y)[DS]) {
+#pragma unroll
+    for (int c = 0; c < DS; c += 4) {
+        const f32x4 v = *reinterpret_cast<const f32x4*>(&T[lane * 36 + c]);
+        y[c] = v[0]; y[c + 1] = v[1]; y[c + 2] = v[2]; y[c + 3] = v[3];
+    }
+}
+}  // namespace sv2
+
+#ifndef UU3D_SPATIAL_WAVES
+#define UU3D_SPATIAL_WAVES 2
+#endif
+template <int J, int FR>
+__global__ void __launch_bounds__(64, UU3D_SPATIAL_WAVES)
+spatial_stack_mfma_kernel(const float* __restrict__ kp2d, const SpatialParams p, float* __restrict__ out)
+{
+    constexpr int DS = 32, HS = 64, HEADS = 8, DH = 4, ROWS = FR * J, LD = 36, LDH = 68;
+    static_assert(ROWS <= 51 || ROWS <= 64, "FR * J must fit one wave");
+    using LY = SpatialBlockLayoutV2<DS, HS>;
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    float* T0 = lds;                   // [64][36]
+    float* TK = lds + 64 * LD;         // [52][36]
+    float* TV = TK + 52 * LD;          // [52][36]
+    float* TH = TK;                    // [64][68], aliases TK/TV
+
+    const int lane = threadIdx.x;
+    const int fl = min(lane / J, FR - 1);
+    const int joint = lane - (lane / J) * J;
+    const int frame = blockIdx.x * FR + fl;
+    const bool valid = (lane < ROWS) && (frame < p.total_frames);
+    const int fbase = fl * J;
+    const int col = lane & 31;
+
+    float x[DS];
+    {
+        float kx = 0.f, ky = 0.f;
+        if (valid) { const float2 k2 = *reinterpret_cast<const float2*>(kp2d + ((size_t)frame * J + joint) * 2); kx = k2.x; ky = k2.y; }
+        const float* pe = p.pe + (lane < ROWS ? joint : 0) * DS;
+#pragma unroll
+        for (int c = 0; c < DS; ++c)
+            x[c] = (fmaf(ky, p.embed_w[DS + c], kx * p.embed_w[c]) + p.embed_b[c]) + pe[c];
+    }
+
+    const float inv_sqrt_dh = 1.0f / sqrtf((float)DH);   // DH = 4: exactly 0.5
+    for (int blk = 0; blk < p.depth; ++blk) {
+        const float* __restrict__ W = p.blocks + (size_t)blk * LY::size;
+        float y[DS];
+        f32x4 a4[2][4];
+        f32x4 b4[4];
+        f32x16 acc[2];
+
+        // ---- attention half ----
+        ln_row<DS>(x, W + LY::ln1_g, W + LY::ln1_b, 1e-5f, y);
+        sv2::write_row<DS>(T0, lane, y);
+        __syncthreads();
+        sv2::load_afrags<4>(T0, LD, lane, a4);
+        __syncthreads();                                   // T0 is rewritten with q below
+        sv2::load_bfrags<4>(W + LY::fq, lane, b4); sv2::mma<4>(a4, b4, acc);
+        sv2::store_ctile(T0, LD, 0, lane, acc, W[LY::bq + col], 63);
+        sv2::load_bfrags<4>(W + LY::fk, lane, b4); sv2::mma<4>(a4, b4, acc);
+        sv2::store_ctile(TK, LD, 0, lane, acc, W[LY::bk + col], 51);
+        sv2::load_bfrags<4>(W + LY::fv, lane, b4); sv2::mma<4>(a4, b4, acc);
+        sv2::store_ctile(TV, LD, 0, lane, acc, W[LY::bv + col], 51);
+        __syncthreads();
+
+        float q[DS];
+        sv2::read_row<DS>(T0, lane, q);
+        float o[DS];
+#pragma unroll
+        for (int h = 0; h < HEADS; ++h) {
+            float s[J];
+            float mx = -INFINITY;
+#pragma unroll
+            for (int j = 0; j < J; ++j) {
+                const f32x4 k4 = *reinterpret_cast<const f32x4*>(&TK[(fbase + j) * LD + h * DH]);
+                float d = q[h * DH] * k4[0];
+                d = fmaf(q[h * DH + 1], k4[1], d); d = fmaf(q[h * DH + 2], k4[2], d); d = fmaf(q[h * DH + 3], k4[3], d);
+                s[j] = d * inv_sqrt_dh;
+                mx = fmaxf(mx, s[j]);
+            }
+            float sum = 0.f;
+#pragma unroll
+            for (int j = 0; j < J; ++j) { s[j] = expf(s[j] - mx); sum += s[j]; }
+            float o0 = 0.f, o1 = 0.f, o2 = 0.f, o3 = 0.f;
+            const float rsum = 1.0f / sum;
+#pragma unroll
+            for (int j = 0; j < J; ++j) {
+                const float pj = s[j] * rsum;
+                const f32x4 v4 = *reinterpret_cast<const f32x4*>(&TV[(fbase + j) * LD + h * DH]);
+                o0 = fmaf(pj, v4[0], o0); o1 = fmaf(pj, v4[1], o1); o2 = fmaf(pj, v4[2], o2); o3 = fmaf(pj, v4[3], o3);
+            }
+            o[h * DH] = o0; o[h * DH + 1] = o1; o[h * DH + 2] = o2; o[h * DH + 3] = o3;
+        }
+        __syncthreads();                                   // all q rows read before T0 is reused
+        sv2::write_row<DS>(T0, lane, o);
+        __syncthreads();
+        sv2::load_afrags<4>(T0, LD, lane, a4);
+        __syncthreads();
+        sv2::load_bfrags<4>(W + LY::fp, lane, b4); sv2::mma<4>(a4, b4, acc);
+        sv2::store_ctile(T0, LD, 0, lane, acc, W[LY::bp + col], 63);
+        __syncthreads();
+        sv2::read_row<DS>(T0, lane, y);
+#pragma unroll
+        for (int c = 0; c < DS; ++c) x[c] += y[c];
+        __syncthreads();
+
+        // ---- MLP half ----
+        ln_row<DS>(x, W + LY::ln2_g, W + LY::ln2_b, 1e-5f, y);
+        sv2::write_row<DS>(T0, lane, y);
+        __syncthreads();
+        sv2::load_afrags<4>(T0, LD, lane, a4);
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt) {
+            sv2::load_bfrags<4>(W + LY::f1 + nt * DS * DS, lane, b4); sv2::mma<4>(a4, b4, acc);
+            const float bias = W[LY::b1 + 32 * nt + col];
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const float hv = acc[mt][r] + bias;
+                    const int row = 32 * mt + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                    TH[row * LDH + 32 * nt + col] = 0.5f * hv * (1.0f + erff(hv * 0.70710678118654752440f));
+                }
+        }
+        __syncthreads();
+        {
+            f32x4 a8[2][8];
+            f32x4 b8[8];
+            sv2::load_afrags<8>(TH, LDH, lane, a8);
+            sv2::load_bfrags<8>(W + LY::f2, lane, b8);
+            sv2::mma<8>(a8, b8, acc);
+        }
+        __syncthreads();                                   // T0 (LN2 output) fully consumed above
+        sv2::store_ctile(T0, LD, 0, lane, acc, W[LY::b2 + col], 63);
+        __syncthreads();
+        sv2::read_row<DS>(T0, lane, y);
+#pragma unroll
+        for (int c = 0; c < DS; ++c) x[c] += y[c];
+        __syncthreads();
     }
 
     float y[DS];
