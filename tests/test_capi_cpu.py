@@ -1,0 +1,59 @@
+"""The C-ABI library builds, loads and exports every symbol include/uu3d.h declares.
+No compute is attempted without a GPU: uu3d_create must refuse cleanly."""
+import ctypes as C
+import os
+import re
+
+import pytest
+
+from tests import util
+
+
+@pytest.fixture(scope="module")
+def lib():
+    import __graft_entry__ as ge
+    ge.build()
+    from uplift_upsample_3dhpe_amd import _capi
+    return _capi.load_library()
+
+
+def test_header_symbols_exported(lib):
+    from uplift_upsample_3dhpe_amd import _capi
+    header = open(os.path.join(util.ROOT, "include", "uu3d.h")).read()
+    declared = set(re.findall(r"\b(uu3d_[a-z_0-9]+)\s*\(", header))
+    declared -= {"uu3d_status", "uu3d_precision"}
+    assert declared == set(_capi.EXPORTED_SYMBOLS)
+    for s in declared:
+        assert hasattr(lib, s), s
+    assert lib.uu3d_version().decode().startswith("uu3d ")
+    assert lib.uu3d_status_string(0) == b"ok" and lib.uu3d_status_string(2) != b"ok"
+
+
+def test_config_struct_matches_header():
+    from uplift_upsample_3dhpe_amd import _capi
+    # 9 scalars + 3 arrays of 8 + 6 scalars, all int32
+    assert C.sizeof(_capi.Uu3dConfig) == 4 * (9 + 3 * 8 + 6)
+    assert C.sizeof(_capi.Uu3dProfileEntry) == 48 + 32 + 4 + 4 + 8 + 8
+
+
+def test_create_rejects_bad_arguments_without_compute(lib):
+    import torch
+    from uplift_upsample_3dhpe_amd import _capi
+    h = C.c_void_p()
+    assert lib.uu3d_create(None, 0, C.byref(h)) == _capi.UU3D_ERR_INVALID_ARGUMENT
+    cfg = _capi.Uu3dConfig()
+    assert lib.uu3d_create(C.byref(cfg), 0, C.byref(h)) == _capi.UU3D_ERR_INVALID_ARGUMENT
+    assert b"num_frames" in lib.uu3d_last_error(None)
+    if not torch.cuda.is_available():
+        import uplift_upsample_3dhpe_amd as pkg
+        with pytest.raises(_capi.Uu3dLibraryError):           # product path fails loudly, no CPU fallback
+            pkg.build_uplift_upsample_transformer(util.load_config("h36m_81"))
+    assert lib.uu3d_workspace_bytes(None, 4) == 0
+    assert lib.uu3d_num_weights(None) == 0
+    assert lib.uu3d_mpjpe(None, None, 1, 17, 6, None, None) == _capi.UU3D_ERR_INVALID_ARGUMENT
+
+
+def test_missing_library_fails_loudly(tmp_path):
+    from uplift_upsample_3dhpe_amd import _capi
+    with pytest.raises(_capi.Uu3dLibraryError):
+        _capi.load_library(str(tmp_path / "nope.so"))

@@ -1,0 +1,101 @@
+"""Config schema, architecture derivation and weight inventory (host logic, no GPU)."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+import uplift_upsample_3dhpe_amd as pkg
+from tests import util
+
+
+@pytest.mark.parametrize("name,N,strided,params,mflop", [
+    ("h36m_351", 71, (71, 23, 3, 1), 10404902, 1051.241344),
+    ("h36m_351_pt", 71, (71, 23, 3, 1), 10404902, 1051.241344),
+    ("amass_351", 71, (71, 23, 3, 1), 10404902, 1051.241344),
+    ("h36m_81", 41, (41, 11, 3, 1), 10377254, 594.506368),
+])
+def test_shipped_configs(name, N, strided, params, mflop):
+    cfg = util.load_config(name)
+    a = pkg.arch_from_config(cfg)
+    assert a.num_frames == N and a.num_keypoints == 17
+    assert (a.d_spatial, a.d_temporal, a.num_heads) == (32, 384, 8)
+    assert a.strided_lengths == strided
+    assert a.has_strided_input and a.full_output
+    assert a.first_strided_token_attention_layer == 1
+    assert pkg.count_params(a) == params
+    assert pkg.flops_per_sequence(a)["total"] / 1e6 == pytest.approx(mflop, rel=1e-9)
+
+
+def test_defaults_and_override(tmp_path):
+    c = pkg.UpliftUpsampleConfig()
+    assert c.TEMPORAL_EMBED_DIM == 348 and c.SEQUENCE_LENGTH == 27 and c.ROOT_KEYTPOINT == 6
+    assert c.MASK_STRIDE is None and c.PADDINGS is None
+    p = tmp_path / "c.json"
+    p.write_text(json.dumps({"SEQUENCE_LENGTH": 9, "UNKNOWN_KEY": [1, 2], "MASK_STRIDE": 1}))
+    c = pkg.UpliftUpsampleConfig(str(p))
+    assert c.SEQUENCE_LENGTH == 9 and c.UNKNOWN_KEY == [1, 2]     # unknown keys tolerated
+    assert c.TEMPORAL_EMBED_DIM == 348                             # missing keys keep defaults
+    t = tmp_path / "c.txt"
+    t.write_text("# comment\nSEQUENCE_LENGTH 11\nSTRIDES [3, 3]\nARCH 'x'\n")
+    c = pkg.UpliftUpsampleConfig(str(t))
+    assert c.SEQUENCE_LENGTH == 11 and c.STRIDES == [3, 3] and c.ARCH == "x"
+
+
+def test_copy_dump_roundtrip(tmp_path):
+    c = util.load_config("h36m_81")
+    d = c.copy()
+    d.STRIDES.append(99)
+    assert c.STRIDES == [4, 4, 3]                                  # deep copy
+    out = tmp_path / "dump.json"
+    c.dump(str(out))
+    e = pkg.UpliftUpsampleConfig(str(out))
+    assert e.to_dict() == c.to_dict()
+
+
+def test_has_strided_input_rule():
+    c = pkg.UpliftUpsampleConfig()
+    c.SEQUENCE_LENGTH, c.STRIDES, c.TEMPORAL_EMBED_DIM = 27, [3, 3, 3], 384
+    for ms, expect in [(None, False), (1, False), ([1, 2], False), (5, True), ([5, 10], True)]:
+        c.MASK_STRIDE = ms
+        assert pkg.arch_from_config(c).has_strided_input is expect   # constructor.py:16-21
+    assert pkg.arch_from_config(c).paddings == ((1, 1),) * 3          # PADDINGS None
+    assert pkg.arch_from_config(c).strided_lengths == (27, 9, 3, 1)
+
+
+def test_bad_configs():
+    c = util.load_config("h36m_351")
+    c.STRIDES = [3, 3, 3]            # 71 -> 23 -> 7 -> 2: does not reduce to one token
+    with pytest.raises((ValueError, AssertionError)):
+        pkg.arch_from_config(c)
+    c = util.load_config("h36m_351")
+    c.TEMPORAL_EMBED_DIM = 380        # not divisible by 8 heads (vit.py:79)
+    with pytest.raises(AssertionError):
+        pkg.arch_from_config(c)
+
+
+def test_weight_spec_order_and_init():
+    a = pkg.arch_from_config(util.load_config("h36m_351"))
+    spec = pkg.weight_spec(a)
+    names = [n for n, _ in spec]
+    assert names[:4] == ["keypoint_embedding/kernel", "keypoint_embedding/bias",
+                         "spatial_pe/positional_encoding_weights", "temporal_pe/positional_encoding_weights"]
+    assert names[-2:] == ["strided_temporal_fc/kernel", "strided_temporal_fc/bias"]
+    blk = [n for n in names if n.startswith("strided_temporal_block_1/")]
+    assert [n.split("/", 1)[1] for n in blk] == [
+        "norm1/gamma", "norm1/beta", "attn/wq/kernel", "attn/wq/bias", "attn/wk/kernel", "attn/wk/bias",
+        "attn/wv/kernel", "attn/wv/bias", "attn/projection/kernel", "attn/projection/bias",
+        "norm2/gamma", "norm2/beta", "mlp/fc1/kernel", "mlp/fc1/bias", "mlp/strided_conv/kernel",
+        "mlp/strided_conv/bias"]
+    shapes = dict(spec)
+    assert shapes["strided_temporal_block_1/mlp/strided_conv/kernel"] == (3, 768, 384)
+    assert shapes["strided_temporal_block_1/mlp/fc1/kernel"] == (1, 384, 768)
+    assert shapes["strided_temporal_pe_2/positional_encoding_weights"] == (23, 384)
+    w = pkg.init_weights(a, seed=3)
+    w2 = pkg.init_weights(a, seed=3)
+    assert all(np.array_equal(w[k], w2[k]) for k in w)               # deterministic
+    k = w["temporal_block_1/attn/wq/kernel"]
+    assert abs(k).max() <= np.sqrt(6.0 / 768) + 1e-7                 # glorot_uniform limit
+    assert np.all(w["temporal_block_1/norm1/gamma"] == 1) and np.all(w["temporal_fc/bias"] == 0)
+    pe = w["temporal_pe/positional_encoding_weights"]
+    assert abs(pe).max() <= 0.04 + 1e-7 and 0.015 < pe.std() < 0.02  # truncated normal, sigma .02

@@ -1,0 +1,54 @@
+"""N > 1 path on CPU: world_size-2 gloo run of the shard + all-gather protocol used by bench.py."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from uplift_upsample_3dhpe_amd import dist as ud
+
+
+def test_shard_bounds_cover_batch():
+    for g, w in [(1024, 8), (10, 3), (2, 4), (7, 1)]:
+        spans = [ud.shard_bounds(g, r, w) for r in range(w)]
+        assert spans[0][0] == 0 and spans[-1][1] == g
+        assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
+        assert max(b - a for a, b in spans) - min(b - a for a, b in spans) <= 1
+    with pytest.raises(ValueError):
+        ud.shard_bounds(4, 2, 2)
+
+
+def _worker(rank, world, port, global_batch, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    rng = np.random.default_rng(0)                        # same table on every rank
+    table = rng.uniform(0, 0.2, size=(global_batch, 17))
+    table[3, 5] = -1.0                                    # an invalid joint
+    lo, hi = ud.shard_bounds(global_batch, rank, world)
+    local = torch.from_numpy(table[lo:hi].copy())
+    out = ud.allgather_errors(local)
+    q.put((rank, out.numpy(), ud.mean_valid_mm(out)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("global_batch", [8, 7])
+def test_allgather_errors_gloo_world2(global_batch):
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, global_batch, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    table = np.random.default_rng(0).uniform(0, 0.2, size=(global_batch, 17)); table[3, 5] = -1.0
+    expect = float(np.mean((table * 1000)[table >= 0]))
+    for rank, out, mean_mm in res:
+        assert np.array_equal(out, table)                 # rank order, ragged shards, bit-exact
+        assert mean_mm == pytest.approx(expect, rel=1e-12)

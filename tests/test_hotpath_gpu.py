@@ -1,0 +1,161 @@
+"""GPU tests of the HIP path through the C ABI: golden fixtures, semantic invariants, the
+harness protocol, error behaviour, and size-independent properties at BASELINE's full sizes."""
+import ctypes as C
+import glob
+import os
+
+import numpy as np
+import pytest
+
+import uplift_upsample_3dhpe_amd as pkg
+from tests import util
+
+torch = pytest.importorskip("torch")
+pytestmark = pytest.mark.gpu
+
+GOLDEN = sorted(glob.glob(os.path.join(util.ROOT, "tests", "golden", "*.npz")))
+
+
+def _model(cfgname, seed=0, perturb=0.1):
+    cfg = util.load_config(cfgname)
+    arch = pkg.arch_from_config(cfg)
+    w = pkg.init_weights(arch, seed=seed, perturb=perturb)
+    return cfg, arch, w, pkg.build_uplift_upsample_transformer(cfg, weights=w)
+
+
+def _call(model, x, m):
+    full, cen = model([torch.as_tensor(x).cuda(), torch.as_tensor(m).cuda()], training=False)
+    torch.cuda.synchronize()
+    return full.cpu().numpy(), cen.cpu().numpy()
+
+
+@pytest.mark.parametrize("path", GOLDEN, ids=[os.path.basename(p) for p in GOLDEN])
+def test_golden_fixtures(path):
+    """Committed oracle vectors (tests/golden/make_golden.py); tolerance = north_star's 1e-4 max-abs."""
+    g = np.load(path)
+    cfg, arch, w, model = _model(str(g["config"]), int(g["seed"]), float(g["perturb"]))
+    full, cen = _call(model, g["x"], g["mask"])
+    assert np.abs(full - g["full_f32"]).max() <= util.TOL_MAX_ABS
+    assert np.abs(cen - g["central_f32"]).max() <= util.TOL_MAX_ABS
+    rows = g["mask"].any(axis=1)
+    assert np.abs(cen - g["central_f64"])[rows].max() <= util.TOL_MAX_ABS
+    mid = arch.num_frames // 2
+    assert np.abs(full[:, mid] - g["full_f64_center"])[rows].max() <= util.TOL_MAX_ABS
+    # MPJPE budget: 0.05 mm against synthetic GT, oracle vs HIP
+    from oracle import uplift_oracle as O
+    gt = np.random.default_rng(0).normal(0, 0.3, size=cen.shape)
+    _, a = O.frame_mpjpe_mm(cen, gt, cfg.ROOT_KEYTPOINT)
+    _, b = O.frame_mpjpe_mm(g["central_f32"], gt, cfg.ROOT_KEYTPOINT)
+    assert abs(a - b) <= util.TOL_MPJPE_MM
+
+
+def test_masked_frames_do_not_matter_bitwise():
+    cfg, arch, w, model = _model("h36m_351", seed=1)
+    x, m = util.synthetic_batch(cfg, 5, seed=1)
+    a = _call(model, x * m[:, :, None, None], m)
+    b = _call(model, x, m)                                  # garbage in masked frames
+    assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
+
+
+def test_batch_rows_are_independent_and_deterministic():
+    cfg, arch, w, model = _model("h36m_81", seed=2)
+    x, m = util.synthetic_batch(cfg, 9, seed=2)
+    x = x * m[:, :, None, None]
+    f, c = _call(model, x, m)
+    f2, c2 = _call(model, x, m)
+    assert np.array_equal(f, f2) and np.array_equal(c, c2)          # run-to-run bit identical
+    perm = np.random.default_rng(0).permutation(9)
+    fp, cp = _call(model, x[perm], m[perm])
+    assert np.array_equal(fp, f[perm]) and np.array_equal(cp, c[perm])   # permutation equivariance
+    f1, c1 = _call(model, x[4:5], m[4:5])                            # ragged: batch of one
+    assert np.array_equal(f1[0], f[4]) and np.array_equal(c1[0], c[4])
+
+
+@pytest.mark.parametrize("cfgname,batch", [("h36m_351", 128), ("h36m_81", 256)])
+def test_full_size_properties(cfgname, batch):
+    """BASELINE.json sizes: finite, equivariant under batch permutation, and the first rows agree
+    with the oracle (which only has to run a handful of sequences)."""
+    from oracle import uplift_oracle as O
+    cfg, arch, w, model = _model(cfgname, seed=3)
+    x, m = util.synthetic_batch(cfg, batch, seed=3)
+    x = x * m[:, :, None, None]
+    f, c = _call(model, x, m)
+    assert f.shape == (batch, arch.num_frames, 17, 3) and c.shape == (batch, 17, 3)
+    assert np.isfinite(f).all() and np.isfinite(c).all()
+    perm = np.random.default_rng(1).permutation(batch)
+    fp, cp = _call(model, x[perm], m[perm])
+    assert np.array_equal(fp, f[perm]) and np.array_equal(cp, c[perm])
+    idx = np.array([0, 1, 2, 3, batch // 2, batch - 1])
+    fo, co = O.forward(util.hp_from_arch(arch), w, x[idx], m[idx], torch.float32)
+    assert np.abs(f[idx] - fo).max() <= util.TOL_MAX_ABS and np.abs(c[idx] - co).max() <= util.TOL_MAX_ABS
+
+
+def test_flip_protocol_and_mpjpe_kernel():
+    from oracle import uplift_oracle as O
+    from uplift_upsample_3dhpe_amd import harness
+    cfg, arch, w, model = _model("h36m_81", seed=4)
+    x, m = util.synthetic_batch(cfg, 4, seed=4)
+    xt, mt = torch.as_tensor(x).cuda(), torch.as_tensor(m).cuda()
+    seq, cen = harness.eval_step_with_flip(model, xt, mt, cfg.AUGM_FLIP_KEYPOINT_ORDER)   # masks inside
+    so, co = O.eval_step_with_flip(util.hp_from_arch(arch), w, x, m, cfg.AUGM_FLIP_KEYPOINT_ORDER)
+    assert np.abs(seq.cpu().numpy() - so).max() <= util.TOL_MAX_ABS
+    assert np.abs(cen.cpu().numpy() - co).max() <= util.TOL_MAX_ABS
+    rng = np.random.default_rng(4)
+    gt = np.concatenate([rng.normal(0, 0.3, size=(4, 17, 3)), np.ones((4, 17, 1))], -1).astype(np.float32)
+    gt[1, 2, 3] = 0.0
+    err = harness.per_joint_error(cen, torch.as_tensor(gt).cuda(), cfg.ROOT_KEYTPOINT).cpu().numpy()
+    ref = O.mpjpe(cen.cpu().numpy(), gt, cfg.ROOT_KEYTPOINT, normalize=False)
+    assert err[1, 2] == -1.0 and np.abs(err - ref).max() < 1e-12          # float64, like numpy
+
+
+def test_weights_roundtrip_and_errors():
+    from uplift_upsample_3dhpe_amd import _capi
+    cfg, arch, w, model = _model("h36m_81", seed=5)
+    back = model.get_weights_dict()
+    assert all(np.array_equal(back[k], w[k]) for k in w)
+    assert [n for n, _ in pkg.weight_spec(arch)] == model.weight_names
+    x, m = util.synthetic_batch(cfg, 2, seed=5)
+    with pytest.raises(ValueError):
+        model([torch.zeros(2, 40, 17, 2).cuda(), torch.as_tensor(m).cuda()])
+    with pytest.raises(ValueError):
+        model([torch.as_tensor(x).cuda(), torch.as_tensor(m[:, :-1]).cuda()])
+    with pytest.raises(ValueError):
+        model([torch.as_tensor(x), torch.as_tensor(m)])                  # host tensors: no CPU fallback
+    with pytest.raises(NotImplementedError):
+        model([torch.as_tensor(x).cuda(), torch.as_tensor(m).cuda()], training=True)
+    bad = dict(w); bad["temporal_fc/bias"] = np.zeros(50, np.float32)
+    with pytest.raises(ValueError):
+        model.set_weights_dict(bad)
+    st = model._lib.uu3d_forward(model._h, None, None, 2, None, None, None, 0, None)
+    assert st == _capi.UU3D_ERR_NOT_READY            # weights were touched but never re-committed
+    model.set_weights_dict(w)
+    # C ABI level: wrong element count, unknown name, workspace too small
+    lib = model._lib
+    buf = (C.c_float * 4)()
+    assert lib.uu3d_set_weight(model._h, b"temporal_fc/bias", buf, 4) == _capi.UU3D_ERR_SHAPE
+    assert lib.uu3d_set_weight(model._h, b"nope", buf, 4) == _capi.UU3D_ERR_INVALID_ARGUMENT
+    xt = torch.as_tensor(x).cuda(); mt = torch.as_tensor(m).cuda().to(torch.uint8)
+    out = torch.empty(2, 17, 3, device="cuda"); full = torch.empty(2, arch.num_frames, 17, 3, device="cuda")
+    ws = torch.empty(1024, dtype=torch.uint8, device="cuda")
+    st = lib.uu3d_forward(model._h, xt.data_ptr(), mt.data_ptr(), 2, full.data_ptr(), out.data_ptr(),
+                          ws.data_ptr(), 1024, None)
+    assert st == _capi.UU3D_ERR_WORKSPACE
+    st = lib.uu3d_forward(model._h, xt.data_ptr(), None, 2, full.data_ptr(), out.data_ptr(), ws.data_ptr(), 1024, None)
+    assert st == _capi.UU3D_ERR_INVALID_ARGUMENT                        # mask required for strided-input models
+
+
+def test_mask_stride_one_config_takes_plain_input():
+    """MASK_STRIDE == 1 -> has_strided_input False (constructor.py:16-21): x alone, no token blend."""
+    from oracle import uplift_oracle as O
+    cfg = util.load_config("h36m_81")
+    cfg.MASK_STRIDE = 1
+    arch = pkg.arch_from_config(cfg)
+    assert not arch.has_strided_input
+    w = pkg.init_weights(arch, seed=6, perturb=0.1)
+    assert "strided_input_token_layer/learnable_masked_token" not in w
+    model = pkg.build_uplift_upsample_transformer(cfg, weights=w)
+    x, _ = util.synthetic_batch(util.load_config("h36m_81"), 3, seed=6)
+    full, cen = model(torch.as_tensor(x).cuda(), training=False)
+    fo, co = O.forward(util.hp_from_arch(arch), w, x, None, torch.float32)
+    assert np.abs(full.cpu().numpy() - fo).max() <= util.TOL_MAX_ABS
+    assert np.abs(cen.cpu().numpy() - co).max() <= util.TOL_MAX_ABS

@@ -1,0 +1,130 @@
+"""Pins the CPU oracle: golden fixtures, an independently written numpy twin, and invariants
+that follow from the reference's semantics.  PARITY UNPINNED against
+TensorFlow itself (the reference ships no tests or vectors and TF cannot be installed here)."""
+import glob
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import uplift_upsample_3dhpe_amd as pkg
+from oracle import uplift_oracle as O
+from oracle import uplift_oracle_np as ON
+from tests import util
+from tests.golden.make_golden import weights_checksum
+
+GOLDEN = sorted(glob.glob(os.path.join(util.ROOT, "tests", "golden", "*.npz")))
+
+
+def _setup(cfgname, seed=0, perturb=0.1):
+    cfg = util.load_config(cfgname)
+    arch = pkg.arch_from_config(cfg)
+    return cfg, arch, util.hp_from_arch(arch), pkg.init_weights(arch, seed=seed, perturb=perturb)
+
+
+@pytest.mark.parametrize("path", GOLDEN, ids=[os.path.basename(p) for p in GOLDEN])
+def test_oracle_reproduces_golden(path):
+    g = np.load(path)
+    cfg, arch, hp, w = _setup(str(g["config"]), int(g["seed"]), float(g["perturb"]))
+    assert weights_checksum(w) == str(g["weights_sha256"])
+    f32, c32 = O.forward(hp, w, g["x"], g["mask"], torch.float32)
+    # same code, same machine class: tight; a different BLAS may reorder sums slightly
+    assert np.abs(f32 - g["full_f32"]).max() <= 2e-5
+    assert np.abs(c32 - g["central_f32"]).max() <= 2e-5
+    rows = g["mask"].any(axis=1)
+    assert np.abs(c32 - g["central_f64"])[rows].max() <= util.TOL_MAX_ABS
+
+
+@pytest.mark.parametrize("cfgname", ["h36m_81", "h36m_351"])
+def test_oracle_matches_numpy_twin(cfgname):
+    cfg, arch, hp, w = _setup(cfgname, seed=5)
+    x, m = util.synthetic_batch(cfg, 2, seed=5, mask_specs=[(cfg.MASK_STRIDE[1], 0), (cfg.MASK_STRIDE[2], cfg.SEQUENCE_STRIDE)])
+    xm = x * m[:, :, None, None]
+    f64, c64 = O.forward(hp, w, xm, m, torch.float64)
+    fn, cn = ON.forward(hp, w, xm, m, np.float64)
+    assert np.abs(f64 - fn).max() < 1e-11 and np.abs(c64 - cn).max() < 1e-11
+
+
+def test_masked_frame_content_is_irrelevant():
+    cfg, arch, hp, w = _setup("h36m_81", seed=1)
+    x, m = util.synthetic_batch(cfg, 2, seed=1, mask_specs=[(10, 0), (20, 2)])
+    a = O.forward(hp, w, x * m[:, :, None, None], m, torch.float32)
+    b = O.forward(hp, w, x, m, torch.float32)                 # garbage left in masked frames
+    assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])   # u_u_t.py:350
+
+
+def test_all_ones_mask_equals_unmasked_blend():
+    cfg, arch, hp, w = _setup("h36m_81", seed=2)
+    x, _ = util.synthetic_batch(cfg, 2, seed=2)
+    ones = np.ones((2, arch.num_frames), bool)
+    a = O.forward(hp, w, x, ones, torch.float64)
+    hp2 = dict(hp, has_strided_input=False)
+    b = O.forward(hp2, w, x, None, torch.float64)
+    assert np.abs(a[0] - b[0]).max() < 1e-12 and np.abs(a[1] - b[1]).max() < 1e-12
+
+
+def test_all_masked_row_is_finite_and_fp32_uniform_attention():
+    """fp32 `logits + (-1e9)` rounds every logit to -1e9: block-1 attention becomes uniform.
+    (float64 keeps the logits; the two differ -- fp32 is what the reference computes.)"""
+    cfg, arch, hp, w = _setup("h36m_81", seed=3)
+    x, _ = util.synthetic_batch(cfg, 1, seed=3)
+    zeros = np.zeros((1, arch.num_frames), bool)
+    f, c, att = O.forward(hp, w, x * 0, zeros, torch.float32, return_attention=True)
+    assert np.isfinite(f).all() and np.isfinite(c).all()
+    assert np.allclose(att[0], 1.0 / arch.num_frames, rtol=0, atol=1e-7)
+
+
+@pytest.mark.parametrize("cfgname", ["h36m_81", "h36m_351"])
+def test_strided_residual_rows(cfgname):
+    """With zero conv/attention weights the strided block is x -> (x + pe)[residual rows]."""
+    cfg, arch, hp, w = _setup(cfgname, seed=4, perturb=0.0)
+    pre = "strided_temporal_block_1"
+    for k in w:
+        if k.startswith(pre) and ("kernel" in k or "bias" in k):
+            w[k] = np.zeros_like(w[k])
+    p = {k: torch.as_tensor(v) for k, v in w.items()}
+    L = arch.num_frames
+    x = torch.arange(L, dtype=torch.float32)[None, :, None].repeat(1, 1, arch.d_temporal)
+    pe = torch.zeros(L, arch.d_temporal)
+    y, _ = O.strided_transformer_block(p, pre, x, pe, arch.num_heads, arch.strides[0], arch.paddings[0])
+    rows = y[0, :, 0].numpy().astype(int).tolist()
+    s, pad = arch.strides[0], arch.paddings[0]
+    expect = list(range(1 if pad[0] == 0 else 0, L - (1 if pad[1] == 0 else 0), s))
+    assert rows == expect
+    assert len(rows) == arch.strided_lengths[1]
+
+
+def test_stride_mask_rule_table():
+    # SURVEY.md appendix B
+    f = O.stride_mask_eval
+    assert f(41, 2, 4, 0).sum() == 21 and f(41, 2, 4, 0)[20]
+    assert f(41, 2, 4, 2).sum() == 20 and not f(41, 2, 4, 2)[20]
+    assert f(41, 2, 4, 1).sum() == 0
+    assert f(71, 5, 5, 0).all() and f(71, 5, 5, 3).sum() == 0
+    assert f(71, 5, 10, 0).sum() == 35 and f(71, 5, 10, 5).sum() == 36
+    assert f(71, 5, 20, 0).sum() == 17 and f(71, 5, 20, 10).sum() == 18
+    assert np.array_equal(f(71, 5, 20, 5), util.eval_stride_mask(71, 5, 20, 5))
+
+
+def test_mpjpe_and_flip_protocol():
+    rng = np.random.default_rng(0)
+    pred = rng.normal(size=(5, 17, 3))
+    gt = np.concatenate([rng.normal(size=(5, 17, 3)), np.ones((5, 17, 1))], -1)
+    gt[0, 3, 3] = 0
+    e = O.mpjpe(pred, gt, 6, normalize=False)
+    assert e[0, 3] == -1 and np.all(e[:, 6] == 0)
+    d = (pred - pred[:, 6:7]) - (gt[..., :3] - gt[:, 6:7, :3])
+    assert np.allclose(e[1], np.sqrt((d[1] ** 2).sum(-1)))
+    assert O.mpjpe(pred, gt, 6) == pytest.approx(np.where(gt[..., 3] > 0, np.sqrt((d ** 2).sum(-1)), 0).sum() / 84)
+    # flip twice = identity on the input transform (eval.py:154-157)
+    cfg, arch, hp, w = _setup("h36m_81", seed=6)
+    order = cfg.AUGM_FLIP_KEYPOINT_ORDER
+    assert sorted(order) == list(range(17)) and [order[i] for i in order] == list(range(17))
+    x, m = util.synthetic_batch(cfg, 1, seed=6, mask_specs=[(4, 0)])
+    seq, cen = O.eval_step_with_flip(hp, w, x, m, order, torch.float64)
+    s1, c1 = O.test_step(hp, w, x, m, torch.float64)
+    xf = np.concatenate([-x[..., :1], x[..., 1:]], -1)[:, :, order]
+    s2, c2 = O.test_step(hp, w, xf, m, torch.float64)
+    c2 = np.concatenate([-c2[..., :1], c2[..., 1:]], -1)[:, order]
+    assert np.allclose(cen, (c1 + c2) / 2, atol=1e-12)
