@@ -490,8 +490,9 @@ int uu3d_commit_weights(uu3d_model* m, void* stream_) {
 // ---- workspace --------------------------------------------------------------------------
 namespace {
 struct Workspace {
-    float *S, *X, *QKV, *O, *Hb, *XA, *XB;
+    float *S, *X, *QKV, *O, *Hb, *XA, *XB, *slab;
     float2* stats;
+    size_t slab_floats;
     size_t bytes;
 };
 Workspace carve(const uu3d_model* m, int B, char* base) {
@@ -509,11 +510,13 @@ Workspace carve(const uu3d_model* m, int B, char* base) {
     const size_t oA = take(rows * c.d_temporal * 4);
     const size_t oB = take(rows_s * c.d_temporal * 4);
     const size_t oT = take(rows * sizeof(float2));
+    w.slab_floats = (size_t)1536 * 4096;            // >= slices * M * N of any split GEMM (slices * tiles <= ~1150)
+    const size_t oSl = take(w.slab_floats * 4);
     w.bytes = off;
     if (base) {
         w.S = (float*)(base + oS); w.X = (float*)(base + oX); w.QKV = (float*)(base + oQ);
         w.O = (float*)(base + oO); w.Hb = (float*)(base + oH); w.XA = (float*)(base + oA);
-        w.XB = (float*)(base + oB); w.stats = (float2*)(base + oT);
+        w.XB = (float*)(base + oB); w.stats = (float2*)(base + oT); w.slab = (float*)(base + oSl);
     }
     return w;
 }
@@ -530,6 +533,8 @@ namespace {
 struct Launcher {
     uu3d_model* m;
     hipStream_t stream;
+    float* slab = nullptr;          // split-K partial sums
+    size_t slab_floats = 0;
     int status = UU3D_OK;
 
     void begin(const char* name, const char* kernel, double flops, double bytes) {
@@ -550,25 +555,38 @@ struct Launcher {
     }
 
     template <int BM, int BN, class AL, class EP>
-    void gemm_tile(const AL& al, const float* Bt, int M, int N, int Kp, const EP& ep) {
+    void gemm_tile(const AL& al, const float* Bt, int M, int N, int Kp, int slices, int kt_per_split, const EP& ep) {
         auto kern = gemm_f32_kernel<BM, BN, AL, EP>;
         constexpr size_t lds = gemm_lds_bytes(BM, BN);
         static bool attr_done = false;   // one attribute call per instantiation
         if (!attr_done) { (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr_done = true; }
         const int mt = (M + BM - 1) / BM, nt = (N + BN - 1) / BN;
         const int grid = round_up(mt, 8) * nt;
-        hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, stream, al, Bt, M, N, Kp, mt, nt, ep);
+        hipLaunchKernelGGL(kern, dim3(grid, slices), dim3(256), lds, stream, al, Bt, M, N, Kp, mt, nt, kt_per_split, ep);
     }
 
-    // C[M][N] = A[M][K] * W ; tile shape picked per problem (see DESIGN.md "GEMM tiling").
+    // C[M][N] = A[M][K] * W.  64x64 tiles (4 workgroups per CU) measured fastest on every shape
+    // of this model (tools/gemm_bench.hip).  Problems with too few tiles to fill the chip are
+    // split along K into slabs and combined deterministically (splitk_reduce_kernel).
     template <class AL, class EP>
     void gemm(const char* name, const AL& al, const float* Bt, int M, int N, int K, const EP& ep, double extra_bytes = 0) {
-        const int Kp = round_up(K, 32);
+        const int Kp = round_up(K, 32), KT = Kp / 32;
+        const int tiles = ((M + 63) / 64) * ((N + 63) / 64);
+        int slices = 1;
+        if (tiles < 384 && KT >= 8) slices = std::max(1, std::min(KT / 4, (768 + tiles / 2) / tiles));
+        int kps = (KT + slices - 1) / slices;
+        slices = (KT + kps - 1) / kps;
+        const int ldslab = round_up(N, 4);
+        if (slices > 1 && (size_t)slices * M * ldslab > slab_floats) { slices = 1; kps = KT; }
         begin(name, "gemm_f32", 2.0 * M * (double)N * K, 4.0 * ((double)M * K + (double)N * K + (double)M * N) + extra_bytes);
-        const long t128 = (long)((M + 127) / 128) * ((N + 127) / 128);
-        if (N >= 512 && t128 >= 256) gemm_tile<128, 128>(al, Bt, M, N, Kp, ep);
-        else if (N > 64 && (long)((M + 127) / 128) * ((N + 63) / 64) >= 256) gemm_tile<128, 64>(al, Bt, M, N, Kp, ep);
-        else gemm_tile<64, 64>(al, Bt, M, N, Kp, ep);
+        if (slices == 1) {
+            gemm_tile<64, 64>(al, Bt, M, N, Kp, 1, KT, ep);
+        } else {
+            EpSlab es{slab, ldslab, (size_t)M * ldslab};
+            gemm_tile<64, 64>(al, Bt, M, N, Kp, slices, kps, es);
+            hipLaunchKernelGGL(splitk_reduce_kernel<EP>, dim3((M * N + 255) / 256), dim3(256), 0, stream,
+                               slab, slices, (size_t)M * ldslab, M, N, ldslab, ep);
+        }
         end();
     }
 
@@ -612,7 +630,7 @@ int uu3d_forward(uu3d_model* m, const float* kp2d, const uint8_t* mask, int32_t 
     if ((long)B * c.num_frames * c.num_keypoints > (1L << 30)) return fail(m, UU3D_ERR_INVALID_ARGUMENT, "batch too large");
 
     HIPCHK(m, hipSetDevice(m->device));
-    Launcher Lh{m, (hipStream_t)stream_};
+    Launcher Lh{m, (hipStream_t)stream_, w.slab, w.slab_floats};
     m->prof_used = 0;
     const int N = c.num_frames, J = c.num_keypoints, ds = c.d_spatial, dt = c.d_temporal, ht = c.h_temporal;
     const int M = B * N;

@@ -206,13 +206,38 @@ struct EpConvResidual {
     }
 };
 
+// split-K partial sums: slice blockIdx.y writes its raw accumulators to slab[slice][row][col]
+struct EpSlab {
+    float* __restrict__ slab; int ld; size_t slice_stride;
+    __device__ __forceinline__ float2 colv(int) const { return make_float2(0.f, 0.f); }
+    __device__ __forceinline__ float2 pre(int, int) const { return make_float2(0.f, 0.f); }
+    __device__ __forceinline__ void store(int row, int col, float v, float2, float2) const {
+        slab[blockIdx.y * slice_stride + (size_t)row * ld + col] = v;
+    }
+};
+
+// Deterministic split-K combine: slices are summed in slice order, then the real epilogue runs.
+template <class EP>
+__global__ void __launch_bounds__(256)
+splitk_reduce_kernel(const float* __restrict__ slab, const int slices, const size_t slice_stride,
+                     const int M, const int N, const int ld, const EP ep)
+{
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx >= M * N) return;
+    const int row = idx / N, col = idx - row * N;
+    const float* p = slab + (size_t)row * ld + col;
+    float v = p[0];
+    for (int s = 1; s < slices; ++s) v += p[s * slice_stride];
+    ep.store(row, col, v, ep.colv(col), ep.pre(row, col));
+}
+
 // ------------------------------------------------------------------------------------
 // kernel
 // ------------------------------------------------------------------------------------
 template <int BM, int BN, class AL, class EP>
 __global__ void __launch_bounds__(256)
 gemm_f32_kernel(const AL al, const float* __restrict__ Bt, const int M, const int N, const int Kp,
-                const int m_tiles, const int n_tiles, const EP ep)
+                const int m_tiles, const int n_tiles, const int kt_per_split, const EP ep)
 {
     constexpr int LD = GEMM_LD;
     constexpr int TM = BM / 64, TN = BN / 64;     // 32x32 MFMA tiles per wave
@@ -254,16 +279,20 @@ gemm_f32_kernel(const AL al, const float* __restrict__ Bt, const int M, const in
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    const int KT = Kp / GEMM_BK;
+    // split-K: blockIdx.y owns k-tiles [kt_lo, KT) of this slice (kt_per_split == all of them
+    // when the GEMM is not split; a split GEMM's epilogue is EpSlab and a reduce pass follows)
+    const int kt_lo = blockIdx.y * kt_per_split;
+    const int KT = min(Kp / GEMM_BK, kt_lo + kt_per_split);
 
-    // prologue: tile 0 -> LDS buffer 0
+    // prologue: first tile -> LDS buffer of its parity
 #pragma unroll
-    for (int i = 0; i < AI; ++i) ra[i] = al.issue(actx[i], scol);
+    for (int i = 0; i < AI; ++i) ra[i] = al.issue(actx[i], kt_lo * GEMM_BK + scol);
 #pragma unroll
-    for (int i = 0; i < BI; ++i) rb[i] = *reinterpret_cast<const f32x4*>(bptr[i]);
+    for (int i = 0; i < BI; ++i) rb[i] = *reinterpret_cast<const f32x4*>(bptr[i] + kt_lo * GEMM_BK);
+    As += (kt_lo & 1) * BM * LD; Bs += (kt_lo & 1) * BN * LD;   // make "cur = (kt - kt_lo) & 1" below
 #pragma unroll
     for (int i = 0; i < AI; ++i)
-        *reinterpret_cast<f32x4*>(&As[(srow + 32 * i) * LD + scol]) = al.finish(actx[i], scol, ra[i]);
+        *reinterpret_cast<f32x4*>(&As[(srow + 32 * i) * LD + scol]) = al.finish(actx[i], kt_lo * GEMM_BK + scol, ra[i]);
 #pragma unroll
     for (int i = 0; i < BI; ++i) *reinterpret_cast<f32x4*>(&Bs[(srow + 32 * i) * LD + scol]) = rb[i];
     __syncthreads();
@@ -271,7 +300,8 @@ gemm_f32_kernel(const AL al, const float* __restrict__ Bt, const int M, const in
     const int fr = lane & 31;            // fragment row
     const int fk = (lane >> 5) * 4;      // fragment k offset inside an 8-slice
 
-    for (int kt = 0; kt < KT; ++kt) {
+    As -= (kt_lo & 1) * BM * LD; Bs -= (kt_lo & 1) * BN * LD;
+    for (int kt = kt_lo; kt < KT; ++kt) {
         const int cur = kt & 1;
         // Next k-tile's global loads are issued first; the last iteration re-loads its own
         // tile (cheap, L1/L2 hit) so the loop body stays branch-free.
