@@ -580,7 +580,9 @@ struct Launcher {
         if (slices > 1 && (size_t)slices * M * ldslab > slab_floats) { slices = 1; kps = KT; }
         begin(name, "gemm_f32", 2.0 * M * (double)N * K, 4.0 * ((double)M * K + (double)N * K + (double)M * N) + extra_bytes);
         if (slices == 1) {
-            gemm_tile<64, 64>(al, Bt, M, N, Kp, 1, KT, ep);
+            // measured (tools/gemm_bench): 64x128 beats 64x64 by ~8 % on the N = 384 GEMMs, loses elsewhere
+            if (N % 128 == 0 && N <= 512 && tiles >= 512) gemm_tile<64, 128>(al, Bt, M, N, Kp, 1, KT, ep);
+            else gemm_tile<64, 64>(al, Bt, M, N, Kp, 1, KT, ep);
         } else {
             EpSlab es{slab, ldslab, (size_t)M * ldslab};
             gemm_tile<64, 64>(al, Bt, M, N, Kp, slices, kps, es);
