@@ -188,6 +188,73 @@ template <int FULL> void runp(const char* name, float* dA, float* dB, float* dC,
     printf("  %-28s %7.1f us %6.1f TF (grid %d)\n", name, ms * 1e3, 2.0 * M * N * K / ms / 1e9, grid);
 }
 
+
+// Baseline structure (prefetch distance 1, 2 LDS buffers, non-persistent) with the 16x16x4 MFMA, stride-40 LDS rows.
+__global__ void __launch_bounds__(256)
+k64_16(const float* __restrict__ A, const float* __restrict__ Bt, float* __restrict__ C, int M, int N, int K, int mt, int nt, unsigned long long* clk)
+{
+    constexpr int BM = 64, BN = 64, LD = 40;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* As = smem; float* Bs = smem + 2 * BM * LD;
+    const int id = blockIdx.x, xcd = id & 7, slot = id >> 3;
+    const int bn = slot % nt, bm = (slot / nt) * 8 + xcd;
+    if (bm >= mt) return;
+    const int bm0 = bm * BM, bn0 = bn * BN;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wm = wave >> 1, wn = wave & 1;
+    const int srow = tid >> 3, scol = (tid & 7) * 4;
+    const float* ap[2]; const float* bp[2];
+    for (int i = 0; i < 2; ++i) { ap[i] = A + (size_t)min(bm0 + srow + 32 * i, M - 1) * K + scol; bp[i] = Bt + (size_t)(bn0 + srow + 32 * i) * K + scol; }
+    f32x4 acc[2][2]; for (int i = 0; i < 2; ++i) for (int j = 0; j < 2; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const int KT = K / 32;
+    f32x4 ra[2], rb[2];
+    const int fr = lane & 15, fg = lane >> 4;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) { ra[i] = *(const f32x4*)(ap[i]); rb[i] = *(const f32x4*)(bp[i]); }
+#pragma unroll
+    for (int i = 0; i < 2; ++i) { *(f32x4*)&As[(srow + 32 * i) * LD + scol] = ra[i]; *(f32x4*)&Bs[(srow + 32 * i) * LD + scol] = rb[i]; }
+    __syncthreads();
+    for (int kt = 0; kt < KT; ++kt) {
+        const int buf = kt & 1, k0 = min(kt + 1, KT - 1) * 32;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) { ra[i] = *(const f32x4*)(ap[i] + k0); rb[i] = *(const f32x4*)(bp[i] + k0); }
+        const float* Ac = As + buf * BM * LD + (wm * 32 + fr) * LD + 4 * fg;
+        const float* Bc = Bs + buf * BN * LD + (wn * 32 + fr) * LD + 4 * fg;
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            f32x4 af[2], bf[2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) { af[i] = *(const f32x4*)(Ac + i * 16 * LD + kk * 16); bf[i] = *(const f32x4*)(Bc + i * 16 * LD + kk * 16); }
+#pragma unroll
+            for (int s = 0; s < 4; ++s)
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[i][s], bf[j][s], acc[i][j], 0, 0, 0);
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i) { *(f32x4*)&As[(buf ^ 1) * BM * LD + (srow + 32 * i) * LD + scol] = ra[i]; *(f32x4*)&Bs[(buf ^ 1) * BN * LD + (srow + 32 * i) * LD + scol] = rb[i]; }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { const int row = bm0 + wm * 32 + 16 * i + 4 * fg + r, col = bn0 + wn * 32 + 16 * j + fr; if (row < M) C[(size_t)row * N + col] = acc[i][j][r]; }
+}
+void run16(const char* name, float* dA, float* dB, float* dC, int M, int N, int K) {
+    size_t lds = 2 * 128 * 40 * 4;
+    int mt = (M + 63) / 64, nt = N / 64, grid = ((mt + 7) / 8 * 8) * nt;
+    static unsigned long long* dclk = nullptr; if (!dclk) CK(hipMalloc(&dclk, 16));
+    hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    for (int i = 0; i < 3; ++i) hipLaunchKernelGGL(k64_16, dim3(grid), dim3(256), lds, 0, dA, dB, dC, M, N, K, mt, nt, dclk);
+    CK(hipEventRecord(e0));
+    for (int i = 0; i < 20; ++i) hipLaunchKernelGGL(k64_16, dim3(grid), dim3(256), lds, 0, dA, dB, dC, M, N, K, mt, nt, dclk);
+    CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
+    float ms; CK(hipEventElapsedTime(&ms, e0, e1)); ms /= 20;
+    printf("  %-28s %7.1f us %6.1f TF\n", name, ms * 1e3, 2.0 * M * N * K / ms / 1e9);
+}
+
 template <int MODE> void run(const char* name, float* dA, float* dB, float* dC, int M, int N, int K) {
     auto kern = k64<MODE>; size_t lds = 2 * 128 * 36 * 4;
     int mt = (M + 63) / 64, nt = N / 64, grid = ((mt + 7) / 8 * 8) * nt;
@@ -212,6 +279,7 @@ int main() {
     for (auto& s : shapes) {
         printf("M=%d N=%d K=%d\n", s[0], s[1], s[2]);
         run<0>("baseline", dA, dB, dC, s[0], s[1], s[2]);
+        run16("baseline, 16x16x4 mfma", dA, dB, dC, s[0], s[1], s[2]);
         run<1>("no global loads in loop", dA, dB, dC, s[0], s[1], s[2]);
         run<4>("lds-read + mfma only", dA, dB, dC, s[0], s[1], s[2]);
         run<2>("prefetch distance 2", dA, dB, dC, s[0], s[1], s[2]);

@@ -491,6 +491,7 @@ int uu3d_commit_weights(uu3d_model* m, void* stream_) {
 namespace {
 struct Workspace {
     float *S, *X, *QKV, *O, *Hb, *XA, *XB, *slab;
+    int* frame_list;
     float2* stats;
     size_t slab_floats;
     size_t bytes;
@@ -512,11 +513,12 @@ Workspace carve(const uu3d_model* m, int B, char* base) {
     const size_t oT = take(rows * sizeof(float2));
     w.slab_floats = (size_t)1536 * 4096;            // >= slices * M * N of any split GEMM (slices * tiles <= ~1150)
     const size_t oSl = take(w.slab_floats * 4);
+    const size_t oFl = take((rows + 1) * sizeof(int));
     w.bytes = off;
     if (base) {
         w.S = (float*)(base + oS); w.X = (float*)(base + oX); w.QKV = (float*)(base + oQ);
         w.O = (float*)(base + oO); w.Hb = (float*)(base + oH); w.XA = (float*)(base + oA);
-        w.XB = (float*)(base + oB); w.stats = (float2*)(base + oT); w.slab = (float*)(base + oSl);
+        w.XB = (float*)(base + oB); w.stats = (float2*)(base + oT); w.slab = (float*)(base + oSl); w.frame_list = (int*)(base + oFl);
     }
     return w;
 }
@@ -642,6 +644,13 @@ int uu3d_forward(uu3d_model* m, const float* kp2d, const uint8_t* mask, int32_t 
     {
         SpatialParams sp = m->sp;
         sp.total_frames = M;
+        sp.frame_list = nullptr;
+        if (mask != nullptr && !m->spatial_valu) {
+            Lh.begin("compact_frames", "compact_frames", 0.0, (double)M * 5.0);
+            hipLaunchKernelGGL(compact_frames_kernel, dim3(1), dim3(1024), 0, Lh.stream, mask, M, w.frame_list);
+            Lh.end();
+            sp.frame_list = w.frame_list;
+        }
         const double fl = (double)M * (2.0 * J * 2 * ds + c.spatial_depth * (4.0 * 2 * J * ds * ds + 8.0 * 4 * J * J * (ds / 8) + 2.0 * 2 * J * ds * kHS));
         if (m->spatial_valu) {
             constexpr int FPW = 256 / kJ;

@@ -66,4 +66,34 @@ mpjpe_kernel(const float* __restrict__ pred, const float* __restrict__ gt, const
     out[idx] = (gp[3] > 0.f) ? sqrt(acc) : -1.0;
 }
 
+// Ordered compaction of the frames that carry real 2D input (stride_mask == 1): the "gather" of
+// the learned-upsampling path.  spatial_transformation's result at masked frames is overwritten
+// by the strided-input token (u_u_t.py:350, ToDo at :320), so the spatial stack only has to run
+// on this list -- an exact, output-preserving saving.  One workgroup, ascending order, deterministic.
+//   list[0 .. count) = indices of valid frames, count stored in list[total]
+__global__ void __launch_bounds__(1024)
+compact_frames_kernel(const uint8_t* __restrict__ mask, const int total, int* __restrict__ list)
+{
+    __shared__ int wave_sum[16];
+    __shared__ int base;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (tid == 0) base = 0;
+    __syncthreads();
+    for (int start = 0; start < total; start += 1024) {
+        const int idx = start + tid;
+        const bool v = (idx < total) && (mask[idx] != 0);
+        const unsigned long long bal = __ballot(v);
+        const int before = __popcll(bal & ((1ull << lane) - 1ull));
+        if (lane == 0) wave_sum[wave] = __popcll(bal);
+        __syncthreads();
+        int off = base;
+        for (int w = 0; w < wave; ++w) off += wave_sum[w];
+        if (v) list[off + before] = idx;
+        __syncthreads();
+        if (tid == 0) { int t = 0; for (int w = 0; w < 16; ++w) t += wave_sum[w]; base += t; }
+        __syncthreads();
+    }
+    if (tid == 0) list[total] = base;
+}
+
 }  // namespace uu3d

@@ -59,6 +59,7 @@ struct SpatialParams {
     const float* __restrict__ norm_b;    // (DS)
     int depth;
     int total_frames;                    // B * N
+    const int* __restrict__ frame_list;  // compacted valid frames + count at [total_frames]; nullptr = all frames
 };
 
 template <int DS>
@@ -324,8 +325,14 @@ spatial_stack_mfma_kernel(const float* __restrict__ kp2d, const SpatialParams p,
     const int lane = threadIdx.x;
     const int fl = min(lane / J, FR - 1);
     const int joint = lane - (lane / J) * J;
-    const int frame = blockIdx.x * FR + fl;
-    const bool valid = (lane < ROWS) && (frame < p.total_frames);
+    int frame = blockIdx.x * FR + fl;
+    int nframes = p.total_frames;
+    if (p.frame_list != nullptr) {
+        nframes = p.frame_list[p.total_frames];
+        if ((int)blockIdx.x * FR >= nframes) return;           // workgroup-uniform: nothing left to do
+        frame = p.frame_list[min(frame, nframes - 1)];
+    }
+    const bool valid = (lane < ROWS) && ((int)blockIdx.x * FR + fl < nframes);
     const int fbase = fl * J;
     const int col = lane & 31;
 
