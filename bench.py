@@ -53,6 +53,7 @@ def main():
     ap.add_argument("--mask-stride", type=int, default=None, help="s_in; default = first MASK_STRIDE")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true", help="launch eagerly instead of replaying a hipGraph")
+    ap.add_argument("--force-dist", action="store_true", help="initialise the process group even at world size 1 (exercises the RCCL path)")
     args = ap.parse_args()
 
     import numpy as np
@@ -67,7 +68,10 @@ def main():
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
     torch.cuda.set_device(local_rank)
-    if world > 1:
+    use_dist = world > 1 or args.force_dist
+    if use_dist:
+        if "MASTER_ADDR" not in os.environ:
+            os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT="29533", RANK="0", WORLD_SIZE="1")
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     cfg = util.load_config(args.config)
@@ -84,37 +88,40 @@ def main():
     m = torch.from_numpy(m_np).cuda()
     gt = torch.from_numpy(gt_np).cuda()
     err = torch.empty((B, J), dtype=torch.float64, device="cuda")
-    gathered = torch.empty((world * B, J), dtype=torch.float64, device="cuda") if world > 1 else None
+    gathered = torch.empty((world * B, J), dtype=torch.float64, device="cuda") if use_dist else None
     from uplift_upsample_3dhpe_amd.harness import per_joint_error
 
-    def step():
+    def compute():
         full, central = model([x, m], training=False)
         per_joint_error(central, gt, cfg.ROOT_KEYTPOINT, out=err)
-        if world > 1:
-            dist.all_gather_into_tensor(gathered, err)
-        return central
 
     def sync_all():
         torch.cuda.synchronize()
-        if world > 1:
+        if use_dist:
             dist.barrier()
             torch.cuda.synchronize()
 
-    use_graph = not args.no_graph and world == 1
-    run = step
+    # the forward + error kernel replay from a hipGraph; the RCCL all-gather stays outside the graph
+    use_graph = not args.no_graph
+    run_compute = compute
     if use_graph:
         try:
             for _ in range(2):
-                step()
+                compute()
             torch.cuda.synchronize()
             g = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g):
-                step()
-            run = g.replay
+                compute()
+            run_compute = g.replay
         except Exception as e:  # pragma: no cover
             print(f"[bench] graph capture failed ({e}); running eagerly", file=sys.stderr)
             use_graph = False
-            run = step
+            run_compute = compute
+
+    def run():
+        run_compute()
+        if use_dist:
+            dist.all_gather_into_tensor(gathered, err)
 
     for _ in range(args.warmup):
         run()
@@ -124,7 +131,7 @@ def main():
         run()
     sync_all()
     elapsed = time.perf_counter() - t0
-    if world > 1:
+    if use_dist:
         t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -178,7 +185,7 @@ def main():
         else:
             out["cpu_baseline"] = None
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 
