@@ -5,6 +5,7 @@
 #include <cstdlib>
 #include <vector>
 #include "../uplift-upsample-3dhpe_amd/csrc/uu3d_gemm.h"
+#include "gemm_persistent_exp.h"
 using namespace uu3d;
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %s:%d\n", hipGetErrorString(e), __FILE__, __LINE__); exit(1);} } while (0)
 
