@@ -153,6 +153,46 @@ int uu3d_set_profiling(uu3d_model* model, int32_t enabled);
 int uu3d_profile_read(uu3d_model* model, uu3d_profile_entry* out_entries, int32_t capacity,
                       int32_t* out_count);
 
+/* ------------------------------------------------------------------------------------------
+ * Training-step arithmetic that does not involve back-propagation through the network
+ * (SURVEY.md section 8(a) rows T1, T3, T4).  The backward pass itself (T2) is not built yet.
+ * ------------------------------------------------------------------------------------------ */
+
+/*
+ * T1 -- replaces the loss of train_step (train.py:464-494, common/utils/losses_3d.py:13-14):
+ *   gt      = gt3d - gt3d[:, :, root]                 (root shift, :467)
+ *   central = sum ||pred_central - gt[:, N/2]||_2 / (batch_size_norm * J)
+ *   seq     = sum ||pred_full    - gt        ||_2 / (batch_size_norm * N * J)
+ *   loss    = w_center * central + w_seq * seq        (pred_full_dev == NULL: (w_center + w_seq) * central, :491-494)
+ * and returns d loss / d pred (what tape.gradient feeds into the network's backward).
+ *   pred_full_dev (B,N,J,3) or NULL, pred_central_dev (B,J,3), gt3d_dev (B,N,J,3) absolute 3D poses.
+ *   batch_size_norm is config.BATCH_SIZE (the GLOBAL batch: per-rank sums simply add up).
+ *   loss_out_dev[3] = {loss, central, seq}; grad_* may be NULL; scratch_dev >= 4096 floats.
+ * Deterministic (fixed-order two-stage reduction).
+ */
+int uu3d_mpjpe_loss(const float* pred_full_dev, const float* pred_central_dev, const float* gt3d_dev,
+                    int32_t batch, int32_t num_frames, int32_t num_keypoints, int32_t root_index,
+                    float w_center, float w_seq, int32_t batch_size_norm,
+                    float* loss_out_dev, float* grad_full_dev, float* grad_central_dev,
+                    float* scratch_dev, void* stream);
+
+/*
+ * T3 -- replaces optimizer.apply_gradients for tfa.optimizers.AdamW (train.py:404-415,499) on
+ * one flat parameter buffer: decoupled decay first, then the Keras/TF ApplyAdam update
+ *   var -= wd * var
+ *   alpha = lr * sqrt(1 - beta2^t) / (1 - beta1^t)              (t = step = iterations + 1)
+ *   m += (g - m) * (1 - beta1);  v += (g*g - v) * (1 - beta2)
+ *   var -= (m * alpha) / (sqrt(v) + epsilon)
+ * lr and wd are the schedule values at `iterations` (both ExponentialDecay for the shipped configs).
+ * HBM-bound: 28 bytes per parameter (read var, g, m, v; write var, m, v).
+ */
+int uu3d_adamw_update(float* var_dev, float* m_dev, float* v_dev, const float* grad_dev, int64_t n,
+                      float lr, float wd, float beta1, float beta2, float epsilon, int64_t step,
+                      void* stream);
+
+/* T4 -- replaces the EMA update of train_step (train.py:502-504): ema -= (1 - decay) * (ema - w). */
+int uu3d_ema_update(float* ema_dev, const float* w_dev, int64_t n, float decay, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

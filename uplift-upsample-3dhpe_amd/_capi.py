@@ -21,6 +21,7 @@ EXPORTED_SYMBOLS = (
     "uu3d_num_weights", "uu3d_weight_info", "uu3d_set_weight", "uu3d_get_weight",
     "uu3d_commit_weights", "uu3d_workspace_bytes", "uu3d_forward", "uu3d_mpjpe",
     "uu3d_set_profiling", "uu3d_profile_read",
+    "uu3d_mpjpe_loss", "uu3d_adamw_update", "uu3d_ema_update",
 )
 
 
@@ -103,6 +104,12 @@ def load_library(path=None):
     lib.uu3d_set_profiling.argtypes = [vp, i32]
     lib.uu3d_profile_read.restype = C.c_int
     lib.uu3d_profile_read.argtypes = [vp, C.POINTER(Uu3dProfileEntry), i32, C.POINTER(i32)]
+    lib.uu3d_mpjpe_loss.restype = C.c_int
+    lib.uu3d_mpjpe_loss.argtypes = [vp, vp, vp, i32, i32, i32, i32, C.c_float, C.c_float, i32, vp, vp, vp, vp, vp]
+    lib.uu3d_adamw_update.restype = C.c_int
+    lib.uu3d_adamw_update.argtypes = [vp, vp, vp, vp, i64, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, i64, vp]
+    lib.uu3d_ema_update.restype = C.c_int
+    lib.uu3d_ema_update.argtypes = [vp, vp, i64, C.c_float, vp]
     if path is None:
         _lib = lib
     return lib

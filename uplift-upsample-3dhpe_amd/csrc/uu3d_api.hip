@@ -28,6 +28,7 @@
 #include "uu3d_attn.h"
 #include "uu3d_spatial.h"
 #include "uu3d_misc.h"
+#include "uu3d_train.h"
 
 using namespace uu3d;
 
@@ -761,3 +762,46 @@ int uu3d_profile_read(uu3d_model* m, uu3d_profile_entry* out, int32_t capacity, 
     return UU3D_OK;
 }
 
+
+// ---- training-step arithmetic without back-propagation (T1, T3, T4) -----------------------------
+int uu3d_mpjpe_loss(const float* pred_full, const float* pred_central, const float* gt3d, int32_t B, int32_t N,
+                    int32_t J, int32_t root, float w_center, float w_seq, int32_t batch_size_norm, float* loss_out,
+                    float* grad_full, float* grad_central, float* scratch, void* stream_) {
+    if (!pred_central || !gt3d || !loss_out || !scratch || B < 1 || N < 1 || J < 1 || root < 0 || root >= J ||
+        batch_size_norm < 1)
+        return UU3D_ERR_INVALID_ARGUMENT;
+    if ((long)B * N * J > (1L << 30)) return UU3D_ERR_INVALID_ARGUMENT;
+    hipStream_t stream = (hipStream_t)stream_;
+    const float norm_cen = (float)batch_size_norm * (float)J;
+    const float norm_seq = (float)batch_size_norm * (float)N * (float)J;
+    const bool has_seq = pred_full != nullptr;
+    // d loss / d dist: w / norm (fallback without sequence loss: (w_c + w_s) / norm_cen)
+    const float gs_cen = (has_seq ? w_center : (w_center + w_seq)) / norm_cen;
+    const float gs_seq = w_seq / norm_seq;
+    hipLaunchKernelGGL(mpjpe_loss_stage1, dim3(kLossGrid), dim3(256), 0, stream, pred_full, pred_central, gt3d, B, N, J,
+                       root, gs_seq, gs_cen, has_seq ? grad_full : nullptr, grad_central, scratch);
+    hipLaunchKernelGGL(mpjpe_loss_stage2, dim3(1), dim3(64), 0, stream, scratch, norm_seq, norm_cen, w_center, w_seq,
+                       has_seq ? 1 : 0, loss_out);
+    return hipGetLastError() == hipSuccess ? UU3D_OK : UU3D_ERR_HIP;
+}
+
+int uu3d_adamw_update(float* var, float* m, float* v, const float* grad, int64_t n, float lr, float wd, float beta1,
+                      float beta2, float epsilon, int64_t step, void* stream) {
+    if (!var || !m || !v || !grad || n < 1 || step < 1) return UU3D_ERR_INVALID_ARGUMENT;
+    if ((((uintptr_t)var | (uintptr_t)m | (uintptr_t)v | (uintptr_t)grad) & 15) != 0) return UU3D_ERR_INVALID_ARGUMENT;
+    // float32 like the TF kernel: alpha = lr * sqrt(1 - beta2^t) / (1 - beta1^t)
+    const float b1p = powf(beta1, (float)step), b2p = powf(beta2, (float)step);
+    const float alpha = lr * sqrtf(1.0f - b2p) / (1.0f - b1p);
+    const long long n4 = n >> 2;
+    const int grid = (int)std::min<long long>(std::max<long long>((n4 + 255) / 256, 1), 256 * 32);
+    hipLaunchKernelGGL(adamw_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, var, m, v, grad, (long long)n, wd, alpha,
+                       1.0f - beta1, 1.0f - beta2, epsilon);
+    return hipGetLastError() == hipSuccess ? UU3D_OK : UU3D_ERR_HIP;
+}
+
+int uu3d_ema_update(float* ema, const float* w, int64_t n, float decay, void* stream) {
+    if (!ema || !w || n < 1) return UU3D_ERR_INVALID_ARGUMENT;
+    const int grid = (int)std::min<long long>((n + 255) / 256, 256 * 8);
+    hipLaunchKernelGGL(ema_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, ema, w, (long long)n, 1.0f - decay);
+    return hipGetLastError() == hipSuccess ? UU3D_OK : UU3D_ERR_HIP;
+}
