@@ -23,7 +23,10 @@ def test_header_symbols_exported(lib):
     declared = set(re.findall(r"\b(uu3d_[a-z_0-9]+)\s*\(", header))
     declared -= {"uu3d_status", "uu3d_precision"}
     assert declared == set(_capi.EXPORTED_SYMBOLS)
-    for s in declared:
+    ops_header = open(os.path.join(util.ROOT, "include", "uu3d_ops.h")).read()
+    ops = set(re.findall(r"\b(uu3d_op_[a-z_0-9]+)\s*\(", ops_header))
+    assert ops == set(_capi.OPS_SYMBOLS)
+    for s in declared | ops:
         assert hasattr(lib, s), s
     assert lib.uu3d_version().decode().startswith("uu3d ")
     assert lib.uu3d_status_string(0) == b"ok" and lib.uu3d_status_string(2) != b"ok"

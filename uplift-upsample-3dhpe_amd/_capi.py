@@ -23,6 +23,11 @@ EXPORTED_SYMBOLS = (
     "uu3d_set_profiling", "uu3d_profile_read",
     "uu3d_mpjpe_loss", "uu3d_adamw_update", "uu3d_ema_update",
 )
+# include/uu3d_ops.h
+OPS_SYMBOLS = (
+    "uu3d_op_gemm_tn", "uu3d_op_gemm_nt", "uu3d_op_colsum", "uu3d_op_row_stats", "uu3d_op_ln_bwd",
+    "uu3d_op_attn_fwd", "uu3d_op_attn_bwd", "uu3d_op_scratch_floats",
+)
 
 
 class Uu3dLibraryError(RuntimeError):
@@ -110,6 +115,22 @@ def load_library(path=None):
     lib.uu3d_adamw_update.argtypes = [vp, vp, vp, vp, i64, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, i64, vp]
     lib.uu3d_ema_update.restype = C.c_int
     lib.uu3d_ema_update.argtypes = [vp, vp, i64, C.c_float, vp]
+    lib.uu3d_op_scratch_floats.restype = sz
+    lib.uu3d_op_scratch_floats.argtypes = []
+    lib.uu3d_op_gemm_tn.restype = C.c_int
+    lib.uu3d_op_gemm_tn.argtypes = [vp, i32, vp, i32, i32, i32, i32, vp, i32, vp, sz, vp]
+    lib.uu3d_op_gemm_nt.restype = C.c_int
+    lib.uu3d_op_gemm_nt.argtypes = [vp, i32, vp, i32, i32, i32, i32, vp, i32, vp, sz, vp]
+    lib.uu3d_op_colsum.restype = C.c_int
+    lib.uu3d_op_colsum.argtypes = [vp, i32, i32, i32, i32, vp, i32, vp, i32, vp, sz, vp]
+    lib.uu3d_op_row_stats.restype = C.c_int
+    lib.uu3d_op_row_stats.argtypes = [vp, i32, i32, i32, C.c_float, vp, vp]
+    lib.uu3d_op_ln_bwd.restype = C.c_int
+    lib.uu3d_op_ln_bwd.argtypes = [vp, vp, vp, vp, i32, i32, i32, vp, i32, vp, vp, vp, sz, vp]
+    lib.uu3d_op_attn_fwd.restype = C.c_int
+    lib.uu3d_op_attn_fwd.argtypes = [vp, i32, i32, i32, i32, i32, i32, vp, vp, i32, vp]
+    lib.uu3d_op_attn_bwd.restype = C.c_int
+    lib.uu3d_op_attn_bwd.argtypes = [vp, vp, i32, i32, i32, i32, i32, i32, vp, vp, i32, vp]
     if path is None:
         _lib = lib
     return lib

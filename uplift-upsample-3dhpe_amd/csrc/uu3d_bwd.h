@@ -1,0 +1,396 @@
+// uu3d_bwd.h -- building blocks of the backward pass, exact f32.
+//
+//   gemm_tn_kernel     C[P][Q] = sum_r A[r][P]^T B[r][Q]   (weight gradients dW = X^T dY; the
+//                      contraction runs over the TOKEN rows, so both operands are staged
+//                      row-major [r][.] and the MFMA fragments are read down the columns)
+//   colsum_kernel      bias / LayerNorm-beta style gradients: column sums over rows (optionally
+//                      with a row period, for positional-encoding gradients)
+//   ln_bwd_kernel      LayerNorm backward for one row per wave (dx) + per-block partial dgamma/dbeta
+//   attn_bwd_kernel    softmax-attention backward for one (sequence, head) per workgroup
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <math.h>
+#include "uu3d_gemm.h"
+
+namespace uu3d {
+
+// ------------------------------------------------------------------------------------
+// A-side loaders for gemm_tn: load(r, p) -> A[r][p .. p+3] (p multiple of 4), zero outside.
+// ------------------------------------------------------------------------------------
+struct TnLoadPlain {
+    const float* __restrict__ A; int lda, R, P;
+    __device__ __forceinline__ f32x4 load(int r, int p) const {
+        if (r >= R || p >= P) return (f32x4){0.f, 0.f, 0.f, 0.f};
+        return *reinterpret_cast<const f32x4*>(A + (size_t)r * lda + p);
+    }
+};
+// LayerNorm output recomputed on the fly: A[r][p] = LN(x)[r][p] (for dW of an LN-fed Dense)
+struct TnLoadLayerNorm {
+    const float* __restrict__ X; const float2* __restrict__ stats;
+    const float* __restrict__ gamma; const float* __restrict__ beta; int ldx, R, P;
+    __device__ __forceinline__ f32x4 load(int r, int p) const {
+        if (r >= R || p >= P) return (f32x4){0.f, 0.f, 0.f, 0.f};
+        const f32x4 x = *reinterpret_cast<const f32x4*>(X + (size_t)r * ldx + p);
+        const f32x4 g = *reinterpret_cast<const f32x4*>(gamma + p);
+        const f32x4 b = *reinterpret_cast<const f32x4*>(beta + p);
+        const float2 s = stats[r];
+        f32x4 y;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { const float inv = s.y * g[e]; y[e] = x[e] * inv + (b[e] - s.x * inv); }
+        return y;
+    }
+};
+// rows of the zero-padded, strided k=3 convolution input (same gather as ALoadConv3)
+struct TnLoadConv3 {
+    const float* __restrict__ Hin; int C, L_in, L_out, stride, pad_left, R, P;   // R = B*L_out, P = 3*C
+    __device__ __forceinline__ f32x4 load(int r, int p) const {
+        if (r >= R || p >= P) return (f32x4){0.f, 0.f, 0.f, 0.f};
+        const int b = r / L_out, t = r - b * L_out;
+        const int j = p / C, cc = p - j * C;
+        const int src = t * stride - pad_left + j;
+        if (src < 0 || src >= L_in) return (f32x4){0.f, 0.f, 0.f, 0.f};
+        return *reinterpret_cast<const f32x4*>(Hin + (size_t)(b * L_in + src) * C + cc);
+    }
+};
+
+// plain store epilogue for split-K reduce / direct store: C[p][q] = v
+struct EpStore {
+    float* __restrict__ out; int ldo;
+    __device__ __forceinline__ float2 colv(int) const { return make_float2(0.f, 0.f); }
+    __device__ __forceinline__ float2 pre(int, int) const { return make_float2(0.f, 0.f); }
+    __device__ __forceinline__ void store(int row, int col, float v, float2, float2) const { out[(size_t)row * ldo + col] = v; }
+};
+
+// C[P][Q] (+= over blockIdx.y slices into slabs) ; 64x64 tile, 4 waves 2x2, BK = 32 rows of R.
+// LDS: TA[2][32][68], TB[2][32][68] (r-major).  MFMA 32x32x2: A operand element (i = p, k = r),
+// lane (p = lane & 31, h) reads TA[8kk + 4h + s][p] for step s -- ds_read_b32 down a column.
+template <class AL, class EP>
+__global__ void __launch_bounds__(256)
+gemm_tn_kernel(const AL al, const float* __restrict__ Bm, const int ldb, const int R, const int P, const int Q,
+               const int p_tiles, const int q_tiles, const int kt_per_split, const EP ep)
+{
+    constexpr int LD = 68;
+    __shared__ __attribute__((aligned(16))) float TA[2 * 32 * LD];
+    __shared__ __attribute__((aligned(16))) float TB[2 * 32 * LD];
+    const int tile = blockIdx.x;
+    const int bp = tile / q_tiles, bq = tile - bp * q_tiles;
+    const int p0 = bp * 64, q0 = bq * 64;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wm = wave >> 1, wn = wave & 1;
+    const int srow = tid >> 4, scol = (tid & 15) * 4;          // 16 rows x 64 columns per pass, 2 passes
+    const int KT_all = (R + 31) / 32;
+    const int kt_lo = blockIdx.y * kt_per_split;
+    const int KT = min(KT_all, kt_lo + kt_per_split);
+
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    f32x4 ra[2], rb[2];
+    auto issue = [&](int kt) {
+        const int r0 = kt * 32;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int r = r0 + srow + 16 * i;
+            ra[i] = al.load(r, p0 + scol);
+            rb[i] = (r < R && q0 + scol < Q) ? *reinterpret_cast<const f32x4*>(Bm + (size_t)r * ldb + q0 + scol)
+                                             : (f32x4){0.f, 0.f, 0.f, 0.f};
+        }
+    };
+    auto stage = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            *reinterpret_cast<f32x4*>(&TA[buf * 32 * LD + (srow + 16 * i) * LD + scol]) = ra[i];
+            *reinterpret_cast<f32x4*>(&TB[buf * 32 * LD + (srow + 16 * i) * LD + scol]) = rb[i];
+        }
+    };
+    if (kt_lo < KT) { issue(kt_lo); stage(kt_lo & 1); }
+    __syncthreads();
+    const int fp = wm * 32 + (lane & 31), fq = wn * 32 + (lane & 31), fh = (lane >> 5) * 4;
+    for (int kt = kt_lo; kt < KT; ++kt) {
+        const int cur = kt & 1;
+        if (kt + 1 < KT) issue(kt + 1);
+        const float* Ac = TA + cur * 32 * LD + fh * LD + fp;
+        const float* Bc = TB + cur * 32 * LD + fh * LD + fq;
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk)
+#pragma unroll
+            for (int s = 0; s < 4; ++s)
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(Ac[(8 * kk + s) * LD], Bc[(8 * kk + s) * LD], acc, 0, 0, 0);
+        if (kt + 1 < KT) stage(cur ^ 1);
+        __syncthreads();
+    }
+    const int crow0 = p0 + wm * 32 + 4 * (lane >> 5), col = q0 + wn * 32 + (lane & 31);
+    if (col < Q) {
+        const float2 cv = ep.colv(col);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = crow0 + (r & 3) + 8 * (r >> 2);
+            if (row < P) ep.store(row, col, acc[r], cv, ep.pre(row, col));
+        }
+    }
+}
+
+// out[c] (period == 0) or out[(r % period)][c] = sum over rows r of scale(r) * X[r][c].
+// One workgroup per 64 columns x row-slice; slices are combined in order by a second pass
+// (deterministic).  mask (optional, per row): only rows with mask[r] == want contribute.
+static __global__ void __launch_bounds__(256)
+colsum_kernel(const float* __restrict__ X, const int ldx, const int R, const int C, const int period,
+              const uint8_t* __restrict__ mask, const int want, float* __restrict__ partial, const int slices)
+{
+    // grid: (ceil(C/64), slices) ; thread (lane = column, 4 row-lanes)
+    const int c = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int rl = threadIdx.x >> 6;
+    const int P = period > 0 ? period : 1;
+    const int rows_per_slice = ((R + slices - 1) / slices + P - 1) / P * P;     // multiple of the period
+    const int r_lo = blockIdx.y * rows_per_slice, r_hi = min(R, r_lo + rows_per_slice);
+    __shared__ float red[4][64];
+    for (int ph = 0; ph < P; ++ph) {
+        float s = 0.f;
+        if (c < C)
+            for (int r = r_lo + ph + rl * P; r < r_hi; r += 4 * P)
+                if (mask == nullptr || (int)(mask[r] != 0) == want) s += X[(size_t)r * ldx + c];
+        red[rl][threadIdx.x & 63] = s;
+        __syncthreads();
+        if (rl == 0 && c < C)
+            partial[((size_t)blockIdx.y * P + ph) * C + c] = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
+        __syncthreads();
+    }
+}
+static __global__ void __launch_bounds__(256)
+colsum_finish_kernel(const float* __restrict__ partial, const int n, const int slices, float* __restrict__ out, const int accumulate)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    float s = partial[i];
+    for (int k = 1; k < slices; ++k) s += partial[(size_t)k * n + i];
+    out[i] = accumulate ? out[i] + s : s;
+}
+
+// ------------------------------------------------------------------------------------
+// LayerNorm backward.  y = xhat * gamma + beta, xhat = (x - mean) * rstd (stats from row_stats_kernel).
+//   g   = dy * gamma ;  dx = rstd * (g - mean_c(g) - xhat * mean_c(g * xhat))
+//   dgamma = sum_r dy * xhat ; dbeta = sum_r dy
+// One wave per row, RPW rows per wave, 4 waves per workgroup; each workgroup writes its partial
+// dgamma / dbeta to partial[wg][2][D]; colsum_finish_kernel adds them in order (deterministic).
+// dx is written, or added to dx_out when accumulate != 0 (residual-stream gradient).
+// ------------------------------------------------------------------------------------
+template <int MAXV>
+__global__ void __launch_bounds__(256)
+ln_bwd_kernel(const float* __restrict__ x, const float* __restrict__ dy, const float2* __restrict__ stats,
+              const float* __restrict__ gamma, const int ld, const int D, const int M, const int rows_per_wave,
+              float* __restrict__ dx_out, const int accumulate, float* __restrict__ partial)
+{
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    f32x4 dg[MAXV], db[MAXV], gm[MAXV];
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) {
+        dg[i] = (f32x4){0.f, 0.f, 0.f, 0.f}; db[i] = dg[i];
+        const int c = (i * 64 + lane) * 4;
+        gm[i] = (c < D) ? *reinterpret_cast<const f32x4*>(gamma + c) : dg[i];
+    }
+    const int row0 = (blockIdx.x * 4 + wave) * rows_per_wave;
+    for (int rr = 0; rr < rows_per_wave; ++rr) {
+        const int row = row0 + rr;
+        if (row >= M) break;
+        const float2 st = stats[row];
+        f32x4 xh[MAXV], g[MAXV];
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int i = 0; i < MAXV; ++i) {
+            const int c = (i * 64 + lane) * 4;
+            xh[i] = (f32x4){0.f, 0.f, 0.f, 0.f}; g[i] = xh[i];
+            if (c < D) {
+                const f32x4 xv = *reinterpret_cast<const f32x4*>(x + (size_t)row * ld + c);
+                const f32x4 dv = *reinterpret_cast<const f32x4*>(dy + (size_t)row * ld + c);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    xh[i][e] = (xv[e] - st.x) * st.y;
+                    g[i][e] = dv[e] * gm[i][e];
+                    s1 += g[i][e]; s2 += g[i][e] * xh[i][e];
+                    dg[i][e] += dv[e] * xh[i][e]; db[i][e] += dv[e];
+                }
+            }
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) { s1 += __shfl_xor(s1, o); s2 += __shfl_xor(s2, o); }
+        const float m1 = s1 / (float)D, m2 = s2 / (float)D;
+#pragma unroll
+        for (int i = 0; i < MAXV; ++i) {
+            const int c = (i * 64 + lane) * 4;
+            if (c < D) {
+                f32x4 o;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) o[e] = st.y * (g[i][e] - m1 - xh[i][e] * m2);
+                float* po = dx_out + (size_t)row * ld + c;
+                if (accumulate) { const f32x4 old = *reinterpret_cast<const f32x4*>(po); o += old; }
+                *reinterpret_cast<f32x4*>(po) = o;
+            }
+        }
+    }
+    // combine the 4 waves' partial dgamma/dbeta through LDS, in wave order
+    __shared__ __attribute__((aligned(16))) float red[4][2][MAXV * 256];
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) {
+        *reinterpret_cast<f32x4*>(&red[wave][0][(i * 64 + lane) * 4]) = dg[i];
+        *reinterpret_cast<f32x4*>(&red[wave][1][(i * 64 + lane) * 4]) = db[i];
+    }
+    __syncthreads();
+    for (int idx = threadIdx.x; idx < 2 * D; idx += 256) {
+        const int which = idx / D, c = idx - which * D;
+        partial[((size_t)blockIdx.x * 2 + which) * D + c] = (red[0][which][c] + red[1][which][c]) + (red[2][which][c] + red[3][which][c]);
+    }
+}
+
+// ------------------------------------------------------------------------------------
+// Generic softmax attention, forward and backward, one (sequence, head) per workgroup, thread = row.
+// Used for the training path of BOTH stacks (spatial: L = 17, d_h = 4; temporal/strided: L <= 128,
+// d_h = 48).  qkv rows are [q | k | v] with head h at channels [h*DH, (h+1)*DH).
+//   forward : S = Q K^T / sqrt(d_h) (+ (1-mask) * -1e9), P = softmax(S), O = P V
+//   backward: dV = P^T dO ; dP = dO V^T ; dS = P * (dP - rowsum(dP * P)) ; dQ = dS K / sqrt(d) ; dK = dS^T Q / sqrt(d)
+// LDS: K, V, (Q, dO) tiles [L][DH+4] and the P / dS matrices [L][L+1].
+// ------------------------------------------------------------------------------------
+template <int DH>
+__host__ __device__ inline size_t attn_generic_lds_bytes(int L, bool backward) {
+    const size_t tile = (size_t)L * (DH + 4);
+    return sizeof(float) * (backward ? 4 * tile + 2 * (size_t)L * (L + 1) : 2 * tile);
+}
+
+template <int DH>
+__global__ void __launch_bounds__(128)
+attn_generic_fwd_kernel(const float* __restrict__ qkv, const int ld, const int D, const int L, const int H,
+                        const uint8_t* __restrict__ key_mask, float* __restrict__ out, const int ldo)
+{
+    constexpr int LD = DH + 4;
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    float* Ks = sm; float* Vs = sm + L * LD;
+    const int bh = blockIdx.x, b = bh / H, h = bh - b * H, i = threadIdx.x;
+    const float* base = qkv + (size_t)b * L * ld + h * DH;
+    for (int idx = threadIdx.x; idx < L * DH; idx += 128) {
+        const int r = idx / DH, c = idx - r * DH;
+        Ks[r * LD + c] = base[(size_t)r * ld + D + c];
+        Vs[r * LD + c] = base[(size_t)r * ld + 2 * D + c];
+    }
+    __syncthreads();
+    if (i >= L) return;
+    float q[DH], o[DH];
+#pragma unroll
+    for (int c = 0; c < DH; ++c) { q[c] = base[(size_t)i * ld + c]; o[c] = 0.f; }
+    const float sq = sqrtf((float)DH);
+    float mx = -INFINITY;
+    for (int j = 0; j < L; ++j) {
+        float s = 0.f;
+#pragma unroll
+        for (int c = 0; c < DH; ++c) s = fmaf(q[c], Ks[j * LD + c], s);
+        s = s / sq;
+        if (key_mask != nullptr) s += (key_mask[(size_t)b * L + j] ? 0.0f : 1.0f) * -1e9f;
+        mx = fmaxf(mx, s);
+    }
+    float sum = 0.f;
+    for (int j = 0; j < L; ++j) {           // recompute (no per-thread score array of run-time length)
+        float s = 0.f;
+#pragma unroll
+        for (int c = 0; c < DH; ++c) s = fmaf(q[c], Ks[j * LD + c], s);
+        s = s / sq;
+        if (key_mask != nullptr) s += (key_mask[(size_t)b * L + j] ? 0.0f : 1.0f) * -1e9f;
+        const float e = expf(s - mx);
+        sum += e;
+#pragma unroll
+        for (int c = 0; c < DH; ++c) o[c] = fmaf(e, Vs[j * LD + c], o[c]);
+    }
+#pragma unroll
+    for (int c = 0; c < DH; ++c) out[((size_t)b * L + i) * ldo + h * DH + c] = o[c] / sum;
+}
+
+template <int DH>
+__global__ void __launch_bounds__(128)
+attn_generic_bwd_kernel(const float* __restrict__ qkv, const float* __restrict__ dO, const int ld, const int D,
+                        const int L, const int H, const uint8_t* __restrict__ key_mask,
+                        float* __restrict__ dqkv /* same layout as qkv */, const int ldo)
+{
+    constexpr int LD = DH + 4;
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    float* Qs = sm; float* Ks = Qs + L * LD; float* Vs = Ks + L * LD; float* Gs = Vs + L * LD;   // Gs = dO
+    float* Pm = Gs + L * LD;                 // [L][L+1]
+    float* Sm = Pm + L * (L + 1);            // dS
+    const int LP = L + 1;
+    const int bh = blockIdx.x, b = bh / H, h = bh - b * H, i = threadIdx.x;
+    const float* base = qkv + (size_t)b * L * ld + h * DH;
+    for (int idx = threadIdx.x; idx < L * DH; idx += 128) {
+        const int r = idx / DH, c = idx - r * DH;
+        Qs[r * LD + c] = base[(size_t)r * ld + c];
+        Ks[r * LD + c] = base[(size_t)r * ld + D + c];
+        Vs[r * LD + c] = base[(size_t)r * ld + 2 * D + c];
+        Gs[r * LD + c] = dO[((size_t)b * L + r) * ldo + h * DH + c];
+    }
+    __syncthreads();
+    const float sq = sqrtf((float)DH);
+    if (i < L) {
+        float q[DH], g[DH];
+#pragma unroll
+        for (int c = 0; c < DH; ++c) { q[c] = Qs[i * LD + c]; g[c] = Gs[i * LD + c]; }
+        float mx = -INFINITY;
+        for (int j = 0; j < L; ++j) {
+            float s = 0.f;
+#pragma unroll
+            for (int c = 0; c < DH; ++c) s = fmaf(q[c], Ks[j * LD + c], s);
+            s = s / sq;
+            if (key_mask != nullptr) s += (key_mask[(size_t)b * L + j] ? 0.0f : 1.0f) * -1e9f;
+            Pm[i * LP + j] = s;
+            mx = fmaxf(mx, s);
+        }
+        float sum = 0.f;
+        for (int j = 0; j < L; ++j) { const float e = expf(Pm[i * LP + j] - mx); Pm[i * LP + j] = e; sum += e; }
+        float delta = 0.f;
+        for (int j = 0; j < L; ++j) {
+            const float pij = Pm[i * LP + j] / sum;
+            float dp = 0.f;
+#pragma unroll
+            for (int c = 0; c < DH; ++c) dp = fmaf(g[c], Vs[j * LD + c], dp);
+            Pm[i * LP + j] = pij; Sm[i * LP + j] = dp;
+            delta = fmaf(pij, dp, delta);
+        }
+        float dq[DH];
+#pragma unroll
+        for (int c = 0; c < DH; ++c) dq[c] = 0.f;
+        for (int j = 0; j < L; ++j) {
+            const float ds = Pm[i * LP + j] * (Sm[i * LP + j] - delta);
+            Sm[i * LP + j] = ds;
+#pragma unroll
+            for (int c = 0; c < DH; ++c) dq[c] = fmaf(ds, Ks[j * LD + c], dq[c]);
+        }
+#pragma unroll
+        for (int c = 0; c < DH; ++c) dqkv[((size_t)b * L + i) * ld + h * DH + c] = dq[c] / sq;
+    }
+    __syncthreads();
+    if (i < L) {                                 // thread = key row j
+        float dk[DH], dv[DH];
+#pragma unroll
+        for (int c = 0; c < DH; ++c) { dk[c] = 0.f; dv[c] = 0.f; }
+        for (int r = 0; r < L; ++r) {
+            const float ds = Sm[r * LP + i], pr = Pm[r * LP + i];
+#pragma unroll
+            for (int c = 0; c < DH; ++c) { dk[c] = fmaf(ds, Qs[r * LD + c], dk[c]); dv[c] = fmaf(pr, Gs[r * LD + c], dv[c]); }
+        }
+#pragma unroll
+        for (int c = 0; c < DH; ++c) {
+            dqkv[((size_t)b * L + i) * ld + D + h * DH + c] = dk[c] / sq;
+            dqkv[((size_t)b * L + i) * ld + 2 * D + h * DH + c] = dv[c];
+        }
+    }
+}
+
+// sums the per-workgroup partials of ln_bwd_kernel ([wg][2][D]) in workgroup order
+static __global__ void __launch_bounds__(256)
+ln_bwd_finish_kernel(const float* __restrict__ partial, const int D, const int wgs, float* __restrict__ dgamma,
+                     float* __restrict__ dbeta, const int accumulate)
+{
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx >= 2 * D) return;
+    const int which = idx / D, c = idx - which * D;
+    float s = 0.f;
+    for (int w = 0; w < wgs; ++w) s += partial[((size_t)w * 2 + which) * D + c];
+    float* out = which == 0 ? dgamma : dbeta;
+    out[c] = accumulate ? out[c] + s : s;
+}
+
+}  // namespace uu3d

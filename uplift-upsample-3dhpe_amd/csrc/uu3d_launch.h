@@ -1,0 +1,106 @@
+// uu3d_launch.h -- host-side launch helpers shared by the ops ABI and the training step.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <algorithm>
+#include "../../include/uu3d.h"
+#include "uu3d_gemm.h"
+#include "uu3d_bwd.h"
+
+namespace uu3d {
+
+constexpr size_t kOpScratchFloats = (size_t)1536 * 4096;
+
+inline int ru(int v, int m) { return (v + m - 1) / m * m; }
+inline int hip_status() { return hipGetLastError() == hipSuccess ? UU3D_OK : UU3D_ERR_HIP; }
+
+// C = A-op x Bt^T with the forward GEMM kernel (64x64 tiles, deterministic split-K when few tiles).
+template <class AL, class EP>
+int launch_gemm(const AL& al, const float* Bt, int M, int N, int K, const EP& ep, float* slab, size_t slab_floats, hipStream_t stream) {
+    const int Kp = ru(K, 32), KT = Kp / 32;
+    const int tiles = ((M + 63) / 64) * ((N + 63) / 64);
+    int slices = 1;
+    if (tiles < 384 && KT >= 8) slices = std::max(1, std::min(KT / 4, (768 + tiles / 2) / tiles));
+    int kps = (KT + slices - 1) / slices;
+    slices = (KT + kps - 1) / kps;
+    const int ldslab = ru(N, 4);
+    if (slices > 1 && (slab == nullptr || (size_t)slices * M * ldslab > slab_floats)) { slices = 1; kps = KT; }
+    const int mt = (M + 63) / 64, nt = (N + 63) / 64;
+    const int grid = ru(mt, 8) * nt;
+    constexpr size_t lds = gemm_lds_bytes(64, 64);
+    if (slices == 1) {
+        hipLaunchKernelGGL((gemm_f32_kernel<64, 64, AL, EP>), dim3(grid, 1), dim3(256), lds, stream, al, Bt, M, N, Kp, mt, nt, KT, ep);
+    } else {
+        EpSlab es{slab, ldslab, (size_t)M * ldslab};
+        hipLaunchKernelGGL((gemm_f32_kernel<64, 64, AL, EpSlab>), dim3(grid, slices), dim3(256), lds, stream, al, Bt, M, N, Kp, mt, nt, kps, es);
+        hipLaunchKernelGGL(splitk_reduce_kernel<EP>, dim3((M * N + 255) / 256), dim3(256), 0, stream, slab, slices,
+                           (size_t)M * ldslab, M, N, ldslab, ep);
+    }
+    return hip_status();
+}
+
+// C[P][Q] = A^T B over R rows, split over R into slabs, combined in order.
+template <class AL, class EP>
+int launch_gemm_tn(const AL& al, const float* B, int ldb, int R, int P, int Q, const EP& ep, float* slab, size_t slab_floats, hipStream_t stream) {
+    const int pt = (P + 63) / 64, qt = (Q + 63) / 64, tiles = pt * qt;
+    const int KT = (R + 31) / 32;
+    int slices = std::max(1, std::min(std::max(KT / 4, 1), (1024 + tiles / 2) / tiles));
+    const int ldslab = ru(Q, 4);
+    while (slices > 1 && (size_t)slices * P * ldslab > slab_floats) --slices;
+    int kps = (KT + slices - 1) / slices;
+    slices = (KT + kps - 1) / kps;
+    if (slices == 1) {
+        hipLaunchKernelGGL((gemm_tn_kernel<AL, EP>), dim3(tiles, 1), dim3(256), 0, stream, al, B, ldb, R, P, Q, pt, qt, KT, ep);
+    } else {
+        EpSlab es{slab, ldslab, (size_t)P * ldslab};
+        hipLaunchKernelGGL((gemm_tn_kernel<AL, EpSlab>), dim3(tiles, slices), dim3(256), 0, stream, al, B, ldb, R, P, Q, pt, qt, kps, es);
+        hipLaunchKernelGGL(splitk_reduce_kernel<EP>, dim3((P * Q + 255) / 256), dim3(256), 0, stream, slab, slices,
+                           (size_t)P * ldslab, P, Q, ldslab, ep);
+    }
+    return hip_status();
+}
+
+inline int launch_colsum(const float* x, int ldx, int R, int C, int period, const uint8_t* mask, int want, float* out,
+                         int accumulate, float* scratch, size_t scratch_floats, hipStream_t stream) {
+    const int P = period > 0 ? period : 1;
+    int slices = std::max(1, std::min(256, R / (64 * P)));
+    while (slices > 1 && (size_t)slices * P * C > scratch_floats) --slices;
+    if ((size_t)slices * P * C > scratch_floats) return UU3D_ERR_WORKSPACE;
+    hipLaunchKernelGGL(colsum_kernel, dim3((C + 63) / 64, slices), dim3(256), 0, stream, x, ldx, R, C, period, mask, want, scratch, slices);
+    hipLaunchKernelGGL(colsum_finish_kernel, dim3((P * C + 255) / 256), dim3(256), 0, stream, scratch, P * C, slices, out, accumulate);
+    return hip_status();
+}
+
+// dgamma/dbeta: written (acc_params == 0) or accumulated.
+inline int launch_ln_bwd(const float* x, const float* dy, const float2* stats, const float* gamma, int ld, int D, int M, float* dx,
+                         int accumulate, float* dgamma, float* dbeta, int acc_params, float* scratch, size_t scratch_floats, hipStream_t stream) {
+    int rpw = 8;
+    int wgs = (M + 4 * rpw - 1) / (4 * rpw);
+    while ((size_t)wgs * 2 * D > scratch_floats) { rpw *= 2; wgs = (M + 4 * rpw - 1) / (4 * rpw); }
+    if (D <= 512) hipLaunchKernelGGL(ln_bwd_kernel<2>, dim3(wgs), dim3(256), 0, stream, x, dy, stats, gamma, ld, D, M, rpw, dx, accumulate, scratch);
+    else hipLaunchKernelGGL(ln_bwd_kernel<4>, dim3(wgs), dim3(256), 0, stream, x, dy, stats, gamma, ld, D, M, rpw, dx, accumulate, scratch);
+    // partial layout [wg][2][D] -> finish over "n = 2*D" with wgs slices; dgamma and dbeta must be adjacent? no: two calls
+    hipLaunchKernelGGL(ln_bwd_finish_kernel, dim3((2 * D + 255) / 256), dim3(256), 0, stream, scratch, D, wgs, dgamma, dbeta, acc_params);
+    return hip_status();
+}
+
+inline int launch_attn_generic(bool backward, const float* qkv, const float* dO, int ld, int D, int B, int L, int H, int dh,
+                               const uint8_t* mask, float* out, int ldo, hipStream_t stream) {
+    const dim3 grid(B * H), block(128);
+    if (dh == 4) {
+        const size_t lds = attn_generic_lds_bytes<4>(L, backward);
+        if (backward) hipLaunchKernelGGL(attn_generic_bwd_kernel<4>, grid, block, lds, stream, qkv, dO, ld, D, L, H, mask, out, ldo);
+        else hipLaunchKernelGGL(attn_generic_fwd_kernel<4>, grid, block, lds, stream, qkv, ld, D, L, H, mask, out, ldo);
+    } else {
+        const size_t lds = attn_generic_lds_bytes<48>(L, backward);
+        if (backward) {
+            static bool done = false;
+            if (!done) { (void)hipFuncSetAttribute((const void*)attn_generic_bwd_kernel<48>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); done = true; }
+            hipLaunchKernelGGL(attn_generic_bwd_kernel<48>, grid, block, lds, stream, qkv, dO, ld, D, L, H, mask, out, ldo);
+        } else {
+            hipLaunchKernelGGL(attn_generic_fwd_kernel<48>, grid, block, lds, stream, qkv, ld, D, L, H, mask, out, ldo);
+        }
+    }
+    return hip_status();
+}
+
+}  // namespace uu3d

@@ -46,7 +46,7 @@ row_stats_kernel(const float* __restrict__ x, const int ld, const int D, const i
 
 // metrics.mpjpe(normalize=False) (common/dataset/metrics.py:13-37), float64 arithmetic on
 // f32 inputs exactly as the reference's numpy call after its astype(np.float64).
-__global__ void __launch_bounds__(256)
+static __global__ void __launch_bounds__(256)
 mpjpe_kernel(const float* __restrict__ pred, const float* __restrict__ gt, const int B, const int J,
              const int root, double* __restrict__ out)
 {
@@ -71,7 +71,7 @@ mpjpe_kernel(const float* __restrict__ pred, const float* __restrict__ gt, const
 // by the strided-input token (u_u_t.py:350, ToDo at :320), so the spatial stack only has to run
 // on this list -- an exact, output-preserving saving.  One workgroup, ascending order, deterministic.
 //   list[0 .. count) = indices of valid frames, count stored in list[total]
-__global__ void __launch_bounds__(1024)
+static __global__ void __launch_bounds__(1024)
 compact_frames_kernel(const uint8_t* __restrict__ mask, const int total, int* __restrict__ list)
 {
     __shared__ int wave_sum[16];

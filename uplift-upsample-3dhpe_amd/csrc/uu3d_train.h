@@ -15,7 +15,7 @@ namespace uu3d {
 // exactly zero distance, as in TensorFlow).
 constexpr int kLossGrid = 1024;
 
-__global__ void __launch_bounds__(256)
+static __global__ void __launch_bounds__(256)
 mpjpe_loss_stage1(const float* __restrict__ pred_full, const float* __restrict__ pred_central,
                   const float* __restrict__ gt3d, const int B, const int N, const int J, const int root,
                   const float gscale_seq, const float gscale_cen,
@@ -53,7 +53,7 @@ mpjpe_loss_stage1(const float* __restrict__ pred_full, const float* __restrict__
     }
 }
 
-__global__ void __launch_bounds__(64)
+static __global__ void __launch_bounds__(64)
 mpjpe_loss_stage2(const float* __restrict__ partial, const float norm_seq, const float norm_cen,
                   const float w_center, const float w_seq, const int has_seq, float* __restrict__ loss_out)
 {
@@ -84,7 +84,7 @@ __device__ __forceinline__ void adamw_one(float& var, float& m, float& v, const 
     var = var - (m * alpha) / (sqrtf(v) + eps);
 }
 
-__global__ void __launch_bounds__(256)
+static __global__ void __launch_bounds__(256)
 adamw_kernel(float* __restrict__ var, float* __restrict__ m, float* __restrict__ v, const float* __restrict__ grad,
              const long long n, const float wd, const float alpha, const float omb1, const float omb2, const float eps)
 {
@@ -109,7 +109,7 @@ adamw_kernel(float* __restrict__ var, float* __restrict__ m, float* __restrict__
 }
 
 // ---- T4: ema -= (1 - decay) * (ema - w) -----------------------------------------------------------
-__global__ void __launch_bounds__(256)
+static __global__ void __launch_bounds__(256)
 ema_kernel(float* __restrict__ ema, const float* __restrict__ w, const long long n, const float one_minus_decay)
 {
     const long long stride = (long long)gridDim.x * 256;
