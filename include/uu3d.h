@@ -193,6 +193,32 @@ int uu3d_adamw_update(float* var_dev, float* m_dev, float* v_dev, const float* g
 /* T4 -- replaces the EMA update of train_step (train.py:502-504): ema -= (1 - decay) * (ema - w). */
 int uu3d_ema_update(float* ema_dev, const float* w_dev, int64_t n, float decay, void* stream);
 
+/*
+ * T2 -- replaces `with tf.GradientTape(): model(..., training=True)` + `tape.gradient(loss, model.trainable_variables)`
+ * (train.py:477-498).  The optimizer owns ONE flat float32 master buffer of all parameters in inventory order,
+ * Keras layouts (uu3d_num_params floats); gradients are returned in a buffer of the same layout.
+ *   uu3d_train_init     uploads the model's current weights into params_dev and builds the device-side operand packs
+ *   uu3d_train_repack   regenerates the packs from params_dev (call after every optimizer step)
+ *   uu3d_train_export   params_dev -> host weights -> inference operands (so uu3d_forward evaluates the trained model)
+ *   uu3d_train_forward_backward: training-mode forward (DropPath, vision_transformer.py:16-43), the loss of
+ *       uu3d_mpjpe_loss, and the full backward pass.
+ *       drop_path_rates[3] = DROP_PATH_RATE (spatial, temporal, strided); per block rate linspace(0, rate, depth)
+ *       drop_path_uniform_dev: U[0,1) draws, layout [spatial blocks][2][B*N] then [temporal blocks][2][B]
+ *                              (two draws per block: attention branch, MLP branch); NULL disables DropPath.
+ *       full_out_dev / central_out_dev may be NULL.  loss_out_dev[3] = {loss, central, sequence}.
+ */
+int64_t uu3d_num_params(const uu3d_model* model);
+int uu3d_train_init(uu3d_model* model, float* params_dev, void* stream);
+int uu3d_train_repack(uu3d_model* model, const float* params_dev, void* stream);
+int uu3d_train_export(uu3d_model* model, const float* params_dev, void* stream);
+size_t uu3d_train_workspace_bytes(const uu3d_model* model, int32_t batch);
+int uu3d_train_forward_backward(uu3d_model* model, const float* params_dev, const float* kp2d_dev,
+                                const uint8_t* stride_mask_dev, const float* gt3d_dev, int32_t batch,
+                                int32_t batch_size_norm, float w_center, float w_seq, int32_t root_index,
+                                const float* drop_path_rates, const float* drop_path_uniform_dev,
+                                float* loss_out_dev, float* full_out_dev, float* central_out_dev,
+                                float* grads_dev, void* workspace_dev, size_t workspace_bytes, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

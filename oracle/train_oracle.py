@@ -80,3 +80,28 @@ def adamw_update(var, m, v, g, lr, wd, beta1, beta2, eps, step):
 def ema_update(ema, w, decay):
     ema, w = np.asarray(ema, f32), np.asarray(w, f32)
     return ema - (f32(1) - f32(decay)) * (ema - w)
+
+
+def train_step_grads(hp, weights, keypoints2d, stride_masks, keypoints3d, root, w_center, w_seq, batch_size_norm,
+                     drop_path_cfg=None, dtype=torch.float64):
+    """Loss and d loss / d weights of train_step (train.py:464-498) by autograd through the forward oracle.
+
+    keypoints2d (B,N,J,2) raw, stride_masks (B,N) bool, keypoints3d (B,N,J,3) absolute.  Returns
+    (dict loss/central/seq, {name: grad ndarray}, full, central).
+    """
+    from oracle import uplift_oracle as O
+    p = {k: torch.tensor(np.asarray(v), dtype=dtype, requires_grad=True) for k, v in weights.items()}
+    x = torch.tensor(np.asarray(keypoints2d), dtype=dtype)
+    if hp["has_strided_input"]:
+        x = x * torch.tensor(np.asarray(stride_masks).astype(np.float64), dtype=dtype)[:, :, None, None]   # train.py:474
+    full, central, _ = O.forward_torch(hp, p, x, stride_masks if hp["has_strided_input"] else None, dtype, drop_path_cfg)
+    gt = torch.tensor(np.asarray(keypoints3d), dtype=dtype)
+    gt = gt - gt[:, :, root:root + 1, :]
+    N, J = gt.shape[1], gt.shape[2]
+    cen = torch.linalg.norm(gt[:, N // 2] - central, dim=-1).sum() / (batch_size_norm * J)
+    seq = torch.linalg.norm(gt - full, dim=-1).sum() / (batch_size_norm * N * J)
+    loss = (w_center * cen) + (w_seq * seq)
+    loss.backward()
+    grads = {k: (v.grad.numpy() if v.grad is not None else np.zeros(v.shape)) for k, v in p.items()}
+    return dict(loss=float(loss.detach()), central=float(cen.detach()), seq=float(seq.detach())), grads, \
+        full.detach().numpy(), central.detach().numpy()

@@ -82,15 +82,26 @@ def mha(p, prefix, x, num_heads, mask=None):
     return out, attn
 
 
-def transformer_block(p, prefix, x, num_heads, activation, mask=None):
-    """vision_transformer.py:176-195, inference (DropPath identity)."""
+def drop_path(x, rate, u):
+    """vision_transformer.py:16-28 with the uniform draw `u` (one per leading-dim sample) given explicitly."""
+    keep = 1.0 - rate
+    gate = torch.floor(u + keep).reshape((-1,) + (1,) * (x.dim() - 1))
+    return (x / keep) * gate
+
+
+def transformer_block(p, prefix, x, num_heads, activation, mask=None, dp=None):
+    """vision_transformer.py:176-195.  dp = (rate, u_attn, u_mlp) in training mode with rate > 0, else None."""
     y = layer_norm(x, p[f"{prefix}/norm1/gamma"], p[f"{prefix}/norm1/beta"], 1e-5)
     y, attn = mha(p, f"{prefix}/attn", y, num_heads, mask)
+    if dp is not None:
+        y = drop_path(y, dp[0], dp[1])
     x = x + y
     z = layer_norm(x, p[f"{prefix}/norm2/gamma"], p[f"{prefix}/norm2/beta"], 1e-5)
     z = dense(z, p[f"{prefix}/mlp/fc1/kernel"], p[f"{prefix}/mlp/fc1/bias"])
     z = activation(z)
     z = dense(z, p[f"{prefix}/mlp/fc2/kernel"], p[f"{prefix}/mlp/fc2/bias"])
+    if dp is not None:
+        z = drop_path(z, dp[0], dp[2])
     x = x + z
     return x, attn
 
@@ -134,7 +145,20 @@ def strided_transformer_block(p, prefix, x, pe, num_heads, stride, pad):
 # the model forward
 # --------------------------------------------------------------------------------------
 def forward(hp, weights, x, stride_mask=None, dtype=torch.float32, return_attention=False):
-    """``UpliftUpsampleTransformer.call`` (u_u_t.py:388-421), ``training=False``.
+    """``UpliftUpsampleTransformer.call`` (u_u_t.py:388-421), ``training=False``; numpy in, numpy out."""
+    p = {k: _t(v, dtype) for k, v in weights.items()}
+    full, central, att_list = forward_torch(hp, p, _t(x, dtype), stride_mask, dtype)
+    full_np = None if full is None else full.numpy()
+    if return_attention:
+        return full_np, central.numpy(), [a.numpy() for a in att_list]
+    return full_np, central.numpy()
+
+
+def forward_torch(hp, p, x, stride_mask=None, dtype=torch.float32, drop_path_cfg=None):
+    """Differentiable core on torch tensors (weights `p` may require grad).
+
+    drop_path_cfg (training mode, vision_transformer.py:31-43): dict(rates=(spatial, temporal, strided),
+    u_spatial (Ls, 2, B*N), u_temporal (Lt, 2, B)) with explicit U[0,1) draws; None = inference.
 
     hp: dict with num_frames, num_keypoints, d_spatial, d_temporal, spatial_depth,
         temporal_depth, strides, paddings, num_heads, has_strided_input,
@@ -142,11 +166,18 @@ def forward(hp, weights, x, stride_mask=None, dtype=torch.float32, return_attent
     x: (B, N, J, 2); stride_mask: (B, N) bool, 1 = real input present.
     Returns (full (B,N,J,3) or None, central (B,J,3)) as numpy arrays of ``dtype``.
     """
-    p = {k: _t(v, dtype) for k, v in weights.items()}
-    x = _t(x, dtype)
     B, N, J, _ = x.shape
     H = hp["num_heads"]
     att_list = []
+
+    def dp_for(stack, i, depth):
+        if drop_path_cfg is None:
+            return None
+        rate = float(np.linspace(0, drop_path_cfg["rates"][stack], depth)[i])
+        if rate == 0:
+            return None                                               # no DropPath layer (vision_transformer.py:170)
+        u = drop_path_cfg["u_spatial" if stack == 0 else "u_temporal"]
+        return (rate, torch.as_tensor(u[i, 0]).to(dtype), torch.as_tensor(u[i, 1]).to(dtype))
 
     # spatial_transformation :313-333
     if hp["spatial_depth"] == 0:
@@ -156,7 +187,7 @@ def forward(hp, weights, x, stride_mask=None, dtype=torch.float32, return_attent
         x = dense(x, p["keypoint_embedding/kernel"], p["keypoint_embedding/bias"])
         x = x + p["spatial_pe/positional_encoding_weights"]
         for i in range(hp["spatial_depth"]):
-            x, _ = transformer_block(p, f"spatial_block_{i + 1}", x, H, gelu_exact)
+            x, _ = transformer_block(p, f"spatial_block_{i + 1}", x, H, gelu_exact, None, dp_for(0, i, hp["spatial_depth"]))
         x = layer_norm(x, p["spatial_norm/gamma"], p["spatial_norm/beta"], 1e-6)
         x = x.reshape(B, N, J * hp["d_spatial"])                        # "(b n) p c -> b n (p c)"
     x = dense(x, p["spatial_to_temporal_fc/kernel"], p["spatial_to_temporal_fc/bias"])
@@ -174,7 +205,7 @@ def forward(hp, weights, x, stride_mask=None, dtype=torch.float32, return_attent
         mask = None
         if hp["has_strided_input"] and i < hp["first_strided_token_attention_layer"]:
             mask = inv[:, None, None, :]                                # :361
-        x, att = transformer_block(p, f"temporal_block_{i + 1}", x, H, torch.relu, mask)
+        x, att = transformer_block(p, f"temporal_block_{i + 1}", x, H, torch.relu, mask, dp_for(1, i, hp["temporal_depth"]))
         att_list.append(att)
 
     full = None
@@ -198,10 +229,7 @@ def forward(hp, weights, x, stride_mask=None, dtype=torch.float32, return_attent
     assert central.shape[1] == 1                                        # einops n=1 at :416
     central = central.reshape(B, J, 3)
 
-    full_np = None if full is None else full.numpy()
-    if return_attention:
-        return full_np, central.numpy(), [a.numpy() for a in att_list]
-    return full_np, central.numpy()
+    return full, central, att_list
 
 
 # --------------------------------------------------------------------------------------

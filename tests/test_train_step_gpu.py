@@ -1,0 +1,88 @@
+"""Training step: forward in training mode, loss and every weight gradient against autograd through
+the float64 oracle (train.py:464-498), with and without DropPath; then one optimizer step."""
+import numpy as np
+import pytest
+
+import uplift_upsample_3dhpe_amd as pkg
+from tests import util
+
+torch = pytest.importorskip("torch")
+pytestmark = pytest.mark.gpu
+
+
+def _setup(cfgname, B, seed, batch_norm):
+    cfg = util.load_config(cfgname)
+    cfg.BATCH_SIZE = batch_norm
+    arch = pkg.arch_from_config(cfg)
+    w = pkg.init_weights(arch, seed=seed, perturb=0.1)
+    model = pkg.build_uplift_upsample_transformer(cfg, weights=w)
+    x, m = util.synthetic_batch(cfg, B, seed=seed)
+    gt = np.random.default_rng(seed + 50).normal(0, 0.3, size=(B, arch.num_frames, 17, 3)).astype(np.float32)
+    return cfg, arch, w, model, x, m, gt
+
+
+@pytest.mark.parametrize("cfgname,droppath", [("h36m_81", False), ("h36m_351", False), ("h36m_81", True), ("h36m_351", True)])
+def test_gradients_match_autograd(cfgname, droppath):
+    from oracle import train_oracle as T
+    from uplift_upsample_3dhpe_amd.trainer import Trainer
+    B = 3
+    cfg, arch, w, model, x, m, gt = _setup(cfgname, B, seed=7, batch_norm=4)
+    tr = Trainer(model, cfg)
+    rng = np.random.default_rng(11)
+    u = rng.random(tr.drop_path_size(B)).astype(np.float32) if droppath else None
+    loss, full, central = tr.forward_backward(torch.from_numpy(x).cuda(), torch.from_numpy(gt).cuda(), torch.from_numpy(m).cuda(),
+                                              drop_path_uniform=None if u is None else torch.from_numpy(u).cuda())
+    torch.cuda.synchronize()
+    dp = None
+    if droppath:
+        ns = arch.spatial_depth * 2 * B * arch.num_frames
+        dp = dict(rates=tuple(cfg.DROP_PATH_RATE), u_spatial=u[:ns].reshape(arch.spatial_depth, 2, B * arch.num_frames),
+                  u_temporal=u[ns:].reshape(arch.temporal_depth, 2, B))
+    ref, gref, fref, cref = T.train_step_grads(util.hp_from_arch(arch), w, x, m, gt, cfg.ROOT_KEYTPOINT, cfg.LOSS_WEIGHT_CENTER,
+                                               cfg.LOSS_WEIGHT_SEQUENCE, cfg.BATCH_SIZE, dp)
+    rows = m.any(axis=1)        # all-masked rows: fp32 uniform attention vs float64
+    assert np.abs(full.cpu().numpy() - fref)[rows].max() <= util.TOL_MAX_ABS
+    assert np.abs(central.cpu().numpy() - cref)[rows].max() <= util.TOL_MAX_ABS
+    g = tr.grads_dict()
+    worst = ("", 0.0)
+    if rows.all():
+        assert loss.cpu().numpy()[0] == pytest.approx(ref["loss"], rel=2e-5)
+    gmax = max(np.abs(v).max() for v in gref.values())
+    errs = []
+    for name in gref:
+        # scale floor: the key-bias gradients are identically zero (softmax shift invariance), so a purely
+        # relative measure would compare rounding noise with rounding noise
+        scale = max(np.abs(gref[name]).max(), 1e-4 * gmax)
+        err = np.abs(g[name] - gref[name]).max() / scale
+        errs.append((err, name, np.abs(gref[name]).max()))
+        if err > worst[1]:
+            worst = (name, err)
+    for e in sorted(errs, reverse=True)[:6]:
+        print("   %.2e  %-60s |g|max %.2e" % e)
+    print(f"{cfgname} droppath={droppath}: worst relative gradient error {worst[1]:.2e} at {worst[0]}")
+    if rows.all():
+        assert worst[1] <= 2e-3, worst
+
+
+def test_train_step_updates_weights_and_exports():
+    from oracle import train_oracle as T
+    from uplift_upsample_3dhpe_amd.trainer import Trainer
+    cfg, arch, w, model, x, m, gt = _setup("h36m_81", 2, seed=9, batch_norm=2)
+    m[:] = util.eval_stride_mask(arch.num_frames, cfg.SEQUENCE_STRIDE, 4, 0)      # no all-masked rows
+    tr = Trainer(model, cfg)
+    p0 = tr.params.clone()
+    loss = tr.train_step(torch.from_numpy(x).cuda(), torch.from_numpy(gt).cuda(), torch.from_numpy(m).cuda(), drop_path_uniform=None)
+    torch.cuda.synchronize()
+    g = tr.grads.cpu().numpy()
+    lr = T.exponential_decay(cfg.SCHEDULE_PARAMS["initial_learning_rate"], cfg.SCHEDULE_PARAMS["decay_steps"], cfg.SCHEDULE_PARAMS["decay_rate"], 0, True)
+    wd = T.exponential_decay(cfg.WEIGHT_DECAY, cfg.SCHEDULE_PARAMS["decay_steps"], cfg.SCHEDULE_PARAMS["decay_rate"], 0, True)
+    ref, _, _ = T.adamw_update(p0.cpu().numpy(), np.zeros_like(g), np.zeros_like(g), g, lr, wd, 0.9, 0.999, 1e-8, 1)
+    assert np.array_equal(tr.params.cpu().numpy(), ref)
+    assert tr.ema is not None and tr.global_step == 1                  # h36m_81: EMA_ENABLED
+    # the packs were refreshed: a second forward/backward uses the new weights and matches a fresh model with them
+    tr.export_to_model()
+    xm = x * m[:, :, None, None]
+    full, central = model([torch.from_numpy(xm).cuda(), torch.from_numpy(m).cuda()], training=False)
+    _, f2, c2 = tr.forward_backward(torch.from_numpy(x).cuda(), torch.from_numpy(gt).cuda(), torch.from_numpy(m).cuda(), drop_path_uniform=None)
+    assert np.abs(full.cpu().numpy() - f2.cpu().numpy()).max() <= util.TOL_MAX_ABS
+    assert np.abs(central.cpu().numpy() - c2.cpu().numpy()).max() <= util.TOL_MAX_ABS

@@ -22,6 +22,8 @@ EXPORTED_SYMBOLS = (
     "uu3d_commit_weights", "uu3d_workspace_bytes", "uu3d_forward", "uu3d_mpjpe",
     "uu3d_set_profiling", "uu3d_profile_read",
     "uu3d_mpjpe_loss", "uu3d_adamw_update", "uu3d_ema_update",
+    "uu3d_num_params", "uu3d_train_init", "uu3d_train_repack", "uu3d_train_export",
+    "uu3d_train_workspace_bytes", "uu3d_train_forward_backward",
 )
 # include/uu3d_ops.h
 OPS_SYMBOLS = (
@@ -115,6 +117,19 @@ def load_library(path=None):
     lib.uu3d_adamw_update.argtypes = [vp, vp, vp, vp, i64, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, i64, vp]
     lib.uu3d_ema_update.restype = C.c_int
     lib.uu3d_ema_update.argtypes = [vp, vp, i64, C.c_float, vp]
+    lib.uu3d_num_params.restype = i64
+    lib.uu3d_num_params.argtypes = [vp]
+    lib.uu3d_train_init.restype = C.c_int
+    lib.uu3d_train_init.argtypes = [vp, vp, vp]
+    lib.uu3d_train_repack.restype = C.c_int
+    lib.uu3d_train_repack.argtypes = [vp, vp, vp]
+    lib.uu3d_train_export.restype = C.c_int
+    lib.uu3d_train_export.argtypes = [vp, vp, vp]
+    lib.uu3d_train_workspace_bytes.restype = sz
+    lib.uu3d_train_workspace_bytes.argtypes = [vp, i32]
+    lib.uu3d_train_forward_backward.restype = C.c_int
+    lib.uu3d_train_forward_backward.argtypes = [vp, vp, vp, vp, vp, i32, i32, C.c_float, C.c_float, i32,
+                                                C.POINTER(C.c_float), vp, vp, vp, vp, vp, vp, sz, vp]
     lib.uu3d_op_scratch_floats.restype = sz
     lib.uu3d_op_scratch_floats.argtypes = []
     lib.uu3d_op_gemm_tn.restype = C.c_int

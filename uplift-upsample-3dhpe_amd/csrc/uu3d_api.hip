@@ -29,6 +29,9 @@
 #include "uu3d_spatial.h"
 #include "uu3d_misc.h"
 #include "uu3d_train.h"
+#include "uu3d_bwd.h"
+#include "uu3d_launch.h"
+#include "uu3d_train_kernels.h"
 
 using namespace uu3d;
 
@@ -66,8 +69,10 @@ struct ProfRec {
 
 }  // namespace
 
+struct uu3d_train_state;
 struct uu3d_model {
     uu3d_config cfg;
+    uu3d_train_state* ts = nullptr;   // training packs (uu3d_train_init)
     int device = 0;
     std::vector<WeightRec> weights;
     std::map<std::string, int> index;
@@ -272,9 +277,11 @@ int uu3d_create(const uu3d_config* c, int device, uu3d_model** out) {
     return UU3D_OK;
 }
 
+static void train_free(uu3d_model* m);
 void uu3d_destroy(uu3d_model* m) {
     if (!m) return;
     (void)hipSetDevice(m->device);
+    train_free(m);
     if (m->arena) (void)hipFree(m->arena);
     for (auto& r : m->prof) { (void)hipEventDestroy(r.e0); (void)hipEventDestroy(r.e1); }
     delete m;
@@ -805,3 +812,5 @@ int uu3d_ema_update(float* ema, const float* w, int64_t n, float decay, void* st
     hipLaunchKernelGGL(ema_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, ema, w, (long long)n, 1.0f - decay);
     return hipGetLastError() == hipSuccess ? UU3D_OK : UU3D_ERR_HIP;
 }
+
+#include "uu3d_train_step.inc"

@@ -1,0 +1,223 @@
+// uu3d_train_kernels.h -- small kernels, loaders and epilogues used only by the training step
+// (training-mode forward that keeps activations, DropPath, and the backward chain).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <math.h>
+#include "uu3d_gemm.h"
+
+namespace uu3d {
+
+// ---- weight repacking on the device -------------------------------------------------------------
+// The optimizer updates ONE flat master buffer (Keras layouts, inventory order).  The GEMM kernels
+// want k-contiguous, padded operands; this table-driven kernel regenerates every packed operand from
+// the master buffer after each optimizer step (padding stays zero from allocation).
+//   kind 1: forward operand   Bt[(n0 + n) * ld + k]        = W[k][n]      (ld = Kp)
+//   kind 4: backward operand  WK[k * ld + n0 + n]          = W[k][n]      (dX = dY W^T reads rows of W)
+//   kind 5: conv-transpose    WT[c * ld + j * N + n]       = Wc[j][c][n]  (K = 3*C rows (j, c), ld = 3*N)
+struct PackDesc { long long src, dst; int kind, K, N, ld, n0, C; };
+
+static __global__ void __launch_bounds__(256)
+repack_kernel(const float* __restrict__ master, float* __restrict__ arena, const PackDesc* __restrict__ desc,
+              const int* __restrict__ blk_first, const int ndesc)
+{
+    int lo = 0, hi = ndesc - 1;                       // last descriptor whose first block <= blockIdx.x
+    while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (blk_first[mid] <= (int)blockIdx.x) lo = mid; else hi = mid - 1; }
+    const PackDesc d = desc[lo];
+    const long long total = (long long)d.K * d.N;
+    const long long base = (long long)(blockIdx.x - blk_first[lo]) * 1024;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const long long e = base + i * 256 + threadIdx.x;
+        if (e >= total) break;
+        const int k = (int)(e / d.N), n = (int)(e - (long long)k * d.N);
+        const float v = master[d.src + e];
+        long long o;
+        if (d.kind == 1) o = (long long)(d.n0 + n) * d.ld + k;
+        else if (d.kind == 4) o = (long long)k * d.ld + d.n0 + n;
+        else { const int j = k / d.C, c = k - j * d.C; o = (long long)c * d.ld + (long long)j * d.N + n; }
+        arena[d.dst + o] = v;
+    }
+}
+
+// ---- DropPath (vision_transformer.py:16-43): gate = floor(u + keep) per leading-dim sample -------
+static __global__ void __launch_bounds__(256)
+droppath_gate_kernel(const float* __restrict__ u, const int n, const float keep, float* __restrict__ gate)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < n) gate[i] = (u != nullptr) ? floorf(u[i] + keep) : 1.0f;
+}
+
+// ---- elementwise helpers ------------------------------------------------------------------------
+// x0 = kp @ We + be + pe[joint]   (u_u_t.py:321-323), rows = frames * J
+static __global__ void __launch_bounds__(256)
+embed_fwd_kernel(const float* __restrict__ kp, const float* __restrict__ We, const float* __restrict__ be,
+                 const float* __restrict__ pe, const int rows, const int J, const int DS, float* __restrict__ out)
+{
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx >= rows * DS) return;
+    const int r = idx / DS, c = idx - r * DS;
+    const float kx = kp[2 * r], ky = kp[2 * r + 1];
+    out[idx] = (fmaf(ky, We[DS + c], kx * We[c]) + be[c]) + pe[(r % J) * DS + c];
+}
+// T[r][0..DS) = kx * dX0[r], T[r][DS..2DS) = ky * dX0[r]  (column sums give dWe (2, DS))
+static __global__ void __launch_bounds__(256)
+embed_bwd_prep_kernel(const float* __restrict__ kp, const float* __restrict__ dx0, const int rows, const int DS, float* __restrict__ T)
+{
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx >= rows * DS) return;
+    const int r = idx / DS, c = idx - r * DS;
+    const float g = dx0[idx];
+    T[(size_t)r * 2 * DS + c] = kp[2 * r] * g;
+    T[(size_t)r * 2 * DS + DS + c] = kp[2 * r + 1] * g;
+}
+// y = LayerNorm(x) written out (spatial_norm, u_u_t.py:329), Keras non-fused formula
+static __global__ void __launch_bounds__(256)
+ln_apply_kernel(const float* __restrict__ x, const float2* __restrict__ stats, const float* __restrict__ g,
+                const float* __restrict__ b, const int rows, const int D, float* __restrict__ y)
+{
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx >= rows * D) return;
+    const int r = idx / D, c = idx - r * D;
+    const float2 s = stats[r];
+    const float inv = s.y * g[c];
+    y[idx] = x[idx] * inv + (b[c] - s.x * inv);
+}
+// out[r][c] = in[r][c] / keep * gate[r / rps]      (DropPath backward; gate == nullptr: plain copy)
+// or, with row_mask: out = in where mask[r] == want else 0   (token blend backward)
+static __global__ void __launch_bounds__(256)
+scale_rows_kernel(const float* __restrict__ in, const int rows, const int D, const float* __restrict__ gate,
+                  const float keep, const int rps, const uint8_t* __restrict__ row_mask, const int want, float* __restrict__ out)
+{
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx >= rows * D) return;
+    const int r = idx / D;
+    float v = in[idx];
+    if (gate != nullptr) v = (v / keep) * gate[r / rps];
+    if (row_mask != nullptr && (int)(row_mask[r] != 0) != want) v = 0.f;
+    out[idx] = v;
+}
+// gradient of the strided block's identity path (trim + MaxPool1D(pool 1, stride s)) as a gather:
+//   dmid[b, r] = dout[b, (r - lo) / s] if (r - lo) % s == 0 and in range, else 0
+static __global__ void __launch_bounds__(256)
+identity_bwd_kernel(const float* __restrict__ dout, const int B, const int L_in, const int L_out, const int stride,
+                    const int lo, const int D, float* __restrict__ dmid)
+{
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx >= B * L_in * D) return;
+    const int row = idx / D, c = idx - row * D;
+    const int b = row / L_in, r = row - b * L_in;
+    const int q = r - lo;
+    float v = 0.f;
+    if (q >= 0 && q % stride == 0 && q / stride < L_out) v = dout[((size_t)b * L_out + q / stride) * D + c];
+    dmid[idx] = v;
+}
+// out[r][0..ldo) = in[r][0..C) followed by zeros   (head gradients: 51 -> 64 columns)
+static __global__ void __launch_bounds__(256)
+pad_cols_kernel(const float* __restrict__ in, const int rows, const int C, const int ldo, float* __restrict__ out)
+{
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx >= rows * ldo) return;
+    const int r = idx / ldo, c = idx - r * ldo;
+    out[idx] = c < C ? in[(size_t)r * C + c] : 0.f;
+}
+// a += b
+static __global__ void __launch_bounds__(256)
+add_inplace_kernel(float* __restrict__ a, const float* __restrict__ b, const long long n)
+{
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) a[i] += b[i];
+}
+
+// ---- loaders / epilogues for the generic GEMM ---------------------------------------------------
+__device__ __forceinline__ float gelu_exact(float h) { return 0.5f * h * (1.0f + erff(h * 0.70710678118654752440f)); }
+__device__ __forceinline__ float gelu_grad(float h) {
+    return 0.5f * (1.0f + erff(h * 0.70710678118654752440f)) + h * 0.39894228040143267794f * expf(-0.5f * h * h);
+}
+// A = gelu(Hpre)  (fc2 input, vision_transformer.py:62-65)
+struct ALoadGelu {
+    const float* __restrict__ A; int lda, M, K;
+    struct Ctx { const float* p; };
+    struct Raw { f32x4 x; };
+    __device__ __forceinline__ Ctx prep(int row) const { Ctx c; c.p = A + (size_t)min(row, M - 1) * lda; return c; }
+    __device__ __forceinline__ Raw issue(const Ctx& c, int k) const { Raw r; r.x = *reinterpret_cast<const f32x4*>(c.p + min(k, K - 4)); return r; }
+    __device__ __forceinline__ f32x4 finish(const Ctx&, int k, const Raw& r) const {
+        f32x4 y;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) y[e] = gelu_exact(r.x[e]);
+        return (k < K) ? y : (f32x4){0.f, 0.f, 0.f, 0.f};
+    }
+};
+// transposed strided conv as a gather GEMM: row (b, src) of dH, k = j * Nn + n reads dz[b, t][n]
+// with t = (src + pad_left - j) / stride when divisible and in range.
+struct ALoadConvT {
+    const float* __restrict__ dz; int Nn, L_in, L_out, stride, pad_left, M, K;   // M = B*L_in, K = 3*Nn
+    struct Ctx { int b, src; };
+    struct Raw { f32x4 x; int ok; };
+    __device__ __forceinline__ Ctx prep(int row) const { const int rc = min(row, M - 1); Ctx c; c.b = rc / L_in; c.src = rc - c.b * L_in; return c; }
+    __device__ __forceinline__ Raw issue(const Ctx& c, int k) const {
+        const int kc = min(k, K - 4);
+        const int j = kc / Nn, n = kc - j * Nn;
+        const int q = c.src + pad_left - j;
+        const int t = q / stride;
+        Raw r;
+        r.ok = (q >= 0) & (q - t * stride == 0) & (t < L_out) & (k < K);
+        const int tc = min(max(t, 0), L_out - 1);
+        r.x = *reinterpret_cast<const f32x4*>(dz + ((size_t)c.b * L_out + tc) * Nn + n);
+        return r;
+    }
+    __device__ __forceinline__ f32x4 finish(const Ctx&, int, const Raw& r) const { return r.ok ? r.x : (f32x4){0.f, 0.f, 0.f, 0.f}; }
+};
+// A rows scaled to zero where the row mask says so (d s2t_out = dX ⊙ m), used by TN/NT through a copy instead.
+
+// out = xin + ((acc + bias) / keep) * gate[row / rps]   (residual branch with DropPath, out of place)
+struct EpBiasResGate {
+    float* __restrict__ out; const float* __restrict__ xin; const float* __restrict__ bias; int ld;
+    const float* __restrict__ gate; float keep; int rps;      // gate == nullptr: no DropPath layer
+    float* out2; const float* __restrict__ pe2; int period;   // optional second stream out + pe2[row % period]
+    __device__ __forceinline__ float2 colv(int col) const { return make_float2(bias[col], 0.f); }
+    __device__ __forceinline__ float2 pre(int rowc, int col) const {
+        float2 p; p.x = xin[(size_t)rowc * ld + col];
+        p.y = (out2 != nullptr) ? pe2[(size_t)(rowc % period) * ld + col] : 0.f;
+        return p;
+    }
+    __device__ __forceinline__ void store(int row, int col, float v, float2 cv, float2 p) const {
+        float y = v + cv.x;
+        if (gate != nullptr) y = (y / keep) * gate[row / rps];
+        const float o = p.x + y;
+        out[(size_t)row * ld + col] = o;
+        if (out2 != nullptr) out2[(size_t)row * ld + col] = o + p.y;
+    }
+};
+struct EpAdd {              // out += acc
+    float* out; int ldo;
+    __device__ __forceinline__ float2 colv(int) const { return make_float2(0.f, 0.f); }
+    __device__ __forceinline__ float2 pre(int rowc, int col) const { return make_float2(out[(size_t)rowc * ldo + col], 0.f); }
+    __device__ __forceinline__ void store(int row, int col, float v, float2, float2 p) const { out[(size_t)row * ldo + col] = p.x + v; }
+};
+struct EpReluMask {         // out = acc * (H > 0)
+    float* __restrict__ out; const float* __restrict__ H; int ldo;
+    __device__ __forceinline__ float2 colv(int) const { return make_float2(0.f, 0.f); }
+    __device__ __forceinline__ float2 pre(int rowc, int col) const { return make_float2(H[(size_t)rowc * ldo + col], 0.f); }
+    __device__ __forceinline__ void store(int row, int col, float v, float2, float2 p) const { out[(size_t)row * ldo + col] = p.x > 0.f ? v : 0.f; }
+};
+struct EpGeluGrad {         // out = acc * gelu'(Hpre)
+    float* __restrict__ out; const float* __restrict__ Hpre; int ldo;
+    __device__ __forceinline__ float2 colv(int) const { return make_float2(0.f, 0.f); }
+    __device__ __forceinline__ float2 pre(int rowc, int col) const { return make_float2(Hpre[(size_t)rowc * ldo + col], 0.f); }
+    __device__ __forceinline__ void store(int row, int col, float v, float2, float2 p) const { out[(size_t)row * ldo + col] = v * gelu_grad(p.x); }
+};
+// TN A-side: gelu(Hpre) rows (dW2 of the spatial MLP)
+struct TnLoadGelu {
+    const float* __restrict__ A; int lda, R, P;
+    __device__ __forceinline__ f32x4 load(int r, int p) const {
+        if (r >= R || p >= P) return (f32x4){0.f, 0.f, 0.f, 0.f};
+        const f32x4 x = *reinterpret_cast<const f32x4*>(A + (size_t)r * lda + p);
+        f32x4 y;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) y[e] = gelu_exact(x[e]);
+        return y;
+    }
+};
+
+}  // namespace uu3d

@@ -1,0 +1,124 @@
+"""Host-side mirror of the reference's train_step (train.py:464-506) over the C-ABI training entry points.
+
+    trainer = Trainer(model, config)                 # uploads the model's weights into a flat master buffer
+    loss = trainer.train_step(kp2d, kp3d, stride_masks, drop_path_uniform=None)   # fwd + bwd + AdamW (+ EMA)
+
+All arithmetic runs in csrc/libuu3d.so (uu3d_train_forward_backward, uu3d_adamw_update, uu3d_ema_update);
+PyTorch holds the device buffers and, with more than one rank, all-reduces the flat gradient over RCCL.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _capi, optim
+
+
+class Trainer(object):
+
+    def __init__(self, model, config, seed=0):
+        import torch
+        self._torch = torch
+        self.model, self.config = model, config
+        self._lib = model._lib
+        lib = self._lib
+        self.n_params = int(lib.uu3d_num_params(model._h))
+        dev = model.device
+        self.params = torch.empty(self.n_params, dtype=torch.float32, device=dev)
+        self.grads = torch.zeros(self.n_params, dtype=torch.float32, device=dev)
+        self.loss = torch.zeros(3, dtype=torch.float32, device=dev)
+        self._ws = None
+        self._ws_batch = 0
+        self._stream = lambda: C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+        _capi.check(lib, lib.uu3d_train_init(model._h, C.c_void_p(self.params.data_ptr()), self._stream()), model._h)
+        sched = optim.scheduler_by_name(config.SCHEDULE)
+        lr = sched(**config.SCHEDULE_PARAMS)
+        if config.OPTIMIZER == "AdamW":
+            wd = sched(**dict(config.SCHEDULE_PARAMS, initial_learning_rate=config.WEIGHT_DECAY))   # train.py:408-411
+        elif config.OPTIMIZER == "Adam":
+            wd = 0.0
+        else:
+            raise ValueError(config.OPTIMIZER)
+        extra = {k: v for k, v in dict(config.OPTIMIZER_PARAMS).items() if k != "amsgrad"}
+        extra.setdefault("epsilon", 1e-8)
+        self.optimizer = optim.AdamW(self.params, weight_decay=wd, learning_rate=lr, **extra)
+        self.ema = self.params.clone() if config.EMA_ENABLED else None
+        self.global_step = 0
+        self._rng = torch.Generator(device=dev)
+        self._rng.manual_seed(seed)
+        self.drop_path_rates = np.asarray(config.DROP_PATH_RATE if isinstance(config.DROP_PATH_RATE, list)
+                                          else [config.DROP_PATH_RATE] * 3, np.float32)
+
+    def _workspace(self, batch):
+        if self._ws is None or batch > self._ws_batch:
+            nbytes = int(self._lib.uu3d_train_workspace_bytes(self.model._h, batch))
+            self._ws = self._torch.empty(nbytes, dtype=self._torch.uint8, device=self.model.device)
+            self._ws_bytes, self._ws_batch = nbytes, batch
+        return self._ws
+
+    def drop_path_size(self, batch):
+        a = self.model.arch
+        return a.spatial_depth * 2 * batch * a.num_frames + a.temporal_depth * 2 * batch
+
+    def forward_backward(self, keypoints2d, keypoints3d, stride_masks, drop_path_uniform="draw"):
+        """Training-mode forward + loss + backward.  Returns (loss[3] tensor, full, central); gradients in self.grads.
+
+        drop_path_uniform: "draw" = fresh U[0,1) draws, None = DropPath disabled, or a flat tensor of draws."""
+        torch = self._torch
+        a, cfg = self.model.arch, self.config
+        B = keypoints2d.shape[0]
+        dev = self.model.device
+        x = keypoints2d.to(device=dev, dtype=torch.float32)
+        m_ptr = None
+        if self.model.has_strided_input:
+            sm = stride_masks.to(device=dev)
+            x = x * sm[:, :, None, None].to(torch.float32)                 # train.py:474
+            sm8 = sm.to(torch.uint8).contiguous()
+            m_ptr = C.c_void_p(sm8.data_ptr())
+        x = x.contiguous()
+        gt = keypoints3d.to(device=dev, dtype=torch.float32).contiguous()
+        if isinstance(drop_path_uniform, str):
+            u = torch.rand(self.drop_path_size(B), generator=self._rng, device=dev, dtype=torch.float32)
+        else:
+            u = drop_path_uniform
+        full = torch.empty((B, a.num_frames, a.num_keypoints, 3), dtype=torch.float32, device=dev)
+        central = torch.empty((B, a.num_keypoints, 3), dtype=torch.float32, device=dev)
+        ws = self._workspace(B)
+        rates = (C.c_float * 3)(*[float(r) for r in self.drop_path_rates])
+        st = self._lib.uu3d_train_forward_backward(
+            self.model._h, C.c_void_p(self.params.data_ptr()), C.c_void_p(x.data_ptr()), m_ptr, C.c_void_p(gt.data_ptr()), B,
+            int(cfg.BATCH_SIZE), float(cfg.LOSS_WEIGHT_CENTER), float(cfg.LOSS_WEIGHT_SEQUENCE), int(cfg.ROOT_KEYTPOINT),
+            rates, None if u is None else C.c_void_p(u.data_ptr()), C.c_void_p(self.loss.data_ptr()),
+            C.c_void_p(full.data_ptr()), C.c_void_p(central.data_ptr()), C.c_void_p(self.grads.data_ptr()),
+            C.c_void_p(ws.data_ptr()), self._ws_bytes, self._stream())
+        _capi.check(self._lib, st, self.model._h)
+        return self.loss, full, central
+
+    def apply_gradients(self):
+        """optimizer.apply_gradients (+ gradient all-reduce over ranks, + EMA), then refresh the operand packs."""
+        import torch.distributed as dist
+        if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+            dist.all_reduce(self.grads, op=dist.ReduceOp.SUM)               # loss normaliser is the GLOBAL batch size
+        self.optimizer.apply_gradients(self.grads)
+        if self.ema is not None:
+            optim.ema_update(self.ema, self.params, optim.ema_decay_value(self.config.EMA_DECAY, self.global_step))
+        _capi.check(self._lib, self._lib.uu3d_train_repack(self.model._h, C.c_void_p(self.params.data_ptr()), self._stream()), self.model._h)
+        self.global_step += 1
+
+    def train_step(self, keypoints2d, keypoints3d, stride_masks, drop_path_uniform="draw"):
+        loss, _, _ = self.forward_backward(keypoints2d, keypoints3d, stride_masks, drop_path_uniform)
+        self.apply_gradients()
+        return loss
+
+    def export_to_model(self, use_ema=False):
+        """Copy the trained (or EMA) weights back into the inference model (val_model, train.py:400-401)."""
+        src = self.ema if (use_ema and self.ema is not None) else self.params
+        _capi.check(self._lib, self._lib.uu3d_train_export(self.model._h, C.c_void_p(src.data_ptr()), self._stream()), self.model._h)
+
+    def grads_dict(self):
+        out, o = {}, 0
+        flat = self.grads.cpu().numpy()
+        for name, shape in self.model._spec:
+            n = int(np.prod(shape))
+            out[name] = flat[o:o + n].reshape(shape)
+            o += n
+        return out
