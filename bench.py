@@ -43,6 +43,60 @@ def cpu_baseline(cfg, arch, weights, x, m, budget_s=12.0):
             "kind": "port", "sample": f"{n} forwards of {nb} sequences, PyTorch-CPU fp32 oracle (oracle/uplift_oracle.py)"}
 
 
+def train_bench(args, world, rank, local_rank, use_dist):
+    """BASELINE config 5: config/h36m_351_pt.json train step on synthetic AMASS-shaped sequences."""
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+    import uplift_upsample_3dhpe_amd as pkg
+    from tests import util
+    from uplift_upsample_3dhpe_amd import harness
+    from uplift_upsample_3dhpe_amd.trainer import Trainer
+    cfgname = args.config if args.config != "h36m_351" else "h36m_351_pt"
+    cfg = util.load_config(cfgname)
+    B = args.batch if args.batch != 128 else 64            # JSON BATCH_SIZE 512 global = 64 per GPU on 8
+    cfg.BATCH_SIZE = B * world                             # loss normaliser = global batch (train.py:482)
+    arch = pkg.arch_from_config(cfg)
+    model = pkg.build_uplift_upsample_transformer(cfg, weights=pkg.init_weights(arch, seed=0), device=f"cuda:{local_rank}")
+    tr = Trainer(model, cfg, seed=100 + rank)
+    rng = np.random.default_rng(3000 + rank)
+    N, J = arch.num_frames, arch.num_keypoints
+    x = torch.from_numpy(rng.uniform(-1, 1, size=(B, N, J, 2)).astype(np.float32)).cuda()
+    gt = torch.from_numpy(rng.normal(0, 0.3, size=(B, N, J, 3)).astype(np.float32)).cuda()
+    m = torch.from_numpy(harness.stride_masks_train(N, cfg.SEQUENCE_STRIDE, cfg.MASK_STRIDE, B, rng, cfg.STRIDE_MASK_RAND_SHIFT)).cuda()
+
+    def sync_all():
+        torch.cuda.synchronize()
+        if use_dist:
+            dist.barrier()
+            torch.cuda.synchronize()
+    for _ in range(args.warmup):
+        tr.train_step(x, gt, m)
+    sync_all()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = tr.train_step(x, gt, m)
+    sync_all()
+    elapsed = time.perf_counter() - t0
+    if use_dist:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    if rank == 0:
+        fl = pkg.flops_per_sequence(arch)["total"] * 3.0       # forward + backward ~ 3x forward GEMM FLOPs
+        seqs = world * B * args.steps
+        print(json.dumps({
+            "metric": "train-sequences/sec", "value": round(seqs / elapsed, 2), "unit": "pose-sequences/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"config/{cfgname}.json train step (fwd+bwd+AdamW), N={N}, J={J}, batch {B}/GPU, "
+                                   f"per-sample mask stride from {cfg.MASK_STRIDE}, DropPath {cfg.DROP_PATH_RATE}",
+                       "global_batch": world * B, "parallelism": f"data-parallel x{world}, flat f32 gradient all-reduce"},
+            "model_tflops_3x_fwd": round(fl * seqs / world / elapsed / 1e12, 2), "loss": float(loss[0].item())}), flush=True)
+    if use_dist:
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -53,6 +107,7 @@ def main():
     ap.add_argument("--mask-stride", type=int, default=None, help="s_in; default = first MASK_STRIDE")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true", help="launch eagerly instead of replaying a hipGraph")
+    ap.add_argument("--mode", default="infer", choices=["infer", "train"], help="train = fwd + bwd + grad all-reduce + AdamW (BASELINE config 5)")
     ap.add_argument("--force-dist", action="store_true", help="initialise the process group even at world size 1 (exercises the RCCL path)")
     args = ap.parse_args()
 
@@ -74,6 +129,8 @@ def main():
             os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT="29533", RANK="0", WORLD_SIZE="1")
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
+    if args.mode == "train":
+        return train_bench(args, world, rank, local_rank, use_dist)
     cfg = util.load_config(args.config)
     arch = pkg.arch_from_config(cfg)
     weights = pkg.init_weights(arch, seed=0)                 # replicated: same seed on every rank

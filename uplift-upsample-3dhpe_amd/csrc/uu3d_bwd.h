@@ -156,14 +156,25 @@ colsum_kernel(const float* __restrict__ X, const int ldx, const int R, const int
         __syncthreads();
     }
 }
+// out[i] (+)= sum_k partial[k * pstride + i], i < n.  Thread (column c of 16, lane q of 16): lane q adds the
+// slices k = q, q+16, ... in order; the 16 lane sums are then added in lane order -> deterministic.
 static __global__ void __launch_bounds__(256)
-colsum_finish_kernel(const float* __restrict__ partial, const int n, const int slices, float* __restrict__ out, const int accumulate)
+reduce_partials_kernel(const float* __restrict__ partial, const int n, const size_t pstride, const int slices,
+                       float* __restrict__ out, const int accumulate)
 {
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= n) return;
-    float s = partial[i];
-    for (int k = 1; k < slices; ++k) s += partial[(size_t)k * n + i];
-    out[i] = accumulate ? out[i] + s : s;
+    __shared__ float red[16][17];
+    const int cl = threadIdx.x & 15, q = threadIdx.x >> 4;
+    const int c = blockIdx.x * 16 + cl;
+    float s = 0.f;
+    if (c < n) for (int k = q; k < slices; k += 16) s += partial[(size_t)k * pstride + c];
+    red[q][cl] = s;
+    __syncthreads();
+    if (q == 0 && c < n) {
+        float t = red[0][cl];
+#pragma unroll
+        for (int k = 1; k < 16; ++k) t += red[k][cl];
+        out[c] = accumulate ? out[c] + t : t;
+    }
 }
 
 // ------------------------------------------------------------------------------------
@@ -171,7 +182,7 @@ colsum_finish_kernel(const float* __restrict__ partial, const int n, const int s
 //   g   = dy * gamma ;  dx = rstd * (g - mean_c(g) - xhat * mean_c(g * xhat))
 //   dgamma = sum_r dy * xhat ; dbeta = sum_r dy
 // One wave per row, RPW rows per wave, 4 waves per workgroup; each workgroup writes its partial
-// dgamma / dbeta to partial[wg][2][D]; colsum_finish_kernel adds them in order (deterministic).
+// dgamma / dbeta to partial[wg][2][D]; reduce_partials_kernel adds them in a fixed order (deterministic).
 // dx is written, or added to dx_out when accumulate != 0 (residual-stream gradient).
 // ------------------------------------------------------------------------------------
 template <int MAXV>
@@ -377,20 +388,6 @@ attn_generic_bwd_kernel(const float* __restrict__ qkv, const float* __restrict__
             dqkv[((size_t)b * L + i) * ld + 2 * D + h * DH + c] = dv[c];
         }
     }
-}
-
-// sums the per-workgroup partials of ln_bwd_kernel ([wg][2][D]) in workgroup order
-static __global__ void __launch_bounds__(256)
-ln_bwd_finish_kernel(const float* __restrict__ partial, const int D, const int wgs, float* __restrict__ dgamma,
-                     float* __restrict__ dbeta, const int accumulate)
-{
-    const int idx = blockIdx.x * 256 + threadIdx.x;
-    if (idx >= 2 * D) return;
-    const int which = idx / D, c = idx - which * D;
-    float s = 0.f;
-    for (int w = 0; w < wgs; ++w) s += partial[((size_t)w * 2 + which) * D + c];
-    float* out = which == 0 ? dgamma : dbeta;
-    out[c] = accumulate ? out[c] + s : s;
 }
 
 }  // namespace uu3d

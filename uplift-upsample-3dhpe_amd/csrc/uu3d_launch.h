@@ -43,7 +43,7 @@ template <class AL, class EP>
 int launch_gemm_tn(const AL& al, const float* B, int ldb, int R, int P, int Q, const EP& ep, float* slab, size_t slab_floats, hipStream_t stream) {
     const int pt = (P + 63) / 64, qt = (Q + 63) / 64, tiles = pt * qt;
     const int KT = (R + 31) / 32;
-    int slices = std::max(1, std::min(std::max(KT / 4, 1), (1024 + tiles / 2) / tiles));
+    int slices = std::max(1, std::min(std::min(std::max(KT / 4, 1), 48), (1024 + tiles / 2) / tiles));   // <= 48 slabs: the ordered combine is serial
     const int ldslab = ru(Q, 4);
     while (slices > 1 && (size_t)slices * P * ldslab > slab_floats) --slices;
     int kps = (KT + slices - 1) / slices;
@@ -62,24 +62,25 @@ int launch_gemm_tn(const AL& al, const float* B, int ldb, int R, int P, int Q, c
 inline int launch_colsum(const float* x, int ldx, int R, int C, int period, const uint8_t* mask, int want, float* out,
                          int accumulate, float* scratch, size_t scratch_floats, hipStream_t stream) {
     const int P = period > 0 ? period : 1;
-    int slices = std::max(1, std::min(256, R / (64 * P)));
+    int slices = std::max(1, std::min(256, R / std::max(128, P)));      // >= 128 rows (and one period) per workgroup
     while (slices > 1 && (size_t)slices * P * C > scratch_floats) --slices;
     if ((size_t)slices * P * C > scratch_floats) return UU3D_ERR_WORKSPACE;
     hipLaunchKernelGGL(colsum_kernel, dim3((C + 63) / 64, slices), dim3(256), 0, stream, x, ldx, R, C, period, mask, want, scratch, slices);
-    hipLaunchKernelGGL(colsum_finish_kernel, dim3((P * C + 255) / 256), dim3(256), 0, stream, scratch, P * C, slices, out, accumulate);
+    hipLaunchKernelGGL(reduce_partials_kernel, dim3((P * C + 15) / 16), dim3(256), 0, stream, scratch, P * C, (size_t)P * C, slices, out, accumulate);
     return hip_status();
 }
 
 // dgamma/dbeta: written (acc_params == 0) or accumulated.
 inline int launch_ln_bwd(const float* x, const float* dy, const float2* stats, const float* gamma, int ld, int D, int M, float* dx,
                          int accumulate, float* dgamma, float* dbeta, int acc_params, float* scratch, size_t scratch_floats, hipStream_t stream) {
-    int rpw = 8;
+    int rpw = std::max(8, (M + 4 * 512 - 1) / (4 * 512));         // at most ~512 partial rows to combine
     int wgs = (M + 4 * rpw - 1) / (4 * rpw);
     while ((size_t)wgs * 2 * D > scratch_floats) { rpw *= 2; wgs = (M + 4 * rpw - 1) / (4 * rpw); }
     if (D <= 512) hipLaunchKernelGGL(ln_bwd_kernel<2>, dim3(wgs), dim3(256), 0, stream, x, dy, stats, gamma, ld, D, M, rpw, dx, accumulate, scratch);
     else hipLaunchKernelGGL(ln_bwd_kernel<4>, dim3(wgs), dim3(256), 0, stream, x, dy, stats, gamma, ld, D, M, rpw, dx, accumulate, scratch);
     // partial layout [wg][2][D] -> finish over "n = 2*D" with wgs slices; dgamma and dbeta must be adjacent? no: two calls
-    hipLaunchKernelGGL(ln_bwd_finish_kernel, dim3((2 * D + 255) / 256), dim3(256), 0, stream, scratch, D, wgs, dgamma, dbeta, acc_params);
+    hipLaunchKernelGGL(reduce_partials_kernel, dim3((D + 15) / 16), dim3(256), 0, stream, scratch, D, (size_t)2 * D, wgs, dgamma, acc_params);
+    hipLaunchKernelGGL(reduce_partials_kernel, dim3((D + 15) / 16), dim3(256), 0, stream, scratch + D, D, (size_t)2 * D, wgs, dbeta, acc_params);
     return hip_status();
 }
 

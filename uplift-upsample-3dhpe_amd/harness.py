@@ -18,6 +18,24 @@ def stride_mask_eval(num_frames, seq_stride, mask_stride, frame_index):
     return np.equal(idx % mask_stride, 0)
 
 
+def stride_masks_train(num_frames, seq_stride, mask_strides, batch, rng, rand_shift=True):
+    """Training-mode stride masks: per sample an absolute mask stride drawn from MASK_STRIDE
+    (uplifiting_dataset.py:329-337) and a random shift of the mask grid (:386-392); 1 = real input."""
+    if not isinstance(mask_strides, (list, tuple)):
+        mask_strides = [mask_strides]
+    mid = num_frames // 2
+    out = np.zeros((batch, num_frames), bool)
+    for b in range(batch):
+        ams = int(mask_strides[rng.integers(0, len(mask_strides))]) if len(mask_strides) > 1 else int(mask_strides[0])
+        r = ams // seq_stride
+        idx = (np.arange(num_frames) - mid) * seq_stride
+        if rand_shift:
+            max_shift = int(np.ceil((r - 1) / 2))
+            idx = idx + int(rng.integers(-max_shift, max_shift, endpoint=(r % 2 != 0))) * seq_stride
+        out[b] = np.equal(idx % ams, 0)
+    return out
+
+
 def per_joint_error(pred, gt, root_index, out=None):
     """pred (B,J,3) f32, gt (B,J,4) f32 [x,y,z,valid] on the GPU -> (B,J) f64 metres, -1 = invalid."""
     import torch
