@@ -52,3 +52,29 @@ def test_allgather_errors_gloo_world2(global_batch):
     for rank, out, mean_mm in res:
         assert np.array_equal(out, table)                 # rank order, ragged shards, bit-exact
         assert mean_mm == pytest.approx(expect, rel=1e-12)
+
+
+def _grad_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    g = torch.full((1000,), float(rank + 1))
+    ud.allreduce_gradients(g)
+    q.put((rank, g.numpy().copy()))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_allreduce_gradients_gloo_world2():
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_grad_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for _, g in res:
+        assert np.all(g == 3.0)                           # 1 + 2 on every rank, no rescale
+    assert ud.allreduce_gradients(torch.ones(3)).sum() == 3    # no process group: identity

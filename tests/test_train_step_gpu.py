@@ -86,3 +86,20 @@ def test_train_step_updates_weights_and_exports():
     _, f2, c2 = tr.forward_backward(torch.from_numpy(x).cuda(), torch.from_numpy(gt).cuda(), torch.from_numpy(m).cuda(), drop_path_uniform=None)
     assert np.abs(full.cpu().numpy() - f2.cpu().numpy()).max() <= util.TOL_MAX_ABS
     assert np.abs(central.cpu().numpy() - c2.cpu().numpy()).max() <= util.TOL_MAX_ABS
+
+
+def test_shard_gradients_add_up_to_full_batch_gradient():
+    """Data parallelism: with the loss normalised by the GLOBAL batch size, the gradients of two half
+    batches sum to the gradient of the whole batch (what the RCCL all-reduce computes)."""
+    from uplift_upsample_3dhpe_amd.trainer import Trainer
+    cfg, arch, w, model, x, m, gt = _setup("h36m_81", 4, seed=13, batch_norm=4)
+    tr = Trainer(model, cfg)
+    T = lambda a: torch.from_numpy(a).cuda()
+    tr.forward_backward(T(x), T(gt), T(m), drop_path_uniform=None)
+    g_full = tr.grads.clone()
+    tr.forward_backward(T(x[:2]), T(gt[:2]), T(m[:2]), drop_path_uniform=None)
+    g_a = tr.grads.clone()
+    tr.forward_backward(T(x[2:]), T(gt[2:]), T(m[2:]), drop_path_uniform=None)
+    g_sum = (g_a + tr.grads).cpu().numpy()
+    ref = g_full.cpu().numpy()
+    assert np.abs(g_sum - ref).max() <= 2e-5 * np.abs(ref).max()

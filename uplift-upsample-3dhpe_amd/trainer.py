@@ -95,9 +95,8 @@ class Trainer(object):
 
     def apply_gradients(self):
         """optimizer.apply_gradients (+ gradient all-reduce over ranks, + EMA), then refresh the operand packs."""
-        import torch.distributed as dist
-        if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
-            dist.all_reduce(self.grads, op=dist.ReduceOp.SUM)               # loss normaliser is the GLOBAL batch size
+        from .dist import allreduce_gradients
+        allreduce_gradients(self.grads)                                      # loss normaliser is the GLOBAL batch size
         self.optimizer.apply_gradients(self.grads)
         if self.ema is not None:
             optim.ema_update(self.ema, self.params, optim.ema_decay_value(self.config.EMA_DECAY, self.global_step))
