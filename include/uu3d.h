@@ -44,7 +44,10 @@ typedef enum uu3d_status {
 
 /* Arithmetic the GEMM-shaped work is carried out in. */
 typedef enum uu3d_precision {
-    UU3D_PREC_F32 = 0      /* f32-input MFMA (v_mfma_f32_32x32x2_f32 / 16x16x4_f32), exact f32 */
+    UU3D_PREC_F32 = 0,     /* f32-input MFMA (v_mfma_f32_32x32x2_f32 / 16x16x4_f32), exact f32 */
+    UU3D_PREC_F16X3 = 1    /* forward GEMMs as 3 f16 MFMA passes on hi/lo-split operands: f32-grade error,
+                              f16-rate matrix pipe (csrc/uu3d_gemm_h3.h).  Attention, spatial stack, LayerNorm,
+                              softmax and every epilogue stay f32.  Training always runs UU3D_PREC_F32. */
 } uu3d_precision;
 
 /*

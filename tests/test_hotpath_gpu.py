@@ -16,11 +16,11 @@ pytestmark = pytest.mark.gpu
 GOLDEN = sorted(glob.glob(os.path.join(util.ROOT, "tests", "golden", "*.npz")))
 
 
-def _model(cfgname, seed=0, perturb=0.1):
+def _model(cfgname, seed=0, perturb=0.1, precision="f16x3"):
     cfg = util.load_config(cfgname)
     arch = pkg.arch_from_config(cfg)
     w = pkg.init_weights(arch, seed=seed, perturb=perturb)
-    return cfg, arch, w, pkg.build_uplift_upsample_transformer(cfg, weights=w)
+    return cfg, arch, w, pkg.build_uplift_upsample_transformer(cfg, weights=w, precision=precision)
 
 
 def _call(model, x, m):
@@ -29,11 +29,12 @@ def _call(model, x, m):
     return full.cpu().numpy(), cen.cpu().numpy()
 
 
+@pytest.mark.parametrize("precision", ["f32", "f16x3"])
 @pytest.mark.parametrize("path", GOLDEN, ids=[os.path.basename(p) for p in GOLDEN])
-def test_golden_fixtures(path):
+def test_golden_fixtures(path, precision):
     """Committed oracle vectors (tests/golden/make_golden.py); tolerance = north_star's 1e-4 max-abs."""
     g = np.load(path)
-    cfg, arch, w, model = _model(str(g["config"]), int(g["seed"]), float(g["perturb"]))
+    cfg, arch, w, model = _model(str(g["config"]), int(g["seed"]), float(g["perturb"]), precision)
     full, cen = _call(model, g["x"], g["mask"])
     assert np.abs(full - g["full_f32"]).max() <= util.TOL_MAX_ABS
     assert np.abs(cen - g["central_f32"]).max() <= util.TOL_MAX_ABS

@@ -9,8 +9,8 @@ torch = pytest.importorskip("torch")
 pytestmark = pytest.mark.gpu
 
 
-def _run_hip(cfg, weights, x, m):
-    model = pkg.build_uplift_upsample_transformer(cfg, weights=weights)
+def _run_hip(cfg, weights, x, m, precision):
+    model = pkg.build_uplift_upsample_transformer(cfg, weights=weights, precision=precision)
     xm = x * m[:, :, None, None].astype(np.float32)          # caller zeroes masked frames (eval.py:67)
     xt = torch.from_numpy(xm).cuda()
     mt = torch.from_numpy(m).cuda()
@@ -21,13 +21,14 @@ def _run_hip(cfg, weights, x, m):
 
 @pytest.mark.parametrize("cfgname", ["h36m_351", "h36m_81"])
 @pytest.mark.parametrize("seed", [0, 1, 2])
-def test_forward_matches_oracle(cfgname, seed):
+@pytest.mark.parametrize("precision", ["f32", "f16x3"])
+def test_forward_matches_oracle(cfgname, seed, precision):
     from oracle import uplift_oracle as O
     cfg = util.load_config(cfgname)
     arch = pkg.arch_from_config(cfg)
     w = pkg.init_weights(arch, seed=seed, perturb=0.1)
     x, m = util.synthetic_batch(cfg, batch=6, seed=seed)
-    full, central, xm = _run_hip(cfg, w, x, m)
+    full, central, xm = _run_hip(cfg, w, x, m, precision)
     hp = util.hp_from_arch(arch)
     f32, c32 = O.forward(hp, w, xm, m, torch.float32)
     f64, c64 = O.forward(hp, w, xm, m, torch.float64)
@@ -38,6 +39,6 @@ def test_forward_matches_oracle(cfgname, seed):
     # -1e9 (uniform attention), which float64 does not reproduce.  fp32 is the reference.
     rows = m.any(axis=1)
     err64 = max(np.abs(full - f64)[rows].max(), np.abs(central - c64)[rows].max())
-    print(f"{cfgname} seed {seed}: max-abs vs oracle f32 {err32:.3e}, vs f64 {err64:.3e}")
+    print(f"{cfgname} seed {seed} {precision}: max-abs vs oracle f32 {err32:.3e}, vs f64 {err64:.3e}")
     assert err32 <= util.TOL_MAX_ABS
     assert err64 <= util.TOL_MAX_ABS

@@ -11,6 +11,7 @@ LIB_PATH = os.path.join(_HERE, "csrc", "libuu3d.so")
 
 UU3D_MAX_STRIDED = 8
 UU3D_PREC_F32 = 0
+UU3D_PREC_F16X3 = 1
 
 (UU3D_OK, UU3D_ERR_INVALID_ARGUMENT, UU3D_ERR_UNSUPPORTED, UU3D_ERR_SHAPE, UU3D_ERR_NOT_READY,
  UU3D_ERR_WORKSPACE, UU3D_ERR_HIP, UU3D_ERR_NO_DEVICE) = range(8)

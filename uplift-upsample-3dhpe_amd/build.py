@@ -10,7 +10,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(CSRC, "libuu3d.so")
 SOURCES = ["uu3d_api.hip", "uu3d_ops.hip"]
-HEADERS = ["uu3d_gemm.h", "uu3d_attn.h", "uu3d_spatial.h", "uu3d_misc.h", "uu3d_train.h", "uu3d_bwd.h", "uu3d_launch.h", "uu3d_train_kernels.h", "uu3d_train_step.inc", os.path.join("..", "..", "include", "uu3d_ops.h"), os.path.join("..", "..", "include", "uu3d.h")]
+HEADERS = ["uu3d_gemm.h", "uu3d_gemm_h3.h", "uu3d_attn.h", "uu3d_spatial.h", "uu3d_misc.h", "uu3d_train.h", "uu3d_bwd.h", "uu3d_launch.h", "uu3d_train_kernels.h", "uu3d_train_step.inc", os.path.join("..", "..", "include", "uu3d_ops.h"), os.path.join("..", "..", "include", "uu3d.h")]
 
 
 def _stale():
@@ -20,16 +20,31 @@ def _stale():
     return any(os.path.getmtime(os.path.join(CSRC, f)) > t for f in SOURCES + HEADERS)
 
 
+# Packed fp32 VALU ops (v_pk_mul_f32 / v_pk_fma_f32 / v_pk_add_f32) are turned OFF for the device code.
+# Measured on MI355X with ROCm 7.2: with them on, the LayerNorm prologue of the f16x3
+# GEMM came out as v_pk_mul_f32 / v_pk_fma_f32 with op_sel broadcasts from a VGPR pair, and the low half of
+# the result was intermittently 0 in lanes 48-63 -- whole output rows wrong by O(1), different on every run.
+# Without the feature the same source is bit-reproducible (tools/gemm_bench DET=1: 0 mismatches in 32 of 32
+# configurations against 19 of 32 failing) and the forward pass costs 1-3 %.
+DEVICE_FLAGS = ["-Xclang", "-target-feature", "-Xclang", "-packed-fp32-ops"]
+_HOST_NOISE = "is not a recognized feature for this target"      # the host half of the compile ignores the feature
+
+
 def build(force=False, verbose=False, extra_flags=()):
     if not force and not _stale():
         return LIB
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     cmd = [hipcc, "-O3", "-std=c++17", "--offload-arch=gfx950", "-shared", "-fPIC",
-           "-Wall", "-Wno-unused-function", *extra_flags,
+           "-Wall", "-Wno-unused-function", *DEVICE_FLAGS, *extra_flags,
            "-o", LIB] + [os.path.join(CSRC, s) for s in SOURCES]
     if verbose:
         print(" ".join(cmd), flush=True)
-    subprocess.run(cmd, check=True, cwd=CSRC)
+    r = subprocess.run(cmd, cwd=CSRC, stderr=subprocess.PIPE, text=True)
+    err = "".join(l for l in r.stderr.splitlines(True) if _HOST_NOISE not in l)
+    if err.strip():
+        sys.stderr.write(err)
+    if r.returncode != 0:
+        raise subprocess.CalledProcessError(r.returncode, cmd)
     return LIB
 
 

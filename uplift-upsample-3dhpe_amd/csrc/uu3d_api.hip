@@ -25,6 +25,7 @@
 
 #include "../../include/uu3d.h"
 #include "uu3d_gemm.h"
+#include "uu3d_gemm_h3.h"
 #include "uu3d_attn.h"
 #include "uu3d_spatial.h"
 #include "uu3d_misc.h"
@@ -80,6 +81,9 @@ struct uu3d_model {
     bool committed = false;
     float* arena = nullptr;        // packed device weights
     size_t arena_floats = 0;
+    _Float16* harena = nullptr;    // f16 hi/lo planes of every GEMM operand (f16x3 mode)
+    size_t harena_halfs = 0;
+    std::map<size_t, std::pair<size_t, size_t>> hplanes;   // Bt float offset -> (hi offset, lo offset) in harena
     // packed views
     SpatialParams sp{};
     const float* sp_blocks_v1 = nullptr;   // VALU kernel layout (kept for A/B runs: UU3D_SPATIAL=valu)
@@ -179,11 +183,13 @@ void build_inventory(uu3d_model* m) {
 // ---- host-side packing ------------------------------------------------------------------
 struct Packer {
     std::vector<float> buf;
+    std::vector<std::pair<size_t, size_t>> dense;  // (offset, floats) of every GEMM operand Bt[Np][Kp]
     size_t alloc(size_t n) {                       // 256-byte aligned segments
         size_t off = align_up(buf.size(), 64);
         buf.resize(off + n, 0.f);
         return off;
     }
+    size_t alloc_dense(size_t n) { const size_t off = alloc(n); dense.emplace_back(off, n); return off; }
 };
 
 const float* W(const uu3d_model* m, const std::string& name) {
@@ -227,7 +233,7 @@ int uu3d_create(const uu3d_config* c, int device, uu3d_model** out) {
     *out = nullptr;
     if (c->num_frames < 1 || c->num_keypoints < 1 || c->num_strided < 0 || c->num_strided > UU3D_MAX_STRIDED)
         return fail(nullptr, UU3D_ERR_INVALID_ARGUMENT, "bad num_frames/num_keypoints/num_strided");
-    if (c->precision != UU3D_PREC_F32) return fail(nullptr, UU3D_ERR_UNSUPPORTED, "only UU3D_PREC_F32 is built");
+    if (c->precision != UU3D_PREC_F32 && c->precision != UU3D_PREC_F16X3) return fail(nullptr, UU3D_ERR_UNSUPPORTED, "unknown precision");
     // limits of the compiled kernels (all shipped configs satisfy them)
     if (c->spatial_depth < 1 || c->num_keypoints != kJ || c->d_spatial != kDS || c->h_spatial != kHS ||
         c->num_heads != kHeads)
@@ -283,6 +289,7 @@ void uu3d_destroy(uu3d_model* m) {
     (void)hipSetDevice(m->device);
     train_free(m);
     if (m->arena) (void)hipFree(m->arena);
+    if (m->harena) (void)hipFree(m->harena);
     for (auto& r : m->prof) { (void)hipEventDestroy(r.e0); (void)hipEventDestroy(r.e1); }
     delete m;
 }
@@ -393,7 +400,7 @@ int uu3d_commit_weights(uu3d_model* m, void* stream_) {
 
     // ---- spatial_to_temporal_fc, token, temporal PE ----
     const int Npdt = round_up(dt, 128);
-    const size_t o_s2t = P.alloc((size_t)Npdt * Ks2t), o_s2tb = P.alloc(Npdt);
+    const size_t o_s2t = P.alloc_dense((size_t)Npdt * Ks2t), o_s2tb = P.alloc(Npdt);
     pack_dense_t(P.buf, o_s2t, W(m, "spatial_to_temporal_fc/kernel"), J * ds, dt, Ks2t, 0);
     std::copy_n(W(m, "spatial_to_temporal_fc/bias"), dt, P.buf.begin() + o_s2tb);
     const size_t o_tok = P.alloc(dt);
@@ -410,7 +417,7 @@ int uu3d_commit_weights(uu3d_model* m, void* stream_) {
         std::copy_n(W(m, p + "/norm1/gamma"), dt, P.buf.begin() + o.ln1_g);
         std::copy_n(W(m, p + "/norm1/beta"), dt, P.buf.begin() + o.ln1_b);
         const int Npq = round_up(3 * dt, 128);
-        o.wqkv = P.alloc((size_t)Npq * Kdt); o.bqkv = P.alloc(Npq);
+        o.wqkv = P.alloc_dense((size_t)Npq * Kdt); o.bqkv = P.alloc(Npq);
         int part = 0;
         for (const char* nm : {"wq", "wk", "wv"}) {
             pack_dense_t(P.buf, o.wqkv, W(m, p + "/attn/" + nm + "/kernel"), dt, dt, Kdt, part * dt);
@@ -418,26 +425,26 @@ int uu3d_commit_weights(uu3d_model* m, void* stream_) {
             if (b) std::copy_n(b, dt, P.buf.begin() + o.bqkv + part * dt);
             ++part;
         }
-        o.wp = P.alloc((size_t)Npdt * Kdt); o.bp = P.alloc(Npdt);
+        o.wp = P.alloc_dense((size_t)Npdt * Kdt); o.bp = P.alloc(Npdt);
         pack_dense_t(P.buf, o.wp, W(m, p + "/attn/projection/kernel"), dt, dt, Kdt, 0);
         std::copy_n(W(m, p + "/attn/projection/bias"), dt, P.buf.begin() + o.bp);
         o.ln2_g = P.alloc(dt); o.ln2_b = P.alloc(dt);
         std::copy_n(W(m, p + "/norm2/gamma"), dt, P.buf.begin() + o.ln2_g);
         std::copy_n(W(m, p + "/norm2/beta"), dt, P.buf.begin() + o.ln2_b);
         const int Nph = round_up(ht, 128);
-        o.w1 = P.alloc((size_t)Nph * Kdt); o.b1 = P.alloc(Nph);
+        o.w1 = P.alloc_dense((size_t)Nph * Kdt); o.b1 = P.alloc(Nph);
         pack_dense_t(P.buf, o.w1, W(m, p + "/mlp/fc1/kernel"), dt, ht, Kdt, 0);   // Conv1D k=1 (1,dt,ht) has the same flat layout
         std::copy_n(W(m, p + "/mlp/fc1/bias"), ht, P.buf.begin() + o.b1);
         if (strided) {
             const int Kc = round_up(3 * ht, 32);
-            o.w2 = P.alloc((size_t)Npdt * Kc); o.b2 = P.alloc(Npdt);
+            o.w2 = P.alloc_dense((size_t)Npdt * Kc); o.b2 = P.alloc(Npdt);
             // Conv1D kernel (3, ht, dt): flat (j*ht + c, n) is exactly a Dense kernel of K = 3*ht
             pack_dense_t(P.buf, o.w2, W(m, p + "/mlp/strided_conv/kernel"), 3 * ht, dt, Kc, 0);
             std::copy_n(W(m, p + "/mlp/strided_conv/bias"), dt, P.buf.begin() + o.b2);
             o.pe = P.alloc((size_t)peL * dt);
             std::copy_n(W(m, pe_name), (size_t)peL * dt, P.buf.begin() + o.pe);
         } else {
-            o.w2 = P.alloc((size_t)Npdt * Kht); o.b2 = P.alloc(Npdt);
+            o.w2 = P.alloc_dense((size_t)Npdt * Kht); o.b2 = P.alloc(Npdt);
             pack_dense_t(P.buf, o.w2, W(m, p + "/mlp/fc2/kernel"), ht, dt, Kht, 0);
             std::copy_n(W(m, p + "/mlp/fc2/bias"), dt, P.buf.begin() + o.b2);
         }
@@ -455,11 +462,11 @@ int uu3d_commit_weights(uu3d_model* m, void* stream_) {
     size_t o_h1 = 0, o_h1b = 0;
     const bool has_h1 = c.full_output && c.temporal_depth > 0;
     if (has_h1) {
-        o_h1 = P.alloc((size_t)Nph * Kdt); o_h1b = P.alloc(Nph);
+        o_h1 = P.alloc_dense((size_t)Nph * Kdt); o_h1b = P.alloc(Nph);
         pack_dense_t(P.buf, o_h1, W(m, "temporal_fc/kernel"), dt, 3 * J, Kdt, 0);
         std::copy_n(W(m, "temporal_fc/bias"), 3 * J, P.buf.begin() + o_h1b);
     }
-    const size_t o_h2 = P.alloc((size_t)Nph * Kdt), o_h2b = P.alloc(Nph);
+    const size_t o_h2 = P.alloc_dense((size_t)Nph * Kdt), o_h2b = P.alloc(Nph);
     pack_dense_t(P.buf, o_h2, W(m, "strided_temporal_fc/kernel"), dt, 3 * J, Kdt, 0);
     std::copy_n(W(m, "strided_temporal_fc/bias"), 3 * J, P.buf.begin() + o_h2b);
 
@@ -472,6 +479,29 @@ int uu3d_commit_weights(uu3d_model* m, void* stream_) {
     }
     HIPCHK(m, hipMemcpyAsync(m->arena, P.buf.data(), P.buf.size() * sizeof(float), hipMemcpyHostToDevice, stream));
     HIPCHK(m, hipStreamSynchronize(stream));
+    if (c.precision == UU3D_PREC_F16X3) {
+        // split every GEMM operand into f16 hi / (lo * 2048) planes (uu3d_gemm_h3.h)
+        std::vector<_Float16> hb;
+        m->hplanes.clear();
+        for (auto& d : P.dense) {
+            const size_t hi = align_up(hb.size(), 64); hb.resize(hi + d.second);
+            const size_t lo = align_up(hb.size(), 64); hb.resize(lo + d.second);
+            for (size_t i = 0; i < d.second; ++i) {
+                const float x = P.buf[d.first + i];
+                const _Float16 h = (_Float16)x;
+                hb[hi + i] = h; hb[lo + i] = (_Float16)((x - (float)h) * H3_SCALE);
+            }
+            m->hplanes[d.first] = {hi, lo};
+        }
+        if (m->harena_halfs < hb.size()) {
+            if (m->harena) HIPCHK(m, hipFree(m->harena));
+            m->harena = nullptr;
+            HIPCHK(m, hipMalloc((void**)&m->harena, hb.size() * sizeof(_Float16)));
+            m->harena_halfs = hb.size();
+        }
+        HIPCHK(m, hipMemcpyAsync(m->harena, hb.data(), hb.size() * sizeof(_Float16), hipMemcpyHostToDevice, stream));
+        HIPCHK(m, hipStreamSynchronize(stream));
+    }
 
     const float* A = m->arena;
     m->sp.embed_w = A + o_ew; m->sp.embed_b = A + o_eb; m->sp.pe = A + o_spe; m->sp.blocks = A + o_sblk;
@@ -575,6 +605,17 @@ struct Launcher {
         hipLaunchKernelGGL(kern, dim3(grid, slices), dim3(256), lds, stream, al, Bt, M, N, Kp, mt, nt, kt_per_split, ep);
     }
 
+    template <int TM, int TN, class AL, class EP>
+    void gemm_h3_tile(const AL& al, const _Float16* Bh, const _Float16* Bl, int M, int N, int Kp, int slices, int kt_per_split, const EP& ep) {
+        auto kern = gemm_h3_kernel<TM, TN, AL, EP>;
+        constexpr size_t lds = gemm_h3_lds_bytes(64 * TM, 64 * TN);
+        static bool attr_done = false;
+        if (!attr_done) { (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr_done = true; }
+        const int mt = (M + 64 * TM - 1) / (64 * TM), nt = (N + 64 * TN - 1) / (64 * TN);
+        const int grid = round_up(mt, 8) * nt;
+        hipLaunchKernelGGL(kern, dim3(grid, slices), dim3(256), lds, stream, al, Bh, Bl, M, N, Kp, mt, nt, kt_per_split, ep);
+    }
+
     // C[M][N] = A[M][K] * W.  64x64 tiles (4 workgroups per CU) measured fastest on every shape
     // of this model (tools/gemm_bench.hip).  Problems with too few tiles to fill the chip are
     // split along K into slabs and combined deterministically (splitk_reduce_kernel).
@@ -588,8 +629,23 @@ struct Launcher {
         slices = (KT + kps - 1) / kps;
         const int ldslab = round_up(N, 4);
         if (slices > 1 && (size_t)slices * M * ldslab > slab_floats) { slices = 1; kps = KT; }
-        begin(name, "gemm_f32", 2.0 * M * (double)N * K, 4.0 * ((double)M * K + (double)N * K + (double)M * N) + extra_bytes);
-        if (slices == 1) {
+        const bool h3 = (m->cfg.precision == UU3D_PREC_F16X3);
+        begin(name, h3 ? "gemm_h3" : "gemm_f32", 2.0 * M * (double)N * K, 4.0 * ((double)M * K + (double)N * K + (double)M * N) + extra_bytes);
+        if (h3) {
+            const auto it = m->hplanes.find((size_t)(Bt - m->arena));
+            if (it == m->hplanes.end()) { status = UU3D_ERR_INVALID_ARGUMENT; m->err = "operand without f16 planes"; end(); return; }
+            const _Float16* Bh = m->harena + it->second.first; const _Float16* Bl = m->harena + it->second.second;
+            if (slices == 1) {
+                // measured (tools/gemm_bench): 64x128 is the fastest f16x3 tile on every shape of the model
+                if (N % 128 == 0 && tiles >= 512) gemm_h3_tile<1, 2>(al, Bh, Bl, M, N, Kp, 1, KT, ep);
+                else gemm_h3_tile<1, 1>(al, Bh, Bl, M, N, Kp, 1, KT, ep);
+            } else {
+                EpSlab es{slab, ldslab, (size_t)M * ldslab};
+                gemm_h3_tile<1, 1>(al, Bh, Bl, M, N, Kp, slices, kps, es);
+                hipLaunchKernelGGL(splitk_reduce_kernel<EP>, dim3((M * N + 255) / 256), dim3(256), 0, stream,
+                                   slab, slices, (size_t)M * ldslab, M, N, ldslab, ep);
+            }
+        } else if (slices == 1) {
             // measured (tools/gemm_bench): 64x128 beats 64x64 by ~8 % on the N = 384 GEMMs, loses elsewhere
             if (N % 128 == 0 && N <= 512 && tiles >= 512) gemm_tile<64, 128>(al, Bt, M, N, Kp, 1, KT, ep);
             else gemm_tile<64, 64>(al, Bt, M, N, Kp, 1, KT, ep);

@@ -21,7 +21,7 @@ from ..weights import init_weights, weight_spec
 
 class UpliftUpsampleTransformer(object):
 
-    def __init__(self, arch: UpliftArch, device=None, seed=0, weights=None, return_attention=False):
+    def __init__(self, arch: UpliftArch, device=None, seed=0, weights=None, return_attention=False, precision="f16x3"):
         import torch
         if return_attention:
             # never used by the reference's scripts (eval.py:70, train.py:478,520)
@@ -53,7 +53,12 @@ class UpliftUpsampleTransformer(object):
         cfg.has_strided_input = int(arch.has_strided_input)
         cfg.first_strided_token_attention_layer = arch.first_strided_token_attention_layer
         cfg.full_output = int(arch.full_output)
-        cfg.precision = _capi.UU3D_PREC_F32
+        # "f16x3": forward GEMMs as three f16 MFMA passes on hi/lo-split operands (f32-grade error);
+        # "f32": exact f32-input MFMA everywhere
+        if precision not in ("f32", "f16x3"):
+            raise ValueError("precision must be 'f32' or 'f16x3'")
+        self.precision = precision
+        cfg.precision = _capi.UU3D_PREC_F16X3 if precision == "f16x3" else _capi.UU3D_PREC_F32
         handle = C.c_void_p()
         st = self._lib.uu3d_create(C.byref(cfg), self.device.index or 0, C.byref(handle))
         _capi.check(self._lib, st, None)
