@@ -138,6 +138,104 @@ void detcheck(const char* name, int M, int N, int K) {
         fclose(f);
     }
 }
+
+static _Float16 *dAh, *dAl, *dOh, *dOl;
+struct EpSink {   // experiment: the whole GEMM but (practically) no output traffic
+    float* __restrict__ out; int ldo;
+    __device__ __forceinline__ float2 colv(int) const { return make_float2(0.f, 0.f); }
+    __device__ __forceinline__ float2 pre(int, int) const { return make_float2(0.f, 0.f); }
+    __device__ __forceinline__ void store(int row, int col, float acc, float2, float2) const { if (acc == 12345.678f) out[(size_t)row * ldo + col] = acc; }
+};
+template <int TM, int TN, class PL, class EP, int DEPTH = 2>
+float runh3p(const PL& pl, const EP& ep, int M, int N, int K, int iters) {
+    auto kern = gemm_h3p_kernel<TM, TN, PL, EP, DEPTH>;
+    size_t lds = gemm_h3_lds_bytes(64 * TM, 64 * TN);
+    CK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    int mt = (M + 64 * TM - 1) / (64 * TM), nt = (N + 64 * TN - 1) / (64 * TN);
+    int grid = ((mt + 7) / 8 * 8) * nt;
+    hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    for (int i = 0; i < 3; ++i) hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, 0, pl, dBh, dBl, M, N, K, mt, nt, K / 32, ep);
+    CK(hipEventRecord(e0));
+    for (int i = 0; i < iters; ++i) hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, 0, pl, dBh, dBl, M, N, K, mt, nt, K / 32, ep);
+    CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
+    float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+    return ms / iters;
+}
+template <int TM, int TN>
+void h3p(int M, int N, int K) {
+    {
+        std::vector<_Float16> bh((size_t)N * K), bl((size_t)N * K);
+        for (size_t i = 0; i < (size_t)N * K; ++i) { float x = hB[i]; _Float16 h = (_Float16)x; bh[i] = h; bl[i] = (_Float16)((x - (float)h) * 2048.0f); }
+        CK(hipMemcpy(dBh, bh.data(), bh.size() * 2, hipMemcpyHostToDevice)); CK(hipMemcpy(dBl, bl.data(), bl.size() * 2, hipMemcpyHostToDevice));
+    }
+    hipLaunchKernelGGL(split_rows_kernel, dim3(((size_t)M * K / 4 + 255) / 256), dim3(256), 0, 0, dA, K, K, M, dAh, dAl, K);
+    PLoadPlain pl{dAh, dAl, K, M}; ALoadPlain ap{dA, K, M, K};
+    EpBias ep{dC, dbias, N}; EpBiasResidual er{dC, dbias, N, nullptr, nullptr, 1}; EpBiasReluSplit es{dOh, dOl, dbias, N};
+    std::vector<float> c1((size_t)M * N), c2((size_t)M * N), c3((size_t)M * N);
+    runh3p<TM, TN>(pl, ep, M, N, K, 1); CK(hipMemcpy(c1.data(), dC, c1.size() * 4, hipMemcpyDeviceToHost));
+    runh3p<TM, TN>(pl, ep, M, N, K, 1); CK(hipMemcpy(c2.data(), dC, c2.size() * 4, hipMemcpyDeviceToHost));
+    runh3<1, 1>(ap, ep, M, N, K, 1); CK(hipMemcpy(c3.data(), dC, c3.size() * 4, hipMemcpyDeviceToHost));
+    size_t nd = 0, nx = 0;
+    for (size_t i = 0; i < c1.size(); ++i) { nd += (c1[i] != c2[i]); nx += (c1[i] != c3[i]); }
+    float t1 = runh3p<TM, TN>(pl, ep, M, N, K, 20), t2 = runh3p<TM, TN>(pl, er, M, N, K, 20), t3 = runh3p<TM, TN>(pl, es, M, N, K, 20);
+    float t0 = runh3p<TM, TN, PLoadPlain, EpBias, 1>(pl, ep, M, N, K, 20);
+    double fl = 2.0 * M * N * K;
+    EpSink sink{dC, N};
+    float t4 = runh3p<TM, TN>(pl, sink, M, N, K, 20);
+#ifdef H3P_CLOCK
+    { unsigned long long z[3] = {0, 0, 0}, h[3]; CK(hipMemcpyToSymbol(HIP_SYMBOL(h3p_clk), z, 24));
+      runh3p<TM, TN>(pl, ep, M, N, K, 20); CK(hipMemcpyFromSymbol(h, HIP_SYMBOL(h3p_clk), 24));
+      printf("   shader clock inside the k loop: %.0f MHz; mean loop time per workgroup %.2f us (%llu samples)\n", (double)h[0] / h[1] * 100.0, (double)h[1] / h[2] / 100.0, h[2]); }
+#endif
+    printf("   depth-1 planes+bias %7.1f us %6.1f TF | depth-2 without output stores %7.1f us %6.1f TF\n", t0 * 1e3, fl / t0 / 1e9, t4 * 1e3, fl / t4 / 1e9);
+    printf(" P%3dx%-3d planes+bias %7.1f us %6.1f TF | +res %7.1f us %6.1f TF | +relu,split %7.1f us %6.1f TF | rerun diff %zu, vs on-the-fly split diff %zu\n", 64 * TM, 64 * TN,
+           t1 * 1e3, fl / t1 / 1e9, t2 * 1e3, fl / t2 / 1e9, t3 * 1e3, fl / t3 / 1e9, nd, nx);
+}
+
+template <int TM, int TN, class GL, class EP, int NBUF = 3>
+float runh3g(const GL& gl, const EP& ep, int M, int N, int K, int iters) {
+    auto kern = gemm_h3g_kernel<TM, TN, GL, EP, NBUF>;
+    size_t lds = gemm_h3g_lds_bytes(64 * TM, 64 * TN, NBUF);
+    CK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    int mt = (M + 64 * TM - 1) / (64 * TM), nt = (N + 64 * TN - 1) / (64 * TN);
+    int grid = ((mt + 7) / 8 * 8) * nt;
+    hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    for (int i = 0; i < 3; ++i) hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, 0, gl, dBh, dBl, M, N, K, mt, nt, K / 32, ep);
+    CK(hipEventRecord(e0));
+    for (int i = 0; i < iters; ++i) hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, 0, gl, dBh, dBl, M, N, K, mt, nt, K / 32, ep);
+    CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
+    float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+    return ms / iters;
+}
+template <int TM, int TN>
+void h3g(int M, int N, int K) {   // call after h3p<> (planes of A and B are in place)
+    GLoadPlain gl{dAh, dAl, K, M}; ALoadPlain ap{dA, K, M, K};
+    EpBias ep{dC, dbias, N}; EpBiasResidual er{dC, dbias, N, nullptr, nullptr, 1}; EpBiasReluSplit es{dOh, dOl, dbias, N};
+    std::vector<float> c1((size_t)M * N), c2((size_t)M * N), c3((size_t)M * N);
+    size_t nd = 0, nx = 0;
+    for (int rep = 0; rep < 3; ++rep) {
+        runh3g<TM, TN>(gl, ep, M, N, K, 1); CK(hipMemcpy(c1.data(), dC, c1.size() * 4, hipMemcpyDeviceToHost));
+        runh3g<TM, TN>(gl, ep, M, N, K, 1); CK(hipMemcpy(c2.data(), dC, c2.size() * 4, hipMemcpyDeviceToHost));
+        if (rep == 0) { runh3<1, 1>(ap, ep, M, N, K, 1); CK(hipMemcpy(c3.data(), dC, c3.size() * 4, hipMemcpyDeviceToHost)); }
+        for (size_t i = 0; i < c1.size(); ++i) { nd += (c1[i] != c2[i]); nx += (c1[i] != c3[i]); }
+    }
+    float t1 = runh3g<TM, TN>(gl, ep, M, N, K, 20), t2 = runh3g<TM, TN>(gl, er, M, N, K, 20), t3 = runh3g<TM, TN>(gl, es, M, N, K, 20);
+    double fl = 2.0 * M * N * K;
+    float u1 = runh3g<TM, TN, GLoadPlain, EpBias, 2>(gl, ep, M, N, K, 20), u2 = runh3g<TM, TN, GLoadPlain, EpBiasResidual, 2>(gl, er, M, N, K, 20), u3 = runh3g<TM, TN, GLoadPlain, EpBiasReluSplit, 2>(gl, es, M, N, K, 20);
+    { EpSink sink{dC, N}; float v1 = runh3g<TM, TN>(gl, sink, M, N, K, 20); printf("   3 buffers, no output stores: %7.1f us %6.1f TF\n", v1 * 1e3, fl / v1 / 1e9); }
+    printf("   2 LDS buffers:      %7.1f us %6.1f TF | +res %7.1f us %6.1f TF | +relu,split %7.1f us %6.1f TF\n", u1 * 1e3, fl / u1 / 1e9, u2 * 1e3, fl / u2 / 1e9, u3 * 1e3, fl / u3 / 1e9);
+    printf(" G%3dx%-3d dma+bias    %7.1f us %6.1f TF | +res %7.1f us %6.1f TF | +relu,split %7.1f us %6.1f TF | rerun diff %zu, vs on-the-fly split diff %zu\n", 64 * TM, 64 * TN,
+           t1 * 1e3, fl / t1 / 1e9, t2 * 1e3, fl / t2 / 1e9, t3 * 1e3, fl / t3 / 1e9, nd, nx);
+}
+void lnsplit_time(int M, int D) {
+    hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    for (int i = 0; i < 3; ++i) hipLaunchKernelGGL(ln_split_kernel<2>, dim3((M + 3) / 4), dim3(256), 0, 0, dA, D, D, M, 1e-6f, dg, db, dAh, dAl, D);
+    CK(hipEventRecord(e0));
+    for (int i = 0; i < 20; ++i) hipLaunchKernelGGL(ln_split_kernel<2>, dim3((M + 3) / 4), dim3(256), 0, 0, dA, D, D, M, 1e-6f, dg, db, dAh, dAl, D);
+    CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
+    float ms; CK(hipEventElapsedTime(&ms, e0, e1)); ms /= 20;
+    printf(" ln_split M=%d D=%d: %6.1f us  %6.2f TB/s (8 B per element)\n", M, D, ms * 1e3, 8.0 * M * D / ms / 1e9);
+}
 template <int TM, int TN>
 void detall(int M, int N, int K) {
     {
@@ -241,16 +339,22 @@ int main() {
     hB.assign(hA.begin(), hA.begin() + (size_t)Nmax * Kmax);
     CK(hipMalloc(&dBh, (size_t)Nmax * Kmax * 2)); CK(hipMalloc(&dBl, (size_t)Nmax * Kmax * 2));
     CK(hipMalloc(&dticket, 4096 * 4));
+    CK(hipMalloc(&dAh, (size_t)Mmax * Kmax * 2)); CK(hipMalloc(&dAl, (size_t)Mmax * Kmax * 2));
+    CK(hipMalloc(&dOh, (size_t)Mmax * Nmax * 2)); CK(hipMalloc(&dOl, (size_t)Mmax * Nmax * 2));
     CK(hipMalloc(&dstats, Mmax * 8)); CK(hipMemcpy(dstats, h.data(), Mmax * 8, hipMemcpyHostToDevice));
     int shapes[][3] = {{9088, 1152, 384}, {9088, 768, 384}, {9088, 384, 768}, {9088, 384, 384}, {9088, 384, 544},
                        {2944, 1152, 384}, {2944, 384, 2304}, {384, 384, 2304}, {128, 384, 2304}, {10496, 1152, 384}};
     const char* only = getenv("SHAPES"); int nshape = only ? atoi(only) : 100; int si = 0;
+    if (const char* one = getenv("SHAPE")) { sscanf(one, "%d,%d,%d", &shapes[0][0], &shapes[0][1], &shapes[0][2]); nshape = 1; }
     for (auto& s : shapes) {
         if (si++ >= nshape) break;
         printf("M=%d N=%d K=%d\n", s[0], s[1], s[2]);
         if (getenv("DET")) { detall<1, 1>(s[0], s[1], s[2]); detall<2, 1>(s[0], s[1], s[2]); detall<1, 2>(s[0], s[1], s[2]); detall<2, 2>(s[0], s[1], s[2]); continue; }
         both<64, 64>(s[0], s[1], s[2]);
         h3<1, 1>(s[0], s[1], s[2]); h3<2, 1>(s[0], s[1], s[2]); h3<1, 2>(s[0], s[1], s[2]); h3<2, 2>(s[0], s[1], s[2]);
+        h3p<1, 1>(s[0], s[1], s[2]); h3p<2, 1>(s[0], s[1], s[2]); h3p<1, 2>(s[0], s[1], s[2]); h3p<2, 2>(s[0], s[1], s[2]);
+        h3g<1, 1>(s[0], s[1], s[2]); h3g<2, 1>(s[0], s[1], s[2]); h3g<1, 2>(s[0], s[1], s[2]); h3g<2, 2>(s[0], s[1], s[2]);
+        if (s[2] == 384) lnsplit_time(s[0], s[2]);
         if (getenv("NOP")) continue;
         bothp<2, 2>(s[0], s[1], s[2], 1024);
         bothp<1, 2>(s[0], s[1], s[2], 1024);

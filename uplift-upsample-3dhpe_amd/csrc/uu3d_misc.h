@@ -71,6 +71,9 @@ mpjpe_kernel(const float* __restrict__ pred, const float* __restrict__ gt, const
 // by the strided-input token (u_u_t.py:350, ToDo at :320), so the spatial stack only has to run
 // on this list -- an exact, output-preserving saving.  One workgroup, ascending order, deterministic.
 //   list[0 .. count) = indices of valid frames, count stored in list[total]
+// Each thread owns kCompactPerThread consecutive frames (one 16-byte load), so up to 1024 * 16 frames take a
+// single pass: in-thread count, wave-level shuffle scan, one barrier for the 16 wave totals.
+static constexpr int kCompactPerThread = 16;
 static __global__ void __launch_bounds__(1024)
 compact_frames_kernel(const uint8_t* __restrict__ mask, const int total, int* __restrict__ list)
 {
@@ -79,16 +82,30 @@ compact_frames_kernel(const uint8_t* __restrict__ mask, const int total, int* __
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     if (tid == 0) base = 0;
     __syncthreads();
-    for (int start = 0; start < total; start += 1024) {
-        const int idx = start + tid;
-        const bool v = (idx < total) && (mask[idx] != 0);
-        const unsigned long long bal = __ballot(v);
-        const int before = __popcll(bal & ((1ull << lane) - 1ull));
-        if (lane == 0) wave_sum[wave] = __popcll(bal);
+    for (int start = 0; start < total; start += 1024 * kCompactPerThread) {
+        const int first = start + tid * kCompactPerThread;
+        uint8_t v[kCompactPerThread];
+        if (first + kCompactPerThread <= total && (((uintptr_t)(mask + first)) & 15) == 0) {
+            const uint4 q = *reinterpret_cast<const uint4*>(mask + first);
+            const uint32_t w[4] = {q.x, q.y, q.z, q.w};
+#pragma unroll
+            for (int e = 0; e < kCompactPerThread; ++e) v[e] = (uint8_t)((w[e >> 2] >> (8 * (e & 3))) & 0xffu);
+        } else {
+#pragma unroll
+            for (int e = 0; e < kCompactPerThread; ++e) v[e] = (first + e < total) ? mask[first + e] : (uint8_t)0;
+        }
+        int cnt = 0;
+#pragma unroll
+        for (int e = 0; e < kCompactPerThread; ++e) cnt += (v[e] != 0);
+        int incl = cnt;                                   // inclusive scan over the wave
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) { const int t = __shfl_up(incl, o); if (lane >= o) incl += t; }
+        if (lane == 63) wave_sum[wave] = incl;
         __syncthreads();
-        int off = base;
+        int off = base + incl - cnt;
         for (int w = 0; w < wave; ++w) off += wave_sum[w];
-        if (v) list[off + before] = idx;
+#pragma unroll
+        for (int e = 0; e < kCompactPerThread; ++e) if (v[e] != 0) list[off++] = first + e;
         __syncthreads();
         if (tid == 0) { int t = 0; for (int w = 0; w < 16; ++w) t += wave_sum[w]; base += t; }
         __syncthreads();

@@ -21,7 +21,11 @@ from ..weights import init_weights, weight_spec
 
 class UpliftUpsampleTransformer(object):
 
-    def __init__(self, arch: UpliftArch, device=None, seed=0, weights=None, return_attention=False, precision="f16x3"):
+    # a batch of at least this many sequences runs as two independent half batches on two HIP streams
+    SPLIT_MIN_BATCH = 64
+
+    def __init__(self, arch: UpliftArch, device=None, seed=0, weights=None, return_attention=False, precision="f16x3",
+                 concurrent_halves=True):
         import torch
         if return_attention:
             # never used by the reference's scripts (eval.py:70, train.py:478,520)
@@ -63,8 +67,10 @@ class UpliftUpsampleTransformer(object):
         st = self._lib.uu3d_create(C.byref(cfg), self.device.index or 0, C.byref(handle))
         _capi.check(self._lib, st, None)
         self._h = handle
-        self._ws = None
-        self._ws_batch = 0
+        self._ws = {}
+        self._profiling = False
+        self._halves = bool(concurrent_halves)
+        self._side_stream = None
         self._spec = self._query_spec()
         expected = [(n, tuple(s)) for n, s in weight_spec(arch)]
         if self._spec != expected:
@@ -123,13 +129,24 @@ class UpliftUpsampleTransformer(object):
             _capi.check(self._lib, self._lib.uu3d_commit_weights(self._h, C.c_void_p(stream)), self._h)
 
     # ---- forward -----------------------------------------------------------------------------
-    def _workspace(self, batch):
-        if self._ws is None or batch > self._ws_batch:
-            nbytes = int(self._lib.uu3d_workspace_bytes(self._h, batch))
-            self._ws = self._torch.empty(nbytes, dtype=self._torch.uint8, device=self.device)
-            self._ws_bytes = nbytes
-            self._ws_batch = batch
-        return self._ws
+    def _workspace(self, batch, slot=0):
+        """One workspace per concurrently running forward (slot 0 / 1), grown on demand."""
+        ws = self._ws.get(slot)
+        nbytes = int(self._lib.uu3d_workspace_bytes(self._h, batch))
+        if ws is None or ws.numel() < nbytes:
+            ws = self._torch.empty(nbytes, dtype=self._torch.uint8, device=self.device)
+            self._ws[slot] = ws
+        return ws
+
+    def _forward(self, x, stride_mask, full, central, slot, stream):
+        B = x.shape[0]
+        ws = self._workspace(B, slot)
+        st = self._lib.uu3d_forward(self._h, C.c_void_p(x.data_ptr()),
+                                    C.c_void_p(stride_mask.data_ptr()) if stride_mask is not None else None, B,
+                                    C.c_void_p(full.data_ptr()) if full is not None else None,
+                                    C.c_void_p(central.data_ptr()), C.c_void_p(ws.data_ptr()),
+                                    C.c_size_t(ws.numel()), C.c_void_p(stream.cuda_stream))
+        _capi.check(self._lib, st, self._h)
 
     def __call__(self, inputs, training=None, mask=None):
         torch = self._torch
@@ -146,26 +163,36 @@ class UpliftUpsampleTransformer(object):
             raise ValueError(f"x is on {x.device}, model is on {self.device}")
         B = x.shape[0]
         x = x.to(torch.float32).contiguous()
-        m_ptr = None
         if stride_mask is not None:
             if tuple(stride_mask.shape) != (B, a.num_frames):
                 raise ValueError(f"stride_mask must be (B, {a.num_frames})")
             stride_mask = stride_mask.to(device=self.device, dtype=torch.uint8).contiguous()
-            m_ptr = C.c_void_p(stride_mask.data_ptr())
         full = torch.empty((B, a.num_frames, a.num_keypoints, 3), dtype=torch.float32, device=self.device) \
             if self._returns_full else None
         central = torch.empty((B, a.num_keypoints, 3), dtype=torch.float32, device=self.device)
-        ws = self._workspace(B)
-        stream = torch.cuda.current_stream(self.device).cuda_stream
-        st = self._lib.uu3d_forward(self._h, C.c_void_p(x.data_ptr()), m_ptr, B,
-                                    C.c_void_p(full.data_ptr()) if full is not None else None,
-                                    C.c_void_p(central.data_ptr()), C.c_void_p(ws.data_ptr()),
-                                    self._ws_bytes, C.c_void_p(stream))
-        _capi.check(self._lib, st, self._h)
+        main = torch.cuda.current_stream(self.device)
+        if not (self._halves and B >= self.SPLIT_MIN_BATCH and not self._profiling):
+            self._forward(x, stride_mask, full, central, 0, main)
+            return full, central
+        # Sequences are independent, so the batch runs as two chains of kernels that the GPU interleaves: the
+        # ramp-up and tail of one chain's (short, 10-50 us) kernels overlap the other chain's work.  Measured
+        # +7 % sequences/s at B = 128 (tools/split_exp.py); three or four chains are slower again.  The fork and
+        # join are stream waits, so the call is still capturable into a hipGraph.
+        if self._side_stream is None:
+            self._side_stream = torch.cuda.Stream(device=self.device)
+        side = self._side_stream
+        h = (B + 1) // 2
+        side.wait_stream(main)
+        self._forward(x[:h], stride_mask[:h] if stride_mask is not None else None,
+                      full[:h] if full is not None else None, central[:h], 0, main)
+        self._forward(x[h:], stride_mask[h:] if stride_mask is not None else None,
+                      full[h:] if full is not None else None, central[h:], 1, side)
+        main.wait_stream(side)
         return full, central
 
     # ---- profiling -------------------------------------------------------------------------
     def set_profiling(self, enabled):
+        self._profiling = bool(enabled)          # per-launch events time one chain, so the batch is not split
         _capi.check(self._lib, self._lib.uu3d_set_profiling(self._h, int(bool(enabled))), self._h)
 
     def read_profile(self):
