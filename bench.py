@@ -98,6 +98,29 @@ def train_bench(args, world, rank, local_rank, use_dist):
         dist.destroy_process_group()
 
 
+PMC_SUMMARY = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_final_unsplit_pmc_summary.csv")
+
+
+def pmc_traffic(precision, dom_key):
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 --pmc summary (FETCH_SIZE x2 on
+    gfx950 + WRITE_SIZE, tools/rocpd_summary.py; collected with --no-halves so one launch = the whole batch, like
+    `achieved`).  None when the summary does not hold that kernel."""
+    import csv
+    want = {"ln_qkv": ("ALoadLayerNorm", "EpBiasE"), "ln_fc1": ("ALoadLayerNorm", "EpBiasRelu"),
+            "fc2_res": ("ALoadPlain", "EpBiasResidual"), "proj_res": ("ALoadPlain", "EpBiasResidual")}.get(dom_key.split(".")[-1])
+    kern = "gemm_h3_kernel" if precision == "f16x3" else "gemm_f32_kernel"
+    if want is None or not os.path.exists(PMC_SUMMARY):
+        return None
+    best = None
+    for r in csv.DictReader(open(PMC_SUMMARY)):
+        k = r["kernel"]
+        if kern in k and all(w in k for w in want) and r["HBM_read_bytes_avg_x2_gfx950_corrected"] and r["HBM_write_bytes_avg"]:
+            t = float(r["HBM_read_bytes_avg_x2_gfx950_corrected"]) + float(r["HBM_write_bytes_avg"])
+            if best is None or int(r["launches"]) > best[0]:
+                best = (int(r["launches"]), t)
+    return None if best is None else round(best[1])
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -110,6 +133,7 @@ def main():
     ap.add_argument("--no-graph", action="store_true", help="launch eagerly instead of replaying a hipGraph")
     ap.add_argument("--precision", default="f16x3", choices=["f16x3", "f32"], help="GEMM arithmetic of the forward (both hold the 1e-4 parity bar)")
     ap.add_argument("--mode", default="infer", choices=["infer", "train"], help="train = fwd + bwd + grad all-reduce + AdamW (BASELINE config 5)")
+    ap.add_argument("--no-halves", action="store_true", help="one chain of kernels per batch instead of two concurrent half batches (per-launch profiling)")
     ap.add_argument("--force-dist", action="store_true", help="initialise the process group even at world size 1 (exercises the RCCL path)")
     args = ap.parse_args()
 
@@ -136,7 +160,8 @@ def main():
     cfg = util.load_config(args.config)
     arch = pkg.arch_from_config(cfg)
     weights = pkg.init_weights(arch, seed=0)                 # replicated: same seed on every rank
-    model = pkg.build_uplift_upsample_transformer(cfg, weights=weights, device=f"cuda:{local_rank}", precision=args.precision)
+    model = pkg.build_uplift_upsample_transformer(cfg, weights=weights, device=f"cuda:{local_rank}", precision=args.precision,
+                                                   concurrent_halves=not args.no_halves)
     s_in = args.mask_stride or (cfg.MASK_STRIDE[0] if isinstance(cfg.MASK_STRIDE, list) else cfg.MASK_STRIDE)
     B, N, J = args.batch, arch.num_frames, arch.num_keypoints
     x_np, m_np = util.synthetic_batch(cfg, B, seed=1000 + rank, mask_specs=[(s_in, 0)])
@@ -232,10 +257,11 @@ def main():
             "config": {"workload": f"config/{args.config}.json forward, N={N} tokens (receptive field "
                                    f"{(N - 1) * cfg.SEQUENCE_STRIDE + 1}), J={J}, batch {B}/GPU, s_in={s_in}, "
                                    f"seeded Keras-default weights", "global_batch": world * B,
-                       "parallelism": f"batch-sharded x{world}", "hipgraph": bool(use_graph)},
+                       "parallelism": f"batch-sharded x{world}", "hipgraph": bool(use_graph),
+                       "concurrent_half_batches": bool(not args.no_halves and B >= 64)},
             "roofline": {"bound": "mfma", "kernel": f"{gk} [{dom_key}]",
                          "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s",
-                         "frac": round(ach / peak, 4), "traffic": None,
+                         "frac": round(ach / peak, 4), "traffic": pmc_traffic(args.precision, dom_key),
                          "note": ("algorithmic 2*M*N*K FLOPs; the f16x3 kernel issues 3 f16 MFMA passes per product, so the "
                                   "matrix pipe does 3x this work (frac of pipe = 3 * frac)") if args.precision == "f16x3" else
                                  "exact f32-input MFMA",

@@ -8,6 +8,7 @@
 #include "../uplift-upsample-3dhpe_amd/csrc/uu3d_gemm.h"
 #include "gemm_persistent_exp.h"
 #include "../uplift-upsample-3dhpe_amd/csrc/uu3d_gemm_h3.h"
+#include "gemm_planes_regstage_exp.h"
 #include <cmath>
 using namespace uu3d;
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %s:%d\n", hipGetErrorString(e), __FILE__, __LINE__); exit(1);} } while (0)

@@ -81,6 +81,8 @@ struct uu3d_model {
     bool committed = false;
     float* arena = nullptr;        // packed device weights
     size_t arena_floats = 0;
+    bool ln_planes = false;        // UU3D_LN_PLANES=1: LayerNorm as a separate pass that writes planes (ln_split) instead of inside the GEMM loader
+    bool no_planes = false;        // UU3D_NO_PLANES=1: keep the on-the-fly split GEMMs in f16x3 mode (A/B measurements)
     _Float16* harena = nullptr;    // f16 hi/lo planes of every GEMM operand (f16x3 mode)
     size_t harena_halfs = 0;
     std::map<size_t, std::pair<size_t, size_t>> hplanes;   // Bt float offset -> (hi offset, lo offset) in harena
@@ -279,6 +281,8 @@ int uu3d_create(const uu3d_config* c, int device, uu3d_model** out) {
     }
     build_inventory(m);
     { const char* e = getenv("UU3D_SPATIAL"); m->spatial_valu = (e != nullptr && std::string(e) == "valu"); }
+    { const char* e = getenv("UU3D_NO_PLANES"); m->no_planes = (e != nullptr && e[0] == '1'); }
+    { const char* e = getenv("UU3D_LN_PLANES"); m->ln_planes = (e != nullptr && e[0] == '1'); }
     *out = m;
     return UU3D_OK;
 }
@@ -481,7 +485,7 @@ int uu3d_commit_weights(uu3d_model* m, void* stream_) {
     HIPCHK(m, hipStreamSynchronize(stream));
     if (c.precision == UU3D_PREC_F16X3) {
         // split every GEMM operand into f16 hi / (lo * 2048) planes (uu3d_gemm_h3.h)
-        std::vector<_Float16> hb;
+        std::vector<_Float16> hb(64, (_Float16)0.f);      // [0, 64): zeros, the source of out-of-range conv taps (GLoadConv3)
         m->hplanes.clear();
         for (auto& d : P.dense) {
             const size_t hi = align_up(hb.size(), 64); hb.resize(hi + d.second);
@@ -616,6 +620,53 @@ struct Launcher {
         hipLaunchKernelGGL(kern, dim3(grid, slices), dim3(256), lds, stream, al, Bh, Bl, M, N, Kp, mt, nt, kt_per_split, ep);
     }
 
+    template <int TM, int TN, class GL, class EP>
+    void gemm_h3g_tile(const GL& gl, const _Float16* Bh, const _Float16* Bl, int M, int N, int Kp, int slices, int kt_per_split, const EP& ep) {
+        auto kern = gemm_h3g_kernel<TM, TN, GL, EP>;
+        constexpr size_t lds = gemm_h3g_lds_bytes(64 * TM, 64 * TN);
+        static bool attr_done = false;
+        if (!attr_done) { (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr_done = true; }
+        const int mt = (M + 64 * TM - 1) / (64 * TM), nt = (N + 64 * TN - 1) / (64 * TN);
+        const int grid = round_up(mt, 8) * nt;
+        hipLaunchKernelGGL(kern, dim3(grid, slices), dim3(256), lds, stream, gl, Bh, Bl, M, N, Kp, mt, nt, kt_per_split, ep);
+    }
+
+    // f16x3 GEMM whose A operand already is a pair of f16 planes (written by ln_split / attention / the ReLU
+    // epilogue): LDS-DMA staged kernel, K % 32 == 0.  Same split-K policy as gemm().
+    template <class GL, class EP>
+    void gemm_g(const char* name, const GL& gl, const float* Bt, int M, int N, int K, const EP& ep, double extra_bytes = 0) {
+        const int KT = K / 32;
+        const int tiles = ((M + 63) / 64) * ((N + 63) / 64);
+        int slices = 1;
+        if (tiles < 384 && KT >= 8) slices = std::max(1, std::min(KT / 4, (768 + tiles / 2) / tiles));
+        int kps = (KT + slices - 1) / slices;
+        slices = (KT + kps - 1) / kps;
+        const int ldslab = round_up(N, 4);
+        if (slices > 1 && (size_t)slices * M * ldslab > slab_floats) { slices = 1; kps = KT; }
+        begin(name, "gemm_h3", 2.0 * M * (double)N * K, 4.0 * ((double)M * K + (double)N * K + (double)M * N) + extra_bytes);
+        const auto it = m->hplanes.find((size_t)(Bt - m->arena));
+        if ((K % 32) != 0 || it == m->hplanes.end()) { status = UU3D_ERR_INVALID_ARGUMENT; m->err = "gemm_g: operand without f16 planes or K % 32 != 0"; end(); return; }
+        const _Float16* Bh = m->harena + it->second.first; const _Float16* Bl = m->harena + it->second.second;
+        if (slices == 1) {
+            // measured (tools/gemm_bench, M = 4544 / 1472 rows): 64x128 is the fastest LDS-DMA tile down to ~200 tiles
+            if (N % 128 == 0 && tiles >= 256) gemm_h3g_tile<1, 2>(gl, Bh, Bl, M, N, K, 1, KT, ep);
+            else gemm_h3g_tile<1, 1>(gl, Bh, Bl, M, N, K, 1, KT, ep);
+        } else {
+            EpSlab es{slab, ldslab, (size_t)M * ldslab};
+            gemm_h3g_tile<1, 1>(gl, Bh, Bl, M, N, K, slices, kps, es);
+            hipLaunchKernelGGL(splitk_reduce_kernel<EP>, dim3((M * N + 255) / 256), dim3(256), 0, stream,
+                               slab, slices, (size_t)M * ldslab, M, N, ldslab, ep);
+        }
+        end();
+    }
+
+    // LayerNorm (eps 1e-5) of M rows of D floats, written as the hi / lo planes [M][D] of the next GEMM's A operand
+    void ln_split(const char* name, const float* x, int D, int M, const float* g, const float* b, _Float16* Ph, _Float16* Pl) {
+        begin(name, "ln_split", 0.0, 8.0 * (double)M * D);
+        hipLaunchKernelGGL(ln_split_kernel<4>, dim3((M + 3) / 4), dim3(256), 0, stream, x, D, D, M, 1e-5f, g, b, Ph, Pl, D);
+        end();
+    }
+
     // C[M][N] = A[M][K] * W.  64x64 tiles (4 workgroups per CU) measured fastest on every shape
     // of this model (tools/gemm_bench.hip).  Problems with too few tiles to fill the chip are
     // split along K into slabs and combined deterministically (splitk_reduce_kernel).
@@ -664,12 +715,16 @@ struct Launcher {
         end();
     }
 
-    void attn(const char* name, const float* qkv, int B, int L, const uint8_t* mask, float* out) {
+    // split_lo_off != 0: the context rows go out as f16 planes (hi at out, lo split_lo_off halfs further)
+    void attn(const char* name, const float* qkv, int B, int L, const uint8_t* mask, float* out, size_t split_lo_off = 0) {
         const int D = m->cfg.d_temporal, H = m->cfg.num_heads;
         const int NT = (L + 15) / 16;
         begin(name, "attn_f32", 4.0 * B * (double)H * L * L * kDH, 4.0 * 4.0 * B * (double)L * D);
         const dim3 grid(B * H);
-#define UU3D_ATTN_CASE(nt) case nt: hipLaunchKernelGGL((attn_f32_kernel<nt, kDH>), grid, dim3(64 * nt), 0, stream, qkv, 3 * D, D, L, H, mask, out, D); break;
+#define UU3D_ATTN_CASE(nt) case nt: \
+        if (split_lo_off) hipLaunchKernelGGL((attn_f32_kernel<nt, kDH, true>), grid, dim3(64 * nt), 0, stream, qkv, 3 * D, D, L, H, mask, out, D, split_lo_off); \
+        else hipLaunchKernelGGL((attn_f32_kernel<nt, kDH, false>), grid, dim3(64 * nt), 0, stream, qkv, 3 * D, D, L, H, mask, out, D, (size_t)0); \
+        break;
         switch (NT) {
             UU3D_ATTN_CASE(1) UU3D_ATTN_CASE(2) UU3D_ATTN_CASE(3) UU3D_ATTN_CASE(4)
             UU3D_ATTN_CASE(5) UU3D_ATTN_CASE(6) UU3D_ATTN_CASE(7) UU3D_ATTN_CASE(8)
@@ -739,11 +794,45 @@ int uu3d_forward(uu3d_model* m, const float* kp2d, const uint8_t* mask, int32_t 
         EpSpatialToTemporal ep{w.X, m->s2t_b, dt, mask, m->token, m->pe_t, N};
         Lh.gemm("s2t", al, m->s2t_wt, M, dt, J * ds, ep);
     }
+    // f16x3 with K % 32 == 0 everywhere: activations that feed a GEMM travel as f16 hi/lo planes (same bytes as the
+    // f32 tensors they replace: O and Hb are reused) and the GEMMs are the LDS-DMA kernel gemm_h3g_kernel
+    const bool planes = (c.precision == UU3D_PREC_F16X3) && (dt % 32 == 0) && (ht % 32 == 0) && !m->no_planes;
+    _Float16* const Ph = reinterpret_cast<_Float16*>(w.O);       // LayerNorm output, then attention output
+    _Float16* const Hh = reinterpret_cast<_Float16*>(w.Hb);      // relu(fc1)
+    const _Float16* const hzero = m->harena;                     // 64 zero halfs (uu3d_commit_weights)
     // 3. temporal blocks
     for (int i = 0; i < c.temporal_depth; ++i) {
         const BlockDev& b = m->tblocks[i];
         const bool masked = c.has_strided_input && i < c.first_strided_token_attention_layer;
         const bool last = (i + 1 == c.temporal_depth);
+        const EpBiasResidual ep_fc2{w.X, b.b2, dt, last ? w.XA : nullptr, last ? m->sblocks[0].pe : nullptr, N};
+        if (planes) {
+            _Float16* const Pl = Ph + (size_t)M * dt; _Float16* const Hl = Hh + (size_t)M * ht;
+            if (m->ln_planes) {
+                snprintf(nm, sizeof nm, "t%d.ln1_split", i + 1); Lh.ln_split(nm, w.X, dt, M, b.ln1_g, b.ln1_b, Ph, Pl);
+                GLoadPlain gl{Ph, Pl, dt, M}; EpBias ep{w.QKV, b.bqkv, 3 * dt};
+                snprintf(nm, sizeof nm, "t%d.ln_qkv", i + 1); Lh.gemm_g(nm, gl, b.wqkv_t, M, 3 * dt, dt, ep);
+            } else {
+                snprintf(nm, sizeof nm, "t%d.stats1", i + 1); Lh.row_stats(nm, w.X, dt, M, w.stats);
+                ALoadLayerNorm al{w.X, w.stats, b.ln1_g, b.ln1_b, dt, M, dt}; EpBias ep{w.QKV, b.bqkv, 3 * dt};
+                snprintf(nm, sizeof nm, "t%d.ln_qkv", i + 1); Lh.gemm(nm, al, b.wqkv_t, M, 3 * dt, dt, ep);
+            }
+            snprintf(nm, sizeof nm, "t%d.attn", i + 1); Lh.attn(nm, w.QKV, B, N, masked ? mask : nullptr, w.O, (size_t)M * dt);
+            { GLoadPlain gl{Ph, Pl, dt, M}; EpBiasResidual ep{w.X, b.bp, dt, nullptr, nullptr, 1};
+              snprintf(nm, sizeof nm, "t%d.proj_res", i + 1); Lh.gemm_g(nm, gl, b.wp_t, M, dt, dt, ep, 4.0 * M * dt); }
+            if (m->ln_planes) {
+                snprintf(nm, sizeof nm, "t%d.ln2_split", i + 1); Lh.ln_split(nm, w.X, dt, M, b.ln2_g, b.ln2_b, Ph, Pl);
+                GLoadPlain gl{Ph, Pl, dt, M}; EpBiasReluSplit ep{Hh, Hl, b.b1, ht};
+                snprintf(nm, sizeof nm, "t%d.ln_fc1", i + 1); Lh.gemm_g(nm, gl, b.w1_t, M, ht, dt, ep);
+            } else {
+                snprintf(nm, sizeof nm, "t%d.stats2", i + 1); Lh.row_stats(nm, w.X, dt, M, w.stats);
+                ALoadLayerNorm al{w.X, w.stats, b.ln2_g, b.ln2_b, dt, M, dt}; EpBiasReluSplit ep{Hh, Hl, b.b1, ht};
+                snprintf(nm, sizeof nm, "t%d.ln_fc1", i + 1); Lh.gemm(nm, al, b.w1_t, M, ht, dt, ep);
+            }
+            { GLoadPlain gl{Hh, Hl, ht, M};
+              snprintf(nm, sizeof nm, "t%d.fc2_res", i + 1); Lh.gemm_g(nm, gl, b.w2_t, M, dt, ht, ep_fc2, 4.0 * M * dt); }
+            continue;
+        }
         snprintf(nm, sizeof nm, "t%d.stats1", i + 1); Lh.row_stats(nm, w.X, dt, M, w.stats);
         { ALoadLayerNorm al{w.X, w.stats, b.ln1_g, b.ln1_b, dt, M, dt}; EpBias ep{w.QKV, b.bqkv, 3 * dt};
           snprintf(nm, sizeof nm, "t%d.ln_qkv", i + 1); Lh.gemm(nm, al, b.wqkv_t, M, 3 * dt, dt, ep); }
@@ -754,8 +843,7 @@ int uu3d_forward(uu3d_model* m, const float* kp2d, const uint8_t* mask, int32_t 
         { ALoadLayerNorm al{w.X, w.stats, b.ln2_g, b.ln2_b, dt, M, dt}; EpBiasRelu ep{w.Hb, b.b1, ht};
           snprintf(nm, sizeof nm, "t%d.ln_fc1", i + 1); Lh.gemm(nm, al, b.w1_t, M, ht, dt, ep); }
         { ALoadPlain al{w.Hb, ht, M, ht};
-          EpBiasResidual ep{w.X, b.b2, dt, last ? w.XA : nullptr, last ? m->sblocks[0].pe : nullptr, N};
-          snprintf(nm, sizeof nm, "t%d.fc2_res", i + 1); Lh.gemm(nm, al, b.w2_t, M, dt, ht, ep, 4.0 * M * dt); }
+          snprintf(nm, sizeof nm, "t%d.fc2_res", i + 1); Lh.gemm(nm, al, b.w2_t, M, dt, ht, ep_fc2, 4.0 * M * dt); }
     }
     // 4. head1
     if (has_h1) {
@@ -767,21 +855,48 @@ int uu3d_forward(uu3d_model* m, const float* kp2d, const uint8_t* mask, int32_t 
     for (int i = 0; i < c.num_strided; ++i) {
         const BlockDev& b = m->sblocks[i];
         const int Li = m->L[i], Lo = m->L[i + 1], Mi = B * Li, Mo = B * Lo;
-        snprintf(nm, sizeof nm, "s%d.stats1", i + 1); Lh.row_stats(nm, xa, dt, Mi, w.stats);
-        { ALoadLayerNorm al{xa, w.stats, b.ln1_g, b.ln1_b, dt, Mi, dt}; EpBias ep{w.QKV, b.bqkv, 3 * dt};
-          snprintf(nm, sizeof nm, "s%d.ln_qkv", i + 1); Lh.gemm(nm, al, b.wqkv_t, Mi, 3 * dt, dt, ep); }
-        snprintf(nm, sizeof nm, "s%d.attn", i + 1); Lh.attn(nm, w.QKV, B, Li, nullptr, w.O);
-        { ALoadPlain al{w.O, dt, Mi, dt}; EpBiasResidual ep{xa, b.bp, dt, nullptr, nullptr, 1};
-          snprintf(nm, sizeof nm, "s%d.proj_res", i + 1); Lh.gemm(nm, al, b.wp_t, Mi, dt, dt, ep, 4.0 * Mi * dt); }
-        snprintf(nm, sizeof nm, "s%d.stats2", i + 1); Lh.row_stats(nm, xa, dt, Mi, w.stats);
-        { ALoadLayerNorm al{xa, w.stats, b.ln2_g, b.ln2_b, dt, Mi, dt}; EpBiasRelu ep{w.Hb, b.b1, ht};
-          snprintf(nm, sizeof nm, "s%d.ln_fc1", i + 1); Lh.gemm(nm, al, b.w1_t, Mi, ht, dt, ep); }
-        { ALoadConv3 al{w.Hb, ht, Li, Lo, c.strides[i], c.pad_left[i], Mo, 3 * ht};
-          // MaxPool1D(pool 1, stride s) on the trimmed sequence; stride 1 keeps x untrimmed (u_u_t.py:138-154)
-          const int lo = (c.strides[i] > 1 && c.pad_left[i] == 0) ? 1 : 0;
-          EpConvResidual ep{xb, b.b2, dt, xa, Li, Lo, c.strides[i], lo,
-                            (i + 1 < c.num_strided) ? m->sblocks[i + 1].pe : nullptr};
-          snprintf(nm, sizeof nm, "s%d.conv_res", i + 1); Lh.gemm(nm, al, b.w2_t, Mo, dt, 3 * ht, ep, 4.0 * Mo * dt); }
+        // MaxPool1D(pool 1, stride s) on the trimmed sequence; stride 1 keeps x untrimmed (u_u_t.py:138-154)
+        const int lo = (c.strides[i] > 1 && c.pad_left[i] == 0) ? 1 : 0;
+        const EpConvResidual ep_conv{xb, b.b2, dt, xa, Li, Lo, c.strides[i], lo,
+                                     (i + 1 < c.num_strided) ? m->sblocks[i + 1].pe : nullptr};
+        if (planes) {
+            _Float16* const Pl = Ph + (size_t)Mi * dt; _Float16* const Hl = Hh + (size_t)Mi * ht;
+            if (m->ln_planes) {
+                snprintf(nm, sizeof nm, "s%d.ln1_split", i + 1); Lh.ln_split(nm, xa, dt, Mi, b.ln1_g, b.ln1_b, Ph, Pl);
+                GLoadPlain gl{Ph, Pl, dt, Mi}; EpBias ep{w.QKV, b.bqkv, 3 * dt};
+                snprintf(nm, sizeof nm, "s%d.ln_qkv", i + 1); Lh.gemm_g(nm, gl, b.wqkv_t, Mi, 3 * dt, dt, ep);
+            } else {
+                snprintf(nm, sizeof nm, "s%d.stats1", i + 1); Lh.row_stats(nm, xa, dt, Mi, w.stats);
+                ALoadLayerNorm al{xa, w.stats, b.ln1_g, b.ln1_b, dt, Mi, dt}; EpBias ep{w.QKV, b.bqkv, 3 * dt};
+                snprintf(nm, sizeof nm, "s%d.ln_qkv", i + 1); Lh.gemm(nm, al, b.wqkv_t, Mi, 3 * dt, dt, ep);
+            }
+            snprintf(nm, sizeof nm, "s%d.attn", i + 1); Lh.attn(nm, w.QKV, B, Li, nullptr, w.O, (size_t)Mi * dt);
+            { GLoadPlain gl{Ph, Pl, dt, Mi}; EpBiasResidual ep{xa, b.bp, dt, nullptr, nullptr, 1};
+              snprintf(nm, sizeof nm, "s%d.proj_res", i + 1); Lh.gemm_g(nm, gl, b.wp_t, Mi, dt, dt, ep, 4.0 * Mi * dt); }
+            if (m->ln_planes) {
+                snprintf(nm, sizeof nm, "s%d.ln2_split", i + 1); Lh.ln_split(nm, xa, dt, Mi, b.ln2_g, b.ln2_b, Ph, Pl);
+                GLoadPlain gl{Ph, Pl, dt, Mi}; EpBiasReluSplit ep{Hh, Hl, b.b1, ht};
+                snprintf(nm, sizeof nm, "s%d.ln_fc1", i + 1); Lh.gemm_g(nm, gl, b.w1_t, Mi, ht, dt, ep);
+            } else {
+                snprintf(nm, sizeof nm, "s%d.stats2", i + 1); Lh.row_stats(nm, xa, dt, Mi, w.stats);
+                ALoadLayerNorm al{xa, w.stats, b.ln2_g, b.ln2_b, dt, Mi, dt}; EpBiasReluSplit ep{Hh, Hl, b.b1, ht};
+                snprintf(nm, sizeof nm, "s%d.ln_fc1", i + 1); Lh.gemm(nm, al, b.w1_t, Mi, ht, dt, ep);
+            }
+            { GLoadConv3 gl{Hh, Hl, hzero, ht, Li, Lo, c.strides[i], c.pad_left[i], Mo};
+              snprintf(nm, sizeof nm, "s%d.conv_res", i + 1); Lh.gemm_g(nm, gl, b.w2_t, Mo, dt, 3 * ht, ep_conv, 4.0 * Mo * dt); }
+        } else {
+            snprintf(nm, sizeof nm, "s%d.stats1", i + 1); Lh.row_stats(nm, xa, dt, Mi, w.stats);
+            { ALoadLayerNorm al{xa, w.stats, b.ln1_g, b.ln1_b, dt, Mi, dt}; EpBias ep{w.QKV, b.bqkv, 3 * dt};
+              snprintf(nm, sizeof nm, "s%d.ln_qkv", i + 1); Lh.gemm(nm, al, b.wqkv_t, Mi, 3 * dt, dt, ep); }
+            snprintf(nm, sizeof nm, "s%d.attn", i + 1); Lh.attn(nm, w.QKV, B, Li, nullptr, w.O);
+            { ALoadPlain al{w.O, dt, Mi, dt}; EpBiasResidual ep{xa, b.bp, dt, nullptr, nullptr, 1};
+              snprintf(nm, sizeof nm, "s%d.proj_res", i + 1); Lh.gemm(nm, al, b.wp_t, Mi, dt, dt, ep, 4.0 * Mi * dt); }
+            snprintf(nm, sizeof nm, "s%d.stats2", i + 1); Lh.row_stats(nm, xa, dt, Mi, w.stats);
+            { ALoadLayerNorm al{xa, w.stats, b.ln2_g, b.ln2_b, dt, Mi, dt}; EpBiasRelu ep{w.Hb, b.b1, ht};
+              snprintf(nm, sizeof nm, "s%d.ln_fc1", i + 1); Lh.gemm(nm, al, b.w1_t, Mi, ht, dt, ep); }
+            { ALoadConv3 al{w.Hb, ht, Li, Lo, c.strides[i], c.pad_left[i], Mo, 3 * ht};
+              snprintf(nm, sizeof nm, "s%d.conv_res", i + 1); Lh.gemm(nm, al, b.w2_t, Mo, dt, 3 * ht, ep_conv, 4.0 * Mo * dt); }
+        }
         std::swap(xa, xb);
         if (i == 0) xb = w.XA;   // XA (B*N rows) is free again; XB only needs B*L_1 rows
     }

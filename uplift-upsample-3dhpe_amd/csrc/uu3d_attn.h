@@ -24,11 +24,13 @@
 
 namespace uu3d {
 
-template <int NT, int DH>
+// SPLIT: the context rows are written as the two f16 planes (hi at out, lo at out + lo_off halfs; x ~= hi + lo / 2048,
+// see uu3d_gemm_h3.h) that the f16x3 projection GEMM reads, instead of f32.
+template <int NT, int DH, bool SPLIT = false>
 __global__ void __launch_bounds__(64 * NT)
 attn_f32_kernel(const float* __restrict__ qkv, const int ld, const int D, const int L, const int H,
                 const uint8_t* __restrict__ key_mask,   // (B, L) 1 = attend; nullptr = no mask
-                float* __restrict__ out, const int ldo)
+                float* __restrict__ out, const int ldo, const size_t lo_off = 0)
 {
     static_assert(DH % 16 == 0, "head dim must be a multiple of 16");
     constexpr int LD = DH + 4;
@@ -130,7 +132,17 @@ attn_f32_kernel(const float* __restrict__ qkv, const int ld, const int D, const 
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int q = 16 * w + 4 * g + r;
-            if (q < L) out[((size_t)b * L + q) * ldo + h * DH + 16 * t + qi] = o[r];
+            if (q < L) {
+                const size_t at = ((size_t)b * L + q) * ldo + h * DH + 16 * t + qi;
+                if (SPLIT) {
+                    _Float16* oh = reinterpret_cast<_Float16*>(out);
+                    const _Float16 hv = (_Float16)o[r];
+                    oh[at] = hv;
+                    oh[lo_off + at] = (_Float16)((o[r] - (float)hv) * 2048.0f);
+                } else {
+                    out[at] = o[r];
+                }
+            }
         }
     }
 }
