@@ -106,9 +106,9 @@ def pmc_traffic(precision, dom_key):
     gfx950 + WRITE_SIZE, tools/rocpd_summary.py; collected with --no-halves so one launch = the whole batch, like
     `achieved`).  None when the summary does not hold that kernel."""
     import csv
-    want = {"ln_qkv": ("ALoadLayerNorm", "EpBiasE"), "ln_fc1": ("ALoadLayerNorm", "EpBiasRelu"),
-            "fc2_res": ("ALoadPlain", "EpBiasResidual"), "proj_res": ("ALoadPlain", "EpBiasResidual")}.get(dom_key.split(".")[-1])
-    kern = "gemm_h3_kernel" if precision == "f16x3" else "gemm_f32_kernel"
+    want = {"ln_qkv": ("LoadLayerNorm", "EpBiasE"), "ln_fc1": ("LoadLayerNorm", "EpBiasRelu"),
+            "fc2_res": ("LoadPlain", "EpBiasResidual"), "proj_res": ("LoadPlain", "EpBiasResidual")}.get(dom_key.split(".")[-1])
+    kern = "gemm_h3" if precision == "f16x3" else "gemm_f32_kernel"        # gemm_h3_kernel (on-the-fly split) or gemm_h3g_kernel (LDS-DMA)
     if want is None or not os.path.exists(PMC_SUMMARY):
         return None
     best = None
@@ -116,8 +116,8 @@ def pmc_traffic(precision, dom_key):
         k = r["kernel"]
         if kern in k and all(w in k for w in want) and r["HBM_read_bytes_avg_x2_gfx950_corrected"] and r["HBM_write_bytes_avg"]:
             t = float(r["HBM_read_bytes_avg_x2_gfx950_corrected"]) + float(r["HBM_write_bytes_avg"])
-            if best is None or int(r["launches"]) > best[0]:
-                best = (int(r["launches"]), t)
+            if best is None or int(r["grid_size"]) > best[0]:       # the temporal-block launch (largest grid) of this instantiation
+                best = (int(r["grid_size"]), t)
     return None if best is None else round(best[1])
 
 
