@@ -28,6 +28,7 @@
 #include "uu3d_gemm_h3.h"
 #include "uu3d_attn.h"
 #include "uu3d_spatial.h"
+#include "uu3d_spatial_h3.h"
 #include "uu3d_misc.h"
 #include "uu3d_train.h"
 #include "uu3d_bwd.h"
@@ -91,6 +92,8 @@ struct uu3d_model {
     const float* sp_blocks_v1 = nullptr;   // VALU kernel layout (kept for A/B runs: UU3D_SPATIAL=valu)
     const float* sp_blocks_v2 = nullptr;   // MFMA kernel layout
     bool spatial_valu = false;
+    bool spatial_f32 = false;      // UU3D_SPATIAL=f32: exact-f32 MFMA spatial stack even in f16x3 mode
+    size_t sp_frag_off = 0;        // offset (halfs) of the spatial f16 fragment planes in harena
     const float *s2t_wt = nullptr, *s2t_b = nullptr, *token = nullptr, *pe_t = nullptr;
     std::vector<BlockDev> tblocks, sblocks;
     const float *h1_wt = nullptr, *h1_b = nullptr, *h2_wt = nullptr, *h2_b = nullptr;
@@ -280,7 +283,8 @@ int uu3d_create(const uu3d_config* c, int device, uu3d_model** out) {
         return fail(nullptr, UU3D_ERR_INVALID_ARGUMENT, "STRIDES/PADDINGS must reduce the sequence to one token");
     }
     build_inventory(m);
-    { const char* e = getenv("UU3D_SPATIAL"); m->spatial_valu = (e != nullptr && std::string(e) == "valu"); }
+    { const char* e = getenv("UU3D_SPATIAL"); m->spatial_valu = (e != nullptr && std::string(e) == "valu");
+      m->spatial_f32 = (e != nullptr && std::string(e) == "f32"); }
     { const char* e = getenv("UU3D_NO_PLANES"); m->no_planes = (e != nullptr && e[0] == '1'); }
     { const char* e = getenv("UU3D_LN_PLANES"); m->ln_planes = (e != nullptr && e[0] == '1'); }
     *out = m;
@@ -492,10 +496,35 @@ int uu3d_commit_weights(uu3d_model* m, void* stream_) {
             const size_t lo = align_up(hb.size(), 64); hb.resize(lo + d.second);
             for (size_t i = 0; i < d.second; ++i) {
                 const float x = P.buf[d.first + i];
-                const _Float16 h = (_Float16)x;
+                const _Float16 h = h3_hi(x);
                 hb[hi + i] = h; hb[lo + i] = (_Float16)((x - (float)h) * H3_SCALE);
             }
             m->hplanes[d.first] = {hi, lo};
+        }
+        {   // spatial stack: A-operand fragments of W^T (uu3d_spatial_h3.h), [n-tile][kk][plane][lane][8]
+            using FL = SpatialFragLayoutH3;
+            m->sp_frag_off = align_up(hb.size(), 64);
+            hb.resize(m->sp_frag_off + (size_t)c.spatial_depth * FL::size);
+            for (int i = 0; i < c.spatial_depth; ++i) {
+                const std::string p = "spatial_block_" + std::to_string(i + 1);
+                _Float16* d = hb.data() + m->sp_frag_off + (size_t)i * FL::size;
+                auto frag = [&](int off, const std::string& nm, int K, int Nn) {
+                    const float* s = W(m, p + nm);
+                    for (int nt = 0; nt < Nn / 32; ++nt)
+                        for (int kk = 0; kk < K / 16; ++kk)
+                            for (int lane = 0; lane < 64; ++lane)
+                                for (int e = 0; e < 8; ++e) {
+                                    const float x = s[(size_t)(16 * kk + 8 * (lane >> 5) + e) * Nn + 32 * nt + (lane & 31)];
+                                    const _Float16 h = h3_hi(x);
+                                    const size_t at = (size_t)off + (((size_t)(nt * (K / 16) + kk) * 2) * 64 + lane) * 8 + e;
+                                    d[at] = h;
+                                    d[at + 64 * 8] = (_Float16)((x - (float)h) * H3_SCALE);
+                                }
+                };
+                frag(FL::fq, "/attn/wq/kernel", ds, ds); frag(FL::fk, "/attn/wk/kernel", ds, ds);
+                frag(FL::fv, "/attn/wv/kernel", ds, ds); frag(FL::fp, "/attn/projection/kernel", ds, ds);
+                frag(FL::f1, "/mlp/fc1/kernel", ds, kHS); frag(FL::f2, "/mlp/fc2/kernel", kHS, ds);
+            }
         }
         if (m->harena_halfs < hb.size()) {
             if (m->harena) HIPCHK(m, hipFree(m->harena));
@@ -779,6 +808,13 @@ int uu3d_forward(uu3d_model* m, const float* kp2d, const uint8_t* mask, int32_t 
             if (!attr_done) { (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)spatial_lds_bytes(kDS)); attr_done = true; }
             Lh.begin("spatial_stack", "spatial_valu", fl, 4.0 * M * J * (2.0 + ds));
             hipLaunchKernelGGL(kern, dim3((M + FPW - 1) / FPW), dim3(256), spatial_lds_bytes(kDS), Lh.stream, kp2d, sp, w.S);
+            Lh.end();
+        } else if (c.precision == UU3D_PREC_F16X3 && !m->spatial_f32) {
+            sp.blocks = m->sp_blocks_v2;             // LayerNorm parameters and biases
+            auto kern = spatial_stack_h3_kernel<kJ, kFR>;
+            Lh.begin("spatial_stack", "spatial_h3", fl, 4.0 * M * J * (2.0 + ds));
+            hipLaunchKernelGGL(kern, dim3((M + kFR - 1) / kFR), dim3(64), sh3::lds_bytes(), Lh.stream, kp2d, sp,
+                               m->harena + m->sp_frag_off, w.S, (_Float16*)nullptr, (_Float16*)nullptr);
             Lh.end();
         } else {
             sp.blocks = m->sp_blocks_v2;

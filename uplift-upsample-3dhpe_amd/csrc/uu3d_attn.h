@@ -136,7 +136,7 @@ attn_f32_kernel(const float* __restrict__ qkv, const int ld, const int D, const 
                 const size_t at = ((size_t)b * L + q) * ldo + h * DH + 16 * t + qi;
                 if (SPLIT) {
                     _Float16* oh = reinterpret_cast<_Float16*>(out);
-                    const _Float16 hv = (_Float16)o[r];
+                    const _Float16 hv = (fabsf(o[r]) < 6.103515625e-05f) ? (_Float16)0.f : (_Float16)o[r];   // = h3_hi (uu3d_gemm_h3.h), explicit: this kernel keeps f16 denormals on
                     oh[at] = hv;
                     oh[lo_off + at] = (_Float16)((o[r] - (float)hv) * 2048.0f);
                 } else {

@@ -33,12 +33,32 @@ __host__ __device__ inline constexpr size_t gemm_h3_lds_bytes(int BM, int BN) {
     return (size_t)2 /*stages*/ * 2 /*planes*/ * (BM + BN) * H3_LD * sizeof(_Float16);
 }
 
+// v_mfma_*_f16 reads f16 DENORMAL inputs as zero (measured: with a plain hi = f16(x) the spatial stack, whose GELU
+// outputs are full of values below the smallest normal half 2^-14 = 6.1e-5, was off by up to 3e-4 on single tokens).
+// A value below that threshold must therefore have hi = 0 and go entirely into lo = x * 2048 (normal down to 3e-8).
+// On the device that costs nothing: every kernel that splits first switches the wave's f16 denormal mode to
+// flush (h3_flush_f16_denormals), so v_cvt_f16_f32 itself returns 0 there.  The host (weights) compares.
+__device__ __forceinline__ void h3_flush_f16_denormals() {
+    // s_setreg_imm32_b32 hwreg(HW_REG_MODE, 6, 2), 0 : MODE.FP_DENORM[3:2] (f16 / f64 denormals) = flush in and out
+    __builtin_amdgcn_s_setreg((1 /*MODE*/) | (6 << 6) | ((2 - 1) << 11), 0);
+}
+__host__ __device__ inline _Float16 h3_hi(const float x) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    // v_cvt_f16_f32 by name: it flushes denormal results under h3_flush_f16_denormals(); hipcc otherwise mixes it
+    // with v_cvt_pk_f16_f32, which keeps them -- two unrolled copies of the same code then disagree by an ulp
+    _Float16 h;
+    asm("v_cvt_f16_f32 %0, %1" : "=v"(h) : "v"(x));
+    return h;
+#else
+    return ((x < 0.f ? -x : x) < 6.103515625e-05f) ? (_Float16)0.f : (_Float16)x;
+#endif
+}
 __device__ __forceinline__ void h3_split(const f32x4 x, h16x4& hi, h16x4& lo) {
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
-        const _Float16 h = (_Float16)x[e];
+        const _Float16 h = h3_hi(x[e]);
         hi[e] = h;
-        lo[e] = (_Float16)((x[e] - (float)h) * H3_SCALE);
+        lo[e] = (_Float16)((x[e] - (float)h) * H3_SCALE);   // a denormal lo is read as 0 by the MFMA either way: any cvt form will do
     }
 }
 
@@ -47,6 +67,7 @@ __global__ void __launch_bounds__(256)
 gemm_h3_kernel(const AL al, const _Float16* __restrict__ Bh, const _Float16* __restrict__ Bl, const int M, const int N,
                const int Kp, const int m_tiles, const int n_tiles, const int kt_per_split, const EP ep)
 {
+    h3_flush_f16_denormals();
     constexpr int BM = 64 * TM, BN = 64 * TN, LD = H3_LD;
     constexpr int AI = BM / 32;                 // f32x4 staging loads per thread per k-tile (A)
     constexpr int BI = BN / 64;                 // 16-byte staging loads per thread per plane per k-tile (B)
@@ -203,7 +224,7 @@ struct EpBiasReluSplit {
     __device__ __forceinline__ float2 pre(int, int) const { return make_float2(0.f, 0.f); }
     __device__ __forceinline__ void store(int row, int col, float acc, float2 cv, float2) const {
         const float v = fmaxf(acc + cv.x, 0.f);
-        const _Float16 h = (_Float16)v;
+        const _Float16 h = h3_hi(v);
         Oh[(size_t)row * ldo + col] = h;
         Ol[(size_t)row * ldo + col] = (_Float16)((v - (float)h) * H3_SCALE);
     }
@@ -261,6 +282,7 @@ __global__ void __launch_bounds__(256)
 gemm_h3g_kernel(const GL gl, const _Float16* __restrict__ Bh, const _Float16* __restrict__ Bl, const int M, const int N,
                 const int Kp, const int m_tiles, const int n_tiles, const int kt_per_split, const EP ep)
 {
+    h3_flush_f16_denormals();                     // the epilogue may split its result (EpBiasReluSplit)
     constexpr int BM = 64 * TM, BN = 64 * TN;
     constexpr int STAGE = 2 * (BM + BN) * 32;     // halfs per stage
     constexpr int NPA = BM / 64, NPB = BN / 64;   // DMA passes (64 rows each) per plane
@@ -402,6 +424,7 @@ ln_split_kernel(const float* __restrict__ x, const int ld, const int D, const in
                 const float* __restrict__ gamma, const float* __restrict__ beta,
                 _Float16* __restrict__ Ph, _Float16* __restrict__ Pl, const int ldp)
 {
+    h3_flush_f16_denormals();
     const int lane = threadIdx.x & 63;
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= M) return;
@@ -455,6 +478,7 @@ static __global__ void __launch_bounds__(256)
 split_rows_kernel(const float* __restrict__ x, const int ld, const int D, const int M,
                   _Float16* __restrict__ Ph, _Float16* __restrict__ Pl, const int ldp)
 {
+    h3_flush_f16_denormals();
     const int per_row = D / 4;
     const long idx = (long)blockIdx.x * 256 + threadIdx.x;
     if (idx >= (long)M * per_row) return;
