@@ -45,7 +45,8 @@ constexpr int ROWS_T = 52;       // 51 tokens + one dummy row that out-of-range 
 constexpr int XLD = 40;          // halfs per row of the K = 32 operand tile (80 B: conflict-free 16-byte reads)
 constexpr int HLD = 72;          // halfs per row of the K = 64 hidden tile (144 B)
 constexpr int KLD = 36;          // floats per row of the K / V tiles
-constexpr size_t lds_bytes() { return (size_t)2 * ROWS_T * XLD * 2 + (size_t)2 * ROWS_T * KLD * 4; }
+constexpr int NPARAM = 352;     // LayerNorm parameters and biases of one block (SpatialBlockLayoutV2 up to fq)
+constexpr size_t lds_bytes() { return (size_t)2 * ROWS_T * XLD * 2 + (size_t)2 * ROWS_T * KLD * 4 + NPARAM * 4; }
 static_assert(2 * ROWS_T * HLD * 2 == 2 * ROWS_T * KLD * 4, "the hidden planes reuse the K / V tiles byte for byte");
 
 // C^T tiles of W^T X^T for NT output tiles (32 channels each) and both token tiles; K = 16 * KK.
@@ -92,7 +93,7 @@ __device__ __forceinline__ void mm(const _Float16* __restrict__ wf, const _Float
 
 // LayerNormalization over the 32 channels of each of the lane's two tokens (16 here, 16 in lane ^ 32); same
 // arithmetic as ln_row (non-fused Keras path: inv = rstd * gamma, y = x * inv + (beta - mean * inv))
-__device__ __forceinline__ void ln_tokens(const float (&x)[2][16], const float* __restrict__ g, const float* __restrict__ b,
+__device__ __forceinline__ void ln_tokens(const float (&x)[2][16], const float* g, const float* b,
                                           const float eps, const int half, float (&y)[2][16]) {
 #pragma clang fp contract(off)      // see the kernel: both unrolled token copies must round identically
 #pragma unroll
@@ -108,10 +109,14 @@ __device__ __forceinline__ void ln_tokens(const float (&x)[2][16], const float* 
         q += __shfl_xor(q, 32);
         const float rstd = 1.0f / sqrtf(q * (1.0f / 32.0f) + eps);
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int c = 8 * (r >> 2) + 4 * half + (r & 3);
-            const float inv = rstd * g[c];
-            y[mt][r] = fmaf(x[mt][r], inv, fmaf(-mean, inv, b[c]));
+        for (int gq = 0; gq < 4; ++gq) {
+            const f32x4 g4 = *reinterpret_cast<const f32x4*>(g + 8 * gq + 4 * half);
+            const f32x4 b4 = *reinterpret_cast<const f32x4*>(b + 8 * gq + 4 * half);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float inv = rstd * g4[e];
+                y[mt][4 * gq + e] = fmaf(x[mt][4 * gq + e], inv, fmaf(-mean, inv, b4[e]));
+            }
         }
     }
 }
@@ -138,34 +143,41 @@ __device__ __forceinline__ void store_planes(_Float16* Th, _Float16* Tl, const i
 // channels of the frame's first key row.
 template <int J>
 __device__ __forceinline__ f32x4 head_attention(const f32x4 q4, const float* Kp, const float* Vp) {
+    // softmax(x) with x = q.k / 2: exp(x - max) = exp2((q * log2e / 2).k - max'), so the scale and the base change are
+    // folded into q once; the 1 / sum normalisation is applied to the 4 outputs instead of the 17 probabilities
+    const f32x4 qs = {q4[0] * 0.72134752044448170368f, q4[1] * 0.72134752044448170368f,
+                      q4[2] * 0.72134752044448170368f, q4[3] * 0.72134752044448170368f};
     float s[J];
     float mx = -INFINITY;
 #pragma unroll
     for (int j = 0; j < J; ++j) {
         const f32x4 k4 = *reinterpret_cast<const f32x4*>(Kp + j * KLD);
-        float d = q4[0] * k4[0];
-        d = fmaf(q4[1], k4[1], d); d = fmaf(q4[2], k4[2], d); d = fmaf(q4[3], k4[3], d);
-        s[j] = d * 0.5f;                                  // / sqrt(d_h), d_h = 4
-        mx = fmaxf(mx, s[j]);
+        float d = qs[0] * k4[0];
+        d = fmaf(qs[1], k4[1], d); d = fmaf(qs[2], k4[2], d); d = fmaf(qs[3], k4[3], d);
+        s[j] = d;
+        mx = fmaxf(mx, d);
     }
     float sum = 0.f;
-#pragma unroll
-    for (int j = 0; j < J; ++j) { s[j] = sv2::fast_exp(s[j] - mx); sum += s[j]; }
-    const float rsum = 1.0f / sum;
     f32x4 o = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int j = 0; j < J; ++j) {
-        const float pj = s[j] * rsum;
+        const float e = __builtin_amdgcn_exp2f(s[j] - mx);
+        sum += e;
         const f32x4 v4 = *reinterpret_cast<const f32x4*>(Vp + j * KLD);
-        o[0] = fmaf(pj, v4[0], o[0]); o[1] = fmaf(pj, v4[1], o[1]); o[2] = fmaf(pj, v4[2], o[2]); o[3] = fmaf(pj, v4[3], o[3]);
+        o[0] = fmaf(e, v4[0], o[0]); o[1] = fmaf(e, v4[1], o[1]); o[2] = fmaf(e, v4[2], o[2]); o[3] = fmaf(e, v4[3], o[3]);
     }
+    const float rsum = 1.0f / sum;
+    o[0] *= rsum; o[1] *= rsum; o[2] *= rsum; o[3] *= rsum;
     return o;
 }
 }  // namespace sh3
 
 // out_lo == nullptr: out is the f32 (frames, J, 32) tensor; otherwise out / out_lo are its two f16 planes
+#ifndef UU3D_SPATIAL_H3_WAVES
+#define UU3D_SPATIAL_H3_WAVES 2     // 3 (168 VGPRs) spills into the block loop: 0.30 ms instead of 0.20
+#endif
 template <int J, int FR>
-__global__ void __launch_bounds__(64, 2)
+__global__ void __launch_bounds__(64, UU3D_SPATIAL_H3_WAVES)
 spatial_stack_h3_kernel(const float* __restrict__ kp2d, const SpatialParams p, const _Float16* __restrict__ wfrag,
                         float* __restrict__ out, _Float16* __restrict__ out_hi, _Float16* __restrict__ out_lo)
 {
@@ -186,6 +198,7 @@ spatial_stack_h3_kernel(const float* __restrict__ kp2d, const SpatialParams p, c
     float* TV = TK + ROWS_T * KLD;                                      // [52][36] V
     _Float16* Hh = reinterpret_cast<_Float16*>(TK);                    // [52][72] GELU(fc1), hi (K / V are dead by then)
     _Float16* Hl = Hh + ROWS_T * HLD;
+    float* P = TV + ROWS_T * KLD;                                       // [352] this block's LayerNorm parameters and biases
 
     const int lane = threadIdx.x, tl = lane & 31, half = lane >> 5;
     int nframes = p.total_frames;
@@ -221,8 +234,14 @@ spatial_stack_h3_kernel(const float* __restrict__ kp2d, const SpatialParams p, c
     }
 
     for (int blk = 0; blk < p.depth; ++blk) {
-        const float* __restrict__ W = p.blocks + (size_t)blk * LY::size;
         const _Float16* __restrict__ F = wfrag + (size_t)blk * FL::size;
+        {   // one coalesced copy of the block's 352 parameters into LDS: the 16-byte group reads below then cost an LDS
+            // round trip instead of a dependent global load each (133 of them per block before)
+            const float* __restrict__ Wg = p.blocks + (size_t)blk * LY::size;
+#pragma unroll
+            for (int i = 0; i < (NPARAM + 63) / 64; ++i) { const int k = 64 * i + lane; if (k < NPARAM) P[k] = Wg[k]; }
+        }
+        const float* W = P;
         float y[2][16];
 
         // ---- attention half ----
@@ -239,9 +258,9 @@ spatial_stack_h3_kernel(const float* __restrict__ kp2d, const SpatialParams p, c
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
                     const int c = 8 * g + 4 * half;
+                    const f32x4 b4 = *reinterpret_cast<const f32x4*>(W + LY::bk + c);
                     *reinterpret_cast<f32x4*>(&TK[row * KLD + c]) =
-                        (f32x4){kv[0][mt][4 * g] + W[LY::bk + c], kv[0][mt][4 * g + 1] + W[LY::bk + c + 1],
-                                kv[0][mt][4 * g + 2] + W[LY::bk + c + 2], kv[0][mt][4 * g + 3] + W[LY::bk + c + 3]};
+                        (f32x4){kv[0][mt][4 * g] + b4[0], kv[0][mt][4 * g + 1] + b4[1], kv[0][mt][4 * g + 2] + b4[2], kv[0][mt][4 * g + 3] + b4[3]};
                 }
             }
             mm<1, 2>(F + FL::fv, Xh, Xl, XLD, lane, kv);
@@ -251,9 +270,9 @@ spatial_stack_h3_kernel(const float* __restrict__ kp2d, const SpatialParams p, c
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
                     const int c = 8 * g + 4 * half;
+                    const f32x4 b4 = *reinterpret_cast<const f32x4*>(W + LY::bv + c);
                     *reinterpret_cast<f32x4*>(&TV[row * KLD + c]) =
-                        (f32x4){kv[0][mt][4 * g] + W[LY::bv + c], kv[0][mt][4 * g + 1] + W[LY::bv + c + 1],
-                                kv[0][mt][4 * g + 2] + W[LY::bv + c + 2], kv[0][mt][4 * g + 3] + W[LY::bv + c + 3]};
+                        (f32x4){kv[0][mt][4 * g] + b4[0], kv[0][mt][4 * g + 1] + b4[1], kv[0][mt][4 * g + 2] + b4[2], kv[0][mt][4 * g + 3] + b4[3]};
                 }
             }
         }
@@ -264,8 +283,8 @@ spatial_stack_h3_kernel(const float* __restrict__ kp2d, const SpatialParams p, c
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 const int c = 8 * g + 4 * half;
-                const f32x4 q4 = {q[0][mt][4 * g] + W[LY::bq + c], q[0][mt][4 * g + 1] + W[LY::bq + c + 1],
-                                  q[0][mt][4 * g + 2] + W[LY::bq + c + 2], q[0][mt][4 * g + 3] + W[LY::bq + c + 3]};
+                const f32x4 b4 = *reinterpret_cast<const f32x4*>(W + LY::bq + c);
+                const f32x4 q4 = {q[0][mt][4 * g] + b4[0], q[0][mt][4 * g + 1] + b4[1], q[0][mt][4 * g + 2] + b4[2], q[0][mt][4 * g + 3] + b4[3]};
                 const f32x4 o4 = head_attention<J>(q4, TK + fbase[mt] * KLD + c, TV + fbase[mt] * KLD + c);
                 o[mt][4 * g] = o4[0]; o[mt][4 * g + 1] = o4[1]; o[mt][4 * g + 2] = o4[2]; o[mt][4 * g + 3] = o4[3];
             }
@@ -274,9 +293,13 @@ spatial_stack_h3_kernel(const float* __restrict__ kp2d, const SpatialParams p, c
             float pr[1][2][16];
             mm<1, 2>(F + FL::fp, Xh, Xl, XLD, lane, pr);
 #pragma unroll
-            for (int mt = 0; mt < 2; ++mt)
+            for (int g = 0; g < 4; ++g) {
+                const f32x4 b4 = *reinterpret_cast<const f32x4*>(W + LY::bp + 8 * g + 4 * half);
 #pragma unroll
-                for (int r = 0; r < 16; ++r) x[mt][r] += pr[0][mt][r] + W[LY::bp + 8 * (r >> 2) + 4 * half + (r & 3)];
+                for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) x[mt][4 * g + e] += pr[0][mt][4 * g + e] + b4[e];
+            }
         }
 
         // ---- MLP half ----
@@ -288,10 +311,13 @@ spatial_stack_h3_kernel(const float* __restrict__ kp2d, const SpatialParams p, c
 #pragma unroll
             for (int nt = 0; nt < 2; ++nt) {
 #pragma unroll
-                for (int mt = 0; mt < 2; ++mt)
+                for (int g = 0; g < 4; ++g) {
+                    const f32x4 b4 = *reinterpret_cast<const f32x4*>(W + LY::b1 + 32 * nt + 8 * g + 4 * half);
 #pragma unroll
-                    for (int r = 0; r < 16; ++r)
-                        hd[nt][mt][r] = sv2::gelu_erf(hd[nt][mt][r] + W[LY::b1 + 32 * nt + 8 * (r >> 2) + 4 * half + (r & 3)]);
+                    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) hd[nt][mt][4 * g + e] = sv2::gelu_erf(hd[nt][mt][4 * g + e] + b4[e]);
+                }
                 store_planes(Hh, Hl, HLD, 32 * nt, lane, hd[nt]);
             }
         }
@@ -299,9 +325,13 @@ spatial_stack_h3_kernel(const float* __restrict__ kp2d, const SpatialParams p, c
             float z[1][2][16];
             mm<1, 4>(F + FL::f2, Hh, Hl, HLD, lane, z);
 #pragma unroll
-            for (int mt = 0; mt < 2; ++mt)
+            for (int g = 0; g < 4; ++g) {
+                const f32x4 b4 = *reinterpret_cast<const f32x4*>(W + LY::b2 + 8 * g + 4 * half);
 #pragma unroll
-                for (int r = 0; r < 16; ++r) x[mt][r] += z[0][mt][r] + W[LY::b2 + 8 * (r >> 2) + 4 * half + (r & 3)];
+                for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) x[mt][4 * g + e] += z[0][mt][4 * g + e] + b4[e];
+            }
         }
     }
 
