@@ -122,6 +122,16 @@ class UpliftUpsampleTransformer(object):
         d = self.get_weights_dict()
         return [d[n] for n, _ in self._spec]
 
+    def save_weights(self, filepath):
+        """``model.save_weights("x.h5")`` (train.py:706,719): Keras HDF5 weight file, top-level layer names of the reference."""
+        from ..utils import weight_io
+        weight_io.save_keras_h5(filepath, self.get_weights_dict(), self._spec)
+
+    def load_weights(self, filepath, skip_mismatch=False, callbacks=(), verbose=False):
+        """By-name / by-position load of a Keras ``.h5`` (reference ``weight_io.load_weights_with_callback``)."""
+        from ..utils import weight_io
+        return weight_io.load_weights_with_callback(self, filepath, skip_mismatch=skip_mismatch, callbacks=callbacks, verbose=verbose)
+
     def _commit(self):
         torch = self._torch
         with torch.cuda.device(self.device):
