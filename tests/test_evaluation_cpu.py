@@ -1,0 +1,96 @@
+"""Evaluation protocol, host side: batched metrics against the per-pose oracle restatement, the
+invariances the metrics are defined by, keyframe interpolation and the action-wise bookkeeping."""
+import numpy as np
+import pytest
+
+from uplift_upsample_3dhpe_amd import evaluation as E
+from oracle import metrics_oracle as MO
+from oracle import uplift_oracle as O
+from tests import util
+
+
+def _data(B=40, K=17, seed=0, invalid=True):
+    rng = np.random.default_rng(seed)
+    gt = rng.normal(0, 0.3, size=(B, K, 3))
+    pred = gt + rng.normal(0, 0.05, size=(B, K, 3))
+    v = np.ones((B, K, 1))
+    if invalid:
+        v[rng.random((B, K, 1)) < 0.1] = 0.0
+        v[:, 6] = 1.0                          # keep the root valid
+    return pred, np.concatenate([gt, v], -1)
+
+
+def _rot(rng):
+    q, _ = np.linalg.qr(rng.normal(size=(3, 3)))
+    return q * np.sign(np.linalg.det(q))
+
+
+def test_batched_metrics_match_the_per_pose_oracle():
+    pred, gt = _data()
+    assert np.allclose(E.pmpjpe(pred, gt, normalize=False), MO.pmpjpe(pred, gt, normalize=False), atol=1e-12)
+    assert abs(E.pmpjpe(pred, gt) - MO.pmpjpe(pred, gt)) < 1e-12
+    for al in ("root", "mean"):
+        assert np.allclose(E.nmpjpe(pred, gt, 6, al, normalize=False), MO.nmpjpe(pred, gt, 6, al, normalize=False), atol=1e-12)
+    assert np.allclose(E.mpjpe(pred, gt, 6, normalize=False), O.mpjpe(pred, gt, 6, normalize=False), atol=1e-12)
+    # a reflected prediction exercises the det < 0 branch of the Procrustes fit (metrics.py:178-182)
+    refl = pred * np.array([-1.0, 1.0, 1.0])
+    assert np.allclose(E.pmpjpe(refl, gt, normalize=False), MO.pmpjpe(refl, gt, normalize=False), atol=1e-12)
+    assert E.pmpjpe(refl, gt) > 2 * E.pmpjpe(pred, gt)            # a rotation cannot undo a reflection
+
+
+def test_metric_invariances():
+    rng = np.random.default_rng(1)
+    pred, gt = _data(invalid=False, seed=1)
+    base_p, base_n = E.pmpjpe(pred, gt, normalize=False), E.nmpjpe(pred, gt, 6, normalize=False)
+    moved = np.stack([2.5 * p @ _rot(rng) + rng.normal(size=3) for p in pred])
+    assert np.allclose(E.pmpjpe(moved, gt, normalize=False), base_p, atol=1e-10)       # similarity transforms of the prediction
+    assert np.allclose(E.nmpjpe(pred * 3.0, gt, 6, normalize=False), base_n, atol=1e-10)   # scale
+    assert np.allclose(E.nmpjpe(pred + 0.7, gt, 6, normalize=False), base_n, atol=1e-10)   # root alignment removes translation
+    assert np.all(base_p <= E.mpjpe(pred, gt, 6, normalize=False).mean(1, keepdims=True) * 17)  # sanity: finite, bounded
+    exact = np.concatenate([gt[:, :, :3]], -1)
+    assert E.pmpjpe(exact, gt) < 1e-12 and E.nmpjpe(exact, gt, 6) < 1e-12
+
+
+def test_invalid_joints_are_flagged_and_excluded():
+    pred, gt = _data(seed=2)
+    for m in (E.mpjpe(pred, gt, 6, normalize=False), E.nmpjpe(pred, gt, 6, normalize=False), E.pmpjpe(pred, gt, normalize=False)):
+        assert np.all((m == -1.0) == (gt[:, :, 3] == 0))
+    v = gt[:, :, 3] > 0
+    per = E.mpjpe(pred, gt, 6, normalize=False)
+    assert abs(E.mpjpe(pred, gt, 6) - per[v].mean()) < 1e-12
+
+
+def test_keyframe_interpolation():
+    # two videos (frame index restarts), stride 4: keyframes 0, 4, 8 ... ; tail after the last keyframe repeats it
+    idx = np.concatenate([np.arange(0, 11), np.arange(0, 6)])
+    pred = np.arange(len(idx), dtype=np.float64)[:, None, None] * np.ones((1, 2, 3))
+    out, key = E.interpolate_between_keyframes(pred, idx, 4)
+    assert key.tolist() == [i % 4 == 0 for i in idx]
+    assert np.allclose(out[:9, 0, 0], np.arange(9))               # linear data interpolates to itself
+    assert np.allclose(out[9:11, 0, 0], 8)                        # after the last keyframe of video 1
+    assert np.allclose(out[11:16, 0, 0], [11, 12, 13, 14, 15]) and np.allclose(out[16, 0, 0], 15)
+    wiggle = pred.copy(); wiggle[1:4] += 100.0                   # non-keyframes are ignored between keyframes
+    out2, _ = E.interpolate_between_keyframes(wiggle, idx, 4)
+    assert np.allclose(out2[1:4, 0, 0], [1, 2, 3])
+    out3, _ = E.interpolate_between_keyframes(pred, idx, np.full(len(idx), 4))   # per-frame stride array, as eval.py passes
+    assert np.array_equal(out3, out)
+
+
+def test_action_wise_eval_and_run_bookkeeping():
+    pred, gt = _data(B=90, seed=3, invalid=False)
+    actions = np.arange(90) % 15
+    frame, avg, per = E.h36_action_wise_eval(pred, gt, actions, 6)
+    assert list(per) == E.H36M_ACTIONS and set(frame) == set(E.METRICS)
+    fm = E.mpjpe(pred, gt, 6, normalize=False) * 1000.0
+    assert abs(per["Eating"]["mpjpe"] - fm[actions == 2].mean()) < 1e-9
+    assert abs(avg["mpjpe"] - np.mean([fm[actions == a].mean() for a in range(15)])) < 1e-9
+    assert abs(frame["mpjpe"] - fm.mean()) < 1e-9 and frame["pampjpe"] <= frame["nmpjpe"] + 1e-9 <= frame["mpjpe"] + 2e-9
+    assert E.frame_wise_eval(pred, gt, 6)["nmpjpe"] == pytest.approx(frame["nmpjpe"])
+    cfg = util.load_config("h36m_351")                            # SEQUENCE_STRIDE 5, MASK_STRIDE 5, TEST_STRIDED_EVAL
+    idx = np.arange(90)
+    res = E.evaluate_predictions(pred, gt[:, :, :3], actions, idx, cfg)
+    assert res["keyframes"] is not None
+    key = idx % 5 == 0
+    assert res["keyframes"][0]["mpjpe"] == pytest.approx(fm[key].mean())
+    interp, _ = E.interpolate_between_keyframes(pred, idx, 5)
+    assert res["all_frames"][0]["mpjpe"] == pytest.approx((E.mpjpe(interp, gt, 6, normalize=False) * 1000).mean())
