@@ -93,6 +93,7 @@ struct uu3d_model {
     const float* sp_blocks_v2 = nullptr;   // MFMA kernel layout
     bool spatial_valu = false;
     bool spatial_f32 = false;      // UU3D_SPATIAL=f32: exact-f32 MFMA spatial stack even in f16x3 mode
+    bool spatial_h3_always = false;   // UU3D_SPATIAL=h3: f16x3 spatial stack for every launch size
     size_t sp_frag_off = 0;        // offset (halfs) of the spatial f16 fragment planes in harena
     const float *s2t_wt = nullptr, *s2t_b = nullptr, *token = nullptr, *pe_t = nullptr;
     std::vector<BlockDev> tblocks, sblocks;
@@ -284,7 +285,7 @@ int uu3d_create(const uu3d_config* c, int device, uu3d_model** out) {
     }
     build_inventory(m);
     { const char* e = getenv("UU3D_SPATIAL"); m->spatial_valu = (e != nullptr && std::string(e) == "valu");
-      m->spatial_f32 = (e != nullptr && std::string(e) == "f32"); }
+      m->spatial_f32 = (e != nullptr && std::string(e) == "f32"); m->spatial_h3_always = (e != nullptr && std::string(e) == "h3"); }
     { const char* e = getenv("UU3D_NO_PLANES"); m->no_planes = (e != nullptr && e[0] == '1'); }
     { const char* e = getenv("UU3D_LN_PLANES"); m->ln_planes = (e != nullptr && e[0] == '1'); }
     *out = m;
@@ -603,6 +604,17 @@ size_t uu3d_workspace_bytes(const uu3d_model* m, int32_t batch) {
 // ---- launch helpers ---------------------------------------------------------------------
 namespace {
 
+// Both spatial kernels are one wave per 3 frames and latency bound: a launch takes (rounds of resident waves) x (one
+// wave's run time).  Measured on MI355X: the f16x3 kernel runs ~100 us per wave and 6 waves fit a CU (24.7 KB LDS
+// each: 1536 per round), the exact-f32 kernel ~133 us with 7 per CU (1792 per round).  E.g. 1515 waves (h36m_351,
+// 64 sequences): 0.10 vs 0.13 ms; 1750 waves (h36m_81, 128 sequences): 0.20 vs 0.14 ms.  The frame count of the
+// launch decides (an upper bound of the waves: masked frames drop out on the device).
+inline bool spatial_h3_pays(int frames) {
+    const int waves = (frames + kFR - 1) / kFR;
+    const int t_h3 = ((waves + 1535) / 1536) * 100, t_f32 = ((waves + 1791) / 1792) * 133;
+    return t_h3 <= t_f32;
+}
+
 struct Launcher {
     uu3d_model* m;
     hipStream_t stream;
@@ -809,7 +821,7 @@ int uu3d_forward(uu3d_model* m, const float* kp2d, const uint8_t* mask, int32_t 
             Lh.begin("spatial_stack", "spatial_valu", fl, 4.0 * M * J * (2.0 + ds));
             hipLaunchKernelGGL(kern, dim3((M + FPW - 1) / FPW), dim3(256), spatial_lds_bytes(kDS), Lh.stream, kp2d, sp, w.S);
             Lh.end();
-        } else if (c.precision == UU3D_PREC_F16X3 && !m->spatial_f32) {
+        } else if (c.precision == UU3D_PREC_F16X3 && !m->spatial_f32 && (m->spatial_h3_always || spatial_h3_pays(M))) {
             sp.blocks = m->sp_blocks_v2;             // LayerNorm parameters and biases
             auto kern = spatial_stack_h3_kernel<kJ, kFR>;
             Lh.begin("spatial_stack", "spatial_h3", fl, 4.0 * M * J * (2.0 + ds));
