@@ -141,6 +141,24 @@ int uu3d_mpjpe(const float* pred_dev, const float* gt_dev, int32_t batch, int32_
                int32_t root_index, double* out_dev, void* stream);
 
 /*
+ * "Next" row 3 of the scope table: the window / stride-mask generator as a gather over a RESIDENT pose table.
+ * Replaces the per-sample slicing, padding, stride mask and flip of H36mSequenceGenerator
+ * (common/dataset/uplifiting_dataset.py:322-407) plus the harness's `x * stride_mask` (eval.py:67, train.py:474).
+ *   poses_dev (F, J, C) f32: all videos back to back (C = 2 for 2D keypoints, 3 for 3D ground truth);
+ *   video_start_dev (V) i64 first row of each video, video_len_dev (V) i32;
+ *   windows_dev (B) uu3d_window: video, centre frame, sampling stride, ABSOLUTE mask stride, mask shift (centre frame
+ *   for globally aligned masks, rand_shift * stride in training, 0 otherwise), flip flag;
+ *   flip_order_dev (J) i32 or NULL (AUGM_FLIP_KEYPOINT_ORDER); pad_edge: 1 = "copy" padding, 0 = zeros.
+ *   out_dev (B, N, J, C); stride_mask_dev (B, N) u8 (1 = real input); pad_mask_dev (B, N) u8 or NULL (1 = frame exists).
+ */
+typedef struct uu3d_window { int32_t video, center, stride, mask_stride, mask_shift, flip; } uu3d_window;
+int uu3d_gather_windows(const float* poses_dev, const int64_t* video_start_dev, const int32_t* video_len_dev,
+                        const uu3d_window* windows_dev, const int32_t* flip_order_dev,
+                        int32_t batch, int32_t num_frames, int32_t num_keypoints, int32_t channels,
+                        int32_t pad_edge, int32_t zero_masked,
+                        float* out_dev, uint8_t* stride_mask_dev, uint8_t* pad_mask_dev, void* stream);
+
+/*
  * Per-kernel timing of the next uu3d_forward calls with HIP events on the launch stream.
  * When enabled, uu3d_forward records an event pair around every launch; uu3d_profile_read
  * synchronises those events and returns the per-launch records of the LAST forward.

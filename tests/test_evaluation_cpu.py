@@ -94,3 +94,19 @@ def test_action_wise_eval_and_run_bookkeeping():
     assert res["keyframes"][0]["mpjpe"] == pytest.approx(fm[key].mean())
     interp, _ = E.interpolate_between_keyframes(pred, idx, 5)
     assert res["all_frames"][0]["mpjpe"] == pytest.approx((E.mpjpe(interp, gt, 6, normalize=False) * 1000).mean())
+
+
+def test_window_oracle_shapes_and_padding():
+    """oracle/window_oracle.py itself: edge / zero padding at both ends, stride-mask alignment."""
+    from oracle import window_oracle as WO
+    v = np.arange(10, dtype=np.float32)[:, None, None] * np.ones((1, 2, 2), np.float32)
+    w, m, s = WO.one_window(v, 1, 9, 2, "edge", 4, "global", 0, False, None)       # frames -7 -5 -3 -1 1 3 5 7 9
+    assert w[:, 0, 0].tolist() == [1, 1, 1, 1, 1, 3, 5, 7, 9] and m.tolist() == [0, 0, 0, 0, 1, 1, 1, 1, 1]
+    assert s.tolist() == [(f % 4 == 0) for f in range(-7, 11, 2)]
+    w, m, _ = WO.one_window(v, 8, 5, 3, "constant", 3, None, 0, False, None)        # frames 2 5 8 11 14
+    assert w[:, 0, 0].tolist() == [2, 5, 8, 0, 0] and m.tolist() == [1, 1, 1, 0, 0]
+    w, _, _ = WO.one_window(v, 8, 5, 3, "edge", 3, None, 0, True, [1, 0])
+    assert w[:, 0, 0].tolist() == [-2, -5, -8, -8, -8] and w[:, 0, 1].tolist() == [2, 5, 8, 8, 8]
+    rows = WO.sample_list([5, 3], [50, 100], 2, True, False)
+    assert rows.tolist() == [[0, 0, 0, 50], [0, 2, 0, 50], [0, 4, 0, 50], [0, 0, 1, 50], [0, 2, 1, 50], [0, 4, 1, 50],
+                             [1, 0, 0, 100], [1, 2, 0, 100], [1, 0, 1, 100], [1, 2, 1, 100]]

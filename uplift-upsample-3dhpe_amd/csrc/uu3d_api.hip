@@ -963,6 +963,19 @@ int uu3d_mpjpe(const float* pred, const float* gt, int32_t B, int32_t J, int32_t
     return hipGetLastError() == hipSuccess ? UU3D_OK : UU3D_ERR_HIP;
 }
 
+int uu3d_gather_windows(const float* poses, const int64_t* video_start, const int32_t* video_len, const uu3d_window* windows,
+                        const int32_t* flip_order, int32_t B, int32_t N, int32_t J, int32_t Cc, int32_t pad_edge,
+                        int32_t zero_masked, float* out, uint8_t* stride_mask, uint8_t* pad_mask, void* stream) {
+    if (!poses || !video_start || !video_len || !windows || !out || !stride_mask || B < 1 || N < 1 || J < 1 || Cc < 1 || Cc > 4)
+        return UU3D_ERR_INVALID_ARGUMENT;
+    static_assert(sizeof(uu3d_window) == sizeof(WindowDesc), "descriptor layouts must agree");
+    const long total = (long)B * N * J;
+    hipLaunchKernelGGL(gather_windows_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                       poses, video_start, video_len, reinterpret_cast<const WindowDesc*>(windows), flip_order,
+                       B, N, J, Cc, pad_edge, zero_masked, out, stride_mask, pad_mask);
+    return hipGetLastError() == hipSuccess ? UU3D_OK : UU3D_ERR_HIP;
+}
+
 int uu3d_set_profiling(uu3d_model* m, int32_t enabled) {
     if (!m) return UU3D_ERR_INVALID_ARGUMENT;
     m->profiling = enabled != 0;

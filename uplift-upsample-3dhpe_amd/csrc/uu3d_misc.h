@@ -113,4 +113,52 @@ compact_frames_kernel(const uint8_t* __restrict__ mask, const int total, int* __
     if (tid == 0) list[total] = base;
 }
 
+
+// Window gather over a resident pose table: the device form of H36mSequenceGenerator's per-sample slicing
+// (common/dataset/uplifiting_dataset.py:322-394).  poses (F, J, C) holds all videos back to back; window w is centred
+// on frame `center` of video `video` and samples every `stride`-th frame:
+//     f_n = center - ((N - 1) * stride) / 2 + n * stride,  n = 0 .. N-1
+// Frames outside [0, video_len) are padding: pad_mask = 0 and the value is the nearest sampled in-range frame
+// (pad_edge, numpy mode "edge" = padding_type "copy") or 0 ("zeros").  stride_mask[n] = ((n - N/2) * stride + shift)
+// % mask_stride == 0 with the caller's shift (the centre frame index for globally aligned masks, :381-384; a random
+// multiple of the stride in training, :386-392).  zero_masked also applies x * stride_mask (eval.py:67, train.py:474).
+// flip: joints permuted by flip_order, channel 0 negated (:403-407).  One thread per (window, frame, joint).
+struct WindowDesc { int32_t video, center, stride, mask_stride, mask_shift, flip; };
+static __global__ void __launch_bounds__(256)
+gather_windows_kernel(const float* __restrict__ poses, const int64_t* __restrict__ video_start, const int32_t* __restrict__ video_len,
+                      const WindowDesc* __restrict__ win, const int32_t* __restrict__ flip_order,
+                      const int B, const int N, const int J, const int C, const int pad_edge, const int zero_masked,
+                      float* __restrict__ out, uint8_t* __restrict__ stride_mask, uint8_t* __restrict__ pad_mask)
+{
+    const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= (long)B * N * J) return;
+    const int j = (int)(idx % J);
+    const int n = (int)((idx / J) % N);
+    const int w = (int)(idx / ((long)J * N));
+    const WindowDesc d = win[w];
+    const int len = video_len[d.video];
+    const int f = d.center - ((N - 1) * d.stride) / 2 + n * d.stride;
+    int src = f;
+    if (f < 0) src = f + ((-f + d.stride - 1) / d.stride) * d.stride;                   // first sampled frame >= 0
+    else if (f >= len) src = f - ((f - len + d.stride) / d.stride) * d.stride;          // last sampled frame < len
+    const bool inside = (f >= 0) && (f < len);
+    const bool have = inside || (pad_edge != 0 && src >= 0 && src < len);
+    const int rel = (n - N / 2) * d.stride + d.mask_shift;
+    int mod = rel % d.mask_stride; if (mod < 0) mod += d.mask_stride;                   // python's % on negative numbers
+    const bool sm = (mod == 0);
+    if (j == 0) {
+        stride_mask[(long)w * N + n] = sm ? 1 : 0;
+        if (pad_mask != nullptr) pad_mask[(long)w * N + n] = inside ? 1 : 0;
+    }
+    const int js = (d.flip && flip_order != nullptr) ? flip_order[j] : j;
+    const float* p = poses + ((video_start[d.video] + (have ? src : 0)) * J + js) * C;
+    float* o = out + idx * C;
+    const bool keep = have && (!zero_masked || sm);
+    for (int c = 0; c < C; ++c) {
+        float v = keep ? p[c] : 0.f;
+        if (c == 0 && d.flip) v = -v;
+        o[c] = v;
+    }
+}
+
 }  // namespace uu3d
