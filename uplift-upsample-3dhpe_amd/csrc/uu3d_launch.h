@@ -65,6 +65,11 @@ inline int launch_colsum(const float* x, int ldx, int R, int C, int period, cons
     int slices = std::max(1, std::min(256, R / std::max(128, P)));      // >= 128 rows (and one period) per workgroup
     while (slices > 1 && (size_t)slices * P * C > scratch_floats) --slices;
     if ((size_t)slices * P * C > scratch_floats) return UU3D_ERR_WORKSPACE;
+    if (period <= 0 && mask == nullptr && (C % 4) == 0 && (ldx % 4) == 0) {
+        slices = std::max(1, std::min(128, R / 64));                    // >= 64 rows per workgroup: enough workgroups to fill the chip
+        while (slices > 1 && (size_t)slices * C > scratch_floats) --slices;
+        hipLaunchKernelGGL(colsum4_kernel, dim3((C + 255) / 256, slices), dim3(256), 0, stream, x, ldx, R, C, scratch, slices);
+    } else
     hipLaunchKernelGGL(colsum_kernel, dim3((C + 63) / 64, slices), dim3(256), 0, stream, x, ldx, R, C, period, mask, want, scratch, slices);
     hipLaunchKernelGGL(reduce_partials_kernel, dim3((P * C + 15) / 16), dim3(256), 0, stream, scratch, P * C, (size_t)P * C, slices, out, accumulate);
     return hip_status();
