@@ -231,6 +231,32 @@ splitk_reduce_kernel(const float* __restrict__ slab, const int slices, const siz
     ep.store(row, col, v, ep.colv(col), ep.pre(row, col));
 }
 
+// The same combine for MANY slices of a SMALL result (tall-skinny weight gradients: 32 x 32 ... 64 x 96 outputs over
+// tens of thousands of rows): 16 lanes per output element, lane q adds slices q, q+16, ... in order, the 16 lane sums
+// are then added in lane order -- deterministic, and 16 x shorter than the one-thread-per-element loop.
+template <class EP>
+__global__ void __launch_bounds__(256)
+splitk_reduce16_kernel(const float* __restrict__ slab, const int slices, const size_t slice_stride,
+                       const int M, const int N, const int ld, const EP ep)
+{
+    __shared__ float red[16][17];
+    const int el = threadIdx.x & 15, q = threadIdx.x >> 4;
+    const int idx = blockIdx.x * 16 + el;
+    const bool ok = idx < M * N;
+    const int row = ok ? idx / N : 0, col = ok ? idx - row * N : 0;
+    const float* p = slab + (size_t)row * ld + col;
+    float v = 0.f;
+    if (ok) for (int s = q; s < slices; s += 16) v += p[s * slice_stride];
+    red[q][el] = v;
+    __syncthreads();
+    if (q == 0 && ok) {
+        float t = red[0][el];
+#pragma unroll
+        for (int k = 1; k < 16; ++k) t += red[k][el];
+        ep.store(row, col, t, ep.colv(col), ep.pre(row, col));
+    }
+}
+
 // ------------------------------------------------------------------------------------
 // kernel
 // ------------------------------------------------------------------------------------

@@ -43,7 +43,11 @@ template <class AL, class EP>
 int launch_gemm_tn(const AL& al, const float* B, int ldb, int R, int P, int Q, const EP& ep, float* slab, size_t slab_floats, hipStream_t stream) {
     const int pt = (P + 63) / 64, qt = (Q + 63) / 64, tiles = pt * qt;
     const int KT = (R + 31) / 32;
-    int slices = std::max(1, std::min(std::min(std::max(KT / 4, 1), 48), (1024 + tiles / 2) / tiles));   // <= 48 slabs: the ordered combine is serial
+    // <= 48 slabs when the combine is one thread per element; tall-skinny results (<= 4 tiles, e.g. the spatial stack's
+    // 32 x 32 weight gradients over 77k rows) take up to 512 slabs and the 16-lane combine instead
+    const bool skinny = tiles <= 4 && KT >= 256;
+    int slices = skinny ? std::max(1, std::min(KT / 4, 512 / tiles))
+                        : std::max(1, std::min(std::min(std::max(KT / 4, 1), 48), (1024 + tiles / 2) / tiles));
     const int ldslab = ru(Q, 4);
     while (slices > 1 && (size_t)slices * P * ldslab > slab_floats) --slices;
     int kps = (KT + slices - 1) / slices;
@@ -53,8 +57,12 @@ int launch_gemm_tn(const AL& al, const float* B, int ldb, int R, int P, int Q, c
     } else {
         EpSlab es{slab, ldslab, (size_t)P * ldslab};
         hipLaunchKernelGGL((gemm_tn_kernel<AL, EpSlab>), dim3(tiles, slices), dim3(256), 0, stream, al, B, ldb, R, P, Q, pt, qt, kps, es);
-        hipLaunchKernelGGL(splitk_reduce_kernel<EP>, dim3((P * Q + 255) / 256), dim3(256), 0, stream, slab, slices,
-                           (size_t)P * ldslab, P, Q, ldslab, ep);
+        if (skinny)
+            hipLaunchKernelGGL(splitk_reduce16_kernel<EP>, dim3((P * Q + 15) / 16), dim3(256), 0, stream, slab, slices,
+                               (size_t)P * ldslab, P, Q, ldslab, ep);
+        else
+            hipLaunchKernelGGL(splitk_reduce_kernel<EP>, dim3((P * Q + 255) / 256), dim3(256), 0, stream, slab, slices,
+                               (size_t)P * ldslab, P, Q, ldslab, ep);
     }
     return hip_status();
 }
