@@ -86,14 +86,18 @@ inline int launch_colsum(const float* x, int ldx, int R, int C, int period, cons
 // dgamma/dbeta: written (acc_params == 0) or accumulated.
 inline int launch_ln_bwd(const float* x, const float* dy, const float2* stats, const float* gamma, int ld, int D, int M, float* dx,
                          int accumulate, float* dgamma, float* dbeta, int acc_params, float* scratch, size_t scratch_floats, hipStream_t stream) {
-    int rpw = std::max(8, (M + 4 * 512 - 1) / (4 * 512));         // at most ~512 partial rows to combine
+    int rpw = std::max(2, (M + 4 * 2048 - 1) / (4 * 2048));       // >= 500 workgroups at M = 4544 (8 rows per wave left 114 of 256 CUs idle); <= 2048 partial rows to combine
     int wgs = (M + 4 * rpw - 1) / (4 * rpw);
     while ((size_t)wgs * 2 * D > scratch_floats) { rpw *= 2; wgs = (M + 4 * rpw - 1) / (4 * rpw); }
     if (D <= 512) hipLaunchKernelGGL(ln_bwd_kernel<2>, dim3(wgs), dim3(256), 0, stream, x, dy, stats, gamma, ld, D, M, rpw, dx, accumulate, scratch);
     else hipLaunchKernelGGL(ln_bwd_kernel<4>, dim3(wgs), dim3(256), 0, stream, x, dy, stats, gamma, ld, D, M, rpw, dx, accumulate, scratch);
     // partial layout [wg][2][D] -> finish over "n = 2*D" with wgs slices; dgamma and dbeta must be adjacent? no: two calls
-    hipLaunchKernelGGL(reduce_partials_kernel, dim3((D + 15) / 16), dim3(256), 0, stream, scratch, D, (size_t)2 * D, wgs, dgamma, acc_params);
-    hipLaunchKernelGGL(reduce_partials_kernel, dim3((D + 15) / 16), dim3(256), 0, stream, scratch + D, D, (size_t)2 * D, wgs, dbeta, acc_params);
+    if (dbeta == dgamma + D) {      // gamma and beta are neighbours in the flat gradient buffer: one combine over [dgamma | dbeta]
+        hipLaunchKernelGGL(reduce_partials_kernel, dim3((2 * D + 15) / 16), dim3(256), 0, stream, scratch, 2 * D, (size_t)2 * D, wgs, dgamma, acc_params);
+    } else {
+        hipLaunchKernelGGL(reduce_partials_kernel, dim3((D + 15) / 16), dim3(256), 0, stream, scratch, D, (size_t)2 * D, wgs, dgamma, acc_params);
+        hipLaunchKernelGGL(reduce_partials_kernel, dim3((D + 15) / 16), dim3(256), 0, stream, scratch + D, D, (size_t)2 * D, wgs, dbeta, acc_params);
+    }
     return hip_status();
 }
 
