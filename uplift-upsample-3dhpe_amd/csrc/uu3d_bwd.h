@@ -416,4 +416,179 @@ attn_generic_bwd_kernel(const float* __restrict__ qkv, const float* __restrict__
     }
 }
 
+// ------------------------------------------------------------------------------------
+// Softmax-attention backward on the matrix pipe (v_mfma_f32_16x16x4_f32, exact f32), one workgroup per (sequence,
+// head), one wave per tile of 16 tokens -- the structure of attn_f32_kernel (uu3d_attn.h).  Two passes, both keep
+// their L x L tiles in REGISTERS:
+//   pass 1, wave = query tile: S^T = K Q^T and dP^T = V dO^T land as [query = lane & 15][key = 16 j + 4 g + r];
+//           softmax over keys, delta = sum_k P dP, dS = P (dP - delta); row max / sum / delta go to LDS;
+//           dQ = dS K uses the registers directly as the A operand (the P V trick of the forward kernel).
+//   pass 2, wave = key tile: S = Q K^T and dP = dO V^T are RECOMPUTED in the other orientation,
+//           [key = lane & 15][query = 16 j + 4 g + r], P and dS rebuilt from the saved row statistics, and
+//           dK = dS^T Q, dV = P^T dO again consume the registers as A operands.
+// The generic kernel holds P and dS in LDS and does one scalar LDS read per FMA: 147 us per launch at L = 71,
+// B = 64; recomputing two small products instead costs ~240 extra MFMAs per wave and no L x L LDS traffic.
+template <int NT, int DH>
+__global__ void __launch_bounds__(64 * NT)
+attn_bwd_mfma_kernel(const float* __restrict__ qkv, const float* __restrict__ dO, const int ld, const int D,
+                     const int L, const int H, const uint8_t* __restrict__ key_mask,
+                     float* __restrict__ dqkv, const int ldo)
+{
+    static_assert(DH % 16 == 0, "head dim must be a multiple of 16");
+    constexpr int LD = DH + 4, F4 = DH / 4, KT = DH / 16, ROWS = NT * 16;
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    float* Qs = sm; float* Ks = Qs + ROWS * LD; float* Vs = Ks + ROWS * LD; float* Gs = Vs + ROWS * LD;
+    float* Mx = Gs + ROWS * LD; float* Sum = Mx + ROWS; float* Dl = Sum + ROWS;
+
+    const int bh = blockIdx.x, b = bh / H, h = bh - b * H, tid = threadIdx.x;
+    const float* base = qkv + (size_t)b * L * ld + h * DH;
+    for (int idx = tid; idx < ROWS * F4; idx += 64 * NT) {
+        const int row = idx / F4, c4 = (idx - row * F4) * 4;
+        f32x4 q = {0.f, 0.f, 0.f, 0.f}, k = q, v = q, g = q;
+        if (row < L) {
+            const float* p = base + (size_t)row * ld + c4;
+            q = *reinterpret_cast<const f32x4*>(p);
+            k = *reinterpret_cast<const f32x4*>(p + D);
+            v = *reinterpret_cast<const f32x4*>(p + 2 * D);
+            g = *reinterpret_cast<const f32x4*>(dO + ((size_t)b * L + row) * ldo + h * DH + c4);
+        }
+        *reinterpret_cast<f32x4*>(&Qs[row * LD + c4]) = q; *reinterpret_cast<f32x4*>(&Ks[row * LD + c4]) = k;
+        *reinterpret_cast<f32x4*>(&Vs[row * LD + c4]) = v; *reinterpret_cast<f32x4*>(&Gs[row * LD + c4]) = g;
+    }
+    __syncthreads();
+
+    const int lane = tid & 63, w = tid >> 6, qi = lane & 15, g = lane >> 4;
+    const float scale_div = sqrtf((float)DH);
+    float* dq_out = dqkv + (size_t)b * L * ld + h * DH;
+
+    // ---------------- pass 1: this wave's 16 queries against all keys ----------------
+    {
+        f32x4 qf[KT], gf[KT];
+#pragma unroll
+        for (int t = 0; t < KT; ++t) {
+            qf[t] = *reinterpret_cast<const f32x4*>(&Qs[(16 * w + qi) * LD + 16 * t + 4 * g]);
+            gf[t] = *reinterpret_cast<const f32x4*>(&Gs[(16 * w + qi) * LD + 16 * t + 4 * g]);
+        }
+        f32x4 st[NT], dp[NT];
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+            f32x4 a = {0.f, 0.f, 0.f, 0.f}, d = a;
+#pragma unroll
+            for (int t = 0; t < KT; ++t) {
+                const f32x4 kf = *reinterpret_cast<const f32x4*>(&Ks[(16 * j + qi) * LD + 16 * t + 4 * g]);
+                const f32x4 vf = *reinterpret_cast<const f32x4*>(&Vs[(16 * j + qi) * LD + 16 * t + 4 * g]);
+#pragma unroll
+                for (int s = 0; s < 4; ++s) {
+                    a = __builtin_amdgcn_mfma_f32_16x16x4f32(kf[s], qf[t][s], a, 0, 0, 0);
+                    d = __builtin_amdgcn_mfma_f32_16x16x4f32(vf[s], gf[t][s], d, 0, 0, 0);
+                }
+            }
+            st[j] = a; dp[j] = d;
+        }
+        float mx = -INFINITY;
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int key = 16 * j + 4 * g + r;
+                float v = st[j][r] / scale_div;
+                if (key < L) { if (key_mask != nullptr) v += (key_mask[(size_t)b * L + key] ? 0.0f : 1.0f) * -1e9f; }
+                else v = -INFINITY;
+                st[j][r] = v;
+                mx = fmaxf(mx, v);
+            }
+        mx = fmaxf(mx, __shfl_xor(mx, 16)); mx = fmaxf(mx, __shfl_xor(mx, 32));
+        float sum = 0.f;
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { const float e = expf(st[j][r] - mx); st[j][r] = e; sum += e; }
+        sum += __shfl_xor(sum, 16); sum += __shfl_xor(sum, 32);
+        float delta = 0.f;
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { st[j][r] = st[j][r] / sum; delta = fmaf(st[j][r], dp[j][r], delta); }
+        delta += __shfl_xor(delta, 16); delta += __shfl_xor(delta, 32);
+        if (g == 0) { Mx[16 * w + qi] = mx; Sum[16 * w + qi] = sum; Dl[16 * w + qi] = delta; }
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) st[j][r] = st[j][r] * (dp[j][r] - delta);          // dS
+#pragma unroll
+        for (int t = 0; t < KT; ++t) {
+            f32x4 o = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int j = 0; j < NT; ++j)
+#pragma unroll
+                for (int s = 0; s < 4; ++s)
+                    o = __builtin_amdgcn_mfma_f32_16x16x4f32(st[j][s], Ks[(16 * j + 4 * g + s) * LD + 16 * t + qi], o, 0, 0, 0);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int q = 16 * w + 4 * g + r;
+                if (q < L) dq_out[(size_t)q * ld + 16 * t + qi] = o[r] / scale_div;
+            }
+        }
+    }
+    __syncthreads();
+
+    // ---------------- pass 2: this wave's 16 keys against all queries ----------------
+    {
+        const int key = 16 * w + qi;
+        f32x4 kf[KT], vf[KT];
+#pragma unroll
+        for (int t = 0; t < KT; ++t) {
+            kf[t] = *reinterpret_cast<const f32x4*>(&Ks[key * LD + 16 * t + 4 * g]);
+            vf[t] = *reinterpret_cast<const f32x4*>(&Vs[key * LD + 16 * t + 4 * g]);
+        }
+        float madd = 0.f;
+        if (key_mask != nullptr && key < L) madd = (key_mask[(size_t)b * L + key] ? 0.0f : 1.0f) * -1e9f;
+        f32x4 pp[NT], ds[NT];
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+            f32x4 a = {0.f, 0.f, 0.f, 0.f}, d = a;
+#pragma unroll
+            for (int t = 0; t < KT; ++t) {
+                const f32x4 qa = *reinterpret_cast<const f32x4*>(&Qs[(16 * j + qi) * LD + 16 * t + 4 * g]);
+                const f32x4 ga = *reinterpret_cast<const f32x4*>(&Gs[(16 * j + qi) * LD + 16 * t + 4 * g]);
+#pragma unroll
+                for (int s = 0; s < 4; ++s) {
+                    a = __builtin_amdgcn_mfma_f32_16x16x4f32(qa[s], kf[t][s], a, 0, 0, 0);      // S[query 16j+4g+r][key]
+                    d = __builtin_amdgcn_mfma_f32_16x16x4f32(ga[s], vf[t][s], d, 0, 0, 0);      // dP[query][key]
+                }
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int q = 16 * j + 4 * g + r;
+                float p = 0.f, dsv = 0.f;
+                if (q < L && key < L) {
+                    p = expf((a[r] / scale_div + madd) - Mx[q]) / Sum[q];
+                    dsv = p * (d[r] - Dl[q]);
+                }
+                pp[j][r] = p; ds[j][r] = dsv;
+            }
+        }
+        float* dk_out = dq_out + D;
+        float* dv_out = dq_out + 2 * D;
+#pragma unroll
+        for (int t = 0; t < KT; ++t) {
+            f32x4 ok = {0.f, 0.f, 0.f, 0.f}, ov = ok;
+#pragma unroll
+            for (int j = 0; j < NT; ++j)
+#pragma unroll
+                for (int s = 0; s < 4; ++s) {
+                    ok = __builtin_amdgcn_mfma_f32_16x16x4f32(ds[j][s], Qs[(16 * j + 4 * g + s) * LD + 16 * t + qi], ok, 0, 0, 0);
+                    ov = __builtin_amdgcn_mfma_f32_16x16x4f32(pp[j][s], Gs[(16 * j + 4 * g + s) * LD + 16 * t + qi], ov, 0, 0, 0);
+                }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int kr = 16 * w + 4 * g + r;
+                if (kr < L) { dk_out[(size_t)kr * ld + 16 * t + qi] = ok[r] / scale_div; dv_out[(size_t)kr * ld + 16 * t + qi] = ov[r]; }
+            }
+        }
+    }
+}
+template <int DH>
+__host__ __device__ inline constexpr size_t attn_bwd_mfma_lds_bytes(int NT) { return (size_t)NT * 16 * (4 * (DH + 4) + 3) * sizeof(float); }
+
 }  // namespace uu3d

@@ -1,5 +1,6 @@
 // uu3d_launch.h -- host-side launch helpers shared by the ops ABI and the training step.
 #pragma once
+#include <cstdlib>
 #include <hip/hip_runtime.h>
 #include <algorithm>
 #include "../../include/uu3d.h"
@@ -110,7 +111,18 @@ inline int launch_attn_generic(bool backward, const float* qkv, const float* dO,
         else hipLaunchKernelGGL(attn_generic_fwd_kernel<4>, grid, block, lds, stream, qkv, ld, D, L, H, mask, out, ldo);
     } else {
         const size_t lds = attn_generic_lds_bytes<48>(L, backward);
-        if (backward) {
+        if (backward && L <= 128 && !getenv("UU3D_ATTN_BWD_GENERIC")) {
+            // MFMA backward, tiles in registers (attn_bwd_mfma_kernel); dqkv has the layout (and leading dimension) of qkv
+            const int NT = (L + 15) / 16;
+            const size_t l2 = attn_bwd_mfma_lds_bytes<48>(NT);
+#define UU3D_ATTNB_CASE(nt) case nt: { static bool d2 = false; if (!d2) { (void)hipFuncSetAttribute((const void*)attn_bwd_mfma_kernel<nt, 48>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)attn_bwd_mfma_lds_bytes<48>(nt)); d2 = true; } \
+            hipLaunchKernelGGL((attn_bwd_mfma_kernel<nt, 48>), grid, dim3(64 * nt), l2, stream, qkv, dO, ld, D, L, H, mask, out, ldo); } break;
+            switch (NT) {
+                UU3D_ATTNB_CASE(1) UU3D_ATTNB_CASE(2) UU3D_ATTNB_CASE(3) UU3D_ATTNB_CASE(4)
+                UU3D_ATTNB_CASE(5) UU3D_ATTNB_CASE(6) UU3D_ATTNB_CASE(7) UU3D_ATTNB_CASE(8)
+            }
+#undef UU3D_ATTNB_CASE
+        } else if (backward) {
             static bool done = false;
             if (!done) { (void)hipFuncSetAttribute((const void*)attn_generic_bwd_kernel<48>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); done = true; }
             hipLaunchKernelGGL(attn_generic_bwd_kernel<48>, grid, block, lds, stream, qkv, dO, ld, D, L, H, mask, out, ldo);
