@@ -58,7 +58,8 @@ def train_bench(args, world, rank, local_rank, use_dist):
     B = args.batch if args.batch != 128 else 64            # JSON BATCH_SIZE 512 global = 64 per GPU on 8
     cfg.BATCH_SIZE = B * world                             # loss normaliser = global batch (train.py:482)
     arch = pkg.arch_from_config(cfg)
-    model = pkg.build_uplift_upsample_transformer(cfg, weights=pkg.init_weights(arch, seed=0), device=f"cuda:{local_rank}")
+    model = pkg.build_uplift_upsample_transformer(cfg, weights=pkg.init_weights(arch, seed=0), device=f"cuda:{local_rank}",
+                                                   precision=args.precision)
     tr = Trainer(model, cfg, seed=100 + rank)
     rng = np.random.default_rng(3000 + rank)
     N, J = arch.num_frames, arch.num_keypoints
@@ -89,7 +90,9 @@ def train_bench(args, world, rank, local_rank, use_dist):
         print(json.dumps({
             "metric": "train-sequences/sec", "value": round(seqs / elapsed, 2), "unit": "pose-sequences/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f16x3 forward / input-gradient GEMMs, f32 weight-gradient GEMMs, attention, optimizer" if args.precision == "f16x3" else "f32",
+            "data": "synthetic",
             "config": {"workload": f"config/{cfgname}.json train step (fwd+bwd+AdamW), N={N}, J={J}, batch {B}/GPU, "
                                    f"per-sample mask stride from {cfg.MASK_STRIDE}, DropPath {cfg.DROP_PATH_RATE}",
                        "global_batch": world * B, "parallelism": f"data-parallel x{world}, flat f32 gradient all-reduce"},

@@ -106,7 +106,11 @@ attn_f32_kernel(const float* __restrict__ qkv, const int ld, const int D, const 
     for (int j = 0; j < NT; ++j)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
+#ifdef UU3D_ATTN_FASTEXP
+            const float e = __builtin_amdgcn_exp2f((st[j][r] - mx) * 1.44269504088896341f);
+#else
             const float e = expf(st[j][r] - mx);
+#endif
             st[j][r] = e;
             sum += e;
         }

@@ -5,6 +5,7 @@
 #include <algorithm>
 #include "../../include/uu3d.h"
 #include "uu3d_gemm.h"
+#include "uu3d_gemm_h3.h"
 #include "uu3d_bwd.h"
 
 namespace uu3d {
@@ -15,8 +16,10 @@ inline int ru(int v, int m) { return (v + m - 1) / m * m; }
 inline int hip_status() { return hipGetLastError() == hipSuccess ? UU3D_OK : UU3D_ERR_HIP; }
 
 // C = A-op x Bt^T with the forward GEMM kernel (64x64 tiles, deterministic split-K when few tiles).
+// Bh / Bl != nullptr: the operand's f16 hi / lo planes (same [Np][Kp] layout) -> f16x3 kernel (uu3d_gemm_h3.h).
 template <class AL, class EP>
-int launch_gemm(const AL& al, const float* Bt, int M, int N, int K, const EP& ep, float* slab, size_t slab_floats, hipStream_t stream) {
+int launch_gemm(const AL& al, const float* Bt, int M, int N, int K, const EP& ep, float* slab, size_t slab_floats, hipStream_t stream,
+                const _Float16* Bh = nullptr, const _Float16* Bl = nullptr) {
     const int Kp = ru(K, 32), KT = Kp / 32;
     const int tiles = ((M + 63) / 64) * ((N + 63) / 64);
     int slices = 1;
@@ -27,6 +30,18 @@ int launch_gemm(const AL& al, const float* Bt, int M, int N, int K, const EP& ep
     if (slices > 1 && (slab == nullptr || (size_t)slices * M * ldslab > slab_floats)) { slices = 1; kps = KT; }
     const int mt = (M + 63) / 64, nt = (N + 63) / 64;
     const int grid = ru(mt, 8) * nt;
+    if (Bh != nullptr && Bl != nullptr) {
+        constexpr size_t ldsh = gemm_h3_lds_bytes(64, 64);
+        if (slices == 1) {
+            hipLaunchKernelGGL((gemm_h3_kernel<1, 1, AL, EP>), dim3(grid, 1), dim3(256), ldsh, stream, al, Bh, Bl, M, N, Kp, mt, nt, KT, ep);
+        } else {
+            EpSlab es{slab, ldslab, (size_t)M * ldslab};
+            hipLaunchKernelGGL((gemm_h3_kernel<1, 1, AL, EpSlab>), dim3(grid, slices), dim3(256), ldsh, stream, al, Bh, Bl, M, N, Kp, mt, nt, kps, es);
+            hipLaunchKernelGGL(splitk_reduce_kernel<EP>, dim3((M * N + 255) / 256), dim3(256), 0, stream, slab, slices,
+                               (size_t)M * ldslab, M, N, ldslab, ep);
+        }
+        return hip_status();
+    }
     constexpr size_t lds = gemm_lds_bytes(64, 64);
     if (slices == 1) {
         hipLaunchKernelGGL((gemm_f32_kernel<64, 64, AL, EP>), dim3(grid, 1), dim3(256), lds, stream, al, Bt, M, N, Kp, mt, nt, KT, ep);
