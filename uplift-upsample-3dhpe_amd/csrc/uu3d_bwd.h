@@ -157,30 +157,37 @@ colsum_kernel(const float* __restrict__ X, const int ldx, const int R, const int
     }
 }
 // Fast path of colsum_kernel for the common case (no period, no mask, C % 4 == 0): 16-byte loads, 4 independent
-// partial sums per thread.  Workgroup = 64 column groups (256 columns) x 4 row lanes; grid (ceil(C / 256), slices).
+// partial sums per thread.  A workgroup covers cgs = min(64, C / 4) column groups and gives the other 256 / cgs thread
+// rows to more matrix rows, so narrow matrices (the spatial stack's 32 .. 96 columns over 77 k rows) use every lane;
+// grid (ceil(C / (4 cgs)), slices).
 static __global__ void __launch_bounds__(256)
-colsum4_kernel(const float* __restrict__ X, const int ldx, const int R, const int C, float* __restrict__ partial, const int slices)
+colsum4_kernel(const float* __restrict__ X, const int ldx, const int R, const int C, float* __restrict__ partial, const int slices,
+               const int cgs)
 {
-    const int cg = threadIdx.x & 63, rl = threadIdx.x >> 6;
-    const int c = (blockIdx.x * 64 + cg) * 4;
+    const int rlanes = 256 / cgs;
+    const int cg = threadIdx.x % cgs, rl = threadIdx.x / cgs;
+    const int c = (blockIdx.x * cgs + cg) * 4;
     const int rows_per_slice = (R + slices - 1) / slices;
     const int r_lo = blockIdx.y * rows_per_slice, r_hi = min(R, r_lo + rows_per_slice);
-    __shared__ f32x4 red[4][64];
+    __shared__ f32x4 red[256];
     f32x4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = s0, s2 = s0, s3 = s0;
-    if (c < C) {
+    if (c < C && rl < rlanes) {
         int r = r_lo + rl;
-        for (; r + 12 < r_hi; r += 16) {
+        for (; r + 3 * rlanes < r_hi; r += 4 * rlanes) {
             s0 += *reinterpret_cast<const f32x4*>(X + (size_t)r * ldx + c);
-            s1 += *reinterpret_cast<const f32x4*>(X + (size_t)(r + 4) * ldx + c);
-            s2 += *reinterpret_cast<const f32x4*>(X + (size_t)(r + 8) * ldx + c);
-            s3 += *reinterpret_cast<const f32x4*>(X + (size_t)(r + 12) * ldx + c);
+            s1 += *reinterpret_cast<const f32x4*>(X + (size_t)(r + rlanes) * ldx + c);
+            s2 += *reinterpret_cast<const f32x4*>(X + (size_t)(r + 2 * rlanes) * ldx + c);
+            s3 += *reinterpret_cast<const f32x4*>(X + (size_t)(r + 3 * rlanes) * ldx + c);
         }
-        for (; r < r_hi; r += 4) s0 += *reinterpret_cast<const f32x4*>(X + (size_t)r * ldx + c);
+        for (; r < r_hi; r += rlanes) s0 += *reinterpret_cast<const f32x4*>(X + (size_t)r * ldx + c);
     }
-    red[rl][cg] = (s0 + s1) + (s2 + s3);
+    red[threadIdx.x] = (s0 + s1) + (s2 + s3);
     __syncthreads();
-    if (rl == 0 && c < C)
-        *reinterpret_cast<f32x4*>(partial + (size_t)blockIdx.y * C + c) = (red[0][cg] + red[1][cg]) + (red[2][cg] + red[3][cg]);
+    if (rl == 0 && c < C) {
+        f32x4 t = red[cg];
+        for (int k = 1; k < rlanes; ++k) t += red[k * cgs + cg];              // fixed order: deterministic
+        *reinterpret_cast<f32x4*>(partial + (size_t)blockIdx.y * C + c) = t;
+    }
 }
 // out[i] (+)= sum_k partial[k * pstride + i], i < n.  Thread (column c of 16, lane q of 16): lane q adds the
 // slices k = q, q+16, ... in order; the 16 lane sums are then added in lane order -> deterministic.

@@ -90,9 +90,11 @@ inline int launch_colsum(const float* x, int ldx, int R, int C, int period, cons
     while (slices > 1 && (size_t)slices * P * C > scratch_floats) --slices;
     if ((size_t)slices * P * C > scratch_floats) return UU3D_ERR_WORKSPACE;
     if (period <= 0 && mask == nullptr && (C % 4) == 0 && (ldx % 4) == 0) {
-        slices = std::max(1, std::min(128, R / 64));                    // >= 64 rows per workgroup: enough workgroups to fill the chip
+        const int cgs = std::max(1, std::min(64, (C + 3) / 4));
+        const int xb = (C + 4 * cgs - 1) / (4 * cgs);
+        slices = std::max(1, std::min(std::max(1, 320 / xb), R / 64));    // ~one workgroup per CU, >= 64 rows each; more slabs only move the time into the combine
         while (slices > 1 && (size_t)slices * C > scratch_floats) --slices;
-        hipLaunchKernelGGL(colsum4_kernel, dim3((C + 255) / 256, slices), dim3(256), 0, stream, x, ldx, R, C, scratch, slices);
+        hipLaunchKernelGGL(colsum4_kernel, dim3(xb, slices), dim3(256), 0, stream, x, ldx, R, C, scratch, slices, cgs);
     } else
     hipLaunchKernelGGL(colsum_kernel, dim3((C + 63) / 64, slices), dim3(256), 0, stream, x, ldx, R, C, period, mask, want, scratch, slices);
     hipLaunchKernelGGL(reduce_partials_kernel, dim3((P * C + 15) / 16), dim3(256), 0, stream, scratch, P * C, (size_t)P * C, slices, out, accumulate);
@@ -102,7 +104,9 @@ inline int launch_colsum(const float* x, int ldx, int R, int C, int period, cons
 // dgamma/dbeta: written (acc_params == 0) or accumulated.
 inline int launch_ln_bwd(const float* x, const float* dy, const float2* stats, const float* gamma, int ld, int D, int M, float* dx,
                          int accumulate, float* dgamma, float* dbeta, int acc_params, float* scratch, size_t scratch_floats, hipStream_t stream) {
-    int rpw = std::max(2, (M + 4 * 2048 - 1) / (4 * 2048));       // >= 500 workgroups at M = 4544 (8 rows per wave left 114 of 256 CUs idle); <= 2048 partial rows to combine
+    // wide rows (D = 384): >= 500 workgroups at M = 4544 (8 rows per wave left 114 of 256 CUs idle), <= 2048 partial rows;
+    // the spatial stack's D = 32 rows are cheap and many (77 k): fewer, longer workgroups keep the combine short
+    int rpw = (D > 64) ? std::max(2, (M + 4 * 2048 - 1) / (4 * 2048)) : std::max(8, (M + 4 * 512 - 1) / (4 * 512));
     int wgs = (M + 4 * rpw - 1) / (4 * rpw);
     while ((size_t)wgs * 2 * D > scratch_floats) { rpw *= 2; wgs = (M + 4 * rpw - 1) / (4 * rpw); }
     if (D <= 512) hipLaunchKernelGGL(ln_bwd_kernel<2>, dim3(wgs), dim3(256), 0, stream, x, dy, stats, gamma, ld, D, M, rpw, dx, accumulate, scratch);
