@@ -302,20 +302,26 @@ __host__ __device__ inline size_t attn_generic_lds_bytes(int L, bool backward) {
 template <int DH>
 __global__ void __launch_bounds__(128)
 attn_generic_fwd_kernel(const float* __restrict__ qkv, const int ld, const int D, const int L, const int H,
-                        const uint8_t* __restrict__ key_mask, float* __restrict__ out, const int ldo)
+                        const uint8_t* __restrict__ key_mask, float* __restrict__ out, const int ldo,
+                        const int pack, const int total)
 {
+    // `pack` (sequence, head) pairs share a workgroup, L threads each (L = 17 leaves 119 of 128 lanes busy instead of 17)
     constexpr int LD = DH + 4;
     extern __shared__ __attribute__((aligned(16))) float sm[];
-    float* Ks = sm; float* Vs = sm + L * LD;
-    const int bh = blockIdx.x, b = bh / H, h = bh - b * H, i = threadIdx.x;
+    const int slot = threadIdx.x / L, i = threadIdx.x - slot * L;
+    const int bh = blockIdx.x * pack + slot;
+    const bool live = slot < pack && bh < total;
+    float* Ks = sm + (size_t)min(slot, pack - 1) * 2 * L * LD; float* Vs = Ks + L * LD;
+    const int b = live ? bh / H : 0, h = live ? bh - b * H : 0;
     const float* base = qkv + (size_t)b * L * ld + h * DH;
-    for (int idx = threadIdx.x; idx < L * DH; idx += 128) {
-        const int r = idx / DH, c = idx - r * DH;
-        Ks[r * LD + c] = base[(size_t)r * ld + D + c];
-        Vs[r * LD + c] = base[(size_t)r * ld + 2 * D + c];
-    }
+    if (live)
+        for (int idx = i; idx < L * DH; idx += L) {
+            const int r = idx / DH, c = idx - r * DH;
+            Ks[r * LD + c] = base[(size_t)r * ld + D + c];
+            Vs[r * LD + c] = base[(size_t)r * ld + 2 * D + c];
+        }
     __syncthreads();
-    if (i >= L) return;
+    if (!live) return;
     float q[DH], o[DH];
 #pragma unroll
     for (int c = 0; c < DH; ++c) { q[c] = base[(size_t)i * ld + c]; o[c] = 0.f; }
@@ -349,26 +355,32 @@ template <int DH>
 __global__ void __launch_bounds__(128)
 attn_generic_bwd_kernel(const float* __restrict__ qkv, const float* __restrict__ dO, const int ld, const int D,
                         const int L, const int H, const uint8_t* __restrict__ key_mask,
-                        float* __restrict__ dqkv /* same layout as qkv */, const int ldo)
+                        float* __restrict__ dqkv /* same layout as qkv */, const int ldo,
+                        const int pack, const int total)
 {
     constexpr int LD = DH + 4;
     extern __shared__ __attribute__((aligned(16))) float sm[];
-    float* Qs = sm; float* Ks = Qs + L * LD; float* Vs = Ks + L * LD; float* Gs = Vs + L * LD;   // Gs = dO
-    float* Pm = Gs + L * LD;                 // [L][L+1]
-    float* Sm = Pm + L * (L + 1);            // dS
     const int LP = L + 1;
-    const int bh = blockIdx.x, b = bh / H, h = bh - b * H, i = threadIdx.x;
+    const int slot = threadIdx.x / L, i = threadIdx.x - slot * L;       // `pack` pairs per workgroup, see the forward kernel
+    const int bh = blockIdx.x * pack + slot;
+    const bool live = slot < pack && bh < total;
+    float* Qs = sm + (size_t)min(slot, pack - 1) * (4 * L * LD + 2 * L * LP);
+    float* Ks = Qs + L * LD; float* Vs = Ks + L * LD; float* Gs = Vs + L * LD;   // Gs = dO
+    float* Pm = Gs + L * LD;                 // [L][L+1]
+    float* Sm = Pm + L * LP;                 // dS
+    const int b = live ? bh / H : 0, h = live ? bh - b * H : 0;
     const float* base = qkv + (size_t)b * L * ld + h * DH;
-    for (int idx = threadIdx.x; idx < L * DH; idx += 128) {
-        const int r = idx / DH, c = idx - r * DH;
-        Qs[r * LD + c] = base[(size_t)r * ld + c];
-        Ks[r * LD + c] = base[(size_t)r * ld + D + c];
-        Vs[r * LD + c] = base[(size_t)r * ld + 2 * D + c];
-        Gs[r * LD + c] = dO[((size_t)b * L + r) * ldo + h * DH + c];
-    }
+    if (live)
+        for (int idx = i; idx < L * DH; idx += L) {
+            const int r = idx / DH, c = idx - r * DH;
+            Qs[r * LD + c] = base[(size_t)r * ld + c];
+            Ks[r * LD + c] = base[(size_t)r * ld + D + c];
+            Vs[r * LD + c] = base[(size_t)r * ld + 2 * D + c];
+            Gs[r * LD + c] = dO[((size_t)b * L + r) * ldo + h * DH + c];
+        }
     __syncthreads();
     const float sq = sqrtf((float)DH);
-    if (i < L) {
+    if (live) {
         float q[DH], g[DH];
 #pragma unroll
         for (int c = 0; c < DH; ++c) { q[c] = Qs[i * LD + c]; g[c] = Gs[i * LD + c]; }
@@ -406,7 +418,7 @@ attn_generic_bwd_kernel(const float* __restrict__ qkv, const float* __restrict__
         for (int c = 0; c < DH; ++c) dqkv[((size_t)b * L + i) * ld + h * DH + c] = dq[c] / sq;
     }
     __syncthreads();
-    if (i < L) {                                 // thread = key row j
+    if (live) {                                  // thread = key row j
         float dk[DH], dv[DH];
 #pragma unroll
         for (int c = 0; c < DH; ++c) { dk[c] = 0.f; dv[c] = 0.f; }

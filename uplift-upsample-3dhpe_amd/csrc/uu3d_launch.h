@@ -123,12 +123,16 @@ inline int launch_ln_bwd(const float* x, const float* dy, const float2* stats, c
 
 inline int launch_attn_generic(bool backward, const float* qkv, const float* dO, int ld, int D, int B, int L, int H, int dh,
                                const uint8_t* mask, float* out, int ldo, hipStream_t stream) {
-    const dim3 grid(B * H), block(128);
+    const int total = B * H;
+    const dim3 block(128);
     if (dh == 4) {
-        const size_t lds = attn_generic_lds_bytes<4>(L, backward);
-        if (backward) hipLaunchKernelGGL(attn_generic_bwd_kernel<4>, grid, block, lds, stream, qkv, dO, ld, D, L, H, mask, out, ldo);
-        else hipLaunchKernelGGL(attn_generic_fwd_kernel<4>, grid, block, lds, stream, qkv, ld, D, L, H, mask, out, ldo);
+        const int pack = std::max(1, 128 / L);                         // (sequence, head) pairs per workgroup
+        const dim3 grid((total + pack - 1) / pack);
+        const size_t lds = attn_generic_lds_bytes<4>(L, backward) * pack;
+        if (backward) hipLaunchKernelGGL(attn_generic_bwd_kernel<4>, grid, block, lds, stream, qkv, dO, ld, D, L, H, mask, out, ldo, pack, total);
+        else hipLaunchKernelGGL(attn_generic_fwd_kernel<4>, grid, block, lds, stream, qkv, ld, D, L, H, mask, out, ldo, pack, total);
     } else {
+        const dim3 grid(total);
         const size_t lds = attn_generic_lds_bytes<48>(L, backward);
         if (backward && L <= 128 && !getenv("UU3D_ATTN_BWD_GENERIC")) {
             // MFMA backward, tiles in registers (attn_bwd_mfma_kernel); dqkv has the layout (and leading dimension) of qkv
@@ -144,9 +148,9 @@ inline int launch_attn_generic(bool backward, const float* qkv, const float* dO,
         } else if (backward) {
             static bool done = false;
             if (!done) { (void)hipFuncSetAttribute((const void*)attn_generic_bwd_kernel<48>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); done = true; }
-            hipLaunchKernelGGL(attn_generic_bwd_kernel<48>, grid, block, lds, stream, qkv, dO, ld, D, L, H, mask, out, ldo);
+            hipLaunchKernelGGL(attn_generic_bwd_kernel<48>, grid, block, lds, stream, qkv, dO, ld, D, L, H, mask, out, ldo, 1, total);
         } else {
-            hipLaunchKernelGGL(attn_generic_fwd_kernel<48>, grid, block, lds, stream, qkv, ld, D, L, H, mask, out, ldo);
+            hipLaunchKernelGGL(attn_generic_fwd_kernel<48>, grid, block, lds, stream, qkv, ld, D, L, H, mask, out, ldo, 1, total);
         }
     }
     return hip_status();
