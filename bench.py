@@ -124,6 +124,17 @@ def pmc_traffic(precision, dom_key):
     return None if best is None else round(best[1])
 
 
+def attention_roofline(agg):
+    """The temporal-attention kernel (QK^T + PV of all heads, exact-f32 MFMA) against the f32 MFMA peak: the north_star's
+    "fraction of the attention roofline".  FLOPs = 4 L^2 d_h per (sequence, head)."""
+    a = agg.get("t.attn")
+    if not a or a["ms"] <= 0:
+        return None
+    ach = a["flops"] / (a["ms"] * 1e-3) / 1e12
+    return {"kernel": "attn_f32 [t.attn]", "achieved": round(ach, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
+            "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 4), "avg_launch_ms": round(a["ms"] / a["n"], 5)}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -269,6 +280,7 @@ def main():
                                   "matrix pipe does 3x this work (frac of pipe = 3 * frac)") if args.precision == "f16x3" else
                                  "exact f32-input MFMA",
                          "avg_launch_ms": round(dom["ms"] / dom["n"], 5),
+                         "attention": attention_roofline(agg),
                          "all_gemm_tflops": round(gemm_fl / (gemm_ms * 1e-3) / 1e12, 2),
                          "model_tflops": round(fl["total"] * seqs / world / elapsed / 1e12, 2)},
             "kernel_ms_per_forward": {k: round(a["ms"] / reps, 4) for k, a in sorted(agg.items(), key=lambda kv: -kv[1]["ms"])},
