@@ -113,6 +113,40 @@ class Trainer(object):
         src = self.ema if (use_ema and self.ema is not None) else self.params
         _capi.check(self._lib, self._lib.uu3d_train_export(self.model._h, C.c_void_p(src.data_ptr()), self._stream()), self.model._h)
 
+    # ---- checkpoint / resume (the role of tf.train.Checkpoint(model, optimizer, ema_model) in train.py:420-436) ----
+    def state_dict(self):
+        """Everything a resumed run needs to continue bit-identically: master weights, Adam moments, iteration counters,
+        EMA weights and the DropPath generator state (host numpy arrays)."""
+        sd = {"params": self.params.cpu().numpy(), "adam_m": self.optimizer.m.cpu().numpy(), "adam_v": self.optimizer.v.cpu().numpy(),
+              "iterations": np.int64(self.optimizer.iterations), "global_step": np.int64(self.global_step),
+              "rng_state": self._rng.get_state().cpu().numpy()}
+        if self.ema is not None:
+            sd["ema"] = self.ema.cpu().numpy()
+        return sd
+
+    def load_state_dict(self, sd):
+        torch = self._torch
+        if sd["params"].shape != (self.n_params,):
+            raise ValueError(f"checkpoint holds {sd['params'].shape[0]} parameters, the model has {self.n_params}")
+        self.params.copy_(torch.from_numpy(np.asarray(sd["params"], np.float32)))
+        self.optimizer.m.copy_(torch.from_numpy(np.asarray(sd["adam_m"], np.float32)))
+        self.optimizer.v.copy_(torch.from_numpy(np.asarray(sd["adam_v"], np.float32)))
+        self.optimizer.iterations = int(sd["iterations"])
+        self.global_step = int(sd["global_step"])
+        self._rng.set_state(torch.from_numpy(np.asarray(sd["rng_state"], np.uint8)))
+        if self.ema is not None:
+            if "ema" not in sd:
+                raise ValueError("EMA is enabled but the checkpoint has no EMA weights")
+            self.ema.copy_(torch.from_numpy(np.asarray(sd["ema"], np.float32)))
+        _capi.check(self._lib, self._lib.uu3d_train_repack(self.model._h, C.c_void_p(self.params.data_ptr()), self._stream()), self.model._h)
+
+    def save_checkpoint(self, path):
+        np.savez(path, **self.state_dict())
+
+    def load_checkpoint(self, path):
+        with np.load(path) as z:
+            self.load_state_dict({k: z[k] for k in z.files})
+
     def grads_dict(self):
         out, o = {}, 0
         flat = self.grads.cpu().numpy()
