@@ -159,6 +159,16 @@ int uu3d_gather_windows(const float* poses_dev, const int64_t* video_start_dev, 
                         float* out_dev, uint8_t* stride_mask_dev, uint8_t* pad_mask_dev, void* stream);
 
 /*
+ * World -> camera coordinates -> 2D projection with the Human3.6M camera model, one camera per window: replaces
+ * tf_world_to_cam_and_2d (common/dataset/uplifiting_dataset.py:669-761), the on-the-fly AMASS projection of training.
+ *   world_dev (B, N, J, 3) f32; cams_dev (B, 19) f32 = quaternion wxyz | translation | 12 intrinsics (res, focal,
+ *   centre, 3 radial, 2 tangential coefficients at [7..18) as the reference stores them);
+ *   cam3d_dev (B, N, J, 3) or NULL; kp2d_dev (B, N, J, 2) or NULL.
+ */
+int uu3d_world_to_cam_2d(const float* world_dev, const float* cams_dev, int32_t batch, int32_t num_frames, int32_t num_keypoints,
+                         float* cam3d_dev, float* kp2d_dev, void* stream);
+
+/*
  * Per-kernel timing of the next uu3d_forward calls with HIP events on the launch stream.
  * When enabled, uu3d_forward records an event pair around every launch; uu3d_profile_read
  * synchronises those events and returns the per-launch records of the LAST forward.

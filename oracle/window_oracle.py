@@ -50,3 +50,22 @@ def one_window(video, i, seq_len, stride, pad_type, abs_mask_stride, shift_mode,
         seq = seq[:, flip_order].copy()
         seq[..., 0] *= -1
     return seq, mask, stride_mask
+
+
+def world_to_cam_and_2d(seq3d, cam):
+    """One window: seq3d (N, J, 3) world coordinates, cam (19,) -> (camera-space 3D, 2D), float64.
+    Follows uplifiting_dataset.py:669-761 (tf_world_to_cam :713-716 with tf_qrot :697-705 / tf_qinverse :707-711,
+    tf_project_to_2d :735-761)."""
+    q, t, intr = cam[:4], cam[4:7], cam[7:19]
+    qi = np.concatenate([q[:1], -q[1:]])
+    v = seq3d - t
+    qv = np.broadcast_to(qi[1:], v.shape)
+    uv = np.cross(qv, v)
+    uuv = np.cross(qv, uv)
+    xc = v + 2 * (qi[0] * uv + uuv)
+    f, c, k, p = intr[2:4], intr[4:6], intr[6:9], intr[9:11]
+    xx = np.clip(xc[..., :2] / xc[..., 2:], -1.0, 1.0)
+    r2 = (xx ** 2).sum(-1, keepdims=True)
+    radial = 1 + (k * np.concatenate([r2, r2 ** 2, r2 ** 3], -1)).sum(-1, keepdims=True)
+    tan = (p * xx).sum(-1, keepdims=True)
+    return xc, f * (xx * (radial + tan) + p * r2) + c

@@ -87,3 +87,25 @@ def test_model_consumes_gathered_batches():
                      for v, i, s, a, sh, fl in gen.descriptors()[:16]]).cuda()
     f2, c2 = model([x * batch["stride_mask"][:, :, None, None].float(), batch["stride_mask"]], training=False)
     assert torch.equal(central, c2) and torch.equal(full, f2)
+
+
+def test_world_to_cam_and_2d_matches_the_restatement():
+    """uu3d_world_to_cam_2d vs oracle/window_oracle.world_to_cam_and_2d (float64): H36M-like cameras incl. distortion."""
+    rng = np.random.default_rng(5)
+    B, N, J = 7, 13, 17
+    world = rng.normal(0, 0.5, size=(B, N, J, 3)) + np.array([0.0, 0.0, 1.0])
+    cams = np.zeros((B, 19))
+    q = rng.normal(size=(B, 4)); q /= np.linalg.norm(q, axis=1, keepdims=True)
+    cams[:, :4] = q
+    cams[:, 4:7] = rng.normal(0, 0.3, size=(B, 3)) + np.array([0.0, 0.0, -4.5])
+    cams[:, 7:9] = [1000, 1002]
+    cams[:, 9:11] = rng.uniform(2.2, 2.4, size=(B, 2)); cams[:, 11:13] = rng.uniform(-0.05, 0.05, size=(B, 2))
+    cams[:, 13:16] = rng.normal(0, 0.1, size=(B, 3)); cams[:, 16:18] = rng.normal(0, 0.01, size=(B, 2))
+    c3, k2 = D.world_to_cam_and_2d(torch.from_numpy(world.astype(np.float32)).cuda(), torch.from_numpy(cams.astype(np.float32)))
+    c3, k2 = c3.cpu().numpy(), k2.cpu().numpy()
+    w32, c32 = world.astype(np.float32).astype(np.float64), cams.astype(np.float32).astype(np.float64)
+    for b in range(B):
+        xc, x2 = WO.world_to_cam_and_2d(w32[b], c32[b])
+        assert np.abs(c3[b] - xc).max() < 5e-6 * max(1.0, np.abs(xc).max())          # float32 arithmetic vs float64 restatement
+        assert np.abs(k2[b] - x2).max() < 2e-5
+    assert np.isfinite(k2).all()

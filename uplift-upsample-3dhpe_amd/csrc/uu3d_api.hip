@@ -976,6 +976,13 @@ int uu3d_gather_windows(const float* poses, const int64_t* video_start, const in
     return hipGetLastError() == hipSuccess ? UU3D_OK : UU3D_ERR_HIP;
 }
 
+int uu3d_world_to_cam_2d(const float* world, const float* cams, int32_t B, int32_t N, int32_t J, float* cam3d, float* kp2d, void* stream) {
+    if (!world || !cams || B < 1 || N < 1 || J < 1 || (!cam3d && !kp2d)) return UU3D_ERR_INVALID_ARGUMENT;
+    const long per = (long)N * J, total = per * B;
+    hipLaunchKernelGGL(world_to_cam_2d_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, world, cams, per, total, cam3d, kp2d);
+    return hipGetLastError() == hipSuccess ? UU3D_OK : UU3D_ERR_HIP;
+}
+
 int uu3d_set_profiling(uu3d_model* m, int32_t enabled) {
     if (!m) return UU3D_ERR_INVALID_ARGUMENT;
     m->profiling = enabled != 0;

@@ -161,4 +161,33 @@ gather_windows_kernel(const float* __restrict__ poses, const int64_t* __restrict
     }
 }
 
+// World -> camera -> 2D of every joint of a batch of windows, one camera per window: the device form of
+// tf_world_to_cam_and_2d (common/dataset/uplifiting_dataset.py:669-761; AMASS training draws a camera per sample).
+// cam (B, 19) = quaternion (w, x, y, z), translation (3), intrinsics (12: res 2, focal 2, centre 2, radial 3, tangential 2 + 1 spare
+// as stored by the reference: indices 7..18).  x_cam = qrot(qinverse(q), x_world - t); XX = clamp(x_cam.xy / x_cam.z, -1, 1);
+// 2D = f * (XX * (1 + k . (r2, r2^2, r2^3) + p . XX) + p * r2) + c.
+static __global__ void __launch_bounds__(256)
+world_to_cam_2d_kernel(const float* __restrict__ world, const float* __restrict__ cams, const long per_window, const long total,
+                       float* __restrict__ cam3d, float* __restrict__ kp2d)
+{
+    const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= total) return;
+    const float* cm = cams + (idx / per_window) * 19;
+    const float qw = cm[0], qx = -cm[1], qy = -cm[2], qz = -cm[3];                 // inverse of a unit quaternion
+    const float vx = world[idx * 3] - cm[4], vy = world[idx * 3 + 1] - cm[5], vz = world[idx * 3 + 2] - cm[6];
+    // uv = qvec x v ; uuv = qvec x uv ; out = v + 2 (w uv + uuv)        (tf_qrot, :697-705)
+    const float ux = qy * vz - qz * vy, uy = qz * vx - qx * vz, uz = qx * vy - qy * vx;
+    const float wx = qy * uz - qz * uy, wy = qz * ux - qx * uz, wz = qx * uy - qy * ux;
+    const float X = vx + 2.f * (qw * ux + wx), Y = vy + 2.f * (qw * uy + wy), Z = vz + 2.f * (qw * uz + wz);
+    if (cam3d != nullptr) { cam3d[idx * 3] = X; cam3d[idx * 3 + 1] = Y; cam3d[idx * 3 + 2] = Z; }
+    if (kp2d == nullptr) return;
+    const float* in = cm + 7;
+    const float a = fminf(fmaxf(X / Z, -1.f), 1.f), b = fminf(fmaxf(Y / Z, -1.f), 1.f);
+    const float r2 = a * a + b * b;
+    const float radial = 1.f + (in[6] * r2 + in[7] * (r2 * r2) + in[8] * (r2 * r2 * r2));
+    const float tan = in[9] * a + in[10] * b;
+    kp2d[idx * 2] = in[2] * (a * (radial + tan) + in[9] * r2) + in[4];
+    kp2d[idx * 2 + 1] = in[3] * (b * (radial + tan) + in[10] * r2) + in[5];
+}
+
 }  // namespace uu3d

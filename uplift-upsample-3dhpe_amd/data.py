@@ -154,3 +154,21 @@ class SequenceGenerator(object):
             if drop_remainder and len(blk) < batch_size:
                 break
             yield self.gather(blk, **kw)
+
+
+def world_to_cam_and_2d(sequences_3d, cams):
+    """tf_world_to_cam_and_2d (uplifiting_dataset.py:669-761) for a batch on the device: sequences_3d (B, N, J, 3) world
+    coordinates, cams (B, 19) -> (camera-space 3D (B, N, J, 3), projected 2D (B, N, J, 2))."""
+    import torch
+    lib = _capi.load_library()
+    x = sequences_3d.to(torch.float32).contiguous()
+    c = cams.to(device=x.device, dtype=torch.float32).contiguous()
+    B, N, J = x.shape[0], x.shape[1], x.shape[2]
+    if tuple(c.shape) != (B, 19) or x.shape[3] != 3:
+        raise ValueError("sequences_3d must be (B, N, J, 3) and cams (B, 19)")
+    cam3d = torch.empty_like(x)
+    kp2d = torch.empty((B, N, J, 2), dtype=torch.float32, device=x.device)
+    st = lib.uu3d_world_to_cam_2d(C.c_void_p(x.data_ptr()), C.c_void_p(c.data_ptr()), B, N, J, C.c_void_p(cam3d.data_ptr()),
+                                  C.c_void_p(kp2d.data_ptr()), C.c_void_p(torch.cuda.current_stream(x.device).cuda_stream))
+    _capi.check(lib, st, None)
+    return cam3d, kp2d
