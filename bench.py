@@ -104,20 +104,24 @@ def train_bench(args, world, rank, local_rank, use_dist):
 PMC_SUMMARY = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_final_unsplit_pmc_summary.csv")
 
 
-def pmc_traffic(precision, dom_key):
+def pmc_traffic(kernel_class, dom_key):
     """HBM bytes per launch of the dominant kernel from the committed rocprofv3 --pmc summary (FETCH_SIZE x2 on
     gfx950 + WRITE_SIZE, tools/rocpd_summary.py; collected with --no-halves so one launch = the whole batch, like
     `achieved`).  None when the summary does not hold that kernel."""
     import csv
-    want = {"ln_qkv": ("LoadLayerNorm", "EpBiasE"), "ln_fc1": ("LoadLayerNorm", "EpBiasRelu"),
-            "fc2_res": ("LoadPlain", "EpBiasResidual"), "proj_res": ("LoadPlain", "EpBiasResidual")}.get(dom_key.split(".")[-1])
-    kern = "gemm_h3" if precision == "f16x3" else "gemm_f32_kernel"        # gemm_h3_kernel (on-the-fly split) or gemm_h3g_kernel (LDS-DMA)
+    op = dom_key.split(".")[-1]
+    if kernel_class == "gemm_panel":
+        kern, want = "gemm_h3_panel_kernel", {"ln_qkv": ("PanelEpBiasE",), "ln_fc1": ("PanelEpBiasReluSplit",)}.get(op)
+    else:
+        kern = "gemm_h3" if kernel_class == "gemm_h3" else "gemm_f32_kernel"    # gemm_h3_kernel (on-the-fly split) or gemm_h3g_kernel (LDS-DMA)
+        want = {"ln_qkv": ("LoadLayerNorm", "EpBiasE"), "ln_fc1": ("LoadLayerNorm", "EpBiasRelu"),
+                "fc2_res": ("LoadPlain", "EpBiasResidual"), "proj_res": ("LoadPlain", "EpBiasResidual")}.get(op)
     if want is None or not os.path.exists(PMC_SUMMARY):
         return None
     best = None
     for r in csv.DictReader(open(PMC_SUMMARY)):
         k = r["kernel"]
-        if kern in k and all(w in k for w in want) and r["HBM_read_bytes_avg_x2_gfx950_corrected"] and r["HBM_write_bytes_avg"]:
+        if kern in k and (("panel" in k) == ("panel" in kern)) and all(w in k for w in want) and r["HBM_read_bytes_avg_x2_gfx950_corrected"] and r["HBM_write_bytes_avg"]:
             t = float(r["HBM_read_bytes_avg_x2_gfx950_corrected"]) + float(r["HBM_write_bytes_avg"])
             if best is None or int(r["grid_size"]) > best[0]:       # the temporal-block launch (largest grid) of this instantiation
                 best = (int(r["grid_size"]), t)
@@ -251,13 +255,15 @@ def main():
     if rank == 0:
         fl = pkg.flops_per_sequence(arch)
         total_ms = sum(a["ms"] for a in agg.values()) / reps
-        gk = "gemm_h3" if args.precision == "f16x3" else "gemm_f32"
+        # GEMM launch classes: the tiled f16x3 kernels ("gemm_h3"), the row-panel f16x3 kernel ("gemm_panel"), exact f32
+        gks = ("gemm_h3", "gemm_panel") if args.precision == "f16x3" else ("gemm_f32",)
         peak = PEAK_F16_MFMA_TFLOPS if args.precision == "f16x3" else PEAK_F32_MFMA_TFLOPS
-        dom_key = max((k for k in agg if agg[k]["kernel"] == gk), key=lambda k: agg[k]["ms"])
+        dom_key = max((k for k in agg if agg[k]["kernel"] in gks), key=lambda k: agg[k]["ms"])
         dom = agg[dom_key]
+        gk = dom["kernel"]
         ach = dom["flops"] / (dom["ms"] * 1e-3) / 1e12
-        gemm_fl = sum(a["flops"] for a in agg.values() if a["kernel"] == gk)
-        gemm_ms = sum(a["ms"] for a in agg.values() if a["kernel"] == gk)
+        gemm_fl = sum(a["flops"] for a in agg.values() if a["kernel"] in gks)
+        gemm_ms = sum(a["ms"] for a in agg.values() if a["kernel"] in gks)
         seqs = world * B * args.steps
         out = {
             "metric": "pose-sequences/sec",
@@ -275,7 +281,7 @@ def main():
                        "concurrent_half_batches": bool(not args.no_halves and B >= 64)},
             "roofline": {"bound": "mfma", "kernel": f"{gk} [{dom_key}]",
                          "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s",
-                         "frac": round(ach / peak, 4), "traffic": pmc_traffic(args.precision, dom_key),
+                         "frac": round(ach / peak, 4), "traffic": pmc_traffic(gk, dom_key),
                          "note": ("algorithmic 2*M*N*K FLOPs; the f16x3 kernel issues 3 f16 MFMA passes per product, so the "
                                   "matrix pipe does 3x this work (frac of pipe = 3 * frac)") if args.precision == "f16x3" else
                                  "exact f32-input MFMA",

@@ -26,6 +26,7 @@
 #include "../../include/uu3d.h"
 #include "uu3d_gemm.h"
 #include "uu3d_gemm_h3.h"
+#include "uu3d_gemm_panel.h"
 #include "uu3d_attn.h"
 #include "uu3d_spatial.h"
 #include "uu3d_spatial_h3.h"
@@ -61,6 +62,11 @@ struct WeightRec {
 struct BlockDev {
     const float *ln1_g, *ln1_b, *wqkv_t, *bqkv, *wp_t, *bp, *ln2_g, *ln2_b, *w1_t, *b1, *w2_t, *b2;
     const float* pe;   // strided blocks: (L_i, d_t)
+    // LayerNorm folded into the following Dense (f16x3 forward, uu3d_gemm_h3.h gemm_h3_lnfold_kernel):
+    //   LN(x) W + b = rstd (x (gamma o W)) - rstd mean (gamma^T W) + (beta^T W + b)
+    const float *wqkv_f, *gqkv, *bqkv_f, *w1_f, *g1, *b1_f;
+    // fragment-ordered f16 planes of wqkv / w1 for the row-panel GEMM (uu3d_gemm_panel.h); offsets in harena, 0 = none
+    size_t wqkv_pf = 0, w1_pf = 0;
 };
 
 struct ProfRec {
@@ -82,11 +88,14 @@ struct uu3d_model {
     bool committed = false;
     float* arena = nullptr;        // packed device weights
     size_t arena_floats = 0;
+    bool no_panel = false;         // UU3D_NO_PANEL=1: LayerNorm-fed GEMMs stay on the tiled kernels (A/B measurements)
+    bool no_lnfold = true;         // UU3D_LNFOLD=1 folds LayerNorm into the next Dense (gemm_h3_lnfold_kernel); measured neutral, off by default
     bool ln_planes = false;        // UU3D_LN_PLANES=1: LayerNorm as a separate pass that writes planes (ln_split) instead of inside the GEMM loader
     bool no_planes = false;        // UU3D_NO_PLANES=1: keep the on-the-fly split GEMMs in f16x3 mode (A/B measurements)
     _Float16* harena = nullptr;    // f16 hi/lo planes of every GEMM operand (f16x3 mode)
     size_t harena_halfs = 0;
     std::map<size_t, std::pair<size_t, size_t>> hplanes;   // Bt float offset -> (hi offset, lo offset) in harena
+    std::map<size_t, size_t> panel_off;                    // Bt float offset -> fragment-ordered planes in harena (uu3d_gemm_panel.h)
     // packed views
     SpatialParams sp{};
     const float* sp_blocks_v1 = nullptr;   // VALU kernel layout (kept for A/B runs: UU3D_SPATIAL=valu)
@@ -288,6 +297,8 @@ int uu3d_create(const uu3d_config* c, int device, uu3d_model** out) {
       m->spatial_f32 = (e != nullptr && std::string(e) == "f32"); m->spatial_h3_always = (e != nullptr && std::string(e) == "h3"); }
     { const char* e = getenv("UU3D_NO_PLANES"); m->no_planes = (e != nullptr && e[0] == '1'); }
     { const char* e = getenv("UU3D_LN_PLANES"); m->ln_planes = (e != nullptr && e[0] == '1'); }
+    { const char* e = getenv("UU3D_NO_PANEL"); m->no_panel = (e != nullptr && e[0] == '1'); }
+    { const char* e = getenv("UU3D_LNFOLD"); m->no_lnfold = !(e != nullptr && e[0] == '1'); }
     *out = m;
     return UU3D_OK;
 }
@@ -419,7 +430,7 @@ int uu3d_commit_weights(uu3d_model* m, void* stream_) {
     std::copy_n(W(m, "temporal_pe/positional_encoding_weights"), (size_t)N * dt, P.buf.begin() + o_pet);
 
     // ---- transformer blocks ----
-    struct BlockOff { size_t ln1_g, ln1_b, wqkv, bqkv, wp, bp, ln2_g, ln2_b, w1, b1, w2, b2, pe; };
+    struct BlockOff { size_t ln1_g, ln1_b, wqkv, bqkv, wp, bp, ln2_g, ln2_b, w1, b1, w2, b2, pe, wqkv_f, gqkv, bqkv_f, w1_f, g1, b1_f; };
     auto pack_block = [&](const std::string& p, bool strided, int peL, const std::string& pe_name) {
         BlockOff o{};
         o.ln1_g = P.alloc(dt); o.ln1_b = P.alloc(dt);
@@ -444,6 +455,21 @@ int uu3d_commit_weights(uu3d_model* m, void* stream_) {
         o.w1 = P.alloc_dense((size_t)Nph * Kdt); o.b1 = P.alloc(Nph);
         pack_dense_t(P.buf, o.w1, W(m, p + "/mlp/fc1/kernel"), dt, ht, Kdt, 0);   // Conv1D k=1 (1,dt,ht) has the same flat layout
         std::copy_n(W(m, p + "/mlp/fc1/bias"), ht, P.buf.begin() + o.b1);
+        // folded operands: Bt'[n][k] = Bt[n][k] gamma[k]; g[n] = sum_k gamma[k] Bt[n][k]; b'[n] = sum_k beta[k] Bt[n][k] + b[n]
+        auto fold = [&](size_t src, size_t bias, size_t gam, size_t bet, int Nrows, int Nreal, size_t& wf, size_t& gf, size_t& bf) {
+            wf = P.alloc_dense((size_t)Nrows * Kdt); gf = P.alloc(Nrows); bf = P.alloc(Nrows);
+            for (int n = 0; n < Nreal; ++n) {
+                double gs = 0.0, bs = 0.0;
+                for (int k = 0; k < dt; ++k) {
+                    const float wv = P.buf[src + (size_t)n * Kdt + k];
+                    P.buf[wf + (size_t)n * Kdt + k] = wv * P.buf[gam + k];
+                    gs += (double)P.buf[gam + k] * wv; bs += (double)P.buf[bet + k] * wv;
+                }
+                P.buf[gf + n] = (float)gs; P.buf[bf + n] = (float)(bs + (double)P.buf[bias + n]);
+            }
+        };
+        fold(o.wqkv, o.bqkv, o.ln1_g, o.ln1_b, Npq, 3 * dt, o.wqkv_f, o.gqkv, o.bqkv_f);
+        fold(o.w1, o.b1, o.ln2_g, o.ln2_b, Nph, ht, o.w1_f, o.g1, o.b1_f);
         if (strided) {
             const int Kc = round_up(3 * ht, 32);
             o.w2 = P.alloc_dense((size_t)Npdt * Kc); o.b2 = P.alloc(Npdt);
@@ -527,6 +553,20 @@ int uu3d_commit_weights(uu3d_model* m, void* stream_) {
                 frag(FL::f1, "/mlp/fc1/kernel", ds, kHS); frag(FL::f2, "/mlp/fc2/kernel", kHS, ds);
             }
         }
+        // row-panel GEMM operands (uu3d_gemm_panel.h): wqkv and w1 of every temporal / strided block, fragment ordered
+        m->panel_off.clear();
+        if (dt % 192 == 0 && ht % 32 == 0) {
+            auto add_panel = [&](size_t bt_off, int Nn) {
+                const auto it = m->hplanes.find(bt_off);
+                if (it == m->hplanes.end()) return;
+                const size_t at = align_up(hb.size(), 64);
+                hb.resize(at + panel_b_halfs(Nn, dt));
+                panel_pack_operand(hb.data() + it->second.first, hb.data() + it->second.second, Nn, dt, Kdt, hb.data() + at);
+                m->panel_off[bt_off] = at;
+            };
+            for (auto& o : toff) { add_panel(o.wqkv, 3 * dt); add_panel(o.w1, ht); }
+            for (auto& o : soff) { add_panel(o.wqkv, 3 * dt); add_panel(o.w1, ht); }
+        }
         if (m->harena_halfs < hb.size()) {
             if (m->harena) HIPCHK(m, hipFree(m->harena));
             m->harena = nullptr;
@@ -548,6 +588,9 @@ int uu3d_commit_weights(uu3d_model* m, void* stream_) {
         b.wp_t = A + o.wp; b.bp = A + o.bp; b.ln2_g = A + o.ln2_g; b.ln2_b = A + o.ln2_b;
         b.w1_t = A + o.w1; b.b1 = A + o.b1; b.w2_t = A + o.w2; b.b2 = A + o.b2;
         b.pe = strided ? A + o.pe : nullptr;
+        { const auto it = m->panel_off.find(o.wqkv); b.wqkv_pf = (it != m->panel_off.end()) ? it->second : 0; }
+        { const auto it = m->panel_off.find(o.w1); b.w1_pf = (it != m->panel_off.end()) ? it->second : 0; }
+        b.wqkv_f = A + o.wqkv_f; b.gqkv = A + o.gqkv; b.bqkv_f = A + o.bqkv_f; b.w1_f = A + o.w1_f; b.g1 = A + o.g1; b.b1_f = A + o.b1_f;
         return b;
     };
     m->tblocks.clear(); m->sblocks.clear();
@@ -578,7 +621,7 @@ Workspace carve(const uu3d_model* m, int B, char* base) {
     const size_t oS = take(rows * c.num_keypoints * c.d_spatial * 4);
     const size_t oX = take(rows * c.d_temporal * 4);
     const size_t oQ = take(rows * 3 * c.d_temporal * 4);
-    const size_t oO = take(rows * c.d_temporal * 4);
+    const size_t oO = take((rows + 32) * c.d_temporal * 4);   // + one 32-row panel: the panel GEMM's A operand is allocated in whole panels
     const size_t oH = take(rows * c.h_temporal * 4);
     const size_t oA = take(rows * c.d_temporal * 4);
     const size_t oB = take(rows_s * c.d_temporal * 4);
@@ -698,6 +741,65 @@ struct Launcher {
             hipLaunchKernelGGL(splitk_reduce_kernel<EP>, dim3((M * N + 255) / 256), dim3(256), 0, stream,
                                slab, slices, (size_t)M * ldslab, M, N, ldslab, ep);
         }
+        end();
+    }
+
+    // LayerNorm folded into the GEMM (gemm_h3_lnfold_kernel): X raw rows [M][K], Wf the folded operand.  Only for
+    // launches that are not split along K (the workgroup must see whole rows); returns false otherwise.
+    template <class EPL>
+    bool gemm_lnfold(const char* name, const float* X, const float* Wf, int M, int N, int K, const EPL& ep) {
+        const int tiles = ((M + 63) / 64) * ((N + 63) / 64);
+        if ((K % 32) != 0 || (tiles < 384 && K / 32 >= 8) || m->no_lnfold) return false;       // gemm() would split this one
+        const auto it = m->hplanes.find((size_t)(Wf - m->arena));
+        if (it == m->hplanes.end()) return false;
+        const _Float16* Bh = m->harena + it->second.first; const _Float16* Bl = m->harena + it->second.second;
+        begin(name, "gemm_h3", 2.0 * M * (double)N * K, 4.0 * ((double)M * K + (double)N * K + (double)M * N));
+        if (N % 128 == 0 && tiles >= 512) {
+            auto kern = gemm_h3_lnfold_kernel<1, 2, EPL>;
+            constexpr size_t lds = gemm_h3_lds_bytes(64, 128);
+            static bool attr_done = false;
+            if (!attr_done) { (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr_done = true; }
+            const int mt = (M + 63) / 64, nt = N / 128;
+            hipLaunchKernelGGL(kern, dim3(round_up(mt, 8) * nt), dim3(256), lds, stream, X, K, Bh, Bl, M, N, K, 1e-5f, mt, nt, ep);
+        } else {
+            auto kern = gemm_h3_lnfold_kernel<1, 1, EPL>;
+            constexpr size_t lds = gemm_h3_lds_bytes(64, 64);
+            const int mt = (M + 63) / 64, nt = (N + 63) / 64;
+            hipLaunchKernelGGL(kern, dim3(round_up(mt, 8) * nt), dim3(256), lds, stream, X, K, Bh, Bl, M, N, K, 1e-5f, mt, nt, ep);
+        }
+        end();
+        return true;
+    }
+
+    // Row-panel GEMM (uu3d_gemm_panel.h): C = A B + colv with A the fragment-ordered planes written by ln_split_frag and
+    // B the fragment-ordered operand at harena + pf.  K = 384.  The split S of the N / 32 column chunks over workgroups
+    // minimises rounds x (prologue + chunks per workgroup) for one workgroup per CU (measured order of the candidates
+    // at M = 9088 / 4544, N = 1152 / 768: tools/gemm_panel_exp).
+    static int panel_splits(int M, int N) {
+        const int mt = (M + 127) / 128, chunks = N / 32;
+        int best = 0; double best_cost = 1e30;
+        for (int S = 1; S <= chunks; ++S) {
+            if (chunks % S != 0 || chunks / S > PANEL_COLV_FLOATS / 32) continue;
+            const double cost = (double)((mt * S + 255) / 256) * (2.5 + (double)chunks / S);
+            if (cost < best_cost) { best_cost = cost; best = S; }
+        }
+        return best;
+    }
+    bool panel_ok(int M, int N, int K, size_t pf) const { return !m->no_panel && pf != 0 && K == 384 && N % 32 == 0 && M >= 1024; }
+    template <class EP>
+    void gemm_panel(const char* name, const _Float16* Af, size_t pf, const float* colv, int M, int N, const EP& ep) {
+        const int K = 384, S = panel_splits(M, N), mt = (M + 127) / 128;
+        begin(name, "gemm_panel", 2.0 * M * (double)N * K, 4.0 * ((double)M * K + (double)N * K + (double)M * N));
+        auto kern = gemm_h3_panel_kernel<24, EP>;
+        static bool attr_done = false;
+        if (!attr_done) { (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)PANEL_LDS_TOTAL); attr_done = true; }
+        hipLaunchKernelGGL(kern, dim3(round_up(mt, 8) * S), dim3(256), PANEL_LDS_TOTAL, stream, Af, m->harena + pf, colv, M, mt, S, (N / 32) / S, ep);
+        end();
+    }
+    // LayerNorm (eps 1e-5) of M rows of 384 floats, written as the fragment-ordered planes of the panel GEMM's A operand
+    void ln_split_frag(const char* name, const float* x, int M, const float* g, const float* b, _Float16* Af) {
+        begin(name, "ln_split_frag", 0.0, 8.0 * (double)M * 384);
+        hipLaunchKernelGGL(ln_split_frag_kernel<24>, dim3((M + 15) / 16), dim3(256), 0, stream, x, 384, M, 1e-5f, g, b, Af);
         end();
     }
 
@@ -856,11 +958,14 @@ int uu3d_forward(uu3d_model* m, const float* kp2d, const uint8_t* mask, int32_t 
         const EpBiasResidual ep_fc2{w.X, b.b2, dt, last ? w.XA : nullptr, last ? m->sblocks[0].pe : nullptr, N};
         if (planes) {
             _Float16* const Pl = Ph + (size_t)M * dt; _Float16* const Hl = Hh + (size_t)M * ht;
-            if (m->ln_planes) {
+            if (Lh.panel_ok(M, 3 * dt, dt, b.wqkv_pf)) {
+                snprintf(nm, sizeof nm, "t%d.ln1_split", i + 1); Lh.ln_split_frag(nm, w.X, M, b.ln1_g, b.ln1_b, Ph);
+                snprintf(nm, sizeof nm, "t%d.ln_qkv", i + 1); Lh.gemm_panel(nm, Ph, b.wqkv_pf, b.bqkv, M, 3 * dt, PanelEpBias{w.QKV, 3 * dt});
+            } else if (m->ln_planes) {
                 snprintf(nm, sizeof nm, "t%d.ln1_split", i + 1); Lh.ln_split(nm, w.X, dt, M, b.ln1_g, b.ln1_b, Ph, Pl);
                 GLoadPlain gl{Ph, Pl, dt, M}; EpBias ep{w.QKV, b.bqkv, 3 * dt};
                 snprintf(nm, sizeof nm, "t%d.ln_qkv", i + 1); Lh.gemm_g(nm, gl, b.wqkv_t, M, 3 * dt, dt, ep);
-            } else {
+            } else if (snprintf(nm, sizeof nm, "t%d.ln_qkv", i + 1), !Lh.gemm_lnfold(nm, w.X, b.wqkv_f, M, 3 * dt, dt, EpLnBias{w.QKV, b.gqkv, b.bqkv_f, 3 * dt})) {
                 snprintf(nm, sizeof nm, "t%d.stats1", i + 1); Lh.row_stats(nm, w.X, dt, M, w.stats);
                 ALoadLayerNorm al{w.X, w.stats, b.ln1_g, b.ln1_b, dt, M, dt}; EpBias ep{w.QKV, b.bqkv, 3 * dt};
                 snprintf(nm, sizeof nm, "t%d.ln_qkv", i + 1); Lh.gemm(nm, al, b.wqkv_t, M, 3 * dt, dt, ep);
@@ -868,11 +973,14 @@ int uu3d_forward(uu3d_model* m, const float* kp2d, const uint8_t* mask, int32_t 
             snprintf(nm, sizeof nm, "t%d.attn", i + 1); Lh.attn(nm, w.QKV, B, N, masked ? mask : nullptr, w.O, (size_t)M * dt);
             { GLoadPlain gl{Ph, Pl, dt, M}; EpBiasResidual ep{w.X, b.bp, dt, nullptr, nullptr, 1};
               snprintf(nm, sizeof nm, "t%d.proj_res", i + 1); Lh.gemm_g(nm, gl, b.wp_t, M, dt, dt, ep, 4.0 * M * dt); }
-            if (m->ln_planes) {
+            if (Lh.panel_ok(M, ht, dt, b.w1_pf)) {
+                snprintf(nm, sizeof nm, "t%d.ln2_split", i + 1); Lh.ln_split_frag(nm, w.X, M, b.ln2_g, b.ln2_b, Ph);
+                snprintf(nm, sizeof nm, "t%d.ln_fc1", i + 1); Lh.gemm_panel(nm, Ph, b.w1_pf, b.b1, M, ht, PanelEpBiasReluSplit{Hh, Hl, ht});
+            } else if (m->ln_planes) {
                 snprintf(nm, sizeof nm, "t%d.ln2_split", i + 1); Lh.ln_split(nm, w.X, dt, M, b.ln2_g, b.ln2_b, Ph, Pl);
                 GLoadPlain gl{Ph, Pl, dt, M}; EpBiasReluSplit ep{Hh, Hl, b.b1, ht};
                 snprintf(nm, sizeof nm, "t%d.ln_fc1", i + 1); Lh.gemm_g(nm, gl, b.w1_t, M, ht, dt, ep);
-            } else {
+            } else if (snprintf(nm, sizeof nm, "t%d.ln_fc1", i + 1), !Lh.gemm_lnfold(nm, w.X, b.w1_f, M, ht, dt, EpLnBiasReluSplit{Hh, Hl, b.g1, b.b1_f, ht})) {
                 snprintf(nm, sizeof nm, "t%d.stats2", i + 1); Lh.row_stats(nm, w.X, dt, M, w.stats);
                 ALoadLayerNorm al{w.X, w.stats, b.ln2_g, b.ln2_b, dt, M, dt}; EpBiasReluSplit ep{Hh, Hl, b.b1, ht};
                 snprintf(nm, sizeof nm, "t%d.ln_fc1", i + 1); Lh.gemm(nm, al, b.w1_t, M, ht, dt, ep);
@@ -909,11 +1017,14 @@ int uu3d_forward(uu3d_model* m, const float* kp2d, const uint8_t* mask, int32_t 
                                      (i + 1 < c.num_strided) ? m->sblocks[i + 1].pe : nullptr};
         if (planes) {
             _Float16* const Pl = Ph + (size_t)Mi * dt; _Float16* const Hl = Hh + (size_t)Mi * ht;
-            if (m->ln_planes) {
+            if (Lh.panel_ok(Mi, 3 * dt, dt, b.wqkv_pf)) {
+                snprintf(nm, sizeof nm, "s%d.ln1_split", i + 1); Lh.ln_split_frag(nm, xa, Mi, b.ln1_g, b.ln1_b, Ph);
+                snprintf(nm, sizeof nm, "s%d.ln_qkv", i + 1); Lh.gemm_panel(nm, Ph, b.wqkv_pf, b.bqkv, Mi, 3 * dt, PanelEpBias{w.QKV, 3 * dt});
+            } else if (m->ln_planes) {
                 snprintf(nm, sizeof nm, "s%d.ln1_split", i + 1); Lh.ln_split(nm, xa, dt, Mi, b.ln1_g, b.ln1_b, Ph, Pl);
                 GLoadPlain gl{Ph, Pl, dt, Mi}; EpBias ep{w.QKV, b.bqkv, 3 * dt};
                 snprintf(nm, sizeof nm, "s%d.ln_qkv", i + 1); Lh.gemm_g(nm, gl, b.wqkv_t, Mi, 3 * dt, dt, ep);
-            } else {
+            } else if (snprintf(nm, sizeof nm, "s%d.ln_qkv", i + 1), !Lh.gemm_lnfold(nm, xa, b.wqkv_f, Mi, 3 * dt, dt, EpLnBias{w.QKV, b.gqkv, b.bqkv_f, 3 * dt})) {
                 snprintf(nm, sizeof nm, "s%d.stats1", i + 1); Lh.row_stats(nm, xa, dt, Mi, w.stats);
                 ALoadLayerNorm al{xa, w.stats, b.ln1_g, b.ln1_b, dt, Mi, dt}; EpBias ep{w.QKV, b.bqkv, 3 * dt};
                 snprintf(nm, sizeof nm, "s%d.ln_qkv", i + 1); Lh.gemm(nm, al, b.wqkv_t, Mi, 3 * dt, dt, ep);
@@ -921,11 +1032,14 @@ int uu3d_forward(uu3d_model* m, const float* kp2d, const uint8_t* mask, int32_t 
             snprintf(nm, sizeof nm, "s%d.attn", i + 1); Lh.attn(nm, w.QKV, B, Li, nullptr, w.O, (size_t)Mi * dt);
             { GLoadPlain gl{Ph, Pl, dt, Mi}; EpBiasResidual ep{xa, b.bp, dt, nullptr, nullptr, 1};
               snprintf(nm, sizeof nm, "s%d.proj_res", i + 1); Lh.gemm_g(nm, gl, b.wp_t, Mi, dt, dt, ep, 4.0 * Mi * dt); }
-            if (m->ln_planes) {
+            if (Lh.panel_ok(Mi, ht, dt, b.w1_pf)) {
+                snprintf(nm, sizeof nm, "s%d.ln2_split", i + 1); Lh.ln_split_frag(nm, xa, Mi, b.ln2_g, b.ln2_b, Ph);
+                snprintf(nm, sizeof nm, "s%d.ln_fc1", i + 1); Lh.gemm_panel(nm, Ph, b.w1_pf, b.b1, Mi, ht, PanelEpBiasReluSplit{Hh, Hl, ht});
+            } else if (m->ln_planes) {
                 snprintf(nm, sizeof nm, "s%d.ln2_split", i + 1); Lh.ln_split(nm, xa, dt, Mi, b.ln2_g, b.ln2_b, Ph, Pl);
                 GLoadPlain gl{Ph, Pl, dt, Mi}; EpBiasReluSplit ep{Hh, Hl, b.b1, ht};
                 snprintf(nm, sizeof nm, "s%d.ln_fc1", i + 1); Lh.gemm_g(nm, gl, b.w1_t, Mi, ht, dt, ep);
-            } else {
+            } else if (snprintf(nm, sizeof nm, "s%d.ln_fc1", i + 1), !Lh.gemm_lnfold(nm, xa, b.w1_f, Mi, ht, dt, EpLnBiasReluSplit{Hh, Hl, b.g1, b.b1_f, ht})) {
                 snprintf(nm, sizeof nm, "s%d.stats2", i + 1); Lh.row_stats(nm, xa, dt, Mi, w.stats);
                 ALoadLayerNorm al{xa, w.stats, b.ln2_g, b.ln2_b, dt, Mi, dt}; EpBiasReluSplit ep{Hh, Hl, b.b1, ht};
                 snprintf(nm, sizeof nm, "s%d.ln_fc1", i + 1); Lh.gemm(nm, al, b.w1_t, Mi, ht, dt, ep);
