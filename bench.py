@@ -101,7 +101,7 @@ def train_bench(args, world, rank, local_rank, use_dist):
         dist.destroy_process_group()
 
 
-PMC_SUMMARY = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_final_unsplit_pmc_summary.csv")
+PMC_SUMMARY = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_h_unsplit_pmc_summary.csv")
 
 
 def pmc_traffic(kernel_class, dom_key):
@@ -123,8 +123,9 @@ def pmc_traffic(kernel_class, dom_key):
         k = r["kernel"]
         if kern in k and (("panel" in k) == ("panel" in kern)) and all(w in k for w in want) and r["HBM_read_bytes_avg_x2_gfx950_corrected"] and r["HBM_write_bytes_avg"]:
             t = float(r["HBM_read_bytes_avg_x2_gfx950_corrected"]) + float(r["HBM_write_bytes_avg"])
-            if best is None or int(r["grid_size"]) > best[0]:       # the temporal-block launch (largest grid) of this instantiation
-                best = (int(r["grid_size"]), t)
+            key = (int(r["grid_size"]), int(r["launches"]))         # the temporal-block launches: largest grid, then most launches
+            if best is None or key > best[0]:
+                best = (key, t)
     return None if best is None else round(best[1])
 
 

@@ -793,7 +793,7 @@ struct Launcher {
         auto kern = gemm_h3_panel_kernel<24, EP>;
         static bool attr_done = false;
         if (!attr_done) { (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)PANEL_LDS_TOTAL); attr_done = true; }
-        hipLaunchKernelGGL(kern, dim3(round_up(mt, 8) * S), dim3(256), PANEL_LDS_TOTAL, stream, Af, m->harena + pf, colv, M, mt, S, (N / 32) / S, ep);
+        hipLaunchKernelGGL(kern, dim3(8 * S, round_up(mt, 8) / 8), dim3(256), PANEL_LDS_TOTAL, stream, Af, m->harena + pf, colv, M, mt, S, (N / 32) / S, ep);
         end();
     }
     // LayerNorm (eps 1e-5) of M rows of 384 floats, written as the fragment-ordered planes of the panel GEMM's A operand

@@ -12,8 +12,8 @@
 //     global_load_lds_dwordx4 with no swizzle; a B fragment is one conflict-free ds_read_b128 at lane * 16;
 //   * a wave owns a PANEL of 32 token rows over the full contraction length and keeps its 2 K/16 A fragments
 //     resident for the whole kernel (K = 384: 192 registers);
-//   * a workgroup = 4 waves = 128 rows shares the weight stream through a 6-slot LDS ring (144 KiB), one barrier per
-//     k-step (36 MFMAs per wave), five k-steps in flight;
+//   * a workgroup = 4 waves = 128 rows shares the weight stream through a 3-slot LDS ring (3 x 48 KiB), one barrier per
+//     k-step of 24 slices (72 MFMAs per wave), two k-steps in flight (6 slots of 12 slices: 3 % slower);
 //   * per k-slice a wave issues 2 ds_read_b128 and 3 MFMAs (ah*bh -> acc0; ah*bl, al*bh -> acc1); the fragment reads
 //     run two slices ahead (asm with counted lgkmcnt waits: hipcc sinks plain loads to their use);
 //   * the epilogue of chunk c-1 is interleaved with the MFMAs of chunk c (two accumulator sets): issued as a block
@@ -21,7 +21,7 @@
 //   * ~330 registers per wave, so ONE wave per SIMD / one workgroup per CU: everything is software pipelined instead
 //     of relying on co-resident waves.
 //
-// Grid: (M / 128) row tiles x S column ranges of N / (32 S) chunks each.  Measured (tools/gemm_panel_exp): see DESIGN.md.
+// Grid: (M / 128) row tiles x S column ranges of N / (32 S) chunks each, launched as (8 S, row tiles / 8).  Measured (tools/gemm_panel_exp): see DESIGN.md.
 // An earlier form that loaded f32 rows, computed LayerNorm statistics and split in its own prologue (LayerNorm folded
 // into the operand) is kept in tools/gemm_panel_lnfold_exp.h: its prologue was 14-35 k cycles of serial VALU work and
 // register spills per workgroup; splitting once per row in a separate wide kernel (ln_split_frag_kernel) is cheaper.
@@ -31,8 +31,13 @@
 
 namespace uu3d {
 
-static constexpr int PANEL_STEP_BYTES = 12 * 2 * 1024;   // one k-step of B: 12 slices x 2 planes x 1 KiB
-static constexpr int PANEL_SLOTS = 6;                    // ring depth: k-steps t+1 .. t+5 in flight while t is consumed
+#ifndef UU3D_PANEL_SS
+#define UU3D_PANEL_SS 24
+#endif
+static constexpr int PANEL_SS = UU3D_PANEL_SS;           // k-slices per k-step (12 or 24)
+static constexpr int PANEL_STEP_BYTES = PANEL_SS * 2 * 1024;   // one k-step of B: slices x 2 planes x 1 KiB
+static constexpr int PANEL_SLOTS = 144 / (2 * PANEL_SS); // ring depth (144 KiB): all but one slot in flight while one is consumed
+static constexpr int PANEL_PIECES = PANEL_SS / 2;        // 1 KiB pieces of a k-step each of the 4 waves moves
 static constexpr size_t PANEL_RING_BYTES = (size_t)PANEL_SLOTS * PANEL_STEP_BYTES;   // 144 KiB
 static constexpr int PANEL_COLV_FLOATS = 1024;           // per-column epilogue vector of this workgroup's columns (<= 32 chunks)
 static constexpr size_t PANEL_LDS_TOTAL = PANEL_RING_BYTES + PANEL_COLV_FLOATS * sizeof(float);
@@ -102,11 +107,11 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))
 gemm_h3_panel_kernel(const _Float16* __restrict__ Af, const _Float16* __restrict__ Bf, const float* __restrict__ colv,
                      const int M, const int m_tiles, const int splits, const int chunks_per_wg, const EP ep)
 {
-    constexpr int SPC = KS / 12;                           // k-steps per chunk
+    constexpr int SPC = KS / PANEL_SS;                           // k-steps per chunk
     h3_flush_f16_denormals();                              // the epilogue may split its result
     extern __shared__ __attribute__((aligned(16))) unsigned char psm[];
 
-    const int id = blockIdx.x;
+    const int id = blockIdx.y * gridDim.x + blockIdx.x;    // grid (8 S, m_tiles / 8): the linear order the dispatcher deals to the 8 XCDs
     const int xcd = id & 7, slot_id = id >> 3;
     const int ns = slot_id % splits;
     const int bm = (slot_id / splits) * 8 + xcd;           // the column ranges of one row tile share an XCD (A panels hit its L2)
@@ -117,15 +122,15 @@ gemm_h3_panel_kernel(const _Float16* __restrict__ Af, const _Float16* __restrict
     const int T = SPC * chunks_per_wg;                     // k-steps this workgroup consumes
 
     // ---- weight stream: k-step t -> ring slot t % PANEL_SLOTS; each wave moves 6 of its 24 pieces of 1 KiB ----
-    const unsigned char* bsrc = reinterpret_cast<const unsigned char*>(Bf) + (size_t)chunk0 * SPC * PANEL_STEP_BYTES + (wave * 6) * 1024 + lane * 16;
+    const unsigned char* bsrc = reinterpret_cast<const unsigned char*>(Bf) + (size_t)chunk0 * SPC * PANEL_STEP_BYTES + (wave * PANEL_PIECES) * 1024 + lane * 16;
     auto dma1 = [&](int t, int slot, int p) __attribute__((always_inline)) {       // piece p (0..5) of this wave's share of k-step t
         const unsigned char* s = bsrc + (size_t)min(t, T - 1) * PANEL_STEP_BYTES;
-        unsigned char* d = psm + slot * PANEL_STEP_BYTES + (wave * 6) * 1024;
+        unsigned char* d = psm + slot * PANEL_STEP_BYTES + (wave * PANEL_PIECES) * 1024;
         __builtin_amdgcn_global_load_lds((h3_glb_void*)(s + p * 1024), (h3_lds_void*)(d + p * 1024), 16, 0, 0);
     };
     auto dma = [&](int t, int slot) __attribute__((always_inline)) {
 #pragma unroll
-        for (int p = 0; p < 6; ++p) dma1(t, slot, p);
+        for (int p = 0; p < PANEL_PIECES; ++p) dma1(t, slot, p);
     };
     PANEL_STAMP(const long long c_start = clock64();)
 
@@ -164,7 +169,7 @@ gemm_h3_panel_kernel(const _Float16* __restrict__ Af, const _Float16* __restrict
         const float pcv = colv_s[max(c - 1, 0) * 32 + ccol];
 #pragma unroll
         for (int st = 0; st < SPC; ++st) {
-            asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" :: "i"(6 * (PANEL_SLOTS - 2)) : "memory");   // k-step t landed (this wave's pieces); own reads of t-1 returned
+            asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" :: "i"(PANEL_PIECES * (PANEL_SLOTS - 2)) : "memory");   // k-step t landed (this wave's pieces); own reads of t-1 returned
             __builtin_amdgcn_sched_barrier(0);
             __builtin_amdgcn_s_barrier();                                  // ... everybody's; the slot refilled below was last read in t-1
             __builtin_amdgcn_sched_barrier(0);
@@ -186,19 +191,19 @@ gemm_h3_panel_kernel(const _Float16* __restrict__ Af, const _Float16* __restrict
             UU3D_PANEL_READ(0, 0);
             UU3D_PANEL_READ(1, 1);
 #pragma unroll
-            for (int kk = 0; kk < 12; ++kk) {
-                if (kk + 2 < 12) {
+            for (int kk = 0; kk < PANEL_SS; ++kk) {
+                if (kk + 2 < PANEL_SS) {
                     UU3D_PANEL_READ((kk + 2) % 3, kk + 2);
                     asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(bh[kk % 3]), "+v"(bl[kk % 3]));
-                } else if (kk + 1 < 12) {
+                } else if (kk + 1 < PANEL_SS) {
                     asm volatile("s_waitcnt lgkmcnt(2)" : "+v"(bh[kk % 3]), "+v"(bl[kk % 3]));
                 } else {
                     asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(bh[kk % 3]), "+v"(bl[kk % 3]));
                 }
-                acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[st * 12 + kk], bh[kk % 3], acc0, 0, 0, 0);
-                acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[st * 12 + kk], bl[kk % 3], acc1, 0, 0, 0);
-                acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[st * 12 + kk], bh[kk % 3], acc1, 0, 0, 0);
-                if (WHOLE && st * 12 + kk < 16 && prev) emit(c - 1, st * 12 + kk, p0, p1, pcv);
+                acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[st * PANEL_SS + kk], bh[kk % 3], acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[st * PANEL_SS + kk], bl[kk % 3], acc1, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[st * PANEL_SS + kk], bh[kk % 3], acc1, 0, 0, 0);
+                if (WHOLE && st * PANEL_SS + kk < 16 && prev) emit(c - 1, st * PANEL_SS + kk, p0, p1, pcv);
                 if (kk & 1) dma1(c * SPC + st + PANEL_SLOTS - 1, slot_w, kk >> 1);   // the refill of the slot read in step t-1, spread over the step (-2 %)
             }
 #undef UU3D_PANEL_READ
