@@ -780,7 +780,8 @@ struct Launcher {
         int best = 0; double best_cost = 1e30;
         for (int S = 1; S <= chunks; ++S) {
             if (chunks % S != 0 || chunks / S > PANEL_COLV_FLOATS / 32) continue;
-            const double cost = (double)((mt * S + 255) / 256) * (2.5 + (double)chunks / S);
+            const int per_xcd = (mt * S + 7) / 8;                           // workgroups on the busiest XCD (32 CUs, one workgroup each)
+            const double cost = (double)((per_xcd + 31) / 32) * (2.5 + (double)chunks / S);
             if (cost < best_cost) { best_cost = cost; best = S; }
         }
         return best;
@@ -793,7 +794,7 @@ struct Launcher {
         auto kern = gemm_h3_panel_kernel<24, EP>;
         static bool attr_done = false;
         if (!attr_done) { (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)PANEL_LDS_TOTAL); attr_done = true; }
-        hipLaunchKernelGGL(kern, dim3(8 * S, round_up(mt, 8) / 8), dim3(256), PANEL_LDS_TOTAL, stream, Af, m->harena + pf, colv, M, mt, S, (N / 32) / S, ep);
+        hipLaunchKernelGGL(kern, dim3(8 * S, ((mt * S + 7) / 8 + S - 1) / S), dim3(256), PANEL_LDS_TOTAL, stream, Af, m->harena + pf, colv, M, mt, S, (N / 32) / S, ep);
         end();
     }
     // LayerNorm (eps 1e-5) of M rows of 384 floats, written as the fragment-ordered planes of the panel GEMM's A operand

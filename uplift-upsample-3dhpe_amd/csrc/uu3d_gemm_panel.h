@@ -21,7 +21,7 @@
 //   * ~330 registers per wave, so ONE wave per SIMD / one workgroup per CU: everything is software pipelined instead
 //     of relying on co-resident waves.
 //
-// Grid: (M / 128) row tiles x S column ranges of N / (32 S) chunks each, launched as (8 S, row tiles / 8).  Measured (tools/gemm_panel_exp): see DESIGN.md.
+// Grid: (M / 128) row tiles x S column ranges of N / (32 S) chunks each, launched as (8 S, ceil(ceil(items / 8) / S)).  Measured (tools/gemm_panel_exp): see DESIGN.md.
 // An earlier form that loaded f32 rows, computed LayerNorm statistics and split in its own prologue (LayerNorm folded
 // into the operand) is kept in tools/gemm_panel_lnfold_exp.h: its prologue was 14-35 k cycles of serial VALU work and
 // register spills per workgroup; splitting once per row in a separate wide kernel (ln_split_frag_kernel) is cheaper.
@@ -111,11 +111,14 @@ gemm_h3_panel_kernel(const _Float16* __restrict__ Af, const _Float16* __restrict
     h3_flush_f16_denormals();                              // the epilogue may split its result
     extern __shared__ __attribute__((aligned(16))) unsigned char psm[];
 
-    const int id = blockIdx.y * gridDim.x + blockIdx.x;    // grid (8 S, m_tiles / 8): the linear order the dispatcher deals to the 8 XCDs
-    const int xcd = id & 7, slot_id = id >> 3;
-    const int ns = slot_id % splits;
-    const int bm = (slot_id / splits) * 8 + xcd;           // the column ranges of one row tile share an XCD (A panels hit its L2)
-    if (bm >= m_tiles) return;
+    // Work item u = row tile * S + column range.  The dispatcher deals workgroups to the 8 XCDs round robin; XCD x takes
+    // the contiguous items [x per, (x + 1) per): the column ranges of a row tile share an L2 (A panels), and no XCD gets
+    // more than ceil(items / 8) workgroups (dealing whole row tiles gave 33 on two XCDs at 82 tiles x 3: a second round).
+    const int id = blockIdx.y * gridDim.x + blockIdx.x;
+    const int total = m_tiles * splits, per = (total + 7) >> 3;
+    const int u = (id & 7) * per + (id >> 3);
+    if ((id >> 3) >= per || u >= total) return;
+    const int bm = u / splits, ns = u - bm * splits;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int row0 = bm * 128 + wave * 32;                 // this wave's panel
     const int chunk0 = ns * chunks_per_wg;
