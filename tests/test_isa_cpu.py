@@ -18,7 +18,11 @@ from tests import util
 CSRC = os.path.join(util.ROOT, "uplift-upsample-3dhpe_amd", "csrc")
 SRC = r'''
 #include "uu3d_gemm_h3.h"
+#include "uu3d_gemm_panel.h"
 using namespace uu3d;
+template __global__ void uu3d::gemm_h3_panel_kernel<24, PanelEpBias>(const _Float16*, const _Float16*, const float*, int, int, int, int, const PanelEpBias);
+template __global__ void uu3d::gemm_h3_panel_kernel<24, PanelEpBiasReluSplit>(const _Float16*, const _Float16*, const float*, int, int, int, int, const PanelEpBiasReluSplit);
+template __global__ void uu3d::ln_split_frag_kernel<24>(const float*, int, int, float, const float*, const float*, _Float16*);
 template __global__ void uu3d::gemm_h3g_kernel<1, 1, GLoadConv3, EpSlab, 3>(const GLoadConv3, const _Float16*, const _Float16*, int, int, int, int, int, int, const EpSlab);
 template __global__ void uu3d::gemm_h3g_kernel<1, 2, GLoadPlain, EpBiasResidual, 3>(const GLoadPlain, const _Float16*, const _Float16*, int, int, int, int, int, int, const EpBiasResidual);
 template __global__ void uu3d::gemm_h3_kernel<1, 2, ALoadLayerNorm, EpBias>(const ALoadLayerNorm, const _Float16*, const _Float16*, int, int, int, int, int, int, const EpBias);
@@ -60,6 +64,23 @@ def test_lds_dma_instruction_counts(asm):
         assert f"s_waitcnt vmcnt({n}) lgkmcnt(0)" in body       # counted wait + LDS reads retired before the barrier
         assert body.count("s_barrier") == 2
         assert "scratch_" not in body
+
+
+def test_row_panel_gemm_code_shape(asm):
+    """uu3d_gemm_panel.h: the counted waits assume exactly PANEL_PIECES = 12 LDS-DMAs per wave and k-step (one k-step
+    left in flight: vmcnt(12)); the kernel only works as designed without scratch (a spill reload is a vmcnt(0) that
+    drains the ring) and with its register budget of one wave per SIMD."""
+    ks = _kernels(asm)
+    for ep in ("PanelEpBiasE", "PanelEpBiasReluSplit"):
+        body = next(v for k, v in ks.items() if "gemm_h3_panel_kernel" in k and ep in k)
+        assert "scratch_" not in body
+        assert "s_waitcnt vmcnt(12) lgkmcnt(0)" in body
+        n_dma = body.count("global_load_lds_dwordx4")
+        # 2 prologue k-steps + one refill k-step per copy of the chunk body (ping-pong x whole / ragged panel, plus whatever
+        # hipcc peels): every copy must hold exactly 12 DMAs next to its 72 MFMAs
+        assert n_dma % 12 == 0 and n_dma >= 2 * 12 + 4 * 12, n_dma
+        assert body.count("v_mfma_f32_32x32x16_f16") == (n_dma // 12 - 2) * 72
+        assert re.search(r"ds_read_b128 v\[\d+:\d+\], v\d+ offset:\d+\n\tds_read_b128", body)     # the asm fragment reads survived
 
 
 def test_no_packed_fp32_valu_ops(asm):
