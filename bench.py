@@ -152,7 +152,8 @@ def main():
     ap.add_argument("--no-graph", action="store_true", help="launch eagerly instead of replaying a hipGraph")
     ap.add_argument("--precision", default="f16x3", choices=["f16x3", "f32"], help="GEMM arithmetic of the forward (both hold the 1e-4 parity bar)")
     ap.add_argument("--mode", default="infer", choices=["infer", "train"], help="train = fwd + bwd + grad all-reduce + AdamW (BASELINE config 5)")
-    ap.add_argument("--no-halves", action="store_true", help="one chain of kernels per batch instead of two concurrent half batches (per-launch profiling)")
+    ap.add_argument("--halves", action="store_true", help="two concurrent half-batch chains on two streams instead of one chain of kernels per batch")
+    ap.add_argument("--no-halves", action="store_true", help="(default since the row-panel GEMM; accepted for older scripts)")
     ap.add_argument("--force-dist", action="store_true", help="initialise the process group even at world size 1 (exercises the RCCL path)")
     args = ap.parse_args()
 
@@ -180,7 +181,7 @@ def main():
     arch = pkg.arch_from_config(cfg)
     weights = pkg.init_weights(arch, seed=0)                 # replicated: same seed on every rank
     model = pkg.build_uplift_upsample_transformer(cfg, weights=weights, device=f"cuda:{local_rank}", precision=args.precision,
-                                                   concurrent_halves=not args.no_halves)
+                                                   concurrent_halves=args.halves and not args.no_halves)
     s_in = args.mask_stride or (cfg.MASK_STRIDE[0] if isinstance(cfg.MASK_STRIDE, list) else cfg.MASK_STRIDE)
     B, N, J = args.batch, arch.num_frames, arch.num_keypoints
     x_np, m_np = util.synthetic_batch(cfg, B, seed=1000 + rank, mask_specs=[(s_in, 0)])
@@ -279,7 +280,7 @@ def main():
                                    f"{(N - 1) * cfg.SEQUENCE_STRIDE + 1}), J={J}, batch {B}/GPU, s_in={s_in}, "
                                    f"seeded Keras-default weights", "global_batch": world * B,
                        "parallelism": f"batch-sharded x{world}", "hipgraph": bool(use_graph),
-                       "concurrent_half_batches": bool(not args.no_halves and B >= 64)},
+                       "concurrent_half_batches": bool(args.halves and not args.no_halves and B >= 64)},
             "roofline": {"bound": "mfma", "kernel": f"{gk} [{dom_key}]",
                          "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s",
                          "frac": round(ach / peak, 4), "traffic": pmc_traffic(gk, dom_key),

@@ -174,3 +174,21 @@ def test_h5_weight_file_roundtrip_through_the_model(tmp_path):
     x, m = util.synthetic_batch(cfg, 3, seed=7)
     a, b = _call(model, x * m[:, :, None, None], m), _call(other, x * m[:, :, None, None], m)
     assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
+
+
+@pytest.mark.parametrize("cfgname,batch", [("h36m_351", 65), ("h36m_81", 129)])
+def test_concurrent_half_batches_option(cfgname, batch):
+    """concurrent_halves=True (two half-batch chains on two streams; the default until the row-panel GEMM made a
+    single chain faster) must give the single chain's results: the halves see different M, hence different tile
+    shapes and split-K choices, so equality is to rounding, not bitwise."""
+    cfg = util.load_config(cfgname)
+    arch = pkg.arch_from_config(cfg)
+    w = pkg.init_weights(arch, seed=4, perturb=0.1)
+    x, m = util.synthetic_batch(cfg, batch, seed=4)
+    x = x * m[:, :, None, None]
+    one = pkg.build_uplift_upsample_transformer(cfg, weights=w)
+    two = pkg.build_uplift_upsample_transformer(cfg, weights=w, concurrent_halves=True)
+    f1, c1 = _call(one, x, m)
+    f2, c2 = _call(two, x, m)
+    assert np.isfinite(f2).all() and np.isfinite(c2).all()
+    assert np.abs(f1 - f2).max() <= 2e-5 and np.abs(c1 - c2).max() <= 2e-5

@@ -55,16 +55,23 @@ def test_row_panel_gemm_path_matches_oracle(cfgname, batch, monkeypatch):
     arch = pkg.arch_from_config(cfg)
     w = pkg.init_weights(arch, seed=3, perturb=0.1)
     x, m = util.synthetic_batch(cfg, batch=batch, seed=3)
-    full, central, xm = _run_hip(cfg, w, x, m, "f16x3")
+    full, central, xm = _run_hip(cfg, w, x, m, "f16x3")          # the product path: ln_split_frag + panel GEMM
     monkeypatch.setenv("UU3D_NO_PANEL", "1")
     full_t, central_t, _ = _run_hip(cfg, w, x, m, "f16x3")
     monkeypatch.delenv("UU3D_NO_PANEL")
+    monkeypatch.setenv("UU3D_LNFUSE", "1")             # opt-in: producer-side split + LayerNorm folded into the panel GEMM (LNF)
+    full_u, central_u, _ = _run_hip(cfg, w, x, m, "f16x3")
+    monkeypatch.delenv("UU3D_LNFUSE")
     hp = util.hp_from_arch(arch)
     f32, c32 = O.forward(hp, w, xm, m, torch.float32)
     err = max(np.abs(full - f32).max(), np.abs(central - c32).max())
     err_t = max(np.abs(full_t - f32).max(), np.abs(central_t - c32).max())
     dev = max(np.abs(full - full_t).max(), np.abs(central - central_t).max())
-    print(f"{cfgname} batch {batch}: panel vs oracle {err:.3e}, tiled vs oracle {err_t:.3e}, panel vs tiled {dev:.3e}")
+    err_u = max(np.abs(full_u - f32).max(), np.abs(central_u - c32).max())
+    dev_u = max(np.abs(full - full_u).max(), np.abs(central - central_u).max())
+    print(f"{cfgname} batch {batch}: panel vs oracle {err:.3e}, fused-LN panel vs oracle {err_u:.3e}, tiled vs oracle {err_t:.3e}, "
+          f"panel vs tiled {dev:.3e}, panel vs fused-LN panel {dev_u:.3e}")
+    assert err_u <= util.TOL_MAX_ABS and dev_u > 0.0
     assert np.isfinite(full).all() and np.isfinite(central).all()
     assert err <= util.TOL_MAX_ABS
     assert dev > 0.0, "UU3D_NO_PANEL=1 did not change the path: the panel kernels were not exercised"

@@ -86,14 +86,14 @@ int main(int argc, char** argv) {
             if (nch % S) continue;
             const int cpw = nch / S;
             CK(hipMemset(dC, 0xff, (size_t)M * N * 4));
-            float ms = timeit([&] { hipLaunchKernelGGL(kern, dim3(8 * S, ((mt * S + 7) / 8 + S - 1) / S), dim3(256), PANEL_LDS_TOTAL, 0, dAf, dBf, dbias, M, mt, S, cpw, ep); });
+            float ms = timeit([&] { hipLaunchKernelGGL(kern, dim3(8 * S, ((mt * S + 7) / 8 + S - 1) / S), dim3(256), PANEL_LDS_TOTAL, 0, dAf, dBf, dbias, M, mt, S, cpw, ep, 0, 0.f); });
             float ms2 = timeit([&] { hipLaunchKernelGGL(ln_split_frag_kernel<24>, dim3((M + 15) / 16), dim3(256), 0, 0, dX, K, M, 1e-5f, dg, db, dAf);
-                                     hipLaunchKernelGGL(kern, dim3(8 * S, ((mt * S + 7) / 8 + S - 1) / S), dim3(256), PANEL_LDS_TOTAL, 0, dAf, dBf, dbias, M, mt, S, cpw, ep); });
+                                     hipLaunchKernelGGL(kern, dim3(8 * S, ((mt * S + 7) / 8 + S - 1) / S), dim3(256), PANEL_LDS_TOTAL, 0, dAf, dBf, dbias, M, mt, S, cpw, ep, 0, 0.f); });
             printf("panel S=%2d (%4d workgroups, %2d chunks each): %7.1f us  %6.1f TFLOP/s algorithmic;  with ln_split_frag in front %7.1f us\n", S, mt * S, cpw, ms * 1e3, fl / ms / 1e9, ms2 * 1e3);
             check(dC, "panel");
 #ifdef STAMP
             { unsigned long long z[8] = {0}, h[8]; CK(hipMemcpyToSymbol(HIP_SYMBOL(panel_clk), z, 64));
-              hipLaunchKernelGGL(kern, dim3(8 * S, ((mt * S + 7) / 8 + S - 1) / S), dim3(256), PANEL_LDS_TOTAL, 0, dAf, dBf, dbias, M, mt, S, cpw, ep); CK(hipDeviceSynchronize());
+              hipLaunchKernelGGL(kern, dim3(8 * S, ((mt * S + 7) / 8 + S - 1) / S), dim3(256), PANEL_LDS_TOTAL, 0, dAf, dBf, dbias, M, mt, S, cpw, ep, 0, 0.f); CK(hipDeviceSynchronize());
               CK(hipMemcpyFromSymbol(h, HIP_SYMBOL(panel_clk), 64)); const double n = (double)h[5];
               printf("  per workgroup (s_memtime ticks): prologue %.0f, loop %.0f (per k-step %.0f), tail %.0f\n", h[0] / n, h[1] / n, h[1] / n / (2 * cpw), h[4] / n); }
 #endif

@@ -6,7 +6,7 @@ set -u
 tag=${1:-r01}
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 rm -rf gpurun_out/${tag}_*
-rocprofv3 --kernel-trace --stats -d gpurun_out/${tag}_trace -o run -- python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline > gpurun_out/${tag}_trace.log 2>&1
+rocprofv3 --kernel-trace --stats -d gpurun_out/${tag}_halves_trace -o run -- python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline --halves > gpurun_out/${tag}_halves_trace.log 2>&1
 rocprofv3 --kernel-trace --stats -d gpurun_out/${tag}_unsplit_trace -o run -- python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-halves > gpurun_out/${tag}_unsplit_trace.log 2>&1
 for c in FETCH_SIZE WRITE_SIZE SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE; do
   rocprofv3 --pmc $c -d gpurun_out/${tag}_unsplit_pmc_$c -o run -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-graph --no-halves > gpurun_out/${tag}_unsplit_pmc_$c.log 2>&1

@@ -67,6 +67,7 @@ struct BlockDev {
     const float *wqkv_f, *gqkv, *bqkv_f, *w1_f, *g1, *b1_f;
     // fragment-ordered f16 planes of wqkv / w1 for the row-panel GEMM (uu3d_gemm_panel.h); offsets in harena, 0 = none
     size_t wqkv_pf = 0, w1_pf = 0;
+    size_t wqkv_fpf = 0, w1_fpf = 0;   // the same for the LayerNorm-folded operands gamma o W (LNF panel kernel)
 };
 
 struct ProfRec {
@@ -88,6 +89,7 @@ struct uu3d_model {
     bool committed = false;
     float* arena = nullptr;        // packed device weights
     size_t arena_floats = 0;
+    bool no_lnfuse = true;         // UU3D_LNFUSE=1: producer-side split + LayerNorm folded into the panel GEMMs (LNF) instead of the ln_split_frag pass; measured +-0.6 %, off
     bool no_panel = false;         // UU3D_NO_PANEL=1: LayerNorm-fed GEMMs stay on the tiled kernels (A/B measurements)
     bool no_lnfold = true;         // UU3D_LNFOLD=1 folds LayerNorm into the next Dense (gemm_h3_lnfold_kernel); measured neutral, off by default
     bool ln_planes = false;        // UU3D_LN_PLANES=1: LayerNorm as a separate pass that writes planes (ln_split) instead of inside the GEMM loader
@@ -297,6 +299,7 @@ int uu3d_create(const uu3d_config* c, int device, uu3d_model** out) {
       m->spatial_f32 = (e != nullptr && std::string(e) == "f32"); m->spatial_h3_always = (e != nullptr && std::string(e) == "h3"); }
     { const char* e = getenv("UU3D_NO_PLANES"); m->no_planes = (e != nullptr && e[0] == '1'); }
     { const char* e = getenv("UU3D_LN_PLANES"); m->ln_planes = (e != nullptr && e[0] == '1'); }
+    { const char* e = getenv("UU3D_LNFUSE"); m->no_lnfuse = !(e != nullptr && e[0] == '1'); }
     { const char* e = getenv("UU3D_NO_PANEL"); m->no_panel = (e != nullptr && e[0] == '1'); }
     { const char* e = getenv("UU3D_LNFOLD"); m->no_lnfold = !(e != nullptr && e[0] == '1'); }
     *out = m;
@@ -564,8 +567,8 @@ int uu3d_commit_weights(uu3d_model* m, void* stream_) {
                 panel_pack_operand(hb.data() + it->second.first, hb.data() + it->second.second, Nn, dt, Kdt, hb.data() + at);
                 m->panel_off[bt_off] = at;
             };
-            for (auto& o : toff) { add_panel(o.wqkv, 3 * dt); add_panel(o.w1, ht); }
-            for (auto& o : soff) { add_panel(o.wqkv, 3 * dt); add_panel(o.w1, ht); }
+            for (auto& o : toff) { add_panel(o.wqkv, 3 * dt); add_panel(o.w1, ht); add_panel(o.wqkv_f, 3 * dt); add_panel(o.w1_f, ht); }
+            for (auto& o : soff) { add_panel(o.wqkv, 3 * dt); add_panel(o.w1, ht); add_panel(o.wqkv_f, 3 * dt); add_panel(o.w1_f, ht); }
         }
         if (m->harena_halfs < hb.size()) {
             if (m->harena) HIPCHK(m, hipFree(m->harena));
@@ -590,6 +593,8 @@ int uu3d_commit_weights(uu3d_model* m, void* stream_) {
         b.pe = strided ? A + o.pe : nullptr;
         { const auto it = m->panel_off.find(o.wqkv); b.wqkv_pf = (it != m->panel_off.end()) ? it->second : 0; }
         { const auto it = m->panel_off.find(o.w1); b.w1_pf = (it != m->panel_off.end()) ? it->second : 0; }
+        { const auto it = m->panel_off.find(o.wqkv_f); b.wqkv_fpf = (it != m->panel_off.end()) ? it->second : 0; }
+        { const auto it = m->panel_off.find(o.w1_f); b.w1_fpf = (it != m->panel_off.end()) ? it->second : 0; }
         b.wqkv_f = A + o.wqkv_f; b.gqkv = A + o.gqkv; b.bqkv_f = A + o.bqkv_f; b.w1_f = A + o.w1_f; b.g1 = A + o.g1; b.b1_f = A + o.b1_f;
         return b;
     };
@@ -605,7 +610,7 @@ int uu3d_commit_weights(uu3d_model* m, void* stream_) {
 // ---- workspace --------------------------------------------------------------------------
 namespace {
 struct Workspace {
-    float *S, *X, *QKV, *O, *Hb, *XA, *XB, *slab;
+    float *S, *X, *QKV, *O, *Hb, *XA, *XB, *slab, *F;
     int* frame_list;
     float2* stats;
     size_t slab_floats;
@@ -629,11 +634,12 @@ Workspace carve(const uu3d_model* m, int B, char* base) {
     w.slab_floats = (size_t)1536 * 4096;            // >= slices * M * N of any split GEMM (slices * tiles <= ~1150)
     const size_t oSl = take(w.slab_floats * 4);
     const size_t oFl = take((rows + 1) * sizeof(int));
+    const size_t oF = take((rows + 32) * c.d_temporal * 4);     // second A-fragment buffer (LN2 input planes written by the projection epilogue)
     w.bytes = off;
     if (base) {
         w.S = (float*)(base + oS); w.X = (float*)(base + oX); w.QKV = (float*)(base + oQ);
         w.O = (float*)(base + oO); w.Hb = (float*)(base + oH); w.XA = (float*)(base + oA);
-        w.XB = (float*)(base + oB); w.stats = (float2*)(base + oT); w.slab = (float*)(base + oSl); w.frame_list = (int*)(base + oFl);
+        w.XB = (float*)(base + oB); w.stats = (float2*)(base + oT); w.slab = (float*)(base + oSl); w.frame_list = (int*)(base + oFl); w.F = (float*)(base + oF);
     }
     return w;
 }
@@ -794,7 +800,20 @@ struct Launcher {
         auto kern = gemm_h3_panel_kernel<24, EP>;
         static bool attr_done = false;
         if (!attr_done) { (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)PANEL_LDS_TOTAL); attr_done = true; }
-        hipLaunchKernelGGL(kern, dim3(8 * S, ((mt * S + 7) / 8 + S - 1) / S), dim3(256), PANEL_LDS_TOTAL, stream, Af, m->harena + pf, colv, M, mt, S, (N / 32) / S, ep);
+        hipLaunchKernelGGL(kern, dim3(8 * S, ((mt * S + 7) / 8 + S - 1) / S), dim3(256), PANEL_LDS_TOTAL, stream, Af, m->harena + pf, colv, M, mt, S, (N / 32) / S, ep, 0, 0.f);
+        end();
+    }
+    // The same with LayerNorm folded in (LNF): Af = raw split rows written by the producer of the residual stream,
+    // pf = planes of gamma o W, gb = g | b' (N floats each, contiguous: gemm_lnfold's per-column vectors)
+    template <class EP>
+    void gemm_panel_ln(const char* name, const _Float16* Af, size_t pf, const float* g, const float* bprime, int M, int N, const EP& ep) {
+        const int K = 384, S = panel_splits(M, N), mt = (M + 127) / 128;
+        begin(name, "gemm_panel", 2.0 * M * (double)N * K, 4.0 * ((double)M * K + (double)N * K + (double)M * N));
+        auto kern = gemm_h3_panel_kernel<24, EP, true>;
+        static bool attr_done = false;
+        if (!attr_done) { (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)PANEL_LDS_TOTAL); attr_done = true; }
+        hipLaunchKernelGGL(kern, dim3(8 * S, ((mt * S + 7) / 8 + S - 1) / S), dim3(256), PANEL_LDS_TOTAL, stream, Af, m->harena + pf, g, M, mt, S, (N / 32) / S, ep,
+                           (int)(bprime - g), 1e-5f);
         end();
     }
     // LayerNorm (eps 1e-5) of M rows of 384 floats, written as the fragment-ordered planes of the panel GEMM's A operand
@@ -939,10 +958,19 @@ int uu3d_forward(uu3d_model* m, const float* kp2d, const uint8_t* mask, int32_t 
             Lh.end();
         }
     }
+    // LayerNorm fused away (f16x3, >= 1024 token rows): every producer of the residual stream (s2t, projection, fc2) also
+    // writes the raw split rows in the panel GEMM's A-fragment order (Fa for the next LN1, Fb for LN2), and the LayerNorm-fed
+    // Dense layers run as the LNF panel kernel on the folded operands -- no row-statistics / LayerNorm launch at all.
+    bool lnfuse = (c.precision == UU3D_PREC_F16X3) && (dt % 32 == 0) && (ht % 32 == 0) && !m->no_planes && !m->no_lnfuse && c.temporal_depth >= 1;
+    for (const BlockDev& b : m->tblocks) lnfuse = lnfuse && Lh.panel_ok(M, 3 * dt, dt, b.wqkv_fpf) && Lh.panel_ok(M, ht, dt, b.w1_fpf);
+    lnfuse = lnfuse && c.num_strided >= 1 && m->sblocks[0].wqkv_fpf != 0 && m->sblocks[0].w1_fpf != 0;
+    _Float16* const Fa = reinterpret_cast<_Float16*>(w.O);       // raw split rows for the next LN1 (the bytes of O: dead between projection and attention)
+    _Float16* const Fb = reinterpret_cast<_Float16*>(w.F);       // raw split rows for LN2
     // 2. spatial_to_temporal_fc + token blend + temporal PE
     {
         ALoadPlain al{w.S, J * ds, M, J * ds};
         EpSpatialToTemporal ep{w.X, m->s2t_b, dt, mask, m->token, m->pe_t, N};
+        if (lnfuse) { ep.frag = reinterpret_cast<_Float16*>(w.O); ep.frag_ks = dt / 16; }
         Lh.gemm("s2t", al, m->s2t_wt, M, dt, J * ds, ep);
     }
     // f16x3 with K % 32 == 0 everywhere: activations that feed a GEMM travel as f16 hi/lo planes (same bytes as the
@@ -956,10 +984,13 @@ int uu3d_forward(uu3d_model* m, const float* kp2d, const uint8_t* mask, int32_t 
         const BlockDev& b = m->tblocks[i];
         const bool masked = c.has_strided_input && i < c.first_strided_token_attention_layer;
         const bool last = (i + 1 == c.temporal_depth);
-        const EpBiasResidual ep_fc2{w.X, b.b2, dt, last ? w.XA : nullptr, last ? m->sblocks[0].pe : nullptr, N};
+        EpBiasResidual ep_fc2{w.X, b.b2, dt, last ? w.XA : nullptr, last ? m->sblocks[0].pe : nullptr, N};
+        if (lnfuse) { ep_fc2.frag = Fa; ep_fc2.frag_ks = dt / 16; }
         if (planes) {
             _Float16* const Pl = Ph + (size_t)M * dt; _Float16* const Hl = Hh + (size_t)M * ht;
-            if (Lh.panel_ok(M, 3 * dt, dt, b.wqkv_pf)) {
+            if (lnfuse) {
+                snprintf(nm, sizeof nm, "t%d.ln_qkv", i + 1); Lh.gemm_panel_ln(nm, Fa, b.wqkv_fpf, b.gqkv, b.bqkv_f, M, 3 * dt, PanelEpBias{w.QKV, 3 * dt});
+            } else if (Lh.panel_ok(M, 3 * dt, dt, b.wqkv_pf)) {
                 snprintf(nm, sizeof nm, "t%d.ln1_split", i + 1); Lh.ln_split_frag(nm, w.X, M, b.ln1_g, b.ln1_b, Ph);
                 snprintf(nm, sizeof nm, "t%d.ln_qkv", i + 1); Lh.gemm_panel(nm, Ph, b.wqkv_pf, b.bqkv, M, 3 * dt, PanelEpBias{w.QKV, 3 * dt});
             } else if (m->ln_planes) {
@@ -973,8 +1004,11 @@ int uu3d_forward(uu3d_model* m, const float* kp2d, const uint8_t* mask, int32_t 
             }
             snprintf(nm, sizeof nm, "t%d.attn", i + 1); Lh.attn(nm, w.QKV, B, N, masked ? mask : nullptr, w.O, (size_t)M * dt);
             { GLoadPlain gl{Ph, Pl, dt, M}; EpBiasResidual ep{w.X, b.bp, dt, nullptr, nullptr, 1};
+              if (lnfuse) { ep.frag = Fb; ep.frag_ks = dt / 16; }
               snprintf(nm, sizeof nm, "t%d.proj_res", i + 1); Lh.gemm_g(nm, gl, b.wp_t, M, dt, dt, ep, 4.0 * M * dt); }
-            if (Lh.panel_ok(M, ht, dt, b.w1_pf)) {
+            if (lnfuse) {
+                snprintf(nm, sizeof nm, "t%d.ln_fc1", i + 1); Lh.gemm_panel_ln(nm, Fb, b.w1_fpf, b.g1, b.b1_f, M, ht, PanelEpBiasReluSplit{Hh, Hl, ht});
+            } else if (Lh.panel_ok(M, ht, dt, b.w1_pf)) {
                 snprintf(nm, sizeof nm, "t%d.ln2_split", i + 1); Lh.ln_split_frag(nm, w.X, M, b.ln2_g, b.ln2_b, Ph);
                 snprintf(nm, sizeof nm, "t%d.ln_fc1", i + 1); Lh.gemm_panel(nm, Ph, b.w1_pf, b.b1, M, ht, PanelEpBiasReluSplit{Hh, Hl, ht});
             } else if (m->ln_planes) {
@@ -1018,7 +1052,10 @@ int uu3d_forward(uu3d_model* m, const float* kp2d, const uint8_t* mask, int32_t 
                                      (i + 1 < c.num_strided) ? m->sblocks[i + 1].pe : nullptr};
         if (planes) {
             _Float16* const Pl = Ph + (size_t)Mi * dt; _Float16* const Hl = Hh + (size_t)Mi * ht;
-            if (Lh.panel_ok(Mi, 3 * dt, dt, b.wqkv_pf)) {
+            const bool fuse1 = lnfuse && i == 0;      // the first strided block reads the rows the last temporal fc2 left in Fa
+            if (fuse1) {
+                snprintf(nm, sizeof nm, "s%d.ln_qkv", i + 1); Lh.gemm_panel_ln(nm, Fa, b.wqkv_fpf, b.gqkv, b.bqkv_f, Mi, 3 * dt, PanelEpBias{w.QKV, 3 * dt});
+            } else if (Lh.panel_ok(Mi, 3 * dt, dt, b.wqkv_pf)) {
                 snprintf(nm, sizeof nm, "s%d.ln1_split", i + 1); Lh.ln_split_frag(nm, xa, Mi, b.ln1_g, b.ln1_b, Ph);
                 snprintf(nm, sizeof nm, "s%d.ln_qkv", i + 1); Lh.gemm_panel(nm, Ph, b.wqkv_pf, b.bqkv, Mi, 3 * dt, PanelEpBias{w.QKV, 3 * dt});
             } else if (m->ln_planes) {
@@ -1032,8 +1069,11 @@ int uu3d_forward(uu3d_model* m, const float* kp2d, const uint8_t* mask, int32_t 
             }
             snprintf(nm, sizeof nm, "s%d.attn", i + 1); Lh.attn(nm, w.QKV, B, Li, nullptr, w.O, (size_t)Mi * dt);
             { GLoadPlain gl{Ph, Pl, dt, Mi}; EpBiasResidual ep{xa, b.bp, dt, nullptr, nullptr, 1};
+              if (fuse1) { ep.frag = Fb; ep.frag_ks = dt / 16; }
               snprintf(nm, sizeof nm, "s%d.proj_res", i + 1); Lh.gemm_g(nm, gl, b.wp_t, Mi, dt, dt, ep, 4.0 * Mi * dt); }
-            if (Lh.panel_ok(Mi, ht, dt, b.w1_pf)) {
+            if (fuse1) {
+                snprintf(nm, sizeof nm, "s%d.ln_fc1", i + 1); Lh.gemm_panel_ln(nm, Fb, b.w1_fpf, b.g1, b.b1_f, Mi, ht, PanelEpBiasReluSplit{Hh, Hl, ht});
+            } else if (Lh.panel_ok(Mi, ht, dt, b.w1_pf)) {
                 snprintf(nm, sizeof nm, "s%d.ln2_split", i + 1); Lh.ln_split_frag(nm, xa, Mi, b.ln2_g, b.ln2_b, Ph);
                 snprintf(nm, sizeof nm, "s%d.ln_fc1", i + 1); Lh.gemm_panel(nm, Ph, b.w1_pf, b.b1, Mi, ht, PanelEpBiasReluSplit{Hh, Hl, ht});
             } else if (m->ln_planes) {

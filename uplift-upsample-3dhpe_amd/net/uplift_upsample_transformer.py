@@ -21,11 +21,14 @@ from ..weights import init_weights, weight_spec
 
 class UpliftUpsampleTransformer(object):
 
-    # a batch of at least this many sequences runs as two independent half batches on two HIP streams
+    # with concurrent_halves=True a batch of at least this many sequences runs as two independent half batches on two
+    # HIP streams.  That was +1..7 % while every kernel left CUs idle; since the LayerNorm-fed Dense layers run on the
+    # row-panel GEMM (one workgroup per CU, a launch fills the chip) a single chain is 2.5-6 % FASTER (h36m_351 batch 128:
+    # 111.8 k vs 108.6 k sequences/s, h36m_81 batch 256: 230 k vs 221 k), so it is off by default.
     SPLIT_MIN_BATCH = 64
 
     def __init__(self, arch: UpliftArch, device=None, seed=0, weights=None, return_attention=False, precision="f16x3",
-                 concurrent_halves=True):
+                 concurrent_halves=False):
         import torch
         if return_attention:
             # never used by the reference's scripts (eval.py:70, train.py:478,520)
