@@ -90,6 +90,7 @@ struct uu3d_model {
     float* arena = nullptr;        // packed device weights
     size_t arena_floats = 0;
     bool no_lnfuse = true;         // UU3D_LNFUSE=1: producer-side split + LayerNorm folded into the panel GEMMs (LNF) instead of the ln_split_frag pass; measured +-0.6 %, off
+    bool no_attn_pipe = true;      // UU3D_ATTN_PIPE=1: two (sequence, head) items per attention workgroup, the second one's loads in flight while the first is computed (+1 % h36m_351, -1.3 % h36m_81: off)
     bool no_panel = false;         // UU3D_NO_PANEL=1: LayerNorm-fed GEMMs stay on the tiled kernels (A/B measurements)
     bool no_lnfold = true;         // UU3D_LNFOLD=1 folds LayerNorm into the next Dense (gemm_h3_lnfold_kernel); measured neutral, off by default
     bool ln_planes = false;        // UU3D_LN_PLANES=1: LayerNorm as a separate pass that writes planes (ln_split) instead of inside the GEMM loader
@@ -300,6 +301,7 @@ int uu3d_create(const uu3d_config* c, int device, uu3d_model** out) {
     { const char* e = getenv("UU3D_NO_PLANES"); m->no_planes = (e != nullptr && e[0] == '1'); }
     { const char* e = getenv("UU3D_LN_PLANES"); m->ln_planes = (e != nullptr && e[0] == '1'); }
     { const char* e = getenv("UU3D_LNFUSE"); m->no_lnfuse = !(e != nullptr && e[0] == '1'); }
+    { const char* e = getenv("UU3D_ATTN_PIPE"); m->no_attn_pipe = !(e != nullptr && e[0] == '1'); }
     { const char* e = getenv("UU3D_NO_PANEL"); m->no_panel = (e != nullptr && e[0] == '1'); }
     { const char* e = getenv("UU3D_LNFOLD"); m->no_lnfold = !(e != nullptr && e[0] == '1'); }
     *out = m;
@@ -883,10 +885,12 @@ struct Launcher {
         const int D = m->cfg.d_temporal, H = m->cfg.num_heads;
         const int NT = (L + 15) / 16;
         begin(name, "attn_f32", 4.0 * B * (double)H * L * L * kDH, 4.0 * 4.0 * B * (double)L * D);
-        const dim3 grid(B * H);
+        // opt-in (UU3D_ATTN_PIPE=1), >= 1024 (sequence, head) items: two per workgroup, the second one's loads in flight while the first is computed
+        const int items = B * H;
+        const dim3 grid((items >= 1024 && !m->no_attn_pipe) ? (items + 1) / 2 : items);
 #define UU3D_ATTN_CASE(nt) case nt: \
-        if (split_lo_off) hipLaunchKernelGGL((attn_f32_kernel<nt, kDH, true>), grid, dim3(64 * nt), 0, stream, qkv, 3 * D, D, L, H, mask, out, D, split_lo_off); \
-        else hipLaunchKernelGGL((attn_f32_kernel<nt, kDH, false>), grid, dim3(64 * nt), 0, stream, qkv, 3 * D, D, L, H, mask, out, D, (size_t)0); \
+        if (split_lo_off) hipLaunchKernelGGL((attn_f32_kernel<nt, kDH, true>), grid, dim3(64 * nt), 0, stream, qkv, 3 * D, D, L, H, mask, out, D, split_lo_off, items); \
+        else hipLaunchKernelGGL((attn_f32_kernel<nt, kDH, false>), grid, dim3(64 * nt), 0, stream, qkv, 3 * D, D, L, H, mask, out, D, (size_t)0, items); \
         break;
         switch (NT) {
             UU3D_ATTN_CASE(1) UU3D_ATTN_CASE(2) UU3D_ATTN_CASE(3) UU3D_ATTN_CASE(4)

@@ -26,46 +26,70 @@ namespace uu3d {
 
 // SPLIT: the context rows are written as the two f16 planes (hi at out, lo at out + lo_off halfs; x ~= hi + lo / 2048,
 // see uu3d_gemm_h3.h) that the f16x3 projection GEMM reads, instead of f32.
+// A workgroup handles the items bh = blockIdx.x, blockIdx.x + gridDim.x, ... (n_items = B * H in all): with fewer
+// workgroups than items the K / V / Q loads of the NEXT item are issued into registers before the current one is computed
+// (one workgroup per item, all 1024 resident at once, ran load -> compute -> store in lockstep on every CU: 31 us of which
+// ~9 is the memory floor of the 42 MB QKV tensor and ~14 the MFMA + softmax work).
 template <int NT, int DH, bool SPLIT = false>
 __global__ void __launch_bounds__(64 * NT)
 attn_f32_kernel(const float* __restrict__ qkv, const int ld, const int D, const int L, const int H,
                 const uint8_t* __restrict__ key_mask,   // (B, L) 1 = attend; nullptr = no mask
-                float* __restrict__ out, const int ldo, const size_t lo_off = 0)
+                float* __restrict__ out, const int ldo, const size_t lo_off = 0, const int n_items = 0)
 {
     static_assert(DH % 16 == 0, "head dim must be a multiple of 16");
     constexpr int LD = DH + 4;
     constexpr int F4 = DH / 4;
     constexpr int KT = DH / 16;             // float4 k-groups per lane
+    constexpr int NS = (16 * F4 + 63) / 64; // staging float4 per thread and matrix
     __shared__ __attribute__((aligned(16))) float Ks[NT * 16 * LD];
     __shared__ __attribute__((aligned(16))) float Vs[NT * 16 * LD];
 
-    const int bh = blockIdx.x;
-    const int b = bh / H, h = bh - b * H;
     const int tid = threadIdx.x;
-    const float* base = qkv + (size_t)b * L * ld + h * DH;
-
-    for (int idx = tid; idx < NT * 16 * F4; idx += 64 * NT) {
-        const int row = idx / F4, c4 = (idx - row * F4) * 4;
-        float4 kv = make_float4(0.f, 0.f, 0.f, 0.f), vv = kv;
-        if (row < L) {
-            const float* p = base + (size_t)row * ld + c4;
-            kv = *reinterpret_cast<const float4*>(p + D);
-            vv = *reinterpret_cast<const float4*>(p + 2 * D);
-        }
-        *reinterpret_cast<float4*>(&Ks[row * LD + c4]) = kv;
-        *reinterpret_cast<float4*>(&Vs[row * LD + c4]) = vv;
-    }
-
     const int lane = tid & 63, w = tid >> 6;
     const int qi = lane & 15, g = lane >> 4;
     const int qrow = 16 * w + qi;
+    const int items = n_items > 0 ? n_items : (int)gridDim.x;
+
+    float4 kreg[NS], vreg[NS];
+    f32x4 qnext[KT];
+    auto issue = [&](const int bh) {
+        const int b = bh / H, h = bh - b * H;
+        const float* base = qkv + (size_t)b * L * ld + h * DH;
+#pragma unroll
+        for (int s = 0; s < NS; ++s) {
+            const int idx = tid + s * 64 * NT;
+            const int row = idx / F4, c4 = (idx - row * F4) * 4;
+            kreg[s] = make_float4(0.f, 0.f, 0.f, 0.f); vreg[s] = kreg[s];
+            if (idx < NT * 16 * F4 && row < L) {
+                const float* p = base + (size_t)row * ld + c4;
+                kreg[s] = *reinterpret_cast<const float4*>(p + D);
+                vreg[s] = *reinterpret_cast<const float4*>(p + 2 * D);
+            }
+        }
+#pragma unroll
+        for (int t = 0; t < KT; ++t) {
+            qnext[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            if (qrow < L) qnext[t] = *reinterpret_cast<const f32x4*>(base + (size_t)qrow * ld + 16 * t + 4 * g);
+        }
+    };
+    issue(blockIdx.x);
+    for (int bh = blockIdx.x; ; ) {
+    const int b = bh / H, h = bh - b * H;
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+        const int idx = tid + s * 64 * NT;
+        const int row = idx / F4, c4 = (idx - row * F4) * 4;
+        if (idx < NT * 16 * F4) {
+            *reinterpret_cast<float4*>(&Ks[row * LD + c4]) = kreg[s];
+            *reinterpret_cast<float4*>(&Vs[row * LD + c4]) = vreg[s];
+        }
+    }
     f32x4 qf[KT];
 #pragma unroll
-    for (int t = 0; t < KT; ++t) {
-        qf[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
-        if (qrow < L) qf[t] = *reinterpret_cast<const f32x4*>(base + (size_t)qrow * ld + 16 * t + 4 * g);
-    }
+    for (int t = 0; t < KT; ++t) qf[t] = qnext[t];
     __syncthreads();
+    const int bh_next = bh + (int)gridDim.x;
+    if (bh_next < items) issue(bh_next);               // in flight while this item is computed
 
     // S^T tiles: st[j][r] = <Q[qrow], K[16j + 4g + r]>
     f32x4 st[NT];
@@ -148,6 +172,10 @@ attn_f32_kernel(const float* __restrict__ qkv, const int ld, const int D, const 
                 }
             }
         }
+    }
+    if (bh_next >= items) break;
+    __syncthreads();                                    // every wave is done with this item's K / V tiles
+    bh = bh_next;
     }
 }
 
