@@ -55,10 +55,16 @@ def test_row_panel_gemm_path_matches_oracle(cfgname, batch, monkeypatch):
     arch = pkg.arch_from_config(cfg)
     w = pkg.init_weights(arch, seed=3, perturb=0.1)
     x, m = util.synthetic_batch(cfg, batch=batch, seed=3)
-    full, central, xm = _run_hip(cfg, w, x, m, "f16x3")          # the product path: ln_split_frag + panel GEMM
+    full, central, xm = _run_hip(cfg, w, x, m, "f16x3")          # the product path: ln_split_frag + panel GEMM for the LayerNorm-fed Dense layers
+    f32_early, c32_early = O.forward(util.hp_from_arch(arch), w, xm, m, torch.float32)
     monkeypatch.setenv("UU3D_NO_PANEL", "1")
     full_t, central_t, _ = _run_hip(cfg, w, x, m, "f16x3")
     monkeypatch.delenv("UU3D_NO_PANEL")
+    monkeypatch.setenv("UU3D_PANEL_ACC", "1")          # opt-in: projection / fc2 on the accumulating row-panel kernel, attention output in fragment order
+    full_a, central_a, _ = _run_hip(cfg, w, x, m, "f16x3")
+    monkeypatch.delenv("UU3D_PANEL_ACC")
+    dev_a = max(np.abs(full - full_a).max(), np.abs(central - central_a).max())
+    assert max(np.abs(full_a - f32_early).max(), np.abs(central_a - c32_early).max()) <= util.TOL_MAX_ABS and dev_a > 0.0
     monkeypatch.setenv("UU3D_LNFUSE", "1")             # opt-in: producer-side split + LayerNorm folded into the panel GEMM (LNF)
     full_u, central_u, _ = _run_hip(cfg, w, x, m, "f16x3")
     monkeypatch.delenv("UU3D_LNFUSE")

@@ -68,6 +68,7 @@ struct BlockDev {
     // fragment-ordered f16 planes of wqkv / w1 for the row-panel GEMM (uu3d_gemm_panel.h); offsets in harena, 0 = none
     size_t wqkv_pf = 0, w1_pf = 0;
     size_t wqkv_fpf = 0, w1_fpf = 0;   // the same for the LayerNorm-folded operands gamma o W (LNF panel kernel)
+    size_t wp_pf = 0, w2_pf = 0;       // projection (K = d) and fc2 (K = h, Dense blocks only) for gemm_h3_panel_acc_kernel
 };
 
 struct ProfRec {
@@ -91,6 +92,7 @@ struct uu3d_model {
     size_t arena_floats = 0;
     bool no_lnfuse = true;         // UU3D_LNFUSE=1: producer-side split + LayerNorm folded into the panel GEMMs (LNF) instead of the ln_split_frag pass; measured +-0.6 %, off
     bool no_attn_pipe = true;      // UU3D_ATTN_PIPE=1: two (sequence, head) items per attention workgroup, the second one's loads in flight while the first is computed (+1 % h36m_351, -1.3 % h36m_81: off)
+    bool no_panel_acc = true;      // UU3D_PANEL_ACC=1: projection / fc2 on gemm_h3_panel_acc_kernel instead of the tiled LDS-DMA kernel (measured slower: DESIGN section 11)
     bool no_panel = false;         // UU3D_NO_PANEL=1: LayerNorm-fed GEMMs stay on the tiled kernels (A/B measurements)
     bool no_lnfold = true;         // UU3D_LNFOLD=1 folds LayerNorm into the next Dense (gemm_h3_lnfold_kernel); measured neutral, off by default
     bool ln_planes = false;        // UU3D_LN_PLANES=1: LayerNorm as a separate pass that writes planes (ln_split) instead of inside the GEMM loader
@@ -302,6 +304,7 @@ int uu3d_create(const uu3d_config* c, int device, uu3d_model** out) {
     { const char* e = getenv("UU3D_LN_PLANES"); m->ln_planes = (e != nullptr && e[0] == '1'); }
     { const char* e = getenv("UU3D_LNFUSE"); m->no_lnfuse = !(e != nullptr && e[0] == '1'); }
     { const char* e = getenv("UU3D_ATTN_PIPE"); m->no_attn_pipe = !(e != nullptr && e[0] == '1'); }
+    { const char* e = getenv("UU3D_PANEL_ACC"); m->no_panel_acc = !(e != nullptr && e[0] == '1'); }
     { const char* e = getenv("UU3D_NO_PANEL"); m->no_panel = (e != nullptr && e[0] == '1'); }
     { const char* e = getenv("UU3D_LNFOLD"); m->no_lnfold = !(e != nullptr && e[0] == '1'); }
     *out = m;
@@ -561,16 +564,19 @@ int uu3d_commit_weights(uu3d_model* m, void* stream_) {
         // row-panel GEMM operands (uu3d_gemm_panel.h): wqkv and w1 of every temporal / strided block, fragment ordered
         m->panel_off.clear();
         if (dt % 192 == 0 && ht % 32 == 0) {
-            auto add_panel = [&](size_t bt_off, int Nn) {
+            auto add_panel = [&](size_t bt_off, int Nn, int K = 0, int Kp = 0) {
+                if (K == 0) { K = dt; Kp = Kdt; }
                 const auto it = m->hplanes.find(bt_off);
-                if (it == m->hplanes.end()) return;
+                if (it == m->hplanes.end() || K % 384 != 0) return;
                 const size_t at = align_up(hb.size(), 64);
-                hb.resize(at + panel_b_halfs(Nn, dt));
-                panel_pack_operand(hb.data() + it->second.first, hb.data() + it->second.second, Nn, dt, Kdt, hb.data() + at);
+                hb.resize(at + panel_b_halfs(Nn, K));
+                panel_pack_operand(hb.data() + it->second.first, hb.data() + it->second.second, Nn, K, Kp, hb.data() + at);
                 m->panel_off[bt_off] = at;
             };
-            for (auto& o : toff) { add_panel(o.wqkv, 3 * dt); add_panel(o.w1, ht); add_panel(o.wqkv_f, 3 * dt); add_panel(o.w1_f, ht); }
-            for (auto& o : soff) { add_panel(o.wqkv, 3 * dt); add_panel(o.w1, ht); add_panel(o.wqkv_f, 3 * dt); add_panel(o.w1_f, ht); }
+            for (auto& o : toff) { add_panel(o.wqkv, 3 * dt); add_panel(o.w1, ht); add_panel(o.wqkv_f, 3 * dt); add_panel(o.w1_f, ht);
+                                   if (dt % 32 == 0) { add_panel(o.wp, dt); add_panel(o.w2, dt, ht, Kht); } }
+            for (auto& o : soff) { add_panel(o.wqkv, 3 * dt); add_panel(o.w1, ht); add_panel(o.wqkv_f, 3 * dt); add_panel(o.w1_f, ht);
+                                   if (dt % 32 == 0) add_panel(o.wp, dt); }
         }
         if (m->harena_halfs < hb.size()) {
             if (m->harena) HIPCHK(m, hipFree(m->harena));
@@ -595,6 +601,8 @@ int uu3d_commit_weights(uu3d_model* m, void* stream_) {
         b.pe = strided ? A + o.pe : nullptr;
         { const auto it = m->panel_off.find(o.wqkv); b.wqkv_pf = (it != m->panel_off.end()) ? it->second : 0; }
         { const auto it = m->panel_off.find(o.w1); b.w1_pf = (it != m->panel_off.end()) ? it->second : 0; }
+        { const auto it = m->panel_off.find(o.wp); b.wp_pf = (it != m->panel_off.end()) ? it->second : 0; }
+        { const auto it = m->panel_off.find(o.w2); b.w2_pf = (!strided && it != m->panel_off.end()) ? it->second : 0; }
         { const auto it = m->panel_off.find(o.wqkv_f); b.wqkv_fpf = (it != m->panel_off.end()) ? it->second : 0; }
         { const auto it = m->panel_off.find(o.w1_f); b.w1_fpf = (it != m->panel_off.end()) ? it->second : 0; }
         b.wqkv_f = A + o.wqkv_f; b.gqkv = A + o.gqkv; b.bqkv_f = A + o.bqkv_f; b.w1_f = A + o.w1_f; b.g1 = A + o.g1; b.b1_f = A + o.b1_f;
@@ -629,7 +637,7 @@ Workspace carve(const uu3d_model* m, int B, char* base) {
     const size_t oX = take(rows * c.d_temporal * 4);
     const size_t oQ = take(rows * 3 * c.d_temporal * 4);
     const size_t oO = take((rows + 32) * c.d_temporal * 4);   // + one 32-row panel: the panel GEMM's A operand is allocated in whole panels
-    const size_t oH = take(rows * c.h_temporal * 4);
+    const size_t oH = take((rows + 32) * c.h_temporal * 4);   // + one 32-row panel (fragment-ordered hidden planes)
     const size_t oA = take(rows * c.d_temporal * 4);
     const size_t oB = take(rows_s * c.d_temporal * 4);
     const size_t oT = take(rows * sizeof(float2));
@@ -805,6 +813,19 @@ struct Launcher {
         hipLaunchKernelGGL(kern, dim3(8 * S, ((mt * S + 7) / 8 + S - 1) / S), dim3(256), PANEL_LDS_TOTAL, stream, Af, m->harena + pf, colv, M, mt, S, (N / 32) / S, ep, 0, 0.f);
         end();
     }
+    // The residual Dense layers on gemm_h3_panel_acc_kernel: x += A B + bias, N = 384 output columns in 3 ranges of 4 chunks,
+    // A = fragment-ordered planes of contraction length 384 NH (attention output / hidden), B at harena + pf.
+    bool panel_acc_ok(int M, int N, size_t pf) const { return !m->no_panel && !m->no_panel_acc && pf != 0 && N == 384 && M >= 1024; }
+    template <int NH>
+    void gemm_panel_acc(const char* name, const _Float16* Af, size_t pf, const float* bias, int M, const PanelEpResidual& ep) {
+        const int N = 384, K = 384 * NH, S = 3, mt = (M + 127) / 128;
+        begin(name, "gemm_panel", 2.0 * M * (double)N * K, 4.0 * ((double)M * K + (double)N * K + 2.0 * M * N));
+        auto kern = gemm_h3_panel_acc_kernel<NH, 4, PanelEpResidual>;
+        static bool attr_done = false;
+        if (!attr_done) { (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)PANEL_LDS_TOTAL); attr_done = true; }
+        hipLaunchKernelGGL(kern, dim3(8 * S, ((mt * S + 7) / 8 + S - 1) / S), dim3(256), PANEL_LDS_TOTAL, stream, Af, m->harena + pf, bias, M, mt, S, ep);
+        end();
+    }
     // The same with LayerNorm folded in (LNF): Af = raw split rows written by the producer of the residual stream,
     // pf = planes of gamma o W, gb = g | b' (N floats each, contiguous: gemm_lnfold's per-column vectors)
     template <class EP>
@@ -968,6 +989,8 @@ int uu3d_forward(uu3d_model* m, const float* kp2d, const uint8_t* mask, int32_t 
     bool lnfuse = (c.precision == UU3D_PREC_F16X3) && (dt % 32 == 0) && (ht % 32 == 0) && !m->no_planes && !m->no_lnfuse && c.temporal_depth >= 1;
     for (const BlockDev& b : m->tblocks) lnfuse = lnfuse && Lh.panel_ok(M, 3 * dt, dt, b.wqkv_fpf) && Lh.panel_ok(M, ht, dt, b.w1_fpf);
     lnfuse = lnfuse && c.num_strided >= 1 && m->sblocks[0].wqkv_fpf != 0 && m->sblocks[0].w1_fpf != 0;
+    // projection / fc2 on gemm_h3_panel_acc_kernel: the attention output and the hidden activations travel as fragment-ordered planes
+    const bool acc_path = (c.precision == UU3D_PREC_F16X3) && (dt % 32 == 0) && (ht % 32 == 0) && !m->no_planes && !lnfuse;
     _Float16* const Fa = reinterpret_cast<_Float16*>(w.O);       // raw split rows for the next LN1 (the bytes of O: dead between projection and attention)
     _Float16* const Fb = reinterpret_cast<_Float16*>(w.F);       // raw split rows for LN2
     // 2. spatial_to_temporal_fc + token blend + temporal PE
@@ -1006,15 +1029,22 @@ int uu3d_forward(uu3d_model* m, const float* kp2d, const uint8_t* mask, int32_t 
                 ALoadLayerNorm al{w.X, w.stats, b.ln1_g, b.ln1_b, dt, M, dt}; EpBias ep{w.QKV, b.bqkv, 3 * dt};
                 snprintf(nm, sizeof nm, "t%d.ln_qkv", i + 1); Lh.gemm(nm, al, b.wqkv_t, M, 3 * dt, dt, ep);
             }
-            snprintf(nm, sizeof nm, "t%d.attn", i + 1); Lh.attn(nm, w.QKV, B, N, masked ? mask : nullptr, w.O, (size_t)M * dt);
-            { GLoadPlain gl{Ph, Pl, dt, M}; EpBiasResidual ep{w.X, b.bp, dt, nullptr, nullptr, 1};
+            const bool acc_p = acc_path && Lh.panel_acc_ok(M, dt, b.wp_pf);
+            const bool acc_f = acc_path && Lh.panel_acc_ok(M, dt, b.w2_pf) && Lh.panel_ok(M, ht, dt, b.w1_pf);
+            snprintf(nm, sizeof nm, "t%d.attn", i + 1); Lh.attn(nm, w.QKV, B, N, masked ? mask : nullptr, w.O, acc_p ? ATTN_FRAG_ORDER : (size_t)M * dt);
+            if (acc_p) {
+                snprintf(nm, sizeof nm, "t%d.proj_res", i + 1); Lh.gemm_panel_acc<1>(nm, Ph, b.wp_pf, b.bp, M, PanelEpResidual{w.X, dt, nullptr, nullptr, 1});
+            } else {
+              GLoadPlain gl{Ph, Pl, dt, M}; EpBiasResidual ep{w.X, b.bp, dt, nullptr, nullptr, 1};
               if (lnfuse) { ep.frag = Fb; ep.frag_ks = dt / 16; }
               snprintf(nm, sizeof nm, "t%d.proj_res", i + 1); Lh.gemm_g(nm, gl, b.wp_t, M, dt, dt, ep, 4.0 * M * dt); }
             if (lnfuse) {
                 snprintf(nm, sizeof nm, "t%d.ln_fc1", i + 1); Lh.gemm_panel_ln(nm, Fb, b.w1_fpf, b.g1, b.b1_f, M, ht, PanelEpBiasReluSplit{Hh, Hl, ht});
             } else if (Lh.panel_ok(M, ht, dt, b.w1_pf)) {
                 snprintf(nm, sizeof nm, "t%d.ln2_split", i + 1); Lh.ln_split_frag(nm, w.X, M, b.ln2_g, b.ln2_b, Ph);
-                snprintf(nm, sizeof nm, "t%d.ln_fc1", i + 1); Lh.gemm_panel(nm, Ph, b.w1_pf, b.b1, M, ht, PanelEpBiasReluSplit{Hh, Hl, ht});
+                snprintf(nm, sizeof nm, "t%d.ln_fc1", i + 1);
+                if (acc_f) Lh.gemm_panel(nm, Ph, b.w1_pf, b.b1, M, ht, PanelEpBiasReluFrag{Hh, ht});
+                else Lh.gemm_panel(nm, Ph, b.w1_pf, b.b1, M, ht, PanelEpBiasReluSplit{Hh, Hl, ht});
             } else if (m->ln_planes) {
                 snprintf(nm, sizeof nm, "t%d.ln2_split", i + 1); Lh.ln_split(nm, w.X, dt, M, b.ln2_g, b.ln2_b, Ph, Pl);
                 GLoadPlain gl{Ph, Pl, dt, M}; EpBiasReluSplit ep{Hh, Hl, b.b1, ht};
@@ -1024,7 +1054,11 @@ int uu3d_forward(uu3d_model* m, const float* kp2d, const uint8_t* mask, int32_t 
                 ALoadLayerNorm al{w.X, w.stats, b.ln2_g, b.ln2_b, dt, M, dt}; EpBiasReluSplit ep{Hh, Hl, b.b1, ht};
                 snprintf(nm, sizeof nm, "t%d.ln_fc1", i + 1); Lh.gemm(nm, al, b.w1_t, M, ht, dt, ep);
             }
-            { GLoadPlain gl{Hh, Hl, ht, M};
+            if (acc_f) {
+                snprintf(nm, sizeof nm, "t%d.fc2_res", i + 1);
+                Lh.gemm_panel_acc<2>(nm, Hh, b.w2_pf, b.b2, M, PanelEpResidual{w.X, dt, last ? w.XA : nullptr, last ? m->sblocks[0].pe : nullptr, N});
+            } else {
+              GLoadPlain gl{Hh, Hl, ht, M};
               snprintf(nm, sizeof nm, "t%d.fc2_res", i + 1); Lh.gemm_g(nm, gl, b.w2_t, M, dt, ht, ep_fc2, 4.0 * M * dt); }
             continue;
         }
@@ -1071,8 +1105,12 @@ int uu3d_forward(uu3d_model* m, const float* kp2d, const uint8_t* mask, int32_t 
                 ALoadLayerNorm al{xa, w.stats, b.ln1_g, b.ln1_b, dt, Mi, dt}; EpBias ep{w.QKV, b.bqkv, 3 * dt};
                 snprintf(nm, sizeof nm, "s%d.ln_qkv", i + 1); Lh.gemm(nm, al, b.wqkv_t, Mi, 3 * dt, dt, ep);
             }
-            snprintf(nm, sizeof nm, "s%d.attn", i + 1); Lh.attn(nm, w.QKV, B, Li, nullptr, w.O, (size_t)Mi * dt);
-            { GLoadPlain gl{Ph, Pl, dt, Mi}; EpBiasResidual ep{xa, b.bp, dt, nullptr, nullptr, 1};
+            const bool acc_p = acc_path && Lh.panel_acc_ok(Mi, dt, b.wp_pf);
+            snprintf(nm, sizeof nm, "s%d.attn", i + 1); Lh.attn(nm, w.QKV, B, Li, nullptr, w.O, acc_p ? ATTN_FRAG_ORDER : (size_t)Mi * dt);
+            if (acc_p) {
+                snprintf(nm, sizeof nm, "s%d.proj_res", i + 1); Lh.gemm_panel_acc<1>(nm, Ph, b.wp_pf, b.bp, Mi, PanelEpResidual{xa, dt, nullptr, nullptr, 1});
+            } else {
+              GLoadPlain gl{Ph, Pl, dt, Mi}; EpBiasResidual ep{xa, b.bp, dt, nullptr, nullptr, 1};
               if (fuse1) { ep.frag = Fb; ep.frag_ks = dt / 16; }
               snprintf(nm, sizeof nm, "s%d.proj_res", i + 1); Lh.gemm_g(nm, gl, b.wp_t, Mi, dt, dt, ep, 4.0 * Mi * dt); }
             if (fuse1) {

@@ -25,7 +25,10 @@
 namespace uu3d {
 
 // SPLIT: the context rows are written as the two f16 planes (hi at out, lo at out + lo_off halfs; x ~= hi + lo / 2048,
-// see uu3d_gemm_h3.h) that the f16x3 projection GEMM reads, instead of f32.
+// see uu3d_gemm_h3.h) that the f16x3 projection GEMM reads, instead of f32.  lo_off == ATTN_FRAG_ORDER: the planes go
+// out in the row-panel GEMM's A-fragment order instead ([32-row panel][16-deep k-slice][plane][lane][8 halfs],
+// uu3d_gemm_panel.h) for a contraction length of D.
+static constexpr size_t ATTN_FRAG_ORDER = ~(size_t)0;
 // A workgroup handles the items bh = blockIdx.x, blockIdx.x + gridDim.x, ... (n_items = B * H in all): with fewer
 // workgroups than items the K / V / Q loads of the NEXT item are issued into registers before the current one is computed
 // (one workgroup per item, all 1024 resident at once, ran load -> compute -> store in lockstep on every CU: 31 us of which
@@ -165,8 +168,15 @@ attn_f32_kernel(const float* __restrict__ qkv, const int ld, const int D, const 
                 if (SPLIT) {
                     _Float16* oh = reinterpret_cast<_Float16*>(out);
                     const _Float16 hv = (fabsf(o[r]) < 6.103515625e-05f) ? (_Float16)0.f : (_Float16)o[r];   // = h3_hi (uu3d_gemm_h3.h), explicit: this kernel keeps f16 denormals on
+                    const _Float16 lv = (_Float16)((o[r] - (float)hv) * 2048.0f);
+                    if (lo_off == ATTN_FRAG_ORDER) {
+                        const int row = b * L + q, k = h * DH + 16 * t + qi;
+                        const size_t fi = ((((size_t)(row >> 5) * (D >> 4) + (k >> 4)) * 2) * 64 + ((k >> 3) & 1) * 32 + (row & 31)) * 8 + (k & 7);
+                        oh[fi] = hv; oh[fi + 512] = lv;
+                        continue;
+                    }
                     oh[at] = hv;
-                    oh[lo_off + at] = (_Float16)((o[r] - (float)hv) * 2048.0f);
+                    oh[lo_off + at] = lv;
                 } else {
                     out[at] = o[r];
                 }

@@ -313,6 +313,126 @@ gemm_h3_panel_kernel(const _Float16* __restrict__ Af, const _Float16* __restrict
 }
 
 // ------------------------------------------------------------------------------------------------
+// The residual Dense layers (projection K = 384, fc2 K = 768; N = 384): x[row][:] += A[row][:] B + bias.
+// Same roles as above, but a workgroup keeps the accumulators of ALL its NCH chunks (NCH x 32 registers) and runs the
+// contraction in NH halves of 384: the wave's A fragments of one half are resident (192 registers), the weight stream is
+// ordered (half, chunk), the second half's fragments are loaded over the first's once those are spent.  So K = 768 fits
+// the register file, there is no epilogue inside the loop (nothing between the MFMAs but fragment reads and DMAs), and the
+// residual rows are read once at the very end -- a global load inside the loop would wait behind the DMA ring, vector
+// memory retires in order.  Grid: (M / 128) row tiles x (N / 32 / NCH) column ranges.
+struct PanelEpResidual {       // x[row][col] += v (+ optionally out2 = x + pe2[row % period][col]: the next stack's input)
+    float* __restrict__ x; int ldo; float* __restrict__ out2; const float* __restrict__ pe2; int period;
+    __device__ __forceinline__ float load(int row, int col) const { return x[(size_t)row * ldo + col]; }
+    __device__ __forceinline__ void store(int row, int col, float y) const {        // y = load(row, col) + v
+        const size_t o = (size_t)row * ldo + col;
+        x[o] = y;
+        if (out2 != nullptr) out2[o] = y + pe2[(size_t)(row % period) * ldo + col];
+    }
+};
+
+template <int NH, int NCH, class EP>
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1)))
+gemm_h3_panel_acc_kernel(const _Float16* __restrict__ Af, const _Float16* __restrict__ Bf, const float* __restrict__ bias,
+                         const int M, const int m_tiles, const int splits, const EP ep)
+{
+    static_assert(PANEL_SS == 24, "one k-step = one half (384) of one chunk");
+    constexpr int KSH = 24, T = NH * NCH;                  // k-slices per half; k-steps of this workgroup
+    h3_flush_f16_denormals();
+    extern __shared__ __attribute__((aligned(16))) unsigned char psm[];
+
+    const int id = blockIdx.y * gridDim.x + blockIdx.x;    // balanced contiguous blocks of work items per XCD (see above)
+    const int total = m_tiles * splits, per = (total + 7) >> 3;
+    const int u = (id & 7) * per + (id >> 3);
+    if ((id >> 3) >= per || u >= total) return;
+    const int bm = u / splits, ns = u - bm * splits;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int row0 = bm * 128 + wave * 32;
+    const int chunk0 = ns * NCH;
+
+    // k-step t = half * NCH + c reads chunk (chunk0 + c), k-range half: [chunk][half] in the operand
+    const unsigned char* bsrc = reinterpret_cast<const unsigned char*>(Bf) + (wave * PANEL_PIECES) * 1024 + lane * 16;
+    auto dma1 = [&](int t, int slot, int p) __attribute__((always_inline)) {
+        const int tc = min(t, T - 1), half = tc / NCH, c = tc - half * NCH;
+        const unsigned char* s = bsrc + (size_t)((chunk0 + c) * NH + half) * PANEL_STEP_BYTES;
+        unsigned char* d = psm + slot * PANEL_STEP_BYTES + (wave * PANEL_PIECES) * 1024;
+        __builtin_amdgcn_global_load_lds((h3_glb_void*)(s + p * 1024), (h3_lds_void*)(d + p * 1024), 16, 0, 0);
+    };
+
+    h16x8 ah[KSH], al[KSH];
+    const h16x8* ap = reinterpret_cast<const h16x8*>(Af) + (size_t)(min(row0, M - 1) >> 5) * (KSH * NH) * 2 * 64 + lane;
+    auto load_a = [&](int half) __attribute__((always_inline)) {
+#pragma unroll
+        for (int q = 0; q < KSH; ++q) { ah[q] = ap[((half * KSH + q) * 2 + 0) * 64]; al[q] = ap[((half * KSH + q) * 2 + 1) * 64]; }
+    };
+    load_a(0);
+#pragma unroll
+    for (int t = 0; t < PANEL_SLOTS - 1; ++t)
+#pragma unroll
+        for (int p = 0; p < PANEL_PIECES; ++p) dma1(t, t, p);
+
+    f32x16 acc0[NCH], acc1[NCH];
+#pragma unroll
+    for (int c = 0; c < NCH; ++c)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { acc0[c][r] = 0.f; acc1[c][r] = 0.f; }
+
+#pragma unroll
+    for (int half = 0; half < NH; ++half) {
+        if (half > 0) load_a(half);                        // over the spent fragments of the previous half
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) {
+            const int t = half * NCH + c;
+            const int slot_r = t % PANEL_SLOTS, slot_w = (t + PANEL_SLOTS - 1) % PANEL_SLOTS;
+            asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" :: "i"(PANEL_PIECES * (PANEL_SLOTS - 2)) : "memory");
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_sched_barrier(0);
+            const unsigned sb = (unsigned)(uintptr_t)(h3_lds_void*)(psm + slot_r * PANEL_STEP_BYTES + lane * 16);
+            h16x8 bh[3], bl[3];
+#define UU3D_PANEL_READ(i, kk) \
+            asm volatile("ds_read_b128 %0, %2 offset:%3\n\tds_read_b128 %1, %2 offset:%4" \
+                         : "=&v"(bh[i]), "=&v"(bl[i]) : "v"(sb), "i"((kk) * 2048), "i"((kk) * 2048 + 1024))
+            UU3D_PANEL_READ(0, 0);
+            UU3D_PANEL_READ(1, 1);
+#pragma unroll
+            for (int kk = 0; kk < PANEL_SS; ++kk) {
+                if (kk + 2 < PANEL_SS) UU3D_PANEL_READ((kk + 2) % 3, kk + 2);
+                asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(bh[kk % 3]), "+v"(bl[kk % 3]) : "i"(panel_wait_count(kk, false, false)));
+                acc0[c] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[kk], bh[kk % 3], acc0[c], 0, 0, 0);
+                acc1[c] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[kk], bl[kk % 3], acc1[c], 0, 0, 0);
+                acc1[c] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[kk], bh[kk % 3], acc1[c], 0, 0, 0);
+                if (kk & 1) dma1(t + PANEL_SLOTS - 1, slot_w, kk >> 1);
+            }
+#undef UU3D_PANEL_READ
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // the clamped tail DMAs must not outlive the LDS allocation
+
+    // epilogue: ALL residual values are loaded before the first store (a load-add-store chain per element waits for the
+    // previous store's acknowledgement 64 times: 33 instead of 13 us for the projection)
+    const int crow = (lane >> 5) * 4, ccol = lane & 31;
+    const int valid = min(32, M - row0);
+    float res[NCH][16];
+#pragma unroll
+    for (int c = 0; c < NCH; ++c)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int lr = 8 * (r >> 2) + crow + (r & 3);
+            res[c][r] = ep.load(row0 + min(lr, max(valid, 1) - 1), (chunk0 + c) * 32 + ccol);
+        }
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+        const int col = (chunk0 + c) * 32 + ccol;
+        const float bv = bias[col];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int lr = 8 * (r >> 2) + crow + (r & 3);
+            if (lr < valid) ep.store(row0 + lr, col, res[c][r] + (acc0[c][r] + acc1[c][r] * (1.0f / H3_SCALE) + bv));
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // LayerNorm (two-pass, eps inside the root) of M rows of D = 16 KS floats, written as the fragment-ordered hi / lo
 // planes of a panel GEMM's A operand.  One workgroup per HALF panel (16 rows): 16 threads per row, 4-float pieces
 // interleaved across them, so that a wave's stores for one piece index are runs of 64-128 contiguous bytes of the
