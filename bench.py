@@ -289,6 +289,12 @@ def main():
                                  "exact f32-input MFMA",
                          "avg_launch_ms": round(dom["ms"] / dom["n"], 5),
                          "attention": attention_roofline(agg),
+                         # the four largest GEMM launch classes (the first two are within a microsecond per launch of each
+                         # other, so which one is "dominant" changes from box to box)
+                         "gemm_classes": [{"kernel": f"{agg[k]['kernel']} [{k}]", "ms_per_forward": round(agg[k]["ms"] / reps, 4),
+                                           "achieved": round(agg[k]["flops"] / (agg[k]["ms"] * 1e-3) / 1e12, 2),
+                                           "frac": round(agg[k]["flops"] / (agg[k]["ms"] * 1e-3) / 1e12 / peak, 4)}
+                                          for k in sorted((k for k in agg if agg[k]["kernel"] in gks), key=lambda k: -agg[k]["ms"])[:4]],
                          "all_gemm_tflops": round(gemm_fl / (gemm_ms * 1e-3) / 1e12, 2),
                          "model_tflops": round(fl["total"] * seqs / world / elapsed / 1e12, 2)},
             "kernel_ms_per_forward": {k: round(a["ms"] / reps, 4) for k, a in sorted(agg.items(), key=lambda kv: -kv[1]["ms"])},
