@@ -23,7 +23,7 @@ using namespace uu3d;
 template __global__ void uu3d::gemm_h3_panel_kernel<24, PanelEpBias>(const _Float16*, const _Float16*, const float*, int, int, int, int, const PanelEpBias, int, float);
 template __global__ void uu3d::gemm_h3_panel_kernel<24, PanelEpBias, true>(const _Float16*, const _Float16*, const float*, int, int, int, int, const PanelEpBias, int, float);
 template __global__ void uu3d::gemm_h3_panel_kernel<24, PanelEpBiasReluSplit>(const _Float16*, const _Float16*, const float*, int, int, int, int, const PanelEpBiasReluSplit, int, float);
-template __global__ void uu3d::ln_split_frag_kernel<24>(const float*, int, int, float, const float*, const float*, _Float16*);
+template __global__ void uu3d::ln_split_frag_kernel<24, 8>(const float*, int, int, float, const float*, const float*, _Float16*);
 template __global__ void uu3d::gemm_h3g_kernel<1, 1, GLoadConv3, EpSlab, 3>(const GLoadConv3, const _Float16*, const _Float16*, int, int, int, int, int, int, const EpSlab);
 template __global__ void uu3d::gemm_h3g_kernel<1, 2, GLoadPlain, EpBiasResidual, 3>(const GLoadPlain, const _Float16*, const _Float16*, int, int, int, int, int, int, const EpBiasResidual);
 template __global__ void uu3d::gemm_h3_kernel<1, 2, ALoadLayerNorm, EpBias>(const ALoadLayerNorm, const _Float16*, const _Float16*, int, int, int, int, int, int, const EpBias);

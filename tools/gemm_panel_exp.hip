@@ -77,7 +77,10 @@ int main(int argc, char** argv) {
     }
     {
         float msl = timeit([&] { hipLaunchKernelGGL(ln_split_frag_kernel<24>, dim3((M + 15) / 16), dim3(256), 0, 0, dX, K, M, 1e-5f, dg, db, dAf); });
-        printf("ln_split_frag: %7.1f us\n", msl * 1e3);
+        float msl8 = timeit([&] { hipLaunchKernelGGL((ln_split_frag_kernel<24, 8>), dim3((M + 7) / 8), dim3(128), 0, 0, dX, K, M, 1e-5f, dg, db, dAf); });
+        float msl4 = timeit([&] { hipLaunchKernelGGL((ln_split_frag_kernel<24, 4>), dim3((M + 3) / 4), dim3(64), 0, 0, dX, K, M, 1e-5f, dg, db, dAf); });
+        float msl32 = timeit([&] { hipLaunchKernelGGL((ln_split_frag_kernel<24, 32>), dim3((M + 31) / 32), dim3(512), 0, 0, dX, K, M, 1e-5f, dg, db, dAf); });
+        printf("ln_split_frag: %7.1f us (16 rows per workgroup); 8 rows %7.1f, 4 rows %7.1f, 32 rows %7.1f\n", msl * 1e3, msl8 * 1e3, msl4 * 1e3, msl32 * 1e3);
         PanelEpBias ep{dC, N};
         auto kern = gemm_h3_panel_kernel<24, PanelEpBias>;
         CK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)PANEL_LDS_TOTAL));

@@ -842,7 +842,7 @@ struct Launcher {
     // LayerNorm (eps 1e-5) of M rows of 384 floats, written as the fragment-ordered planes of the panel GEMM's A operand
     void ln_split_frag(const char* name, const float* x, int M, const float* g, const float* b, _Float16* Af) {
         begin(name, "ln_split_frag", 0.0, 8.0 * (double)M * 384);
-        hipLaunchKernelGGL(ln_split_frag_kernel<24>, dim3((M + 15) / 16), dim3(256), 0, stream, x, 384, M, 1e-5f, g, b, Af);
+        hipLaunchKernelGGL((ln_split_frag_kernel<24, 8>), dim3((M + 7) / 8), dim3(128), 0, stream, x, 384, M, 1e-5f, g, b, Af);   // 8 rows per workgroup: 6.6 us at 9088 rows (16: 7.0, 32: 7.9, 4: 6.6)
         end();
     }
 

@@ -434,18 +434,19 @@ gemm_h3_panel_acc_kernel(const _Float16* __restrict__ Af, const _Float16* __rest
 
 // ------------------------------------------------------------------------------------------------
 // LayerNorm (two-pass, eps inside the root) of M rows of D = 16 KS floats, written as the fragment-ordered hi / lo
-// planes of a panel GEMM's A operand.  One workgroup per HALF panel (16 rows): 16 threads per row, 4-float pieces
-// interleaved across them, so that a wave's stores for one piece index are runs of 64-128 contiguous bytes of the
-// operand and there are M / 16 workgroups to hide the latency with (one per 32 rows: 8.2 us at M = 9088; this form: see DESIGN.md).
-template <int KS>
-__global__ void __launch_bounds__(256)
+// planes of a panel GEMM's A operand.  ROWS rows per workgroup, 16 threads per row, 4-float pieces interleaved across
+// them, so that a wave's stores for one piece index are runs of 64 contiguous bytes of the operand.  At M = 9088:
+// 6.6 us with 8 or 4 rows per workgroup, 7.0 with 16, 7.9 with 32 -- the floor of 28 MB through the Infinity Cache in
+// one short launch.
+template <int KS, int ROWS = 16>
+__global__ void __launch_bounds__(16 * ROWS)
 ln_split_frag_kernel(const float* __restrict__ x, const int ld, const int M, const float eps,
                      const float* __restrict__ gamma, const float* __restrict__ beta, _Float16* __restrict__ Af)
 {
     constexpr int D = 16 * KS, NV = D / 64;                // float4 pieces per thread
     h3_flush_f16_denormals();
     const int tid = threadIdx.x, j = tid & 15, lr = tid >> 4;
-    const int row = blockIdx.x * 16 + lr;
+    const int row = blockIdx.x * ROWS + lr;
     const float* p = x + (size_t)min(row, M - 1) * ld;
     f32x4 v[NV];
     float s = 0.f;
