@@ -93,6 +93,7 @@ struct uu3d_model {
     bool no_lnfuse = true;         // UU3D_LNFUSE=1: producer-side split + LayerNorm folded into the panel GEMMs (LNF) instead of the ln_split_frag pass; measured +-0.6 %, off
     bool no_attn_pipe = true;      // UU3D_ATTN_PIPE=1: two (sequence, head) items per attention workgroup, the second one's loads in flight while the first is computed (+1 % h36m_351, -1.3 % h36m_81: off)
     bool no_panel_acc = true;      // UU3D_PANEL_ACC=1: projection / fc2 on gemm_h3_panel_acc_kernel instead of the tiled LDS-DMA kernel (measured slower: DESIGN section 11)
+    bool s2t_planes = false;       // UU3D_S2T_PLANES=1 (see uu3d_forward)
     bool no_panel = false;         // UU3D_NO_PANEL=1: LayerNorm-fed GEMMs stay on the tiled kernels (A/B measurements)
     bool no_lnfold = true;         // UU3D_LNFOLD=1 folds LayerNorm into the next Dense (gemm_h3_lnfold_kernel); measured neutral, off by default
     bool ln_planes = false;        // UU3D_LN_PLANES=1: LayerNorm as a separate pass that writes planes (ln_split) instead of inside the GEMM loader
@@ -305,6 +306,7 @@ int uu3d_create(const uu3d_config* c, int device, uu3d_model** out) {
     { const char* e = getenv("UU3D_LNFUSE"); m->no_lnfuse = !(e != nullptr && e[0] == '1'); }
     { const char* e = getenv("UU3D_ATTN_PIPE"); m->no_attn_pipe = !(e != nullptr && e[0] == '1'); }
     { const char* e = getenv("UU3D_PANEL_ACC"); m->no_panel_acc = !(e != nullptr && e[0] == '1'); }
+    { const char* e = getenv("UU3D_S2T_PLANES"); m->s2t_planes = (e != nullptr && e[0] == '1'); }
     { const char* e = getenv("UU3D_NO_PANEL"); m->no_panel = (e != nullptr && e[0] == '1'); }
     { const char* e = getenv("UU3D_LNFOLD"); m->no_lnfold = !(e != nullptr && e[0] == '1'); }
     *out = m;
@@ -948,6 +950,7 @@ int uu3d_forward(uu3d_model* m, const float* kp2d, const uint8_t* mask, int32_t 
     char nm[48];
 
     // 1. spatial stack
+    bool s_planes = false;
     {
         SpatialParams sp = m->sp;
         sp.total_frames = M;
@@ -972,8 +975,12 @@ int uu3d_forward(uu3d_model* m, const float* kp2d, const uint8_t* mask, int32_t 
             sp.blocks = m->sp_blocks_v2;             // LayerNorm parameters and biases
             auto kern = spatial_stack_h3_kernel<kJ, kFR>;
             Lh.begin("spatial_stack", "spatial_h3", fl, 4.0 * M * J * (2.0 + ds));
+            // UU3D_S2T_PLANES=1: the spatial stack writes its output as f16 hi / lo planes and spatial_to_temporal_fc runs on the
+            // LDS-DMA kernel (A/B measurement)
+            s_planes = m->s2t_planes && (J * ds) % 32 == 0 && m->hplanes.count((size_t)(m->s2t_wt - m->arena)) != 0;
+            _Float16* const Sh = reinterpret_cast<_Float16*>(w.S);
             hipLaunchKernelGGL(kern, dim3((M + kFR - 1) / kFR), dim3(64), sh3::lds_bytes(), Lh.stream, kp2d, sp,
-                               m->harena + m->sp_frag_off, w.S, (_Float16*)nullptr, (_Float16*)nullptr);
+                               m->harena + m->sp_frag_off, w.S, s_planes ? Sh : (_Float16*)nullptr, s_planes ? Sh + (size_t)M * J * ds : (_Float16*)nullptr);
             Lh.end();
         } else {
             sp.blocks = m->sp_blocks_v2;
@@ -998,6 +1005,11 @@ int uu3d_forward(uu3d_model* m, const float* kp2d, const uint8_t* mask, int32_t 
         ALoadPlain al{w.S, J * ds, M, J * ds};
         EpSpatialToTemporal ep{w.X, m->s2t_b, dt, mask, m->token, m->pe_t, N};
         if (lnfuse) { ep.frag = reinterpret_cast<_Float16*>(w.O); ep.frag_ks = dt / 16; }
+        if (s_planes) {
+            const _Float16* Sh = reinterpret_cast<const _Float16*>(w.S);
+            GLoadPlain gl{Sh, Sh + (size_t)M * J * ds, J * ds, M};
+            Lh.gemm_g("s2t", gl, m->s2t_wt, M, dt, J * ds, ep);
+        } else
         Lh.gemm("s2t", al, m->s2t_wt, M, dt, J * ds, ep);
     }
     // f16x3 with K % 32 == 0 everywhere: activations that feed a GEMM travel as f16 hi/lo planes (same bytes as the
