@@ -41,6 +41,19 @@ int uu3d_op_attn_bwd(const float* qkv_dev, const float* dout_dev, int32_t ld, in
                      int32_t head_dim, const uint8_t* key_mask_dev, float* dqkv_dev, int32_t ldo, void* stream);
 size_t uu3d_op_scratch_floats(void);
 
+/* The forward's row-panel path for a LayerNorm-fed Dense layer on its own (csrc/uu3d_gemm_panel.h; in the model:
+ * kl.LayerNormalization + kl.Dense of vit.TransformerBlock / vit.MLP, vision_transformer.py:46-68,135-137,183,188):
+ *   out[M][N] = LayerNorm(x[M][384]; gamma, beta, eps) W[384][N] + bias          (relu = 0: f32, row stride ldo)
+ *   relu = 1: ReLU of that, written as two f16 planes hi[M][N] | lo[M][N] at out_dev (value = hi + lo / 2048)
+ * W comes as the fragment-ordered f16 planes made by uu3d_op_panel_pack from the Keras (in, out) kernel on the HOST;
+ * a_scratch_dev holds the fragment-ordered LayerNorm output (uu3d_op_panel_a_bytes(M)).  N % 32 == 0, N <= 1024 * 32 / 32. */
+size_t uu3d_op_panel_operand_bytes(int32_t N);
+size_t uu3d_op_panel_a_bytes(int32_t M);
+int uu3d_op_panel_pack(const float* w_host, int32_t N, void* operand_dev, void* stream);
+int uu3d_op_ln_dense_panel(const float* x_dev, int32_t ldx, int32_t M, const float* gamma_dev, const float* beta_dev, float eps,
+                           const void* operand_dev, const float* bias_dev, int32_t N, int32_t relu, void* a_scratch_dev,
+                           void* out_dev, int32_t ldo, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

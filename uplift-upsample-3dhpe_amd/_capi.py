@@ -30,6 +30,7 @@ EXPORTED_SYMBOLS = (
 OPS_SYMBOLS = (
     "uu3d_op_gemm_tn", "uu3d_op_gemm_nt", "uu3d_op_colsum", "uu3d_op_row_stats", "uu3d_op_ln_bwd",
     "uu3d_op_attn_fwd", "uu3d_op_attn_bwd", "uu3d_op_scratch_floats",
+    "uu3d_op_panel_operand_bytes", "uu3d_op_panel_a_bytes", "uu3d_op_panel_pack", "uu3d_op_ln_dense_panel",
 )
 
 
@@ -151,6 +152,14 @@ def load_library(path=None):
     lib.uu3d_op_attn_fwd.argtypes = [vp, i32, i32, i32, i32, i32, i32, vp, vp, i32, vp]
     lib.uu3d_op_attn_bwd.restype = C.c_int
     lib.uu3d_op_attn_bwd.argtypes = [vp, vp, i32, i32, i32, i32, i32, i32, vp, vp, i32, vp]
+    lib.uu3d_op_panel_operand_bytes.restype = sz
+    lib.uu3d_op_panel_operand_bytes.argtypes = [i32]
+    lib.uu3d_op_panel_a_bytes.restype = sz
+    lib.uu3d_op_panel_a_bytes.argtypes = [i32]
+    lib.uu3d_op_panel_pack.restype = C.c_int
+    lib.uu3d_op_panel_pack.argtypes = [vp, i32, vp, vp]
+    lib.uu3d_op_ln_dense_panel.restype = C.c_int
+    lib.uu3d_op_ln_dense_panel.argtypes = [vp, i32, i32, vp, vp, C.c_float, vp, vp, i32, i32, vp, vp, i32, vp]
     if path is None:
         _lib = lib
     return lib

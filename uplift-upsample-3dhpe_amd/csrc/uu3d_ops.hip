@@ -7,6 +7,8 @@
 #include "uu3d_misc.h"
 #include "uu3d_bwd.h"
 #include "uu3d_launch.h"
+#include "uu3d_gemm_panel.h"
+#include <vector>
 
 using namespace uu3d;
 
@@ -56,4 +58,48 @@ int uu3d_op_attn_bwd(const float* qkv, const float* dout, int32_t ld, int32_t D,
     if (!qkv || !dout || !dqkv || L < 1 || (dh != 4 && dh != 48)) return UU3D_ERR_INVALID_ARGUMENT;
     if (L > 96) return UU3D_ERR_UNSUPPORTED;      // P and dS matrices of one head must fit the 160 KiB LDS
     return launch_attn_generic(true, qkv, dout, ld, D, B, L, H, dh, mask, dqkv, ldo, (hipStream_t)stream);
+}
+
+// ---- row-panel path of a LayerNorm-fed Dense layer (uu3d_gemm_panel.h) --------------------------------------------
+size_t uu3d_op_panel_operand_bytes(int32_t N) { return (N < 32 || (N & 31)) ? 0 : panel_b_halfs(N, 384) * sizeof(_Float16); }
+size_t uu3d_op_panel_a_bytes(int32_t M) { return M < 1 ? 0 : panel_a_halfs(M, 384) * sizeof(_Float16); }
+
+int uu3d_op_panel_pack(const float* w, int32_t N, void* operand_dev, void* stream) {
+    if (!w || !operand_dev || N < 32 || (N & 31)) return UU3D_ERR_INVALID_ARGUMENT;
+    const int K = 384;
+    std::vector<_Float16> bh((size_t)N * K), bl((size_t)N * K), out(panel_b_halfs(N, K));
+    for (int n = 0; n < N; ++n)
+        for (int k = 0; k < K; ++k) {
+            const float x = w[(size_t)k * N + n];                     // Keras (in, out) -> Bt[n][k]
+            const _Float16 h = h3_hi(x);
+            bh[(size_t)n * K + k] = h; bl[(size_t)n * K + k] = (_Float16)((x - (float)h) * H3_SCALE);
+        }
+    panel_pack_operand(bh.data(), bl.data(), N, K, K, out.data());
+    if (hipMemcpyAsync(operand_dev, out.data(), out.size() * sizeof(_Float16), hipMemcpyHostToDevice, (hipStream_t)stream) != hipSuccess) return UU3D_ERR_HIP;
+    return hipStreamSynchronize((hipStream_t)stream) == hipSuccess ? UU3D_OK : UU3D_ERR_HIP;
+}
+
+int uu3d_op_ln_dense_panel(const float* x, int32_t ldx, int32_t M, const float* gamma, const float* beta, float eps, const void* operand,
+                           const float* bias, int32_t N, int32_t relu, void* a_scratch, void* out, int32_t ldo, void* stream_) {
+    if (!x || !gamma || !beta || !operand || !bias || !a_scratch || !out || M < 1 || N < 32 || (N & 31) || ldx < 384 || (ldx & 3)) return UU3D_ERR_INVALID_ARGUMENT;
+    hipStream_t stream = (hipStream_t)stream_;
+    _Float16* Af = reinterpret_cast<_Float16*>(a_scratch);
+    hipLaunchKernelGGL((ln_split_frag_kernel<24, 8>), dim3((M + 7) / 8), dim3(128), 0, stream, x, ldx, M, eps, gamma, beta, Af);
+    const int mt = (M + 127) / 128, chunks = N / 32;
+    int S = 0;                                                        // any divisor that keeps <= 32 chunks per workgroup; prefer ~one round
+    for (int s = 1; s <= chunks; ++s) if (chunks % s == 0 && chunks / s <= 32 && (S == 0 || (mt * s + 7) / 8 <= 32)) S = s;
+    if (S == 0) return UU3D_ERR_UNSUPPORTED;
+    const dim3 grid(8 * S, ((mt * S + 7) / 8 + S - 1) / S);
+    const _Float16* Bf = reinterpret_cast<const _Float16*>(operand);
+    if (relu) {
+        auto kern = gemm_h3_panel_kernel<24, PanelEpBiasReluSplit, false>;
+        (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)PANEL_LDS_TOTAL);
+        _Float16* oh = reinterpret_cast<_Float16*>(out);
+        hipLaunchKernelGGL(kern, grid, dim3(256), PANEL_LDS_TOTAL, stream, Af, Bf, bias, M, mt, S, chunks / S, PanelEpBiasReluSplit{oh, oh + (size_t)M * N, N}, 0, 0.f);
+    } else {
+        auto kern = gemm_h3_panel_kernel<24, PanelEpBias, false>;
+        (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)PANEL_LDS_TOTAL);
+        hipLaunchKernelGGL(kern, grid, dim3(256), PANEL_LDS_TOTAL, stream, Af, Bf, bias, M, mt, S, chunks / S, PanelEpBias{reinterpret_cast<float*>(out), ldo}, 0, 0.f);
+    }
+    return hipGetLastError() == hipSuccess ? UU3D_OK : UU3D_ERR_HIP;
 }
