@@ -1,4 +1,7 @@
-// uu3d_gemm_panel.h -- f16x3 "row panel" GEMM for the LayerNorm-fed Dense layers (K = d_t = 384).
+// tools/gemm_panel_lnfold_exp.h -- EXPERIMENT RECORD: the first form of the row-panel GEMM, with the
+// LayerNorm statistics + split in its own prologue (LayerNorm folded into the operand).  Superseded by
+// csrc/uu3d_gemm_panel.h + ln_split_frag_kernel; kept because the numbers quoted in DESIGN.md come from it.
+//   hipcc -O3 -std=c++17 --offload-arch=gfx950 -Xclang -target-feature -Xclang -packed-fp32-ops [-DSTAMP] [-DUU3D_PANEL_LOADALL] -o tools/gemm_panel_lnfold_exp tools/gemm_panel_lnfold_exp.hip
 //
 // The tiled kernels of uu3d_gemm_h3.h restart a 12-iteration k-loop in every 64 x 128 tile, re-stage (and
 // re-normalise, re-split) the same A rows in each of the N / 128 workgroups along N, and move four f16 planes
@@ -26,7 +29,7 @@
 //
 // Grid: (M / 128) row tiles x S column ranges of N / (32 S) chunks each.
 #pragma once
-#include "uu3d_gemm_h3.h"
+#include "../uplift-upsample-3dhpe_amd/csrc/uu3d_gemm_h3.h"
 #include <type_traits>
 
 namespace uu3d {
