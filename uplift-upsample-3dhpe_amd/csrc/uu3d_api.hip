@@ -93,6 +93,7 @@ struct uu3d_model {
     bool no_lnfuse = true;         // UU3D_LNFUSE=1: producer-side split + LayerNorm folded into the panel GEMMs (LNF) instead of the ln_split_frag pass; measured +-0.6 %, off
     bool no_attn_pipe = true;      // UU3D_ATTN_PIPE=1: two (sequence, head) items per attention workgroup, the second one's loads in flight while the first is computed (+1 % h36m_351, -1.3 % h36m_81: off)
     bool no_panel_acc = true;      // UU3D_PANEL_ACC=1: projection / fc2 on gemm_h3_panel_acc_kernel instead of the tiled LDS-DMA kernel (measured slower: DESIGN section 11)
+    bool g_tile22 = false;         // UU3D_G_TILE22=1: 128 x 128 tiles for the large LDS-DMA GEMMs (experiment)
     bool s2t_planes = false;       // UU3D_S2T_PLANES=1 (see uu3d_forward)
     bool no_panel = false;         // UU3D_NO_PANEL=1: LayerNorm-fed GEMMs stay on the tiled kernels (A/B measurements)
     bool no_lnfold = true;         // UU3D_LNFOLD=1 folds LayerNorm into the next Dense (gemm_h3_lnfold_kernel); measured neutral, off by default
@@ -306,6 +307,7 @@ int uu3d_create(const uu3d_config* c, int device, uu3d_model** out) {
     { const char* e = getenv("UU3D_LNFUSE"); m->no_lnfuse = !(e != nullptr && e[0] == '1'); }
     { const char* e = getenv("UU3D_ATTN_PIPE"); m->no_attn_pipe = !(e != nullptr && e[0] == '1'); }
     { const char* e = getenv("UU3D_PANEL_ACC"); m->no_panel_acc = !(e != nullptr && e[0] == '1'); }
+    { const char* e = getenv("UU3D_G_TILE22"); m->g_tile22 = (e != nullptr && e[0] == '1'); }
     { const char* e = getenv("UU3D_S2T_PLANES"); m->s2t_planes = (e != nullptr && e[0] == '1'); }
     { const char* e = getenv("UU3D_NO_PANEL"); m->no_panel = (e != nullptr && e[0] == '1'); }
     { const char* e = getenv("UU3D_LNFOLD"); m->no_lnfold = !(e != nullptr && e[0] == '1'); }
@@ -751,7 +753,8 @@ struct Launcher {
         const _Float16* Bh = m->harena + it->second.first; const _Float16* Bl = m->harena + it->second.second;
         if (slices == 1) {
             // measured (tools/gemm_bench, M = 4544 / 1472 rows): 64x128 is the fastest LDS-DMA tile down to ~200 tiles
-            if (N % 128 == 0 && tiles >= 256) gemm_h3g_tile<1, 2>(gl, Bh, Bl, M, N, K, 1, KT, ep);
+            if (m->g_tile22 && N % 128 == 0 && tiles >= 512) gemm_h3g_tile<2, 2>(gl, Bh, Bl, M, N, K, 1, KT, ep);     // UU3D_G_TILE22=1 (experiment)
+            else if (N % 128 == 0 && tiles >= 256) gemm_h3g_tile<1, 2>(gl, Bh, Bl, M, N, K, 1, KT, ep);
             else gemm_h3g_tile<1, 1>(gl, Bh, Bl, M, N, K, 1, KT, ep);
         } else {
             EpSlab es{slab, ldslab, (size_t)M * ldslab};

@@ -499,6 +499,13 @@ gemm_h3g_kernel(const GL gl, const _Float16* __restrict__ Bh, const _Float16* __
         for (int p = 0; p < 2 * NPB; ++p)
             __builtin_amdgcn_global_load_lds((h3_glb_void*)(bsrc[p] + k), (h3_lds_void*)(d + (2 * NPA + p) * 64 * 32), 16, 0, 0);
     };
+    // one piece (0 .. NP-1) of the same transfer: the 128 x 128 form spreads them between its MFMAs
+    auto dma_piece = [&](int kt, int buf, int p) __attribute__((always_inline)) {
+        const int k = min(kt, KT - 1) * GEMM_BK + dk;
+        _Float16* d = hsm + buf * STAGE + 16 * wave * 32;
+        if (p < 2 * NPA) __builtin_amdgcn_global_load_lds((h3_glb_void*)gl.src(actx[p % NPA], k, p / NPA), (h3_lds_void*)(d + p * 64 * 32), 16, 0, 0);
+        else __builtin_amdgcn_global_load_lds((h3_glb_void*)(bsrc[p - 2 * NPA] + k), (h3_lds_void*)(d + p * 64 * 32), 16, 0, 0);
+    };
 
     f32x16 acc0[TM][TN], acc1[TM][TN];
 #pragma unroll
@@ -519,6 +526,63 @@ gemm_h3g_kernel(const GL gl, const _Float16* __restrict__ Bh, const _Float16* __
 
     const int fr = lane & 31, fkc = lane >> 5;
     int cur = 0;
+    // 128 x 128 tiles leave one workgroup per CU = one wave per SIMD: nothing hides an LDS read that hipcc sinks to its
+    // use, so this form issues all 16 fragment reads of a k-tile up front by asm (counted lgkmcnt waits, LDS returns in
+    // order) and spreads the next tile's 8 DMAs between the MFMAs instead of issuing them in front of them.
+    constexpr bool PIPE = (TM == 2 && TN == 2 && NBUF == 3);
+    if (PIPE) {
+        unsigned aoff[2][TM][2], boff[2][TN][2];           // byte offsets inside a stage: [kk][fragment][plane]
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                const int r = wm * (BM / 2) + 32 * i + fr, c = (2 * kk + fkc) ^ ((r >> 2) & 3);
+                aoff[kk][i][0] = (unsigned)((r * 32 + c * 8) * 2); aoff[kk][i][1] = (unsigned)(((BM + r) * 32 + c * 8) * 2);
+            }
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                const int r = wn * (BN / 2) + 32 * j + fr, c = (2 * kk + fkc) ^ ((r >> 2) & 3);
+                boff[kk][j][0] = (unsigned)(((2 * BM + r) * 32 + c * 8) * 2); boff[kk][j][1] = (unsigned)(((2 * BM + BN + r) * 32 + c * 8) * 2);
+            }
+        }
+        const unsigned lds0 = (unsigned)(uintptr_t)(h3_lds_void*)hsm;
+        for (int kt = kt_lo; kt < KT; ++kt) {
+            const unsigned sb = lds0 + (unsigned)(cur * STAGE * 2);
+            const int wbuf = cur >= 1 ? cur - 1 : 2;            // buffer (cur + 2) % 3: last read in iteration kt-1, every wave is past that barrier
+            h16x8 fa[2][TM][2], fb[2][TN][2];
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk) {
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int pl = 0; pl < 2; ++pl) asm volatile("ds_read_b128 %0, %1" : "=&v"(fa[kk][i][pl]) : "v"(sb + aoff[kk][i][pl]));
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+#pragma unroll
+                    for (int pl = 0; pl < 2; ++pl) asm volatile("ds_read_b128 %0, %1" : "=&v"(fb[kk][j][pl]) : "v"(sb + boff[kk][j][pl]));
+            }
+            int piece = 0;
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk) {
+                if (kk == 0) asm volatile("s_waitcnt lgkmcnt(8)" : "+v"(fa[0][0][0]), "+v"(fa[0][0][1]), "+v"(fa[0][1][0]), "+v"(fa[0][1][1]), "+v"(fb[0][0][0]), "+v"(fb[0][0][1]), "+v"(fb[0][1][0]), "+v"(fb[0][1][1]));
+                else asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(fa[1][0][0]), "+v"(fa[1][0][1]), "+v"(fa[1][1][0]), "+v"(fa[1][1][1]), "+v"(fb[1][0][0]), "+v"(fb[1][0][1]), "+v"(fb[1][1][0]), "+v"(fb[1][1][1]));
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j) {
+                        acc0[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[kk][i][0], fb[kk][j][0], acc0[i][j], 0, 0, 0);
+                        acc1[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[kk][i][0], fb[kk][j][1], acc1[i][j], 0, 0, 0);
+                        acc1[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[kk][i][1], fb[kk][j][0], acc1[i][j], 0, 0, 0);
+                        dma_piece(kt + 2, wbuf, piece); ++piece;     // NP = 8 pieces over the 8 (kk, i, j) groups
+                    }
+            }
+            asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" :: "i"(NP) : "memory");
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_sched_barrier(0);
+            cur = (cur == 2 ? 0 : cur + 1);
+        }
+    } else
     for (int kt = kt_lo; kt < KT; ++kt) {
         // buffer (cur + 2) % 3 was last read in iteration kt-1; every wave is past that barrier
         if (NBUF == 3) dma(kt + 2, cur >= 1 ? cur - 1 : 2); else dma(kt + 1, cur ^ 1);
