@@ -472,7 +472,7 @@ gemm_h3g_kernel(const GL gl, const _Float16* __restrict__ Bh, const _Float16* __
     if (bm >= m_tiles) return;
     const int bm0 = bm * BM, bn0 = bn * BN;
 
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wm = wave >> 1, wn = wave & 1;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), wm = wave >> 1, wn = wave & 1;
     const int drow = 16 * wave + (lane >> 2);                       // row inside a 64-row DMA pass
     const int dk = ((lane & 3) ^ ((lane >> 4) & 3)) * 8;            // logical chunk this lane fetches (halfs)
 

@@ -145,7 +145,7 @@ gemm_h3_panel_kernel(const _Float16* __restrict__ Af, const _Float16* __restrict
     const int u = (id & 7) * per + (id >> 3);
     if ((id >> 3) >= per || u >= total) return;
     const int bm = u / splits, ns = u - bm * splits;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // scalar: the LDS-DMA destinations (M0) then come from SALU arithmetic
     const int row0 = bm * 128 + wave * 32;                 // this wave's panel
     const int chunk0 = ns * chunks_per_wg;
     const int T = SPC * chunks_per_wg;                     // k-steps this workgroup consumes
@@ -155,7 +155,14 @@ gemm_h3_panel_kernel(const _Float16* __restrict__ Af, const _Float16* __restrict
     auto dma1 = [&](int t, int slot, int p) __attribute__((always_inline)) {       // piece p (0..5) of this wave's share of k-step t
         const unsigned char* s = bsrc + (size_t)min(t, T - 1) * PANEL_STEP_BYTES;
         unsigned char* d = psm + slot * PANEL_STEP_BYTES + (wave * PANEL_PIECES) * 1024;
-        __builtin_amdgcn_global_load_lds((h3_glb_void*)(s + p * 1024), (h3_lds_void*)(d + p * 1024), 16, 0, 0);
+        // the instruction's immediate offset advances the global and the LDS address alike: one M0 value / address pair per
+        // 4 pieces instead of a v_readfirstlane + s_mov m0 + 64-bit add for every piece (31.4 -> 30.1 us for the QKV projection)
+        switch (p & 3) {
+            case 0: __builtin_amdgcn_global_load_lds((h3_glb_void*)(s + (p >> 2) * 4096), (h3_lds_void*)(d + (p >> 2) * 4096), 16, 0, 0); break;
+            case 1: __builtin_amdgcn_global_load_lds((h3_glb_void*)(s + (p >> 2) * 4096), (h3_lds_void*)(d + (p >> 2) * 4096), 16, 1024, 0); break;
+            case 2: __builtin_amdgcn_global_load_lds((h3_glb_void*)(s + (p >> 2) * 4096), (h3_lds_void*)(d + (p >> 2) * 4096), 16, 2048, 0); break;
+            default: __builtin_amdgcn_global_load_lds((h3_glb_void*)(s + (p >> 2) * 4096), (h3_lds_void*)(d + (p >> 2) * 4096), 16, 3072, 0); break;
+        }
     };
     auto dma = [&](int t, int slot) __attribute__((always_inline)) {
 #pragma unroll
@@ -345,7 +352,7 @@ gemm_h3_panel_acc_kernel(const _Float16* __restrict__ Af, const _Float16* __rest
     const int u = (id & 7) * per + (id >> 3);
     if ((id >> 3) >= per || u >= total) return;
     const int bm = u / splits, ns = u - bm * splits;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int row0 = bm * 128 + wave * 32;
     const int chunk0 = ns * NCH;
 
