@@ -109,3 +109,29 @@ def test_world_to_cam_and_2d_matches_the_restatement():
         assert np.abs(c3[b] - xc).max() < 5e-6 * max(1.0, np.abs(xc).max())          # float32 arithmetic vs float64 restatement
         assert np.abs(k2[b] - x2).max() < 2e-5
     assert np.isfinite(k2).all()
+
+
+def test_h36m_npz_to_model_end_to_end():
+    """Files on disk -> Human3.6M ingestion (h36m.py, pinned against the reference in tests/test_h36m_cpu.py) -> device
+    pose table -> windows + stride masks -> forward -> root-relative MPJPE: the eval.py data path on the tiny fixture."""
+    import os
+    import uplift_upsample_3dhpe_amd as pkg
+    from uplift_upsample_3dhpe_amd import h36m, harness
+    g = os.path.join(util.ROOT, "tests", "golden")
+    dataset, keypoints = h36m.load_dataset_and_2d_poses(os.path.join(g, "h36m_tiny_3d.npz"), os.path.join(g, "h36m_tiny_2d.npz"), verbose=False)
+    cams, p3d, p2d, names, subj, act, fps = h36m.filter_and_subsample_dataset(dataset, keypoints, ["S9"], "*", verbose=False)           # the tiny fixture holds S1 and S9
+    table = h36m.pose_table(p2d, p3d, subj, act, fps)
+    cfg = util.load_config("h36m_81")
+    gen = D.SequenceGenerator(table, seq_len=cfg.SEQUENCE_LENGTH, stride=cfg.SEQUENCE_STRIDE, padding_type="copy",
+                              mask_stride=cfg.MASK_STRIDE[0], stride_mask_align_global=True, flip_augment=False, shuffle=False)
+    assert len(gen) == sum(len(v) for v in p2d)                       # one window per frame of the 8 test videos (S9: 8 + 6 frames x 4 cameras)
+    model = pkg.build_uplift_upsample_transformer(cfg, seed=1)
+    batch = next(gen.batches(16))
+    full, central = model([batch["kp2d"], batch["stride_mask"]], training=False)
+    mid = cfg.SEQUENCE_LENGTH // 2
+    gt = torch.cat([batch["kp3d"][:, mid], torch.ones_like(batch["kp3d"][:, mid, :, :1])], -1)
+    err = harness.per_joint_error(central, gt, cfg.ROOT_KEYTPOINT)
+    assert tuple(err.shape) == (16, 17) and bool(torch.isfinite(err).all())
+    # the window centres are the videos' own frames: the generator's 3D target equals the ingested camera-frame pose
+    v, i = gen.descriptors()[0][:2]
+    assert np.allclose(batch["kp3d"][0, mid].cpu().numpy(), p3d[int(v)][int(i)], atol=1e-6)
