@@ -13,7 +13,7 @@ from tests import util
 torch = pytest.importorskip("torch")
 pytestmark = pytest.mark.gpu
 
-GOLDEN = sorted(glob.glob(os.path.join(util.ROOT, "tests", "golden", "*.npz")))
+GOLDEN = sorted(glob.glob(os.path.join(util.ROOT, "tests", "golden", "*_seed*.npz")))      # the forward fixtures (make_golden.py); h36m_tiny_* belong to test_h36m_cpu.py
 
 
 def _model(cfgname, seed=0, perturb=0.1, precision="f16x3"):

@@ -14,7 +14,7 @@ from oracle import uplift_oracle_np as ON
 from tests import util
 from tests.golden.make_golden import weights_checksum
 
-GOLDEN = sorted(glob.glob(os.path.join(util.ROOT, "tests", "golden", "*.npz")))
+GOLDEN = sorted(glob.glob(os.path.join(util.ROOT, "tests", "golden", "*_seed*.npz")))
 
 
 def _setup(cfgname, seed=0, perturb=0.1):

@@ -807,7 +807,9 @@ struct Launcher {
         }
         return best;
     }
-    bool panel_ok(int M, int N, int K, size_t pf) const { return !m->no_panel && pf != 0 && K == 384 && N % 32 == 0 && M >= 1024; }
+    bool panel_ok(int M, int N, int K, size_t pf) const {
+        return !m->no_panel && pf != 0 && K == 384 && N % 32 == 0 && M >= 1024 && (double)M * N * 4.0 < 4.0e9;      // 32-bit byte offsets in the epilogue stores
+    }
     template <class EP>
     void gemm_panel(const char* name, const _Float16* Af, size_t pf, const float* colv, int M, int N, const EP& ep) {
         const int K = 384, S = panel_splits(M, N), mt = (M + 127) / 128;

@@ -66,9 +66,14 @@ inline void panel_pack_operand(const _Float16* Bh, const _Float16* Bl, int N, in
 }
 
 // ---- epilogues: v = acc + colv[col] ----
+// Addresses are a scalar base + a 32-bit BYTE offset per lane (global_store ... saddr): a 64-bit address pair per unrolled
+// output register cost the fc1 kernel its register budget (512 + scratch).  The launcher keeps M * ldo * 4 below 2^32.
 struct PanelEpBias {           // out[row][col] = v
     float* __restrict__ out; int ldo;
-    __device__ __forceinline__ void store(int row, int col, float v) const { out[(size_t)row * ldo + col] = v; }
+    __device__ __forceinline__ void store(int row, int col, float v) const {
+        const unsigned b = ((unsigned)row * (unsigned)ldo + (unsigned)col) * 4u;
+        *reinterpret_cast<float*>(reinterpret_cast<char*>(out) + b) = v;
+    }
 };
 struct PanelEpBiasResidual {   // x[row][col] += v  (residual stream, in place)
     float* __restrict__ x; int ldo;
@@ -79,8 +84,9 @@ struct PanelEpBiasReluSplit {  // ReLU(v) as row-major hi / lo planes [M][ldo] (
     __device__ __forceinline__ void store(int row, int col, float x) const {
         const float v = fmaxf(x, 0.f);
         const _Float16 h = h3_hi(v);
-        Oh[(size_t)row * ldo + col] = h;
-        Ol[(size_t)row * ldo + col] = (_Float16)((v - (float)h) * H3_SCALE);
+        const unsigned b = ((unsigned)row * (unsigned)ldo + (unsigned)col) * 2u;
+        *reinterpret_cast<_Float16*>(reinterpret_cast<char*>(Oh) + b) = h;
+        *reinterpret_cast<_Float16*>(reinterpret_cast<char*>(Ol) + b) = (_Float16)((v - (float)h) * H3_SCALE);
     }
 };
 struct PanelEpBiasReluFrag {   // ReLU(v) as fragment-ordered planes of the next GEMM's A operand (contraction length Kn)
@@ -151,17 +157,19 @@ gemm_h3_panel_kernel(const _Float16* __restrict__ Af, const _Float16* __restrict
     const int T = SPC * chunks_per_wg;                     // k-steps this workgroup consumes
 
     // ---- weight stream: k-step t -> ring slot t % PANEL_SLOTS; each wave moves 6 of its 24 pieces of 1 KiB ----
-    const unsigned char* bsrc = reinterpret_cast<const unsigned char*>(Bf) + (size_t)chunk0 * SPC * PANEL_STEP_BYTES + (wave * PANEL_PIECES) * 1024 + lane * 16;
-    auto dma1 = [&](int t, int slot, int p) __attribute__((always_inline)) {       // piece p (0..5) of this wave's share of k-step t
-        const unsigned char* s = bsrc + (size_t)min(t, T - 1) * PANEL_STEP_BYTES;
-        unsigned char* d = psm + slot * PANEL_STEP_BYTES + (wave * PANEL_PIECES) * 1024;
-        // the instruction's immediate offset advances the global and the LDS address alike: one M0 value / address pair per
-        // 4 pieces instead of a v_readfirstlane + s_mov m0 + 64-bit add for every piece (31.4 -> 30.1 us for the QKV projection)
+    // the global address of a piece = scalar base (SGPR arithmetic) + lane * 16 as a 32-bit offset: no 64-bit VGPR address pairs
+    const unsigned char* bsrc = reinterpret_cast<const unsigned char*>(Bf) + (size_t)chunk0 * SPC * PANEL_STEP_BYTES + (wave * PANEL_PIECES) * 1024;
+    const unsigned lane16 = (unsigned)lane * 16u;
+    auto dma1 = [&](int t, int slot, int p) __attribute__((always_inline)) {       // piece p of this wave's share of k-step t
+        const unsigned char* s = bsrc + (size_t)min(t, T - 1) * PANEL_STEP_BYTES + (p >> 2) * 4096;
+        unsigned char* d = psm + slot * PANEL_STEP_BYTES + (wave * PANEL_PIECES) * 1024 + (p >> 2) * 4096;
+        // the instruction's immediate offset advances the global and the LDS address alike: one M0 value / base per 4 pieces
+        // instead of a v_readfirstlane + s_mov m0 + 64-bit add for every piece (31.4 -> 30.1 us for the QKV projection)
         switch (p & 3) {
-            case 0: __builtin_amdgcn_global_load_lds((h3_glb_void*)(s + (p >> 2) * 4096), (h3_lds_void*)(d + (p >> 2) * 4096), 16, 0, 0); break;
-            case 1: __builtin_amdgcn_global_load_lds((h3_glb_void*)(s + (p >> 2) * 4096), (h3_lds_void*)(d + (p >> 2) * 4096), 16, 1024, 0); break;
-            case 2: __builtin_amdgcn_global_load_lds((h3_glb_void*)(s + (p >> 2) * 4096), (h3_lds_void*)(d + (p >> 2) * 4096), 16, 2048, 0); break;
-            default: __builtin_amdgcn_global_load_lds((h3_glb_void*)(s + (p >> 2) * 4096), (h3_lds_void*)(d + (p >> 2) * 4096), 16, 3072, 0); break;
+            case 0: __builtin_amdgcn_global_load_lds((h3_glb_void*)(s + lane16), (h3_lds_void*)d, 16, 0, 0); break;
+            case 1: __builtin_amdgcn_global_load_lds((h3_glb_void*)(s + lane16), (h3_lds_void*)d, 16, 1024, 0); break;
+            case 2: __builtin_amdgcn_global_load_lds((h3_glb_void*)(s + lane16), (h3_lds_void*)d, 16, 2048, 0); break;
+            default: __builtin_amdgcn_global_load_lds((h3_glb_void*)(s + lane16), (h3_lds_void*)d, 16, 3072, 0); break;
         }
     };
     auto dma = [&](int t, int slot) __attribute__((always_inline)) {

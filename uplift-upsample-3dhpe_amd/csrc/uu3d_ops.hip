@@ -82,6 +82,7 @@ int uu3d_op_panel_pack(const float* w, int32_t N, void* operand_dev, void* strea
 int uu3d_op_ln_dense_panel(const float* x, int32_t ldx, int32_t M, const float* gamma, const float* beta, float eps, const void* operand,
                            const float* bias, int32_t N, int32_t relu, void* a_scratch, void* out, int32_t ldo, void* stream_) {
     if (!x || !gamma || !beta || !operand || !bias || !a_scratch || !out || M < 1 || N < 32 || (N & 31) || ldx < 384 || (ldx & 3)) return UU3D_ERR_INVALID_ARGUMENT;
+    if ((double)M * (relu ? N : ldo) * 4.0 >= 4.0e9) return UU3D_ERR_UNSUPPORTED;          // 32-bit byte offsets in the epilogue stores
     hipStream_t stream = (hipStream_t)stream_;
     _Float16* Af = reinterpret_cast<_Float16*>(a_scratch);
     hipLaunchKernelGGL((ln_split_frag_kernel<24, 8>), dim3((M + 7) / 8), dim3(128), 0, stream, x, ldx, M, eps, gamma, beta, Af);
