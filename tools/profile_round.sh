@@ -12,3 +12,5 @@ for c in FETCH_SIZE WRITE_SIZE SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE; do
   rocprofv3 --pmc $c -d gpurun_out/${tag}_unsplit_pmc_$c -o run -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-graph --no-halves > gpurun_out/${tag}_unsplit_pmc_$c.log 2>&1
 done
 ls gpurun_out/${tag}_*/*
+# the databases of one round exceed the 64 MiB gpurun pulls back: reduce them on the box (tools/rocpd_summary.py, tools/rocpd_counters.py)
+# into gpurun_out/sum/ and delete the gpurun_out/${tag}_* directories before the call ends
