@@ -81,3 +81,24 @@ def test_world_camera_round_trip(H):
     X = rng.normal(size=(5, 17, 3))
     back = H.camera_to_world(H.world_to_camera(X, q, t), q, t)
     assert np.abs(back - X).max() < 1e-12
+
+
+def test_amass_matches_reference_outputs():
+    """amass.py against the reference's AMASSDataset run on tests/golden/amass_tiny (make_amass_golden.py): split patterns,
+    regex filters, joint reorder, down-sampling, and the 18-value camera vectors -- bit exact."""
+    A = importlib.import_module("uplift_upsample_3dhpe_amd.amass")
+    exp = np.load(os.path.join(G, "amass_tiny_expected.npz"))
+    cases = {"train": ("train", 1), "val": ("val", 1), "train_ds2": ("train", 2),
+             "custom": ([("CMU", "0[12]", ".*_01_poses"), ("ACCAD", ".*", "A2.*")], 1)}
+    for tag, (split, ds) in cases.items():
+        a = A.AMASSDataset(os.path.join(G, "amass_tiny"), os.path.join(G, "h36m_tiny_3d.npz"), split, downsample=ds)
+        want = {k[len(tag) + 1:]: exp[k] for k in exp.files if k.startswith(tag + "/") and not k.endswith("__cameras__")}
+        got = {f"{d}/{s}/{n}": rec["positions"] for d, ss in a._data.items() for s, aa in ss.items() for n, rec in aa.items()}
+        assert sorted(got) == sorted(want), (tag, sorted(got), sorted(want))
+        for k in want:
+            assert got[k].dtype == want[k].dtype and np.array_equal(got[k], want[k]), (tag, k)
+        cams = A.camera_table(a)
+        assert cams.dtype == np.float32 and np.array_equal(cams, exp[f"{tag}/__cameras__"])
+        seqs, rates = A.sequences(a)
+        assert len(seqs) == len(want) and all(r == 50 for r in rates)
+    assert sorted(a._data) == ["ACCAD", "CMU"] and len(cams) == 28 and cams.shape[1] == 18       # 7 subjects x 4 cameras
