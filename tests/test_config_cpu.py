@@ -99,3 +99,29 @@ def test_weight_spec_order_and_init():
     assert np.all(w["temporal_block_1/norm1/gamma"] == 1) and np.all(w["temporal_fc/bias"] == 0)
     pe = w["temporal_pe/positional_encoding_weights"]
     assert abs(pe).max() <= 0.04 + 1e-7 and 0.015 < pe.std() < 0.02  # truncated normal, sigma .02
+
+
+def test_config_matches_the_reference_classes(tmp_path):
+    """UpliftUpsampleConfig against what the reference's own Config / UpliftUpsampleConfig (pure Python, run in the build
+    container by tests/golden/make_config_golden.py) make of the class defaults, of every shipped config/*.json and of a
+    text-mode file: the same set of public attributes with the same values."""
+    exp = json.load(open(os.path.join(util.ROOT, "tests", "golden", "config_expected.json")))
+
+    def public(c):
+        return {k: getattr(c, k) for k in dir(c) if not k.startswith("_") and not callable(getattr(c, k))}
+
+    def same(got, want, tag):
+        assert sorted(got) == sorted(want), (tag, sorted(set(got) ^ set(want)))
+        for k, v in want.items():
+            g = got[k]
+            g = json.loads(json.dumps(g, default=str))            # tuples -> lists etc., as the fixture was serialised
+            assert g == v, (tag, k, g, v)
+
+    same(public(pkg.UpliftUpsampleConfig()), exp["__defaults__"], "defaults")
+    for name in ("amass_351.json", "h36m_351.json", "h36m_351_pt.json", "h36m_81.json"):
+        same(public(pkg.UpliftUpsampleConfig(os.path.join(util.ROOT, "config", name))), exp[name], name)
+    t = tmp_path / "c.txt"
+    t.write_text("# comment\nSEQUENCE_LENGTH 11\nSTRIDES [3, 3]\nARCH 'x'\nMASK_STRIDE [2, 4]\n")
+    with pytest.warns(UserWarning):                   # single quotes: the reference warns and reads them as double quotes
+        c = pkg.UpliftUpsampleConfig(str(t))
+    same(public(c), exp["__text_mode__"], "text mode")

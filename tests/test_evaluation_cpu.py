@@ -110,3 +110,32 @@ def test_window_oracle_shapes_and_padding():
     rows = WO.sample_list([5, 3], [50, 100], 2, True, False)
     assert rows.tolist() == [[0, 0, 0, 50], [0, 2, 0, 50], [0, 4, 0, 50], [0, 0, 1, 50], [0, 2, 1, 50], [0, 4, 1, 50],
                              [1, 0, 0, 100], [1, 2, 0, 100], [1, 0, 1, 100], [1, 2, 1, 100]]
+
+
+def test_metrics_match_the_reference_modules():
+    """evaluation.py against outputs of the reference's own common/dataset/metrics.py and action_wise_eval.py (both numpy
+    only; tests/golden/make_metrics_golden.py ran them in the build container).  The batched SVD / vectorised code paths
+    differ from the reference's per-pose loops, so agreement is to rounding (1e-9 m), not bitwise."""
+    import os
+    g = np.load(os.path.join(util.ROOT, "tests", "golden", "metrics_expected.npz"))
+    pred, gt, root, actions = g["pred"], g["gt"], int(g["root"]), g["actions"]
+    tol = 1e-9
+    assert np.abs(E.mpjpe(pred, gt, root, normalize=False) - g["mpjpe_jp"]).max() < tol
+    assert abs(E.mpjpe(pred, gt, root) - float(g["mpjpe"])) < tol
+    assert np.abs(E.nmpjpe(pred, gt, root, alignment="root", normalize=False) - g["nmpjpe_root_jp"]).max() < tol
+    assert abs(E.nmpjpe(pred, gt, root) - float(g["nmpjpe_root"])) < tol
+    assert np.abs(E.nmpjpe(pred, gt, root, alignment="mean", normalize=False) - g["nmpjpe_mean_jp"]).max() < tol
+    assert np.abs(E.pmpjpe(pred, gt, normalize=False) - g["pmpjpe_jp"]).max() < 1e-8
+    assert abs(E.pmpjpe(pred, gt) - float(g["pmpjpe"])) < 1e-8
+    fr = E.frame_wise_eval(pred, gt, root)
+    assert np.abs(np.array([fr["mpjpe"], fr["nmpjpe"], fr["pampjpe"]]) - g["frame_wise"]).max() < 1e-5        # millimetres
+    frame_results, average_results, per_action = E.h36_action_wise_eval(pred, gt, actions, root)
+    keys = ("mpjpe", "nmpjpe", "pampjpe")
+    assert np.abs(np.array([frame_results[k] for k in keys]) - g["aw_frame"]).max() < 1e-5
+    assert np.abs(np.array([average_results[k] for k in keys]) - g["aw_average"]).max() < 1e-5
+    assert list(per_action.keys()) == [str(a) for a in g["aw_actions"]]
+    assert np.abs(np.array([[d[k] for k in keys] for d in per_action.values()]) - g["aw_per_action"]).max() < 1e-5
+    for stride in (5, 10):
+        interp, keyframes = E.interpolate_between_keyframes(pred, g[f"frame_indices_{stride}"], stride)
+        assert np.array_equal(keyframes, g[f"keyframes_{stride}"])
+        assert np.abs(interp - g[f"interp_{stride}"]).max() < 1e-12

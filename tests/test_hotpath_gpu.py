@@ -217,3 +217,20 @@ def test_optional_kernel_paths_agree(env, monkeypatch):
     assert d <= 3e-5, d
     if env not in ("UU3D_ATTN_PIPE", "UU3D_G_TILE22", "UU3D_S2T_PLANES"):      # those only reschedule / re-tile the same products (bit-identical is fine)
         assert d > 0.0, "the switch did not change the path"
+
+
+def test_mpjpe_kernel_matches_the_reference_metric():
+    """uu3d_mpjpe against the reference's own metrics.mpjpe(normalize=False) (tests/golden/make_metrics_golden.py
+    ran common/dataset/metrics.py in the build container): per-joint errors incl. the -1 flags of invalid joints.  The
+    kernel takes float32 poses, the fixture holds float64: agreement to float32 input rounding (2e-7 m)."""
+    from uplift_upsample_3dhpe_amd import harness
+    g = np.load(os.path.join(util.ROOT, "tests", "golden", "metrics_expected.npz"))
+    pred = torch.from_numpy(g["pred"].astype(np.float32)).cuda()
+    gt = torch.from_numpy(g["gt"].astype(np.float32)).cuda()
+    err = harness.per_joint_error(pred, gt, int(g["root"])).cpu().numpy()
+    want = g["mpjpe_jp"]
+    assert err.dtype == np.float64 and err.shape == want.shape
+    assert np.array_equal(err < 0, want < 0) and np.all(err[want < 0] == -1.0)
+    assert np.abs(err - want)[want >= 0].max() < 2e-7
+    mean_mm = err[err >= 0].mean() * 1000.0
+    assert abs(mean_mm - float(g["mpjpe"]) * 1000.0) < 1e-3

@@ -13,6 +13,7 @@ Mirrors the behaviour of the reference's two config classes so that the unmodifi
 """
 import copy as _copy
 import json
+import warnings
 import os
 
 
@@ -53,7 +54,10 @@ class Config(object):
                     parts = line.split(" ", 1)
                     if len(parts) < 2 or not parts[1].strip():
                         continue
-                    text = parts[1].strip().replace("'", '"')
+                    text = parts[1].strip()
+                    if "'" in text:            # same warning as the reference (common/utils/config.py:78-81), then treated as double quotes
+                        warnings.warn("Avoid single quotes literals in config files. Use double quotes instead")
+                        text = text.replace("'", '"')
                     setattr(self, parts[0], json.loads(text))
         else:
             with open(config_file, "r") as f:
