@@ -135,3 +135,37 @@ def test_h36m_npz_to_model_end_to_end():
     # the window centres are the videos' own frames: the generator's 3D target equals the ingested camera-frame pose
     v, i = gen.descriptors()[0][:2]
     assert np.allclose(batch["kp3d"][0, mid].cpu().numpy(), p3d[int(v)][int(i)], atol=1e-6)
+
+
+@pytest.mark.parametrize("tag,mode", [
+    ("eval41", dict(seq_len=41, stride=2, padding_type="copy", mask_stride=4, stride_mask_align_global=True, flip_augment=False, shuffle=False)),
+    ("train71", dict(seq_len=71, stride=5, padding_type="copy", mask_stride=[5, 10, 20], rand_shift_stride_mask=True, flip_augment=True, shuffle=True, subsample=3)),
+    ("inbatch9", dict(seq_len=9, stride=1, padding_type="zeros", mask_stride=None, flip_augment=True, in_batch_augment=True, shuffle=True)),
+    ("zeros27", dict(seq_len=27, stride=3, padding_type="zeros", mask_stride=[3, 9], stride_mask_align_global=True, flip_augment=False, shuffle=False, subsample=2)),
+])
+def test_windows_match_the_reference_generator(tag, mode):
+    """data.SequenceGenerator + uu3d_gather_windows against what the reference's own H36mSequenceGenerator yields
+    (tests/golden/make_windows_golden.py executed the class from uplifiting_dataset.py:213-428 in the build container):
+    sample order incl. shuffling and random draws, windows, padding masks, stride masks, flips -- bit exact; the first 24
+    windows of an epoch are stored, the rest enters weighted float64 checksums."""
+    import os
+    g = np.load(os.path.join(util.ROOT, "tests", "golden", "windows_expected.npz"))
+    n_videos = len(g["lens"])
+    p2 = [g[f"video2d_{v}"] for v in range(n_videos)]
+    p3 = [g[f"video3d_{v}"] for v in range(n_videos)]
+    table = D.PoseTable(p2, p3, subjects=g["subjects"], actions=g["actions"], frame_rates=g["rates"])
+    gen = D.SequenceGenerator(table, flip_lr_indices=FLIP, seed=3, **mode)
+    desc = gen.descriptors()
+    assert len(desc) == len(gen) == int(g[f"{tag}/count"])
+    out = gen.gather(desc, zero_masked=False)
+    k2, k3 = out["kp2d"].cpu().numpy(), out["kp3d"].cpu().numpy()
+    sm, pm = out["stride_mask"].cpu().numpy(), out["mask"].cpu().numpy()
+    assert np.array_equal(out["index"], g[f"{tag}/index"])
+    assert np.array_equal(out["subjects"], g[f"{tag}/subject"]) and np.array_equal(out["actions"], g[f"{tag}/action"])
+    k = len(g[f"{tag}/seq2d"])
+    assert np.array_equal(k2[:k], g[f"{tag}/seq2d"]) and np.array_equal(k3[:k], g[f"{tag}/seq3d"])
+    assert np.array_equal(pm[:k].astype(np.float32), g[f"{tag}/mask"]) and np.array_equal(sm[:k].astype(bool), g[f"{tag}/stride_mask"])
+    w = 1.0 + (np.arange(len(desc)) % 7)
+    chk = np.array([(w * k3.astype(np.float64).sum(axis=(1, 2, 3))).sum(), (w * k2.astype(np.float64).sum(axis=(1, 2, 3))).sum(),
+                    (w * pm.astype(np.float64).sum(axis=1)).sum(), (w * sm.astype(np.float64).sum(axis=1)).sum()])
+    assert np.allclose(chk, g[f"{tag}/checksum"], rtol=1e-9, atol=1e-6), (chk, g[f"{tag}/checksum"])
