@@ -161,7 +161,7 @@ int uu3d_gather_windows(const float* poses_dev, const int64_t* video_start_dev, 
 /*
  * World -> camera coordinates -> 2D projection with the Human3.6M camera model, one camera per window: replaces
  * tf_world_to_cam_and_2d (common/dataset/uplifiting_dataset.py:669-761), the on-the-fly AMASS projection of training.
- *   world_dev (B, N, J, 3) f32; cams_dev (B, 19) f32 = quaternion wxyz | translation | 12 intrinsics (res, focal,
+ *   world_dev (B, N, J, 3) f32; cams_dev (B, 18) f32 = quaternion wxyz | translation | 11 intrinsics (res, focal,
  *   centre, 3 radial, 2 tangential coefficients at [7..18) as the reference stores them);
  *   cam3d_dev (B, N, J, 3) or NULL; kp2d_dev (B, N, J, 2) or NULL.
  */

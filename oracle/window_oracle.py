@@ -53,7 +53,8 @@ def one_window(video, i, seq_len, stride, pad_type, abs_mask_stride, shift_mode,
 
 
 def world_to_cam_and_2d(seq3d, cam):
-    """One window: seq3d (N, J, 3) world coordinates, cam (19,) -> (camera-space 3D, 2D), float64.
+    """One window: seq3d (N, J, 3) world coordinates, cam (18,) = quaternion | translation | 11 intrinsics -> (camera-space 3D,
+    2D), float64 (the reference slices cam[7:19]; its vectors hold 18 values, uplifiting_dataset.py:506-515).
     Follows uplifiting_dataset.py:669-761 (tf_world_to_cam :713-716 with tf_qrot :697-705 / tf_qinverse :707-711,
     tf_project_to_2d :735-761)."""
     q, t, intr = cam[:4], cam[4:7], cam[7:19]

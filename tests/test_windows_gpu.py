@@ -94,7 +94,7 @@ def test_world_to_cam_and_2d_matches_the_restatement():
     rng = np.random.default_rng(5)
     B, N, J = 7, 13, 17
     world = rng.normal(0, 0.5, size=(B, N, J, 3)) + np.array([0.0, 0.0, 1.0])
-    cams = np.zeros((B, 19))
+    cams = np.zeros((B, 18))
     q = rng.normal(size=(B, 4)); q /= np.linalg.norm(q, axis=1, keepdims=True)
     cams[:, :4] = q
     cams[:, 4:7] = rng.normal(0, 0.3, size=(B, 3)) + np.array([0.0, 0.0, -4.5])
@@ -169,3 +169,32 @@ def test_windows_match_the_reference_generator(tag, mode):
     chk = np.array([(w * k3.astype(np.float64).sum(axis=(1, 2, 3))).sum(), (w * k2.astype(np.float64).sum(axis=(1, 2, 3))).sum(),
                     (w * pm.astype(np.float64).sum(axis=1)).sum(), (w * sm.astype(np.float64).sum(axis=1)).sum()])
     assert np.allclose(chk, g[f"{tag}/checksum"], rtol=1e-9, atol=1e-6), (chk, g[f"{tag}/checksum"])
+
+
+@pytest.mark.parametrize("tag,mode", [
+    ("train9", dict(seq_len=9, stride=2, padding_type="copy", mask_stride=[2, 4, 8], rand_shift_stride_mask=True, flip_augment=True, shuffle=True)),
+    ("eval27", dict(seq_len=27, stride=1, padding_type="zeros", mask_stride=5, stride_mask_align_global=True, flip_augment=False, shuffle=False)),
+    ("inbatch5", dict(seq_len=5, stride=1, padding_type="copy", mask_stride=None, flip_augment=True, in_batch_augment=True, shuffle=True, subsample=2)),
+])
+def test_amass_windows_match_the_reference_generator(tag, mode):
+    """amass.AMASSDataset -> data.AmassSequenceGenerator against what the reference's own AMASSSequenceGenerator yields on the
+    same tiny files (tests/golden/make_amass_windows_golden.py): sample order, per-sample camera draws, 3D windows, masks,
+    flips -- bit exact -- and the camera projection kernel runs on the result."""
+    import os
+    from uplift_upsample_3dhpe_amd import amass
+    gdir = os.path.join(util.ROOT, "tests", "golden")
+    g = np.load(os.path.join(gdir, "amass_windows_expected.npz"))
+    a = amass.AMASSDataset(os.path.join(gdir, "amass_tiny"), os.path.join(gdir, "h36m_tiny_3d.npz"), "train")
+    seqs, rates = amass.sequences(a)
+    table = D.PoseTable(None, seqs, frame_rates=rates)
+    gen = D.AmassSequenceGenerator(table, amass.camera_table(a), flip_lr_indices=FLIP, seed=4, **mode)
+    desc = gen.descriptors()
+    assert len(desc) == len(gen) == len(g[f"{tag}/index"])
+    out = gen.gather(desc, gen.camera_indices)
+    assert np.array_equal(out["index"], g[f"{tag}/index"])
+    assert np.array_equal(out["kp3d"].cpu().numpy(), g[f"{tag}/seq3d"])
+    assert np.array_equal(out["cams"].cpu().numpy(), g[f"{tag}/cams"])
+    assert np.array_equal(out["mask"].cpu().numpy().astype(np.float32), g[f"{tag}/mask"])
+    assert np.array_equal(out["stride_mask"].cpu().numpy().astype(bool), g[f"{tag}/stride_mask"])
+    cam3d, kp2d = D.world_to_cam_and_2d(out["kp3d"], out["cams"])[:2]
+    assert tuple(kp2d.shape) == tuple(out["kp3d"].shape[:3]) + (2,) and bool(torch.isfinite(cam3d).all())

@@ -172,7 +172,7 @@ world_to_cam_2d_kernel(const float* __restrict__ world, const float* __restrict_
 {
     const long idx = (long)blockIdx.x * 256 + threadIdx.x;
     if (idx >= total) return;
-    const float* cm = cams + (idx / per_window) * 19;
+    const float* cm = cams + (idx / per_window) * 18;       // quaternion wxyz | translation | 11 intrinsics: the reference's vectors are 18 wide
     const float qw = cm[0], qx = -cm[1], qy = -cm[2], qz = -cm[3];                 // inverse of a unit quaternion
     const float vx = world[idx * 3] - cm[4], vy = world[idx * 3 + 1] - cm[5], vz = world[idx * 3 + 2] - cm[6];
     // uv = qvec x v ; uuv = qvec x uv ; out = v + 2 (w uv + uuv)        (tf_qrot, :697-705)

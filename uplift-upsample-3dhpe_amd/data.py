@@ -20,17 +20,18 @@ class PoseTable(object):
         import torch
         self.torch = torch
         self.device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
-        self.lens = np.array([len(v) for v in poses_2d], np.int32)
+        main = poses_2d if poses_2d is not None else poses_3d          # AMASS: 3D sequences only, 2D comes from the camera projection
+        self.lens = np.array([len(v) for v in main], np.int32)
         self.starts = np.concatenate([[0], np.cumsum(self.lens)[:-1]]).astype(np.int64)
-        self.J = poses_2d[0].shape[1]
-        self.kp2d = torch.from_numpy(np.concatenate(poses_2d, 0).astype(np.float32)).to(self.device)
+        self.J = main[0].shape[1]
+        self.kp2d = None if poses_2d is None else torch.from_numpy(np.concatenate(poses_2d, 0).astype(np.float32)).to(self.device)
         self.kp3d = None
         if poses_3d is not None:
-            assert all(len(a) == len(b) for a, b in zip(poses_2d, poses_3d))
+            assert all(len(a) == len(b) for a, b in zip(main, poses_3d))
             self.kp3d = torch.from_numpy(np.concatenate(poses_3d, 0).astype(np.float32)).to(self.device)
         self.d_starts = torch.from_numpy(self.starts).to(self.device)
         self.d_lens = torch.from_numpy(self.lens).to(self.device)
-        n = len(poses_2d)
+        n = len(main)
         self.subjects = np.asarray(subjects if subjects is not None else np.zeros(n, np.int64))
         self.actions = np.asarray(actions if actions is not None else np.zeros(n, np.int64))
         self.frame_rates = np.asarray(frame_rates if frame_rates is not None else np.full(n, 50), np.int64)
@@ -84,13 +85,17 @@ class SequenceGenerator(object):
         """One epoch of window descriptors (W, 6) int32 = (video, centre, stride, abs mask stride, mask shift, flip), in
         the order and with the random draws of next_epoch_iterator (:303-428)."""
         locs = self.sequence_locations
+        n_cams = getattr(self, "_n_cameras", None)         # AmassSequenceGenerator: one camera drawn per sample from self.rng
         if self.shuffle:
             locs = locs.copy()
             self.rng.shuffle(locs)
         else:
+            if n_cams is not None:
+                self.rng = np.random.default_rng(self.seed)             # uplifiting_dataset.py:549-551: deterministic cameras in eval
             self.stride_shift_rng = np.random.default_rng(self.seed)
             self.mask_stride_rng = np.random.default_rng(self.seed)
         out = []
+        self.camera_indices = []
         for s_i, i, do_flip, frame_rate in locs:
             stride, mult = self.stride, 1
             if frame_rate % self.target_frame_rate != 0:
@@ -114,8 +119,12 @@ class SequenceGenerator(object):
                 max_shift = int(np.ceil((r - 1) / 2))
                 shift = int(self.stride_shift_rng.integers(low=-max_shift, high=max_shift, endpoint=(r % 2 != 0))) * stride
             out.append((s_i, i, stride, ams, shift, int(do_flip)))
+            if n_cams is not None:
+                self.camera_indices.append(int(self.rng.integers(low=0, high=n_cams, size=1)[0]))
             if self.in_batch_augment and self.flip_augment:
                 out.append((s_i, i, stride, ams, shift, 1 - int(do_flip)))
+                if n_cams is not None:
+                    self.camera_indices.append(self.camera_indices[-1])      # the flipped copy keeps the sample's camera
         return np.array(out, dtype=np.int32).reshape(-1, 6)
 
     def gather(self, desc, zero_masked=True, with_3d=True):
@@ -156,16 +165,68 @@ class SequenceGenerator(object):
             yield self.gather(blk, **kw)
 
 
+class AmassSequenceGenerator(SequenceGenerator):
+    """``AMASSSequenceGenerator`` (uplifiting_dataset.py:431-661): 3D windows of world-frame sequences, each with one of the
+    Human3.6M cameras drawn at random (``amass.camera_table``); the 2D input and the camera-frame target come from
+    ``world_to_cam_and_2d`` afterwards.  A flip mirrors the pose sequence only, never the camera (:641-650)."""
+
+    def __init__(self, table, cameras, seq_len, **kw):
+        super().__init__(table, seq_len, **kw)
+        self.cameras = np.ascontiguousarray(cameras, np.float32)
+        self._n_cameras = len(self.cameras)
+
+    def descriptors(self):
+        """As the base class, plus ``self.camera_indices``.  Reference quirk kept for parity: without in-batch augmentation
+        the reference tests ``if do_flip is True`` on a numpy bool (uplifiting_dataset.py:583,641), which is never true, so
+        the samples listed as flipped come out UNFLIPPED (duplicates); only the in-batch copy (:654-659) is mirrored."""
+        desc = super().descriptors()
+        if not self.in_batch_augment:
+            desc[:, 5] = 0
+        return desc
+
+    def gather(self, desc, camera_indices=None):
+        """-> {"kp3d" (B, N, J, 3) world frame, "cams" (B, 18), "stride_mask", "mask", "index"} on the device."""
+        torch, t = self._torch, self.table
+        lib = _capi.load_library()
+        desc = np.ascontiguousarray(desc, np.int32)
+        B, N, J = len(desc), self.seq_len, t.J
+        d_desc = torch.from_numpy(desc).to(t.device)
+        stream = torch.cuda.current_stream(t.device).cuda_stream
+        kp3d = torch.empty((B, N, J, 3), dtype=torch.float32, device=t.device)
+        smask = torch.empty((B, N), dtype=torch.uint8, device=t.device)
+        pmask = torch.empty((B, N), dtype=torch.uint8, device=t.device)
+        fl = C.c_void_p(self._d_flip.data_ptr()) if self._d_flip is not None else None
+        st = lib.uu3d_gather_windows(C.c_void_p(t.kp3d.data_ptr()), C.c_void_p(t.d_starts.data_ptr()), C.c_void_p(t.d_lens.data_ptr()),
+                                     C.c_void_p(d_desc.data_ptr()), fl, B, N, J, 3, int(self.pad_edge), 0,
+                                     C.c_void_p(kp3d.data_ptr()), C.c_void_p(smask.data_ptr()), C.c_void_p(pmask.data_ptr()),
+                                     C.c_void_p(stream))
+        _capi.check(lib, st, None)
+        out = {"kp3d": kp3d, "stride_mask": smask, "mask": pmask, "index": desc[:, 1].copy()}
+        if camera_indices is not None:
+            out["cams"] = torch.from_numpy(self.cameras[np.asarray(camera_indices, np.int64)]).to(t.device)
+        return out
+
+    def batches(self, batch_size, drop_remainder=False):
+        desc = self.descriptors()
+        cams = np.asarray(self.camera_indices, np.int64)
+        for b in range(0, len(desc), batch_size):
+            if drop_remainder and len(desc) - b < batch_size:
+                break
+            yield self.gather(desc[b:b + batch_size], cams[b:b + batch_size])
+
+
 def world_to_cam_and_2d(sequences_3d, cams):
     """tf_world_to_cam_and_2d (uplifiting_dataset.py:669-761) for a batch on the device: sequences_3d (B, N, J, 3) world
-    coordinates, cams (B, 19) -> (camera-space 3D (B, N, J, 3), projected 2D (B, N, J, 2))."""
+    coordinates, cams (B, 18) = orientation quaternion | translation | 11 intrinsics (``amass.camera_table``; the reference
+    documents "4+3+11" and slices ``cam[7:19]``, which on an 18-vector is those 11) -> (camera-space 3D (B, N, J, 3),
+    projected 2D (B, N, J, 2))."""
     import torch
     lib = _capi.load_library()
     x = sequences_3d.to(torch.float32).contiguous()
     c = cams.to(device=x.device, dtype=torch.float32).contiguous()
     B, N, J = x.shape[0], x.shape[1], x.shape[2]
-    if tuple(c.shape) != (B, 19) or x.shape[3] != 3:
-        raise ValueError("sequences_3d must be (B, N, J, 3) and cams (B, 19)")
+    if tuple(c.shape) != (B, 18) or x.shape[3] != 3:
+        raise ValueError("sequences_3d must be (B, N, J, 3) and cams (B, 18)")
     cam3d = torch.empty_like(x)
     kp2d = torch.empty((B, N, J, 2), dtype=torch.float32, device=x.device)
     st = lib.uu3d_world_to_cam_2d(C.c_void_p(x.data_ptr()), C.c_void_p(c.data_ptr()), B, N, J, C.c_void_p(cam3d.data_ptr()),
