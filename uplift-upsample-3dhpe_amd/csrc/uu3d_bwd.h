@@ -190,24 +190,41 @@ colsum4_kernel(const float* __restrict__ X, const int ldx, const int R, const in
     }
 }
 // out[i] (+)= sum_k partial[k * pstride + i], i < n.  Thread (column c of 16, lane q of 16): lane q adds the
-// slices k = q, q+16, ... in order; the 16 lane sums are then added in lane order -> deterministic.
-static __global__ void __launch_bounds__(256)
+// slices k = q, q+QL, ... in order; the QL lane sums are then added in lane order -> deterministic.
+template <int QL>
+__global__ void __launch_bounds__(16 * QL)
 reduce_partials_kernel(const float* __restrict__ partial, const int n, const size_t pstride, const int slices,
                        float* __restrict__ out, const int accumulate)
 {
-    __shared__ float red[16][17];
+    __shared__ float red[QL][17];
     const int cl = threadIdx.x & 15, q = threadIdx.x >> 4;
     const int c = blockIdx.x * 16 + cl;
-    float s = 0.f;
-    if (c < n) for (int k = q; k < slices; k += 16) s += partial[(size_t)k * pstride + c];
-    red[q][cl] = s;
+    // four slices in flight per lane (the loop is the latency of its loads: a 500-slice combine of a 32-float result
+    // ran 32 dependent rounds on 2 workgroups); s0..s3 are added in a fixed order
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    if (c < n) {
+        const float* p = partial + c;
+        int k = q;
+        for (; k + 3 * QL < slices; k += 4 * QL) {
+            const float a0 = p[(size_t)k * pstride], a1 = p[(size_t)(k + QL) * pstride];
+            const float a2 = p[(size_t)(k + 2 * QL) * pstride], a3 = p[(size_t)(k + 3 * QL) * pstride];
+            s0 += a0; s1 += a1; s2 += a2; s3 += a3;
+        }
+        for (; k < slices; k += QL) s0 += p[(size_t)k * pstride];
+    }
+    red[q][cl] = (s0 + s1) + (s2 + s3);
     __syncthreads();
     if (q == 0 && c < n) {
         float t = red[0][cl];
 #pragma unroll
-        for (int k = 1; k < 16; ++k) t += red[k][cl];
+        for (int k = 1; k < QL; ++k) t += red[k][cl];
         out[c] = accumulate ? out[c] + t : t;
     }
+}
+// out[0..n) (+)= sum over `slices` partial rows: 64 lanes per column when there are many slices, 16 otherwise.
+inline void launch_reduce_partials(const float* partial, int n, size_t pstride, int slices, float* out, int accumulate, hipStream_t stream) {
+    if (slices >= 128) hipLaunchKernelGGL(reduce_partials_kernel<64>, dim3((n + 15) / 16), dim3(1024), 0, stream, partial, n, pstride, slices, out, accumulate);
+    else hipLaunchKernelGGL(reduce_partials_kernel<16>, dim3((n + 15) / 16), dim3(256), 0, stream, partial, n, pstride, slices, out, accumulate);
 }
 
 // ------------------------------------------------------------------------------------
@@ -282,6 +299,65 @@ ln_bwd_kernel(const float* __restrict__ x, const float* __restrict__ dy, const f
     for (int idx = threadIdx.x; idx < 2 * D; idx += 256) {
         const int which = idx / D, c = idx - which * D;
         partial[((size_t)blockIdx.x * 2 + which) * D + c] = (red[0][which][c] + red[1][which][c]) + (red[2][which][c] + red[3][which][c]);
+    }
+}
+
+// LayerNorm backward for NARROW rows (D == 4 * LPR <= 64, the spatial stack's D = 32): LPR lanes per row, 256 / LPR rows
+// per workgroup at once (the one-row-per-wave kernel used 8 of 64 lanes and ran its rows one after the other: 43 us for a
+// 30 MB pass).  Row group rg of workgroup b takes the rows b*RG*rpg + rr*RG + rg, so that a wave reads consecutive rows.
+// dx is bit-identical to ln_bwd_kernel (the LPR-lane butterfly is the tail of the 64-lane one); the dgamma / dbeta partials
+// are combined over the row groups in group order.
+template <int LPR>
+__global__ void __launch_bounds__(256)
+ln_bwd_narrow_kernel(const float* __restrict__ x, const float* __restrict__ dy, const float2* __restrict__ stats,
+                     const float* __restrict__ gamma, const int ld, const int M, const int rows_per_group,
+                     float* __restrict__ dx_out, const int accumulate, float* __restrict__ partial)
+{
+    constexpr int RG = 256 / LPR, D = 4 * LPR;
+    const int l = threadIdx.x % LPR, rg = threadIdx.x / LPR;
+    const f32x4 gm = *reinterpret_cast<const f32x4*>(gamma + 4 * l);
+    f32x4 dg = (f32x4){0.f, 0.f, 0.f, 0.f}, db = dg;
+    const int base = blockIdx.x * RG * rows_per_group + rg;
+#pragma unroll 2
+    for (int rr = 0; rr < rows_per_group; ++rr) {
+        const int row = base + rr * RG;
+        const bool ok = row < M;
+        const int rw = ok ? row : 0;
+        const float2 st = stats[rw];
+        f32x4 xv = *reinterpret_cast<const f32x4*>(x + (size_t)rw * ld + 4 * l);
+        f32x4 dv = *reinterpret_cast<const f32x4*>(dy + (size_t)rw * ld + 4 * l);
+        if (!ok) { xv = (f32x4){st.x, st.x, st.x, st.x}; dv = (f32x4){0.f, 0.f, 0.f, 0.f}; }
+        f32x4 xh, g;
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            xh[e] = (xv[e] - st.x) * st.y;
+            g[e] = dv[e] * gm[e];
+            s1 += g[e]; s2 += g[e] * xh[e];
+            dg[e] += dv[e] * xh[e]; db[e] += dv[e];
+        }
+#pragma unroll
+        for (int o = LPR / 2; o > 0; o >>= 1) { s1 += __shfl_xor(s1, o); s2 += __shfl_xor(s2, o); }
+        const float m1 = s1 / (float)D, m2 = s2 / (float)D;
+        if (ok) {
+            f32x4 o;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o[e] = st.y * (g[e] - m1 - xh[e] * m2);
+            float* po = dx_out + (size_t)row * ld + 4 * l;
+            if (accumulate) { const f32x4 old = *reinterpret_cast<const f32x4*>(po); o += old; }
+            *reinterpret_cast<f32x4*>(po) = o;
+        }
+    }
+    __shared__ __attribute__((aligned(16))) float red[RG][2][D];
+    *reinterpret_cast<f32x4*>(&red[rg][0][4 * l]) = dg;
+    *reinterpret_cast<f32x4*>(&red[rg][1][4 * l]) = db;
+    __syncthreads();
+    if (threadIdx.x < 2 * D) {
+        const int which = threadIdx.x / D, c = threadIdx.x - which * D;
+        float t = red[0][which][c];
+#pragma unroll 8
+        for (int k = 1; k < RG; ++k) t += red[k][which][c];
+        partial[((size_t)blockIdx.x * 2 + which) * D + c] = t;
     }
 }
 

@@ -97,7 +97,7 @@ inline int launch_colsum(const float* x, int ldx, int R, int C, int period, cons
         hipLaunchKernelGGL(colsum4_kernel, dim3(xb, slices), dim3(256), 0, stream, x, ldx, R, C, scratch, slices, cgs);
     } else
     hipLaunchKernelGGL(colsum_kernel, dim3((C + 63) / 64, slices), dim3(256), 0, stream, x, ldx, R, C, period, mask, want, scratch, slices);
-    hipLaunchKernelGGL(reduce_partials_kernel, dim3((P * C + 15) / 16), dim3(256), 0, stream, scratch, P * C, (size_t)P * C, slices, out, accumulate);
+    launch_reduce_partials(scratch, P * C, (size_t)P * C, slices, out, accumulate, stream);
     return hip_status();
 }
 
@@ -106,6 +106,20 @@ inline int launch_ln_bwd(const float* x, const float* dy, const float2* stats, c
                          int accumulate, float* dgamma, float* dbeta, int acc_params, float* scratch, size_t scratch_floats, hipStream_t stream) {
     // wide rows (D = 384): >= 500 workgroups at M = 4544 (8 rows per wave left 114 of 256 CUs idle), <= 2048 partial rows;
     // the spatial stack's D = 32 rows are cheap and many (77 k): fewer, longer workgroups keep the combine short
+    if ((D == 32 || D == 64) && ld % 4 == 0) {          // narrow rows: D / 4 lanes per row, 256 * 4 / D rows per workgroup at once
+        const int RG = 1024 / D;
+        int rpg = std::max(4, (M + RG * 512 - 1) / (RG * 512));
+        int wgs = (M + RG * rpg - 1) / (RG * rpg);
+        while ((size_t)wgs * 2 * D > scratch_floats) { rpg *= 2; wgs = (M + RG * rpg - 1) / (RG * rpg); }
+        if (D == 32) hipLaunchKernelGGL(ln_bwd_narrow_kernel<8>, dim3(wgs), dim3(256), 0, stream, x, dy, stats, gamma, ld, M, rpg, dx, accumulate, scratch);
+        else hipLaunchKernelGGL(ln_bwd_narrow_kernel<16>, dim3(wgs), dim3(256), 0, stream, x, dy, stats, gamma, ld, M, rpg, dx, accumulate, scratch);
+        if (dbeta == dgamma + D) launch_reduce_partials(scratch, 2 * D, (size_t)2 * D, wgs, dgamma, acc_params, stream);
+        else {
+            launch_reduce_partials(scratch, D, (size_t)2 * D, wgs, dgamma, acc_params, stream);
+            launch_reduce_partials(scratch + D, D, (size_t)2 * D, wgs, dbeta, acc_params, stream);
+        }
+        return hip_status();
+    }
     int rpw = (D > 64) ? std::max(2, (M + 4 * 2048 - 1) / (4 * 2048)) : std::max(8, (M + 4 * 512 - 1) / (4 * 512));
     int wgs = (M + 4 * rpw - 1) / (4 * rpw);
     while ((size_t)wgs * 2 * D > scratch_floats) { rpw *= 2; wgs = (M + 4 * rpw - 1) / (4 * rpw); }
@@ -113,10 +127,10 @@ inline int launch_ln_bwd(const float* x, const float* dy, const float2* stats, c
     else hipLaunchKernelGGL(ln_bwd_kernel<4>, dim3(wgs), dim3(256), 0, stream, x, dy, stats, gamma, ld, D, M, rpw, dx, accumulate, scratch);
     // partial layout [wg][2][D] -> finish over "n = 2*D" with wgs slices; dgamma and dbeta must be adjacent? no: two calls
     if (dbeta == dgamma + D) {      // gamma and beta are neighbours in the flat gradient buffer: one combine over [dgamma | dbeta]
-        hipLaunchKernelGGL(reduce_partials_kernel, dim3((2 * D + 15) / 16), dim3(256), 0, stream, scratch, 2 * D, (size_t)2 * D, wgs, dgamma, acc_params);
+        launch_reduce_partials(scratch, 2 * D, (size_t)2 * D, wgs, dgamma, acc_params, stream);
     } else {
-        hipLaunchKernelGGL(reduce_partials_kernel, dim3((D + 15) / 16), dim3(256), 0, stream, scratch, D, (size_t)2 * D, wgs, dgamma, acc_params);
-        hipLaunchKernelGGL(reduce_partials_kernel, dim3((D + 15) / 16), dim3(256), 0, stream, scratch + D, D, (size_t)2 * D, wgs, dbeta, acc_params);
+        launch_reduce_partials(scratch, D, (size_t)2 * D, wgs, dgamma, acc_params, stream);
+        launch_reduce_partials(scratch + D, D, (size_t)2 * D, wgs, dbeta, acc_params, stream);
     }
     return hip_status();
 }

@@ -44,6 +44,37 @@ row_stats_kernel(const float* __restrict__ x, const int ld, const int D, const i
     if (lane == 0) stats[row] = make_float2(mean, 1.0f / sqrtf(q / (float)D + eps));
 }
 
+// The same statistics for NARROW rows (D == 4 * LPR <= 64: the spatial stack's D = 32): LPR lanes per row, 64 / LPR rows
+// per wave at once instead of one row on 8 of 64 lanes.  Bit-identical to row_stats_kernel: the butterfly over the LPR
+// lanes is the tail of the 64-lane one, whose other lanes hold zeros.
+template <int LPR>
+__global__ void __launch_bounds__(256)
+row_stats_narrow_kernel(const float* __restrict__ x, const int ld, const int M, const float eps, float2* __restrict__ stats)
+{
+    constexpr int RG = 256 / LPR;
+    const int l = threadIdx.x % LPR;
+    const int row = blockIdx.x * RG + threadIdx.x / LPR;
+    const bool ok = row < M;
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (ok) v = *reinterpret_cast<const float4*>(x + (size_t)row * ld + 4 * l);
+    float s = (v.x + v.y) + (v.z + v.w);
+#pragma unroll
+    for (int o = LPR / 2; o > 0; o >>= 1) s += __shfl_xor(s, o);
+    const float mean = s / (float)(4 * LPR);
+    const float a = v.x - mean, b = v.y - mean, cc = v.z - mean, d = v.w - mean;
+    float q = (a * a + b * b) + (cc * cc + d * d);
+#pragma unroll
+    for (int o = LPR / 2; o > 0; o >>= 1) q += __shfl_xor(q, o);
+    if (ok && l == 0) stats[row] = make_float2(mean, 1.0f / sqrtf(q / (float)(4 * LPR) + eps));
+}
+
+// Launch the row statistics: the narrow form when the rows are exactly 32 or 64 floats.
+inline void launch_row_stats(const float* x, int ld, int D, int M, float eps, float2* stats, hipStream_t stream) {
+    if (D == 32) hipLaunchKernelGGL(row_stats_narrow_kernel<8>, dim3((M + 31) / 32), dim3(256), 0, stream, x, ld, M, eps, stats);
+    else if (D == 64) hipLaunchKernelGGL(row_stats_narrow_kernel<16>, dim3((M + 15) / 16), dim3(256), 0, stream, x, ld, M, eps, stats);
+    else hipLaunchKernelGGL(row_stats_kernel<4>, dim3((M + 3) / 4), dim3(256), 0, stream, x, ld, D, M, eps, stats);
+}
+
 // metrics.mpjpe(normalize=False) (common/dataset/metrics.py:13-37), float64 arithmetic on
 // f32 inputs exactly as the reference's numpy call after its astype(np.float64).
 static __global__ void __launch_bounds__(256)

@@ -38,7 +38,7 @@ int uu3d_op_colsum(const float* x, int32_t ldx, int32_t R, int32_t C, int32_t pe
 
 int uu3d_op_row_stats(const float* x, int32_t ld, int32_t D, int32_t M, float eps, float* stats, void* stream) {
     if (!x || !stats || D < 4 || (D & 3) || D > 1024 || M < 1) return UU3D_ERR_INVALID_ARGUMENT;
-    hipLaunchKernelGGL(row_stats_kernel<4>, dim3((M + 3) / 4), dim3(256), 0, (hipStream_t)stream, x, ld, D, M, eps, (float2*)stats);
+    launch_row_stats(x, ld, D, M, eps, (float2*)stats, (hipStream_t)stream);
     return hipGetLastError() == hipSuccess ? UU3D_OK : UU3D_ERR_HIP;
 }
 
