@@ -78,6 +78,7 @@ def train_bench(args, world, rank, local_rank, use_dist):
     t0 = time.perf_counter()
     for _ in range(args.steps):
         loss = tr.train_step(x, gt, m)
+    enqueue = time.perf_counter() - t0                         # host time to launch the steps (no synchronisation inside a step)
     sync_all()
     elapsed = time.perf_counter() - t0
     if use_dist:
@@ -96,7 +97,7 @@ def train_bench(args, world, rank, local_rank, use_dist):
             "config": {"workload": f"config/{cfgname}.json train step (fwd+bwd+AdamW), N={N}, J={J}, batch {B}/GPU, "
                                    f"per-sample mask stride from {cfg.MASK_STRIDE}, DropPath {cfg.DROP_PATH_RATE}",
                        "global_batch": world * B, "parallelism": f"data-parallel x{world}, flat f32 gradient all-reduce"},
-            "model_tflops_3x_fwd": round(fl * seqs / world / elapsed / 1e12, 2), "loss": float(loss[0].item())}), flush=True)
+            "host_enqueue_ms_per_step": round(enqueue / args.steps * 1e3, 3), "model_tflops_3x_fwd": round(fl * seqs / world / elapsed / 1e12, 2), "loss": float(loss[0].item())}), flush=True)
     if use_dist:
         dist.destroy_process_group()
 

@@ -20,6 +20,10 @@ extern "C" {
 /* C[P][Q] = A[R][P]^T B[R][Q]  (dW = X^T dY).  scratch_dev holds split-K slabs (>= uu3d_op_scratch_floats()). */
 int uu3d_op_gemm_tn(const float* a_dev, int32_t lda, const float* b_dev, int32_t ldb, int32_t R, int32_t P, int32_t Q,
                     float* c_dev, int32_t ldc, float* scratch_dev, size_t scratch_floats, void* stream);
+/* The same product in the f16x3 arithmetic of the training step (gemm_tn_h3_kernel: f16 MFMA on hi / lo planes, fragments
+ * read transposed from LDS) when P, Q >= 128; narrower results fall back to the exact-f32 kernel. */
+int uu3d_op_gemm_tn_h3(const float* a_dev, int32_t lda, const float* b_dev, int32_t ldb, int32_t R, int32_t P, int32_t Q,
+                       float* c_dev, int32_t ldc, float* scratch_dev, size_t scratch_floats, void* stream);
 /* C[M][N] = A[M][K] W[N][K]^T (dX = dY W^T with W in Keras (in,out) layout: N = in, K = out).
  * N % 64 == 0 and K % 32 == 0 (the training path keeps padded copies). */
 int uu3d_op_gemm_nt(const float* a_dev, int32_t lda, const float* w_dev, int32_t ldw, int32_t M, int32_t N, int32_t K,

@@ -47,6 +47,23 @@ def test_gemm_tn(lib, R, P, Q):
     assert torch.equal(c, c2)                                 # deterministic split-K
 
 
+@pytest.mark.parametrize("R,P,Q", [(9088, 384, 1152), (4544, 384, 384), (1472, 2304, 384), (4544, 544, 384), (777, 132, 200), (33, 128, 128)])
+def test_gemm_tn_h3(lib, R, P, Q):
+    """Weight-gradient product on the f16 matrix cores (f16x3, fragments through ds_read_b64_tr_b16): ragged tiles, rows
+    that are no multiple of the k-step, operands with gradient-sized entries (f16 denormal range)."""
+    rng = np.random.default_rng(2)
+    a = rng.normal(size=(R, P)).astype(np.float32)
+    b = (rng.normal(size=(R, Q)) * np.exp(rng.uniform(-14, 0, size=(R, 1)))).astype(np.float32)      # rows from 1e-6 to 1
+    ad, bd = _d(a), _d(b)
+    c = torch.full((P, Q), float("nan"), device="cuda"); sc, n = _scratch(lib)
+    assert lib.uu3d_op_gemm_tn_h3(_p(ad), P, _p(bd), Q, R, P, Q, _p(c), Q, _p(sc), n, None) == 0
+    ref = a.astype(np.float64).T @ b.astype(np.float64)
+    _close(c.cpu().numpy(), ref, 2e-6)
+    c2 = torch.empty_like(c)
+    assert lib.uu3d_op_gemm_tn_h3(_p(ad), P, _p(bd), Q, R, P, Q, _p(c2), Q, _p(sc), n, None) == 0
+    assert torch.equal(c, c2)
+
+
 @pytest.mark.parametrize("M,N,K", [(9088, 384, 1152), (384, 768, 384), (128, 64, 384)])
 def test_gemm_nt(lib, M, N, K):
     rng = np.random.default_rng(1)

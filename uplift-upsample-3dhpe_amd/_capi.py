@@ -28,7 +28,7 @@ EXPORTED_SYMBOLS = (
 )
 # include/uu3d_ops.h
 OPS_SYMBOLS = (
-    "uu3d_op_gemm_tn", "uu3d_op_gemm_nt", "uu3d_op_colsum", "uu3d_op_row_stats", "uu3d_op_ln_bwd",
+    "uu3d_op_gemm_tn", "uu3d_op_gemm_tn_h3", "uu3d_op_gemm_nt", "uu3d_op_colsum", "uu3d_op_row_stats", "uu3d_op_ln_bwd",
     "uu3d_op_attn_fwd", "uu3d_op_attn_bwd", "uu3d_op_scratch_floats",
     "uu3d_op_panel_operand_bytes", "uu3d_op_panel_a_bytes", "uu3d_op_panel_pack", "uu3d_op_ln_dense_panel",
 )
@@ -140,6 +140,8 @@ def load_library(path=None):
     lib.uu3d_op_scratch_floats.argtypes = []
     lib.uu3d_op_gemm_tn.restype = C.c_int
     lib.uu3d_op_gemm_tn.argtypes = [vp, i32, vp, i32, i32, i32, i32, vp, i32, vp, sz, vp]
+    lib.uu3d_op_gemm_tn_h3.restype = C.c_int
+    lib.uu3d_op_gemm_tn_h3.argtypes = [vp, i32, vp, i32, i32, i32, i32, vp, i32, vp, sz, vp]
     lib.uu3d_op_gemm_nt.restype = C.c_int
     lib.uu3d_op_gemm_nt.argtypes = [vp, i32, vp, i32, i32, i32, i32, vp, i32, vp, sz, vp]
     lib.uu3d_op_colsum.restype = C.c_int

@@ -12,46 +12,67 @@
 #include <stdint.h>
 #include <math.h>
 #include "uu3d_gemm.h"
+#include "uu3d_gemm_h3.h"
 
 namespace uu3d {
 
 // ------------------------------------------------------------------------------------
 // A-side loaders for gemm_tn: load(r, p) -> A[r][p .. p+3] (p multiple of 4), zero outside.
 // ------------------------------------------------------------------------------------
+// fetch() issues the loads without a branch (indices clamped, validity kept as a flag) and finish() does the arithmetic and
+// the zeroing: a kernel can then put ALL the loads of a k-step in flight before it waits for the first (with the test inside
+// load() hipcc emitted one divergent branch per call and waited for each call's data inside it -- four serial memory round
+// trips per k-step).  col() holds what depends on the thread's column only (it is fixed over the k-loop).
+struct TnNoCol {};
 struct TnLoadPlain {
     const float* __restrict__ A; int lda, R, P;
-    __device__ __forceinline__ f32x4 load(int r, int p) const {
-        if (r >= R || p >= P) return (f32x4){0.f, 0.f, 0.f, 0.f};
-        return *reinterpret_cast<const f32x4*>(A + (size_t)r * lda + p);
+    struct Raw { f32x4 x; bool ok; };
+    typedef TnNoCol Col;
+    __device__ __forceinline__ Col col(int) const { return Col{}; }
+    __device__ __forceinline__ Raw fetch(int r, int p) const {
+        const bool ok = r < R && p < P;
+        return Raw{*reinterpret_cast<const f32x4*>(A + (ok ? (size_t)r * lda + p : 0)), ok};
     }
+    __device__ __forceinline__ f32x4 finish(const Raw& w, const Col&) const { return w.ok ? w.x : (f32x4){0.f, 0.f, 0.f, 0.f}; }
+    __device__ __forceinline__ f32x4 load(int r, int p) const { return finish(fetch(r, p), col(p)); }
 };
 // LayerNorm output recomputed on the fly: A[r][p] = LN(x)[r][p] (for dW of an LN-fed Dense)
 struct TnLoadLayerNorm {
     const float* __restrict__ X; const float2* __restrict__ stats;
     const float* __restrict__ gamma; const float* __restrict__ beta; int ldx, R, P;
-    __device__ __forceinline__ f32x4 load(int r, int p) const {
-        if (r >= R || p >= P) return (f32x4){0.f, 0.f, 0.f, 0.f};
-        const f32x4 x = *reinterpret_cast<const f32x4*>(X + (size_t)r * ldx + p);
-        const f32x4 g = *reinterpret_cast<const f32x4*>(gamma + p);
-        const f32x4 b = *reinterpret_cast<const f32x4*>(beta + p);
-        const float2 s = stats[r];
+    struct Raw { f32x4 x; float2 s; bool ok; };
+    struct Col { f32x4 g, b; };
+    __device__ __forceinline__ Col col(int p) const {
+        const int pp = p < P ? p : 0;
+        return Col{*reinterpret_cast<const f32x4*>(gamma + pp), *reinterpret_cast<const f32x4*>(beta + pp)};
+    }
+    __device__ __forceinline__ Raw fetch(int r, int p) const {
+        const bool ok = r < R && p < P;
+        return Raw{*reinterpret_cast<const f32x4*>(X + (ok ? (size_t)r * ldx + p : 0)), stats[ok ? r : 0], ok};
+    }
+    __device__ __forceinline__ f32x4 finish(const Raw& w, const Col& c) const {
         f32x4 y;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) { const float inv = s.y * g[e]; y[e] = x[e] * inv + (b[e] - s.x * inv); }
-        return y;
+        for (int e = 0; e < 4; ++e) { const float inv = w.s.y * c.g[e]; y[e] = w.x[e] * inv + (c.b[e] - w.s.x * inv); }
+        return w.ok ? y : (f32x4){0.f, 0.f, 0.f, 0.f};
     }
+    __device__ __forceinline__ f32x4 load(int r, int p) const { return finish(fetch(r, p), col(p)); }
 };
 // rows of the zero-padded, strided k=3 convolution input (same gather as ALoadConv3)
 struct TnLoadConv3 {
     const float* __restrict__ Hin; int C, L_in, L_out, stride, pad_left, R, P;   // R = B*L_out, P = 3*C
-    __device__ __forceinline__ f32x4 load(int r, int p) const {
-        if (r >= R || p >= P) return (f32x4){0.f, 0.f, 0.f, 0.f};
+    struct Raw { f32x4 x; bool ok; };
+    typedef TnNoCol Col;
+    __device__ __forceinline__ Col col(int) const { return Col{}; }
+    __device__ __forceinline__ Raw fetch(int r, int p) const {
         const int b = r / L_out, t = r - b * L_out;
         const int j = p / C, cc = p - j * C;
         const int src = t * stride - pad_left + j;
-        if (src < 0 || src >= L_in) return (f32x4){0.f, 0.f, 0.f, 0.f};
-        return *reinterpret_cast<const f32x4*>(Hin + (size_t)(b * L_in + src) * C + cc);
+        const bool ok = r < R && p < P && src >= 0 && src < L_in;
+        return Raw{*reinterpret_cast<const f32x4*>(Hin + (ok ? (size_t)(b * L_in + src) * C + cc : 0)), ok};
     }
+    __device__ __forceinline__ f32x4 finish(const Raw& w, const Col&) const { return w.ok ? w.x : (f32x4){0.f, 0.f, 0.f, 0.f}; }
+    __device__ __forceinline__ f32x4 load(int r, int p) const { return finish(fetch(r, p), col(p)); }
 };
 
 // plain store epilogue for split-K reduce / direct store: C[p][q] = v
@@ -85,22 +106,25 @@ gemm_tn_kernel(const AL al, const float* __restrict__ Bm, const int ldb, const i
     f32x16 acc;
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-    f32x4 ra[2], rb[2];
-    auto issue = [&](int kt) {
+    typename AL::Raw ra[2];
+    const typename AL::Col colc = al.col(p0 + scol);
+    f32x4 rb[2];
+    bool okb[2];
+    auto issue = [&](int kt) {                       // loads only (see the loaders): the loader's arithmetic runs in stage()
         const int r0 = kt * 32;
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             const int r = r0 + srow + 16 * i;
-            ra[i] = al.load(r, p0 + scol);
-            rb[i] = (r < R && q0 + scol < Q) ? *reinterpret_cast<const f32x4*>(Bm + (size_t)r * ldb + q0 + scol)
-                                             : (f32x4){0.f, 0.f, 0.f, 0.f};
+            ra[i] = al.fetch(r, p0 + scol);
+            okb[i] = r < R && q0 + scol < Q;
+            rb[i] = *reinterpret_cast<const f32x4*>(Bm + (okb[i] ? (size_t)r * ldb + q0 + scol : 0));
         }
     };
     auto stage = [&](int buf) {
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
-            *reinterpret_cast<f32x4*>(&TA[buf * 32 * LD + (srow + 16 * i) * LD + scol]) = ra[i];
-            *reinterpret_cast<f32x4*>(&TB[buf * 32 * LD + (srow + 16 * i) * LD + scol]) = rb[i];
+            *reinterpret_cast<f32x4*>(&TA[buf * 32 * LD + (srow + 16 * i) * LD + scol]) = al.finish(ra[i], colc);
+            *reinterpret_cast<f32x4*>(&TB[buf * 32 * LD + (srow + 16 * i) * LD + scol]) = okb[i] ? rb[i] : (f32x4){0.f, 0.f, 0.f, 0.f};
         }
     };
     if (kt_lo < KT) { issue(kt_lo); stage(kt_lo & 1); }
@@ -128,6 +152,125 @@ gemm_tn_kernel(const AL al, const float* __restrict__ Bm, const int ldb, const i
             if (row < P) ep.store(row, col, acc[r], cv, ep.pre(row, col));
         }
     }
+}
+
+// The same product on the f16 matrix cores (f16x3, uu3d_gemm_h3.h): 128 x 128 tile, 4 waves 2 x 2, wave tile 64 x 64 = 2 x 2
+// v_mfma_f32_32x32x16_f16 tiles, BK = 32 rows of R per step.  The contraction index is the ROW of both operands, so an
+// MFMA fragment (8 consecutive k of one output row / column) runs DOWN a column of the row-major tiles: the tiles are
+// staged as f16 planes [hi | lo] x [A | B], [32 rows][128 columns] with 320-byte rows, and the fragments come back
+// transposed by gfx950's ds_read_b64_tr_b16 (per 16-lane group a 4-row x 16-column block, delivered column-major: lane
+// 4q + p of the group supplies the address of row q, columns 4p .. 4p+3; lane i receives column i).  With 320-byte rows
+// the four rows of a block fall on four different 16-bank groups: every read is conflict-free.  The instruction needs
+// EXEC all ones -- there is no divergent code around the reads, out-of-range rows / columns are staged as zeros.
+static constexpr int TNH_ROW_BYTES = 320;
+static constexpr int TNH_PLANE_BYTES = 32 * TNH_ROW_BYTES;
+static constexpr int TNH_STAGE_BYTES = 4 * TNH_PLANE_BYTES;          // A hi, A lo, B hi, B lo
+static constexpr size_t TNH_LDS_BYTES = 2 * TNH_STAGE_BYTES;
+typedef __fp16 tnh_fp16x4 __attribute__((__vector_size__(4 * sizeof(__fp16))));
+typedef __attribute__((address_space(3))) tnh_fp16x4 tnh_lds_fp16x4;
+
+template <class AL, class EP>
+__global__ void __launch_bounds__(256, 2)
+gemm_tn_h3_kernel(const AL al, const float* __restrict__ Bm, const int ldb, const int R, const int P, const int Q,
+                  const int p_tiles, const int q_tiles, const int kt_per_split, const EP ep)
+{
+    h3_flush_f16_denormals();
+    extern __shared__ __attribute__((aligned(16))) unsigned char tnh_smem[];
+    const int tile = blockIdx.x;
+    const int bp = tile / q_tiles, bq = tile - bp * q_tiles;
+    const int p0 = bp * 128, q0 = bq * 128;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wm = wave >> 1, wn = wave & 1;
+    const int srow = tid >> 5, scol = (tid & 31) * 4;          // 8 rows x 128 columns per pass, 4 passes
+    const int KT_all = (R + 31) / 32;
+    const int kt_lo = blockIdx.y * kt_per_split;
+    const int KT = min(KT_all, kt_lo + kt_per_split);
+
+    f32x16 acc0[2][2], acc1[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { acc0[i][j][r] = 0.f; acc1[i][j][r] = 0.f; }
+    typename AL::Raw ra[4];
+    const typename AL::Col colc = al.col(p0 + scol);
+    f32x4 rb[4];
+    bool okb[4];
+    auto issue = [&](int kt) {                       // loads only: the arithmetic of the loader runs in stage(), behind the MFMAs
+        const int r0 = kt * 32;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int r = r0 + srow + 8 * i;
+            ra[i] = al.fetch(r, p0 + scol);
+            okb[i] = r < R && q0 + scol < Q;
+            rb[i] = *reinterpret_cast<const f32x4*>(Bm + (okb[i] ? (size_t)r * ldb + q0 + scol : 0));
+        }
+    };
+    auto stage = [&](int buf) {
+        unsigned char* st = tnh_smem + buf * TNH_STAGE_BYTES + srow * TNH_ROW_BYTES + scol * 2;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            h16x4 hi, lo;
+            h3_split(al.finish(ra[i], colc), hi, lo);
+            *reinterpret_cast<h16x4*>(st + 8 * i * TNH_ROW_BYTES) = hi;
+            *reinterpret_cast<h16x4*>(st + 8 * i * TNH_ROW_BYTES + TNH_PLANE_BYTES) = lo;
+            h3_split(okb[i] ? rb[i] : (f32x4){0.f, 0.f, 0.f, 0.f}, hi, lo);
+            *reinterpret_cast<h16x4*>(st + 8 * i * TNH_ROW_BYTES + 2 * TNH_PLANE_BYTES) = hi;
+            *reinterpret_cast<h16x4*>(st + 8 * i * TNH_ROW_BYTES + 3 * TNH_PLANE_BYTES) = lo;
+        }
+    };
+    if (kt_lo < KT) { issue(kt_lo); stage(kt_lo & 1); }
+    __syncthreads();
+    // this lane's address inside a plane for the block (k-slice 0, first four rows) of MFMA tile 0 of the wave
+    const int frow = 8 * (lane >> 5) + ((lane & 15) >> 2), fcol = 16 * ((lane >> 4) & 1) + 4 * (lane & 3);
+    const int fa = frow * TNH_ROW_BYTES + (wm * 64 + fcol) * 2, fb = frow * TNH_ROW_BYTES + (wn * 64 + fcol) * 2 + 2 * TNH_PLANE_BYTES;
+    auto frag = [&](const unsigned char* base) -> h16x8 {          // 8 consecutive k (rows) of this lane's column
+        const tnh_fp16x4 u = __builtin_amdgcn_ds_read_tr16_b64_v4f16((tnh_lds_fp16x4*)(base));
+        const tnh_fp16x4 v = __builtin_amdgcn_ds_read_tr16_b64_v4f16((tnh_lds_fp16x4*)(base + 4 * TNH_ROW_BYTES));
+        const h16x4 a = __builtin_bit_cast(h16x4, u), b = __builtin_bit_cast(h16x4, v);
+        return (h16x8){a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
+    };
+    for (int kt = kt_lo; kt < KT; ++kt) {
+        const int cur = kt & 1;
+        if (kt + 1 < KT) issue(kt + 1);
+        const unsigned char* sa = tnh_smem + cur * TNH_STAGE_BYTES + fa;
+        const unsigned char* sb = tnh_smem + cur * TNH_STAGE_BYTES + fb;
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            h16x8 ah[2], al_[2], bh[2], bl[2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                ah[i] = frag(sa + s * 16 * TNH_ROW_BYTES + i * 64);
+                al_[i] = frag(sa + s * 16 * TNH_ROW_BYTES + i * 64 + TNH_PLANE_BYTES);
+                bh[i] = frag(sb + s * 16 * TNH_ROW_BYTES + i * 64);
+                bl[i] = frag(sb + s * 16 * TNH_ROW_BYTES + i * 64 + TNH_PLANE_BYTES);
+            }
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    acc0[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bh[j], acc0[i][j], 0, 0, 0);
+                    acc1[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bl[j], acc1[i][j], 0, 0, 0);
+                    acc1[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al_[i], bh[j], acc1[i][j], 0, 0, 0);
+                }
+        }
+        if (kt + 1 < KT) stage(cur ^ 1);
+        __syncthreads();
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int crow0 = p0 + wm * 64 + 32 * i + 4 * (lane >> 5), col = q0 + wn * 64 + 32 * j + (lane & 31);
+            if (col < Q) {
+                const float2 cv = ep.colv(col);
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = crow0 + (r & 3) + 8 * (r >> 2);
+                    if (row < P) ep.store(row, col, acc0[i][j][r] + acc1[i][j][r] * (1.0f / H3_SCALE), cv, ep.pre(row, col));
+                }
+            }
+        }
 }
 
 // out[c] (period == 0) or out[(r % period)][c] = sum over rows r of scale(r) * X[r][c].

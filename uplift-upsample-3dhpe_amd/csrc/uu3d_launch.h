@@ -54,9 +54,35 @@ int launch_gemm(const AL& al, const float* Bt, int M, int N, int K, const EP& ep
     return hip_status();
 }
 
+inline int tnh_target_wgs() { static const int v = getenv("UU3D_TNH_WGS") ? atoi(getenv("UU3D_TNH_WGS")) : 384; return v; }
 // C[P][Q] = A^T B over R rows, split over R into slabs, combined in order.
 template <class AL, class EP>
-int launch_gemm_tn(const AL& al, const float* B, int ldb, int R, int P, int Q, const EP& ep, float* slab, size_t slab_floats, hipStream_t stream) {
+int launch_gemm_tn(const AL& al, const float* B, int ldb, int R, int P, int Q, const EP& ep, float* slab, size_t slab_floats, hipStream_t stream,
+                   bool h3 = false) {
+    if (h3 && P >= 128 && Q >= 128) {        // f16x3 on 128 x 128 tiles (gemm_tn_h3_kernel); narrow results stay on the exact-f32 kernel
+        const int pt = (P + 127) / 128, qt = (Q + 127) / 128, tiles = pt * qt;
+        const int KT = (R + 31) / 32;
+        const int ldslab = ru(Q, 4);
+        int slices = std::max(1, std::min(KT / 2, (tnh_target_wgs() + tiles - 1) / tiles));
+        while (slices > 1 && (size_t)slices * P * ldslab > slab_floats) --slices;
+        const int kps = (KT + slices - 1) / slices;
+        slices = (KT + kps - 1) / kps;
+        auto k1 = gemm_tn_h3_kernel<AL, EP>; auto ks = gemm_tn_h3_kernel<AL, EpSlab>;
+        static const bool attr_set = [&] {            // once per instantiation (one device per process)
+            (void)hipFuncSetAttribute((const void*)k1, hipFuncAttributeMaxDynamicSharedMemorySize, (int)TNH_LDS_BYTES);
+            (void)hipFuncSetAttribute((const void*)ks, hipFuncAttributeMaxDynamicSharedMemorySize, (int)TNH_LDS_BYTES);
+            return true; }();
+        (void)attr_set;
+        if (slices == 1) {
+            hipLaunchKernelGGL(k1, dim3(tiles, 1), dim3(256), TNH_LDS_BYTES, stream, al, B, ldb, R, P, Q, pt, qt, KT, ep);
+        } else {
+            EpSlab es{slab, ldslab, (size_t)P * ldslab};
+            hipLaunchKernelGGL(ks, dim3(tiles, slices), dim3(256), TNH_LDS_BYTES, stream, al, B, ldb, R, P, Q, pt, qt, kps, es);
+            hipLaunchKernelGGL(splitk_reduce_kernel<EP>, dim3((P * Q + 255) / 256), dim3(256), 0, stream, slab, slices,
+                               (size_t)P * ldslab, P, Q, ldslab, ep);
+        }
+        return hip_status();
+    }
     const int pt = (P + 63) / 64, qt = (Q + 63) / 64, tiles = pt * qt;
     const int KT = (R + 31) / 32;
     // <= 48 slabs when the combine is one thread per element; tall-skinny results (<= 4 tiles, e.g. the spatial stack's

@@ -21,6 +21,13 @@ int uu3d_op_gemm_tn(const float* a, int32_t lda, const float* b, int32_t ldb, in
     EpStore ep{c, ldc};
     return launch_gemm_tn(al, b, ldb, R, P, Q, ep, scratch, scratch_floats, (hipStream_t)stream);
 }
+int uu3d_op_gemm_tn_h3(const float* a, int32_t lda, const float* b, int32_t ldb, int32_t R, int32_t P, int32_t Q, float* c,
+                       int32_t ldc, float* scratch, size_t scratch_floats, void* stream) {
+    if (!a || !b || !c || !scratch || R < 1 || P < 1 || Q < 1 || (lda & 3) || (ldb & 3) || (P & 3) || (Q & 3)) return UU3D_ERR_INVALID_ARGUMENT;
+    TnLoadPlain al{a, lda, R, P};
+    EpStore ep{c, ldc};
+    return launch_gemm_tn(al, b, ldb, R, P, Q, ep, scratch, scratch_floats, (hipStream_t)stream, true);
+}
 
 int uu3d_op_gemm_nt(const float* a, int32_t lda, const float* w, int32_t ldw, int32_t M, int32_t N, int32_t K, float* c,
                     int32_t ldc, float* scratch, size_t scratch_floats, void* stream) {

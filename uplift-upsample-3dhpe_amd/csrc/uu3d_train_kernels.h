@@ -210,14 +210,20 @@ struct EpGeluGrad {         // out = acc * gelu'(Hpre)
 // TN A-side: gelu(Hpre) rows (dW2 of the spatial MLP)
 struct TnLoadGelu {
     const float* __restrict__ A; int lda, R, P;
-    __device__ __forceinline__ f32x4 load(int r, int p) const {
-        if (r >= R || p >= P) return (f32x4){0.f, 0.f, 0.f, 0.f};
-        const f32x4 x = *reinterpret_cast<const f32x4*>(A + (size_t)r * lda + p);
+    struct Raw { f32x4 x; bool ok; };
+    typedef TnNoCol Col;
+    __device__ __forceinline__ Col col(int) const { return Col{}; }
+    __device__ __forceinline__ Raw fetch(int r, int p) const {
+        const bool ok = r < R && p < P;
+        return Raw{*reinterpret_cast<const f32x4*>(A + (ok ? (size_t)r * lda + p : 0)), ok};
+    }
+    __device__ __forceinline__ f32x4 finish(const Raw& w, const Col&) const {
         f32x4 y;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) y[e] = gelu_exact(x[e]);
+        for (int e = 0; e < 4; ++e) y[e] = w.ok ? gelu_exact(w.x[e]) : 0.f;
         return y;
     }
+    __device__ __forceinline__ f32x4 load(int r, int p) const { return finish(fetch(r, p), col(p)); }
 };
 
 }  // namespace uu3d
