@@ -132,3 +132,33 @@ def test_checkpoint_resume_is_bit_identical(tmp_path):
     assert t2.global_step == 4 and t2.optimizer.iterations == 4
     if t1.ema is not None:
         assert torch.equal(t1.ema, t2.ema)
+
+
+@pytest.mark.parametrize("cfgname,B", [("h36m_351", 16), ("h36m_81", 5)])
+def test_side_stream_schedule_is_bit_identical_to_in_order(cfgname, B, monkeypatch):
+    """The backward pass runs the parameter-gradient work on a second stream (uu3d_train_step.inc).  Both schedules launch
+    the same kernels on the same data, so every gradient must agree BIT FOR BIT with the in-order run -- a missing
+    dependency between the streams shows up here as a mismatch (repeated: a race need not lose every time)."""
+    from uplift_upsample_3dhpe_amd.trainer import Trainer
+    cfg, arch, w, model, x, m, gt = _setup(cfgname, B, seed=21, batch_norm=B)
+    xs, gts, ms = torch.from_numpy(x).cuda(), torch.from_numpy(gt).cuda(), torch.from_numpy(m).cuda()
+    u = torch.from_numpy(np.random.default_rng(5).random(Trainer(model, cfg).drop_path_size(B)).astype(np.float32)).cuda()
+
+    def grads(in_order):
+        if in_order:
+            monkeypatch.setenv("UU3D_TRAIN_1STREAM", "1")
+        else:
+            monkeypatch.delenv("UU3D_TRAIN_1STREAM", raising=False)
+        tr = Trainer(model, cfg)                                  # the switch is read by uu3d_train_init
+        out = []
+        for _ in range(4):
+            loss, _, _ = tr.forward_backward(xs, gts, ms, drop_path_uniform=u)
+            torch.cuda.synchronize()
+            out.append((tr.grads.clone(), loss.clone()))
+        return out
+    ref = grads(True)
+    two = grads(False)
+    for (g1, l1), (g2, l2) in zip(ref, two):
+        assert torch.equal(l1, l2)
+        assert torch.equal(g1, g2), int((g1 != g2).sum())
+    assert torch.equal(ref[0][0], ref[-1][0])
