@@ -1,0 +1,49 @@
+"""Experiment: replay uu3d_train_forward_backward (both streams) from a hipGraph instead of ~570 eager launches.
+   python tools/train_graph_exp.py [steps]"""
+import sys, time, os
+import numpy as np, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import uplift_upsample_3dhpe_amd as pkg
+from uplift_upsample_3dhpe_amd import harness
+from uplift_upsample_3dhpe_amd.trainer import Trainer
+from tests import util
+
+steps = int(sys.argv[1]) if len(sys.argv) > 1 else 50
+cfg = util.load_config("h36m_351_pt"); B = 64; cfg.BATCH_SIZE = B
+arch = pkg.arch_from_config(cfg)
+model = pkg.build_uplift_upsample_transformer(cfg, weights=pkg.init_weights(arch, seed=0), device="cuda:0")
+tr = Trainer(model, cfg, seed=100)
+rng = np.random.default_rng(3000)
+N, J = arch.num_frames, arch.num_keypoints
+x = torch.from_numpy(rng.uniform(-1, 1, size=(B, N, J, 2)).astype(np.float32)).cuda()
+gt = torch.from_numpy(rng.normal(0, 0.3, size=(B, N, J, 3)).astype(np.float32)).cuda()
+m = torch.from_numpy(harness.stride_masks_train(N, cfg.SEQUENCE_STRIDE, cfg.MASK_STRIDE, B, rng, cfg.STRIDE_MASK_RAND_SHIFT)).cuda()
+u = torch.rand(tr.drop_path_size(B), device="cuda")
+
+def eager():
+    tr.forward_backward(x, gt, m, drop_path_uniform=u); tr.apply_gradients()
+for _ in range(10): eager()
+torch.cuda.synchronize()
+t0 = time.perf_counter()
+for _ in range(steps): eager()
+torch.cuda.synchronize()
+print(f"eager: {(time.perf_counter() - t0) / steps * 1e3:.3f} ms per step")
+g_ref = tr.grads.clone()
+
+s = torch.cuda.Stream()
+s.wait_stream(torch.cuda.current_stream())
+with torch.cuda.stream(s):
+    tr.forward_backward(x, gt, m, drop_path_uniform=u)
+torch.cuda.current_stream().wait_stream(s)
+torch.cuda.synchronize()
+g = torch.cuda.CUDAGraph()
+with torch.cuda.graph(g):
+    tr.forward_backward(x, gt, m, drop_path_uniform=u)
+def graphed():
+    g.replay(); tr.apply_gradients()
+for _ in range(10): graphed()
+torch.cuda.synchronize()
+t0 = time.perf_counter()
+for _ in range(steps): graphed()
+torch.cuda.synchronize()
+print(f"graph replay of forward_backward + eager optimizer: {(time.perf_counter() - t0) / steps * 1e3:.3f} ms per step")
