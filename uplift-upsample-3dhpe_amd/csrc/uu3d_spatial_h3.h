@@ -49,6 +49,70 @@ constexpr int NPARAM = 352;     // LayerNorm parameters and biases of one block 
 constexpr size_t lds_bytes() { return (size_t)2 * ROWS_T * XLD * 2 + (size_t)2 * ROWS_T * KLD * 4 + NPARAM * 4; }
 static_assert(2 * ROWS_T * HLD * 2 == 2 * ROWS_T * KLD * 4, "the hidden planes reuse the K / V tiles byte for byte");
 
+// The weight fragments of one product, loaded AHEAD of the product (hipcc otherwise issues each pair of fragment loads
+// right in front of the MFMAs that use it: 16 exposed L2 round trips per block and wave).
+template <int NT, int KK>
+struct WFrag { h16x8 h[NT][KK], l[NT][KK]; };
+// Issued by name (the compiler sinks a plain load back to its use) and waited for with a COUNTED s_waitcnt: vector loads
+// return in order, so wait_w(w, n) lets the n loads issued after w's stay in flight.  The compiler's own vmcnt accounting
+// does not see these loads; its waits can only become more conservative by that, never too weak.
+template <int NT, int KK>
+__device__ __forceinline__ void load_w(const _Float16* __restrict__ wf, const int lane, WFrag<NT, KK>& w) {
+    const h16x8* base = reinterpret_cast<const h16x8*>(wf) + lane;
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+        for (int kk = 0; kk < KK; ++kk) {
+            asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(w.h[nt][kk]) : "v"(base + ((nt * KK + kk) * 2 + 0) * 64) : "memory");
+            asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(w.l[nt][kk]) : "v"(base + ((nt * KK + kk) * 2 + 1) * 64) : "memory");
+        }
+}
+template <int NLATER, int NT, int KK>
+__device__ __forceinline__ void wait_w(WFrag<NT, KK>& w) {
+    static_assert(NT * KK == 2 || NT * KK == 4, "2 or 4 fragment pairs");
+    if constexpr (NT * KK == 2)
+        asm volatile("s_waitcnt vmcnt(%4)" : "+v"(w.h[0][0]), "+v"(w.l[0][0]), "+v"(w.h[0][1]), "+v"(w.l[0][1]) : "i"(NLATER));
+    else
+        asm volatile("s_waitcnt vmcnt(%8)" : "+v"(w.h[0][0]), "+v"(w.l[0][0]), "+v"(w.h[0][1]), "+v"(w.l[0][1]),
+                     "+v"(w.h[NT - 1][KK - 2]), "+v"(w.l[NT - 1][KK - 2]), "+v"(w.h[NT - 1][KK - 1]), "+v"(w.l[NT - 1][KK - 1]) : "i"(NLATER));
+}
+template <int NT, int KK>
+__device__ __forceinline__ void mm(const WFrag<NT, KK>& w, const _Float16* Bh, const _Float16* Bl, const int ldb,
+                                   const int lane, float (&out)[NT][2][16]) {
+    f32x16 acc0[NT][2], acc1[NT][2];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { acc0[nt][mt][r] = 0.f; acc1[nt][mt][r] = 0.f; }
+    const int tl = lane & 31, half = lane >> 5;
+#pragma unroll
+    for (int kk = 0; kk < KK; ++kk) {
+        h16x8 bh[2], bl[2];
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt) {
+            const int row = min(32 * mt + tl, ROWS_T - 1);
+            bh[mt] = *reinterpret_cast<const h16x8*>(Bh + row * ldb + 16 * kk + 8 * half);
+            bl[mt] = *reinterpret_cast<const h16x8*>(Bl + row * ldb + 16 * kk + 8 * half);
+        }
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt) {
+                acc0[nt][mt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w.h[nt][kk], bh[mt], acc0[nt][mt], 0, 0, 0);
+                acc1[nt][mt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w.h[nt][kk], bl[mt], acc1[nt][mt], 0, 0, 0);
+                acc1[nt][mt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w.l[nt][kk], bh[mt], acc1[nt][mt], 0, 0, 0);
+            }
+    }
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) out[nt][mt][r] = acc0[nt][mt][r] + acc1[nt][mt][r] * (1.0f / H3_SCALE);
+}
+
 // C^T tiles of W^T X^T for NT output tiles (32 channels each) and both token tiles; K = 16 * KK.
 // out[nt][mt][r]: token = 32 mt + (lane & 31), channel = 32 nt + 8 (r >> 2) + 4 (lane >> 5) + (r & 3).
 template <int NT, int KK>
@@ -245,13 +309,17 @@ spatial_stack_h3_kernel(const float* __restrict__ kp2d, const SpatialParams p, c
         float y[2][16];
 
         // ---- attention half ----
+        WFrag<1, 2> wq, wk, wv, wp;
+        load_w<1, 2>(F + FL::fq, lane, wq); load_w<1, 2>(F + FL::fk, lane, wk); load_w<1, 2>(F + FL::fv, lane, wv);
         ln_tokens(x, W + LY::ln1_g, W + LY::ln1_b, 1e-5f, half, y);
         store_planes(Xh, Xl, XLD, 0, lane, y);
         float q[1][2][16];
         {
             float kv[1][2][16];
-            mm<1, 2>(F + FL::fq, Xh, Xl, XLD, lane, q);
-            mm<1, 2>(F + FL::fk, Xh, Xl, XLD, lane, kv);
+            wait_w<8>(wq);
+            mm<1, 2>(wq, Xh, Xl, XLD, lane, q);
+            wait_w<4>(wk);
+            mm<1, 2>(wk, Xh, Xl, XLD, lane, kv);
 #pragma unroll
             for (int mt = 0; mt < 2; ++mt) {
                 const int row = min(32 * mt + tl, ROWS_T - 1);
@@ -263,7 +331,9 @@ spatial_stack_h3_kernel(const float* __restrict__ kp2d, const SpatialParams p, c
                         (f32x4){kv[0][mt][4 * g] + b4[0], kv[0][mt][4 * g + 1] + b4[1], kv[0][mt][4 * g + 2] + b4[2], kv[0][mt][4 * g + 3] + b4[3]};
                 }
             }
-            mm<1, 2>(F + FL::fv, Xh, Xl, XLD, lane, kv);
+            load_w<1, 2>(F + FL::fp, lane, wp);            // in flight over the attention arithmetic
+            wait_w<4>(wv);
+            mm<1, 2>(wv, Xh, Xl, XLD, lane, kv);
 #pragma unroll
             for (int mt = 0; mt < 2; ++mt) {
                 const int row = min(32 * mt + tl, ROWS_T - 1);
@@ -291,7 +361,8 @@ spatial_stack_h3_kernel(const float* __restrict__ kp2d, const SpatialParams p, c
         store_planes(Xh, Xl, XLD, 0, lane, o);
         {
             float pr[1][2][16];
-            mm<1, 2>(F + FL::fp, Xh, Xl, XLD, lane, pr);
+            wait_w<0>(wp);
+            mm<1, 2>(wp, Xh, Xl, XLD, lane, pr);
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 const f32x4 b4 = *reinterpret_cast<const f32x4*>(W + LY::bp + 8 * g + 4 * half);
@@ -303,11 +374,16 @@ spatial_stack_h3_kernel(const float* __restrict__ kp2d, const SpatialParams p, c
         }
 
         // ---- MLP half ----
+        WFrag<2, 2> w1;
+        load_w<2, 2>(F + FL::f1, lane, w1);
         ln_tokens(x, W + LY::ln2_g, W + LY::ln2_b, 1e-5f, half, y);
         store_planes(Xh, Xl, XLD, 0, lane, y);
+        WFrag<1, 4> w2;
         {
             float hd[2][2][16];
-            mm<2, 2>(F + FL::f1, Xh, Xl, XLD, lane, hd);
+            wait_w<0>(w1);
+            mm<2, 2>(w1, Xh, Xl, XLD, lane, hd);
+            load_w<1, 4>(F + FL::f2, lane, w2);             // in flight over the GELU
 #pragma unroll
             for (int nt = 0; nt < 2; ++nt) {
 #pragma unroll
@@ -323,7 +399,8 @@ spatial_stack_h3_kernel(const float* __restrict__ kp2d, const SpatialParams p, c
         }
         {
             float z[1][2][16];
-            mm<1, 4>(F + FL::f2, Hh, Hl, HLD, lane, z);
+            wait_w<0>(w2);
+            mm<1, 4>(w2, Hh, Hl, HLD, lane, z);
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 const f32x4 b4 = *reinterpret_cast<const f32x4*>(W + LY::b2 + 8 * g + 4 * half);
