@@ -110,14 +110,17 @@ attn_f32_kernel(const float* __restrict__ qkv, const int ld, const int D, const 
     }
 
     // logits / sqrt(d_h) (+ mask * -1e9), softmax over keys
-    const float scale_div = sqrtf((float)DH);
+    // 1 / sqrt(d_h) as a multiplication, exp as exp2 of a pre-scaled argument and one reciprocal of the sum: the division,
+    // libm expf and per-probability division cost ~1000 VALU instructions per wave (as much SIMD time as the MFMAs);
+    // the results differ from those forms by rounding only (parity bar 1e-4 on the outputs, checked by the tests)
+    const float scale_mul = 1.0f / sqrtf((float)DH);
     float mx = -INFINITY;
 #pragma unroll
     for (int j = 0; j < NT; ++j)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int key = 16 * j + 4 * g + r;
-            float v = st[j][r] / scale_div;
+            float v = st[j][r] * scale_mul;
             if (key < L) {
                 if (key_mask != nullptr) v += (key_mask[(size_t)b * L + key] ? 0.0f : 1.0f) * -1e9f;
             } else {
@@ -133,7 +136,7 @@ attn_f32_kernel(const float* __restrict__ qkv, const int ld, const int D, const 
     for (int j = 0; j < NT; ++j)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-#ifdef UU3D_ATTN_FASTEXP
+#ifndef UU3D_ATTN_LIBM_EXP
             const float e = __builtin_amdgcn_exp2f((st[j][r] - mx) * 1.44269504088896341f);
 #else
             const float e = expf(st[j][r] - mx);
@@ -143,10 +146,11 @@ attn_f32_kernel(const float* __restrict__ qkv, const int ld, const int D, const 
         }
     sum += __shfl_xor(sum, 16);
     sum += __shfl_xor(sum, 32);
+    const float rsum = 1.0f / sum;
 #pragma unroll
     for (int j = 0; j < NT; ++j)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) st[j][r] = st[j][r] / sum;
+        for (int r = 0; r < 4; ++r) st[j][r] = st[j][r] * rsum;
 
     // O = P V : tile t covers head channels 16t .. 16t+15
 #pragma unroll
