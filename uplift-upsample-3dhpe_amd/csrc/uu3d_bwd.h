@@ -544,13 +544,13 @@ attn_generic_fwd_kernel(const float* __restrict__ qkv, const int ld, const int D
     float q[DH], o[DH];
 #pragma unroll
     for (int c = 0; c < DH; ++c) { q[c] = base[(size_t)i * ld + c]; o[c] = 0.f; }
-    const float sq = sqrtf((float)DH);
+    const float rsq = 1.0f / sqrtf((float)DH);          // multiplications by reciprocals and exp2 instead of divisions and libm expf
     float mx = -INFINITY;
     for (int j = 0; j < L; ++j) {
         float s = 0.f;
 #pragma unroll
         for (int c = 0; c < DH; ++c) s = fmaf(q[c], Ks[j * LD + c], s);
-        s = s / sq;
+        s = s * rsq;
         if (key_mask != nullptr) s += (key_mask[(size_t)b * L + j] ? 0.0f : 1.0f) * -1e9f;
         mx = fmaxf(mx, s);
     }
@@ -559,15 +559,16 @@ attn_generic_fwd_kernel(const float* __restrict__ qkv, const int ld, const int D
         float s = 0.f;
 #pragma unroll
         for (int c = 0; c < DH; ++c) s = fmaf(q[c], Ks[j * LD + c], s);
-        s = s / sq;
+        s = s * rsq;
         if (key_mask != nullptr) s += (key_mask[(size_t)b * L + j] ? 0.0f : 1.0f) * -1e9f;
-        const float e = expf(s - mx);
+        const float e = __builtin_amdgcn_exp2f((s - mx) * 1.44269504088896341f);
         sum += e;
 #pragma unroll
         for (int c = 0; c < DH; ++c) o[c] = fmaf(e, Vs[j * LD + c], o[c]);
     }
+    const float rsum = 1.0f / sum;
 #pragma unroll
-    for (int c = 0; c < DH; ++c) out[((size_t)b * L + i) * ldo + h * DH + c] = o[c] / sum;
+    for (int c = 0; c < DH; ++c) out[((size_t)b * L + i) * ldo + h * DH + c] = o[c] * rsum;
 }
 
 template <int DH>
@@ -598,7 +599,7 @@ attn_generic_bwd_kernel(const float* __restrict__ qkv, const float* __restrict__
             Gs[r * LD + c] = dO[((size_t)b * L + r) * ldo + h * DH + c];
         }
     __syncthreads();
-    const float sq = sqrtf((float)DH);
+    const float rsq = 1.0f / sqrtf((float)DH);
     if (live) {
         float q[DH], g[DH];
 #pragma unroll
@@ -608,16 +609,17 @@ attn_generic_bwd_kernel(const float* __restrict__ qkv, const float* __restrict__
             float s = 0.f;
 #pragma unroll
             for (int c = 0; c < DH; ++c) s = fmaf(q[c], Ks[j * LD + c], s);
-            s = s / sq;
+            s = s * rsq;
             if (key_mask != nullptr) s += (key_mask[(size_t)b * L + j] ? 0.0f : 1.0f) * -1e9f;
             Pm[i * LP + j] = s;
             mx = fmaxf(mx, s);
         }
         float sum = 0.f;
-        for (int j = 0; j < L; ++j) { const float e = expf(Pm[i * LP + j] - mx); Pm[i * LP + j] = e; sum += e; }
+        for (int j = 0; j < L; ++j) { const float e = __builtin_amdgcn_exp2f((Pm[i * LP + j] - mx) * 1.44269504088896341f); Pm[i * LP + j] = e; sum += e; }
         float delta = 0.f;
+        const float rsum = 1.0f / sum;
         for (int j = 0; j < L; ++j) {
-            const float pij = Pm[i * LP + j] / sum;
+            const float pij = Pm[i * LP + j] * rsum;
             float dp = 0.f;
 #pragma unroll
             for (int c = 0; c < DH; ++c) dp = fmaf(g[c], Vs[j * LD + c], dp);
@@ -634,7 +636,7 @@ attn_generic_bwd_kernel(const float* __restrict__ qkv, const float* __restrict__
             for (int c = 0; c < DH; ++c) dq[c] = fmaf(ds, Ks[j * LD + c], dq[c]);
         }
 #pragma unroll
-        for (int c = 0; c < DH; ++c) dqkv[((size_t)b * L + i) * ld + h * DH + c] = dq[c] / sq;
+        for (int c = 0; c < DH; ++c) dqkv[((size_t)b * L + i) * ld + h * DH + c] = dq[c] * rsq;
     }
     __syncthreads();
     if (live) {                                  // thread = key row j
@@ -648,7 +650,7 @@ attn_generic_bwd_kernel(const float* __restrict__ qkv, const float* __restrict__
         }
 #pragma unroll
         for (int c = 0; c < DH; ++c) {
-            dqkv[((size_t)b * L + i) * ld + D + h * DH + c] = dk[c] / sq;
+            dqkv[((size_t)b * L + i) * ld + D + h * DH + c] = dk[c] * rsq;
             dqkv[((size_t)b * L + i) * ld + 2 * D + h * DH + c] = dv[c];
         }
     }
@@ -696,7 +698,7 @@ attn_bwd_mfma_kernel(const float* __restrict__ qkv, const float* __restrict__ dO
     __syncthreads();
 
     const int lane = tid & 63, w = tid >> 6, qi = lane & 15, g = lane >> 4;
-    const float scale_div = sqrtf((float)DH);
+    const float scale_mul = 1.0f / sqrtf((float)DH);      // reciprocal multiplies and exp2 in both passes (same P in both)
     float* dq_out = dqkv + (size_t)b * L * ld + h * DH;
 
     // ---------------- pass 1: this wave's 16 queries against all keys ----------------
@@ -729,7 +731,7 @@ attn_bwd_mfma_kernel(const float* __restrict__ qkv, const float* __restrict__ dO
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int key = 16 * j + 4 * g + r;
-                float v = st[j][r] / scale_div;
+                float v = st[j][r] * scale_mul;
                 if (key < L) { if (key_mask != nullptr) v += (key_mask[(size_t)b * L + key] ? 0.0f : 1.0f) * -1e9f; }
                 else v = -INFINITY;
                 st[j][r] = v;
@@ -740,15 +742,16 @@ attn_bwd_mfma_kernel(const float* __restrict__ qkv, const float* __restrict__ dO
 #pragma unroll
         for (int j = 0; j < NT; ++j)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) { const float e = expf(st[j][r] - mx); st[j][r] = e; sum += e; }
+            for (int r = 0; r < 4; ++r) { const float e = __builtin_amdgcn_exp2f((st[j][r] - mx) * 1.44269504088896341f); st[j][r] = e; sum += e; }
         sum += __shfl_xor(sum, 16); sum += __shfl_xor(sum, 32);
+        const float rsum = 1.0f / sum;
         float delta = 0.f;
 #pragma unroll
         for (int j = 0; j < NT; ++j)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) { st[j][r] = st[j][r] / sum; delta = fmaf(st[j][r], dp[j][r], delta); }
+            for (int r = 0; r < 4; ++r) { st[j][r] = st[j][r] * rsum; delta = fmaf(st[j][r], dp[j][r], delta); }
         delta += __shfl_xor(delta, 16); delta += __shfl_xor(delta, 32);
-        if (g == 0) { Mx[16 * w + qi] = mx; Sum[16 * w + qi] = sum; Dl[16 * w + qi] = delta; }
+        if (g == 0) { Mx[16 * w + qi] = mx; Sum[16 * w + qi] = rsum; Dl[16 * w + qi] = delta; }
 #pragma unroll
         for (int j = 0; j < NT; ++j)
 #pragma unroll
@@ -764,7 +767,7 @@ attn_bwd_mfma_kernel(const float* __restrict__ qkv, const float* __restrict__ dO
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int q = 16 * w + 4 * g + r;
-                if (q < L) dq_out[(size_t)q * ld + 16 * t + qi] = o[r] / scale_div;
+                if (q < L) dq_out[(size_t)q * ld + 16 * t + qi] = o[r] * scale_mul;
             }
         }
     }
@@ -800,7 +803,7 @@ attn_bwd_mfma_kernel(const float* __restrict__ qkv, const float* __restrict__ dO
                 const int q = 16 * j + 4 * g + r;
                 float p = 0.f, dsv = 0.f;
                 if (q < L && key < L) {
-                    p = expf((a[r] / scale_div + madd) - Mx[q]) / Sum[q];
+                    p = __builtin_amdgcn_exp2f(((a[r] * scale_mul + madd) - Mx[q]) * 1.44269504088896341f) * Sum[q];      // Sum holds 1 / sum
                     dsv = p * (d[r] - Dl[q]);
                 }
                 pp[j][r] = p; ds[j][r] = dsv;
@@ -821,7 +824,7 @@ attn_bwd_mfma_kernel(const float* __restrict__ qkv, const float* __restrict__ dO
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int kr = 16 * w + 4 * g + r;
-                if (kr < L) { dk_out[(size_t)kr * ld + 16 * t + qi] = ok[r] / scale_div; dv_out[(size_t)kr * ld + 16 * t + qi] = ov[r]; }
+                if (kr < L) { dk_out[(size_t)kr * ld + 16 * t + qi] = ok[r] * scale_mul; dv_out[(size_t)kr * ld + 16 * t + qi] = ov[r]; }
             }
         }
     }
