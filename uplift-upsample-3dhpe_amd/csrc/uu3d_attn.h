@@ -52,6 +52,10 @@ attn_f32_kernel(const float* __restrict__ qkv, const int ld, const int D, const 
     const int qi = lane & 15, g = lane >> 4;
     const int qrow = 16 * w + qi;
     const int items = n_items > 0 ? n_items : (int)gridDim.x;
+    // Workgroups go round-robin over the 8 XCDs; remapped so that CONSECUTIVE items (the H heads of one sequence) run on the
+    // SAME XCD: a head's 192-byte q / k / v slices straddle 128-byte lines that the neighbouring head also needs, and the heads'
+    // partial-line output writes meet in one L2 instead of eight.
+    const int first = ((int)gridDim.x & 7) == 0 ? ((int)blockIdx.x & 7) * ((int)gridDim.x >> 3) + ((int)blockIdx.x >> 3) : (int)blockIdx.x;
 
     float4 kreg[NS], vreg[NS];
     f32x4 qnext[KT];
@@ -75,8 +79,8 @@ attn_f32_kernel(const float* __restrict__ qkv, const int ld, const int D, const 
             if (qrow < L) qnext[t] = *reinterpret_cast<const f32x4*>(base + (size_t)qrow * ld + 16 * t + 4 * g);
         }
     };
-    issue(blockIdx.x);
-    for (int bh = blockIdx.x; ; ) {
+    issue(first);
+    for (int bh = first; ; ) {
     const int b = bh / H, h = bh - b * H;
 #pragma unroll
     for (int s = 0; s < NS; ++s) {
