@@ -102,7 +102,7 @@ def train_bench(args, world, rank, local_rank, use_dist):
         dist.destroy_process_group()
 
 
-PMC_SUMMARY = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_h_unsplit_pmc_summary.csv")
+PMC_SUMMARY = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_i_unsplit_pmc_summary.csv")
 
 
 def pmc_traffic(kernel_class, dom_key):
