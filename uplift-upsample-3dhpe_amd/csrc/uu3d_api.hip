@@ -91,6 +91,7 @@ struct uu3d_model {
     float* arena = nullptr;        // packed device weights
     size_t arena_floats = 0;
     bool no_lnfuse = true;         // UU3D_LNFUSE=1: producer-side split + LayerNorm folded into the panel GEMMs (LNF) instead of the ln_split_frag pass; measured +-0.6 %, off
+    bool attn_wg = false;          // UU3D_ATTN_WG=1: attention with one workgroup per (sequence, head) (attn_f32_kernel) instead of one wave per item
     bool no_attn_pipe = true;      // UU3D_ATTN_PIPE=1: two (sequence, head) items per attention workgroup, the second one's loads in flight while the first is computed (+1 % h36m_351, -1.3 % h36m_81: off)
     bool no_panel_acc = true;      // UU3D_PANEL_ACC=1: projection / fc2 on gemm_h3_panel_acc_kernel instead of the tiled LDS-DMA kernel (measured slower: DESIGN section 11)
     bool g_tile22 = false;         // UU3D_G_TILE22=1: 128 x 128 tiles for the large LDS-DMA GEMMs (experiment)
@@ -305,6 +306,7 @@ int uu3d_create(const uu3d_config* c, int device, uu3d_model** out) {
     { const char* e = getenv("UU3D_NO_PLANES"); m->no_planes = (e != nullptr && e[0] == '1'); }
     { const char* e = getenv("UU3D_LN_PLANES"); m->ln_planes = (e != nullptr && e[0] == '1'); }
     { const char* e = getenv("UU3D_LNFUSE"); m->no_lnfuse = !(e != nullptr && e[0] == '1'); }
+    { const char* e = getenv("UU3D_ATTN_WG"); m->attn_wg = (e != nullptr && e[0] == '1'); }
     { const char* e = getenv("UU3D_ATTN_PIPE"); m->no_attn_pipe = !(e != nullptr && e[0] == '1'); }
     { const char* e = getenv("UU3D_PANEL_ACC"); m->no_panel_acc = !(e != nullptr && e[0] == '1'); }
     { const char* e = getenv("UU3D_G_TILE22"); m->g_tile22 = (e != nullptr && e[0] == '1'); }
@@ -916,6 +918,22 @@ struct Launcher {
         // opt-in (UU3D_ATTN_PIPE=1), >= 1024 (sequence, head) items: two per workgroup, the second one's loads in flight while the first is computed
         const int items = B * H;
         const dim3 grid((items >= 1024 && !m->no_attn_pipe) ? (items + 1) / 2 : items);
+        // one wave per (sequence, head), four heads per workgroup (attn_head_wave_kernel): whenever the heads come in fours and the
+        // K / V tiles of four heads fit the LDS; UU3D_ATTN_WG=1 keeps the workgroup-per-item kernel
+        if (!m->attn_wg && H % 4 == 0 && NT >= 4 && NT <= 5) {       // shorter sequences: more, smaller workgroups hide latency better (measured: NT <= 3)
+            const dim3 hgrid((items + 3) / 4);
+#define UU3D_ATTN_HW(nt) case nt: { \
+            constexpr size_t lds = attn_head_wave_lds_bytes<nt, kDH>(); \
+            if (split_lo_off) { auto k = attn_head_wave_kernel<nt, kDH, true>; static const bool once = (hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) == hipSuccess); (void)once; \
+                hipLaunchKernelGGL(k, hgrid, dim3(256), lds, stream, qkv, 3 * D, D, L, H, mask, out, D, split_lo_off, items); } \
+            else { auto k = attn_head_wave_kernel<nt, kDH, false>; static const bool once = (hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) == hipSuccess); (void)once; \
+                hipLaunchKernelGGL(k, hgrid, dim3(256), lds, stream, qkv, 3 * D, D, L, H, mask, out, D, (size_t)0, items); } \
+            } break;
+            switch (NT) { UU3D_ATTN_HW(4) UU3D_ATTN_HW(5) default: break; }
+#undef UU3D_ATTN_HW
+            end();
+            return;
+        }
 #define UU3D_ATTN_CASE(nt) case nt: \
         if (split_lo_off) hipLaunchKernelGGL((attn_f32_kernel<nt, kDH, true>), grid, dim3(64 * nt), 0, stream, qkv, 3 * D, D, L, H, mask, out, D, split_lo_off, items); \
         else hipLaunchKernelGGL((attn_f32_kernel<nt, kDH, false>), grid, dim3(64 * nt), 0, stream, qkv, 3 * D, D, L, H, mask, out, D, (size_t)0, items); \

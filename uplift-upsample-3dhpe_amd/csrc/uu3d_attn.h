@@ -29,6 +29,13 @@ namespace uu3d {
 // out in the row-panel GEMM's A-fragment order instead ([32-row panel][16-deep k-slice][plane][lane][8 halfs],
 // uu3d_gemm_panel.h) for a contraction length of D.
 static constexpr size_t ATTN_FRAG_ORDER = ~(size_t)0;
+typedef _Float16 h16x8v __attribute__((ext_vector_type(8)));
+#ifdef UU3D_ATTN_STAMP
+__device__ unsigned long long attn_clk[8];     // tools/attn_stamp_exp: s_memtime ticks per phase, summed over workgroups (wave 0)
+#define ATTN_STAMP(...) __VA_ARGS__
+#else
+#define ATTN_STAMP(...)
+#endif
 // A workgroup handles the items bh = blockIdx.x, blockIdx.x + gridDim.x, ... (n_items = B * H in all): with fewer
 // workgroups than items the K / V / Q loads of the NEXT item are issued into registers before the current one is computed
 // (one workgroup per item, all 1024 resident at once, ran load -> compute -> store in lockstep on every CU: 31 us of which
@@ -79,6 +86,7 @@ attn_f32_kernel(const float* __restrict__ qkv, const int ld, const int D, const 
             if (qrow < L) qnext[t] = *reinterpret_cast<const f32x4*>(base + (size_t)qrow * ld + 16 * t + 4 * g);
         }
     };
+    ATTN_STAMP(const long long c0 = clock64();)
     issue(first);
     for (int bh = first; ; ) {
     const int b = bh / H, h = bh - b * H;
@@ -95,6 +103,7 @@ attn_f32_kernel(const float* __restrict__ qkv, const int ld, const int D, const 
 #pragma unroll
     for (int t = 0; t < KT; ++t) qf[t] = qnext[t];
     __syncthreads();
+    ATTN_STAMP(const long long c1 = clock64();)
     const int bh_next = bh + (int)gridDim.x;
     if (bh_next < items) issue(bh_next);               // in flight while this item is computed
 
@@ -113,6 +122,7 @@ attn_f32_kernel(const float* __restrict__ qkv, const int ld, const int D, const 
         st[j] = a;
     }
 
+    ATTN_STAMP(asm volatile("s_nop 0" :: "v"(st[NT - 1][3])); const long long c2 = clock64();)
     // logits / sqrt(d_h) (+ mask * -1e9), softmax over keys
     // 1 / sqrt(d_h) as a multiplication, exp as exp2 of a pre-scaled argument and one reciprocal of the sum: the division,
     // libm expf and per-probability division cost ~1000 VALU instructions per wave (as much SIMD time as the MFMAs);
@@ -124,12 +134,9 @@ attn_f32_kernel(const float* __restrict__ qkv, const int ld, const int D, const 
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int key = 16 * j + 4 * g + r;
-            float v = st[j][r] * scale_mul;
-            if (key < L) {
-                if (key_mask != nullptr) v += (key_mask[(size_t)b * L + key] ? 0.0f : 1.0f) * -1e9f;
-            } else {
-                v = -INFINITY;
-            }
+            // clamped, branch-free byte load (a test around it costs one branch + wait, i.e. a memory round trip, per key)
+            const uint8_t mk = (key_mask != nullptr) ? key_mask[(size_t)b * L + min(key, L - 1)] : (uint8_t)1;
+            const float v = (key < L) ? st[j][r] * scale_mul + (mk ? 0.0f : 1.0f) * -1e9f : -INFINITY;
             st[j][r] = v;
             mx = fmaxf(mx, v);
         }
@@ -156,6 +163,7 @@ attn_f32_kernel(const float* __restrict__ qkv, const int ld, const int D, const 
 #pragma unroll
         for (int r = 0; r < 4; ++r) st[j][r] = st[j][r] * rsum;
 
+    ATTN_STAMP(asm volatile("s_nop 0" :: "v"(st[NT - 1][3])); const long long c3 = clock64();)
     // O = P V : tile t covers head channels 16t .. 16t+15
 #pragma unroll
     for (int t = 0; t < KT; ++t) {
@@ -191,10 +199,228 @@ attn_f32_kernel(const float* __restrict__ qkv, const int ld, const int D, const 
             }
         }
     }
+    ATTN_STAMP(asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); if (tid == 0) { const long long c4 = clock64();
+        atomicAdd(&attn_clk[0], (unsigned long long)(c1 - c0)); atomicAdd(&attn_clk[1], (unsigned long long)(c2 - c1));
+        atomicAdd(&attn_clk[2], (unsigned long long)(c3 - c2)); atomicAdd(&attn_clk[3], (unsigned long long)(c4 - c3)); atomicAdd(&attn_clk[4], 1ull); })
     if (bh_next >= items) break;
     __syncthreads();                                    // every wave is done with this item's K / V tiles
     bh = bh_next;
     }
 }
+
+// ---------------------------------------------------------------------------------------------------------------------
+// The same attention with ONE WAVE PER (sequence, head): a workgroup is 4 waves = 4 consecutive heads of one sequence, every
+// wave stages the K and V of its own head in its own LDS region and walks over the NT query tiles itself.
+// Why: with one workgroup of NT = 5 waves per item, a CU holds 4 workgroups = 20 waves, the kernel's phases (load, Q K^T,
+// softmax, P V, store) run in lockstep on all of them, and 5 waves do not divide over 4 SIMDs (s_memtime stamps,
+// tools/attn_stamp_exp: 20 k cycles per workgroup of which the MFMAs are 3.8 k).  Here a SIMD runs exactly one wave = one
+// item from start to end: no barrier (LDS traffic is ordered by the wave itself), 1024 items = 1024 SIMDs in one round.
+// LDS: 4 x 2 x NT*16 x 52 floats (NT = 5: 130 KiB) -> one workgroup per CU.
+template <int NT, int DH, bool SPLIT = false>
+__global__ void __launch_bounds__(256, 1) __attribute__((amdgpu_waves_per_eu(1, 1)))
+attn_head_wave_kernel(const float* __restrict__ qkv, const int ld, const int D, const int L, const int H,
+                      const uint8_t* __restrict__ key_mask, float* __restrict__ out, const int ldo, const size_t lo_off, const int items)
+{
+    static_assert(DH % 16 == 0, "head dim must be a multiple of 16");
+    constexpr int LD = DH + 4;
+    constexpr int F4 = DH / 4;
+    constexpr int KT = DH / 16;
+    constexpr int NS = (NT * 16 * F4 + 63) / 64;          // staging float4 per lane and matrix
+    constexpr int OS_HALFS = 2 * 16 * DH;                  // per-wave output tile [plane][16 rows][DH] (SPLIT)
+    extern __shared__ __attribute__((aligned(16))) float attn_lds[];
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int qi = lane & 15, g = lane >> 4;
+    float* Ks = attn_lds + (size_t)w * 2 * NT * 16 * LD;
+    float* Vs = Ks + NT * 16 * LD;
+    _Float16* Os = reinterpret_cast<_Float16*>(attn_lds + (size_t)4 * 2 * NT * 16 * LD) + w * OS_HALFS;
+    // the two workgroups of a sequence on one XCD (see attn_f32_kernel)
+    const int wg = ((int)gridDim.x & 7) == 0 ? ((int)blockIdx.x & 7) * ((int)gridDim.x >> 3) + ((int)blockIdx.x >> 3) : (int)blockIdx.x;
+    const int bh = wg * 4 + w;
+    if (bh >= items) return;                               // whole waves only: no barrier anywhere below
+    const int b = bh / H, h = bh - b * H;
+    const float* base = qkv + (size_t)b * L * ld + h * DH;
+    ATTN_STAMP(const long long c0 = clock64(); long long tqk = 0, tsm = 0, tpv = 0;)
+
+    // ---- K, V of this head -> LDS (zero rows above L) ----
+    static_assert((NT * 16 * F4) % 64 == 0, "whole staging passes");
+    {
+        // branch-free (row clamped, zeroed afterwards): a test around a load costs a divergent branch with the wait for the data
+        // inside it, i.e. one memory round trip per load instead of one for all of them
+        // two register groups (one array of all NS float4 per matrix ended up in scratch memory)
+        constexpr int NA = (NS + 1) / 2, NB = NS - NA;
+        f32x4 ka[NA], va[NA], kb[NB > 0 ? NB : 1], vb2[NB > 0 ? NB : 1];      // (vector types: a ?: on the float4 struct goes through a stack array)
+        auto src = [&](const int s) { const int idx = lane + s * 64; const int row = idx / F4; return base + (size_t)min(row, L - 1) * ld + (idx - row * F4) * 4; };
+        auto put = [&](const int s, const f32x4 k4, const f32x4 v4) {
+            const int idx = lane + s * 64;
+            const int row = idx / F4, c4 = (idx - row * F4) * 4;
+            const float keep = row < L ? 1.0f : 0.0f;                       // finite inputs: x * 0 = 0
+            *reinterpret_cast<f32x4*>(&Ks[row * LD + c4]) = k4 * keep;
+            *reinterpret_cast<f32x4*>(&Vs[row * LD + c4]) = v4 * keep;
+        };
+#pragma unroll
+        for (int s = 0; s < NA; ++s) { const float* p = src(s); ka[s] = *reinterpret_cast<const f32x4*>(p + D); va[s] = *reinterpret_cast<const f32x4*>(p + 2 * D); }
+#pragma unroll
+        for (int s = 0; s < NB; ++s) { const float* p = src(NA + s); kb[s] = *reinterpret_cast<const f32x4*>(p + D); vb2[s] = *reinterpret_cast<const f32x4*>(p + 2 * D); }
+#pragma unroll
+        for (int s = 0; s < NA; ++s) put(s, ka[s], va[s]);
+#pragma unroll
+        for (int s = 0; s < NB; ++s) put(NA + s, kb[s], vb2[s]);
+    }
+    f32x4 qnext[KT];
+    auto issue_q = [&](const int tile) {
+        const int qrow = min(16 * tile + qi, L - 1);        // rows above L: a copy of the last row, never stored
+#pragma unroll
+        for (int t = 0; t < KT; ++t) qnext[t] = *reinterpret_cast<const f32x4*>(base + (size_t)qrow * ld + 16 * t + 4 * g);
+    };
+    issue_q(0);
+    // key mask of this sequence as additive terms, once (the same for every query tile)
+    float madd[NT][4];
+#pragma unroll
+    for (int j = 0; j < NT; ++j)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int key = 16 * j + 4 * g + r;
+            // branch-free (clamped) byte load: with the test around it hipcc emits one branch + wait per key, 4 NT serial round trips
+            const uint8_t mk = (key_mask != nullptr) ? key_mask[(size_t)b * L + min(key, L - 1)] : (uint8_t)1;
+            madd[j][r] = (key < L) ? (mk ? 0.0f : 1.0f) * -1e9f : -INFINITY;
+        }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    const float scale_mul = 1.0f / sqrtf((float)DH);
+    ATTN_STAMP(asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); const long long c1 = clock64();)
+
+#pragma unroll 1
+    for (int tile = 0; tile < NT; ++tile) {
+        ATTN_STAMP(const long long t0 = clock64();)
+        f32x4 qf[KT];
+#pragma unroll
+        for (int t = 0; t < KT; ++t) qf[t] = qnext[t];
+        if (tile + 1 < NT) issue_q(tile + 1);              // in flight while this tile is computed
+        // S^T tiles: st[j][r] = <Q[16 tile + qi], K[16j + 4g + r]>; the NT chains are independent, interleaved
+        f32x4 st[NT];
+#pragma unroll
+        for (int j = 0; j < NT; ++j) st[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int t = 0; t < KT; ++t) {
+            f32x4 kf[NT];
+#pragma unroll
+            for (int j = 0; j < NT; ++j) kf[j] = *reinterpret_cast<const f32x4*>(&Ks[(16 * j + qi) * LD + 16 * t + 4 * g]);
+#pragma unroll
+            for (int s = 0; s < 4; ++s)
+#pragma unroll
+                for (int j = 0; j < NT; ++j)
+                    st[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(kf[j][s], qf[t][s], st[j], 0, 0, 0);
+        }
+        ATTN_STAMP(asm volatile("s_nop 0" :: "v"(st[NT - 1][3])); const long long t1 = clock64();)
+        float mx = -INFINITY;
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float v = st[j][r] * scale_mul + madd[j][r];
+                st[j][r] = v;
+                mx = fmaxf(mx, v);
+            }
+        mx = fmaxf(mx, __shfl_xor(mx, 16));
+        mx = fmaxf(mx, __shfl_xor(mx, 32));
+        float sum = 0.f;
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float e = __builtin_amdgcn_exp2f((st[j][r] - mx) * 1.44269504088896341f);
+                st[j][r] = e;
+                sum += e;
+            }
+        sum += __shfl_xor(sum, 16);
+        sum += __shfl_xor(sum, 32);
+        const float rsum = 1.0f / sum;
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) st[j][r] = st[j][r] * rsum;
+
+        ATTN_STAMP(asm volatile("s_nop 0" :: "v"(st[NT - 1][3])); const long long t2 = clock64();)
+        // O = P V : the KT channel tiles are independent chains, interleaved
+        f32x4 o[KT];
+#pragma unroll
+        for (int t = 0; t < KT; ++t) o[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        {
+            // V values by name, two key tiles ahead of the MFMAs that use them, with counted waits (LDS returns in order):
+            // hipcc placed each ds_read directly in front of its two MFMAs -- an LDS round trip per 64 MFMA cycles
+            float vv[3][4 * KT];
+            const unsigned vb = (unsigned)(uintptr_t)(__attribute__((address_space(3))) void*)(Vs + (4 * g) * LD + qi);
+#define UU3D_ATTN_VREAD(buf, jj) \
+            _Pragma("unroll") for (int s = 0; s < 4; ++s) \
+            _Pragma("unroll") for (int t = 0; t < KT; ++t) \
+                asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(vv[buf][s * KT + t]) : "v"(vb), "i"(((16 * (jj) + s) * LD + 16 * t) * 4));
+            UU3D_ATTN_VREAD(0, 0)
+            if (NT > 1) { UU3D_ATTN_VREAD(1, 1) }
+#pragma unroll
+            for (int j = 0; j < NT; ++j) {
+                if (j + 2 < NT) { UU3D_ATTN_VREAD((j + 2) % 3, j + 2) }
+                static_assert(KT == 3, "the counted wait below lists 4 * KT = 12 registers");
+                float (&c)[4 * KT] = vv[j % 3];
+                if (j + 2 < NT)      asm volatile("s_waitcnt lgkmcnt(15)" : "+v"(c[0]), "+v"(c[1]), "+v"(c[2]), "+v"(c[3]), "+v"(c[4]), "+v"(c[5]), "+v"(c[6]), "+v"(c[7]), "+v"(c[8]), "+v"(c[9]), "+v"(c[10]), "+v"(c[11]));
+                else if (j + 1 < NT) asm volatile("s_waitcnt lgkmcnt(12)" : "+v"(c[0]), "+v"(c[1]), "+v"(c[2]), "+v"(c[3]), "+v"(c[4]), "+v"(c[5]), "+v"(c[6]), "+v"(c[7]), "+v"(c[8]), "+v"(c[9]), "+v"(c[10]), "+v"(c[11]));
+                else                 asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(c[0]), "+v"(c[1]), "+v"(c[2]), "+v"(c[3]), "+v"(c[4]), "+v"(c[5]), "+v"(c[6]), "+v"(c[7]), "+v"(c[8]), "+v"(c[9]), "+v"(c[10]), "+v"(c[11]));
+#pragma unroll
+                for (int s = 0; s < 4; ++s)
+#pragma unroll
+                    for (int t = 0; t < KT; ++t)
+                        o[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(st[j][s], c[s * KT + t], o[t], 0, 0, 0);
+            }
+#undef UU3D_ATTN_VREAD
+        }
+        if constexpr (SPLIT) {
+            // The two f16 planes of the 16 x DH tile go through a per-wave LDS image and leave as 16-byte pieces (direct from
+            // the C/D registers they were 8 * KT two-byte stores per lane, each a 64-address scatter: the longest phase of a tile).
+#pragma unroll
+            for (int t = 0; t < KT; ++t)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const _Float16 hv = (fabsf(o[t][r]) < 6.103515625e-05f) ? (_Float16)0.f : (_Float16)o[t][r];   // = h3_hi, f16 denormals stay on in this kernel
+                    const _Float16 lv = (_Float16)((o[t][r] - (float)hv) * 2048.0f);
+                    Os[(4 * g + r) * DH + 16 * t + qi] = hv;
+                    Os[(16 + 4 * g + r) * DH + 16 * t + qi] = lv;
+                }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            constexpr int PPR = DH / 8, PIECES = 2 * 16 * PPR;             // 16-byte pieces per row / per tile
+            _Float16* oh = reinterpret_cast<_Float16*>(out);
+#pragma unroll
+            for (int i = 0; i < (PIECES + 63) / 64; ++i) {
+                const int pc = lane + 64 * i;
+                const int plane = pc / (16 * PPR), rem = pc - plane * 16 * PPR, row = rem / PPR, c8 = rem - row * PPR;
+                const int q = 16 * tile + row;
+                if (pc < PIECES && q < L) {
+                    const h16x8v piece = *reinterpret_cast<const h16x8v*>(&Os[(plane * 16 + row) * DH + 8 * c8]);
+                    const int grow = b * L + q, k = h * DH + 8 * c8;
+                    size_t at;
+                    if (lo_off == ATTN_FRAG_ORDER)
+                        at = ((((size_t)(grow >> 5) * (D >> 4) + (k >> 4)) * 2 + plane) * 64 + ((k >> 3) & 1) * 32 + (grow & 31)) * 8;
+                    else
+                        at = (size_t)plane * lo_off + (size_t)grow * ldo + k;
+                    *reinterpret_cast<h16x8v*>(oh + at) = piece;
+                }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+        } else {
+#pragma unroll
+            for (int t = 0; t < KT; ++t)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int q = 16 * tile + 4 * g + r;
+                    if (q < L) out[((size_t)b * L + q) * ldo + h * DH + 16 * t + qi] = o[t][r];
+                }
+        }
+        ATTN_STAMP(asm volatile("s_nop 0" :: "v"(o[KT - 1])); const long long t3 = clock64(); tqk += t1 - t0; tsm += t2 - t1; tpv += t3 - t2;)
+    }
+    ATTN_STAMP(if (tid == 0) { atomicAdd(&attn_clk[0], (unsigned long long)(c1 - c0)); atomicAdd(&attn_clk[1], (unsigned long long)tqk);
+        atomicAdd(&attn_clk[2], (unsigned long long)tsm); atomicAdd(&attn_clk[3], (unsigned long long)tpv); atomicAdd(&attn_clk[4], 1ull); })
+}
+template <int NT, int DH>
+constexpr size_t attn_head_wave_lds_bytes() { return (size_t)4 * 2 * NT * 16 * (DH + 4) * sizeof(float) + (size_t)4 * 2 * 16 * DH * sizeof(_Float16); }
 
 }  // namespace uu3d
