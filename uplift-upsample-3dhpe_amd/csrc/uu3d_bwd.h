@@ -762,9 +762,9 @@ attn_bwd_mfma_kernel(const float* __restrict__ qkv, const float* __restrict__ dO
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int key = 16 * j + 4 * g + r;
-                float v = st[j][r] * scale_mul;
-                if (key < L) { if (key_mask != nullptr) v += (key_mask[(size_t)b * L + key] ? 0.0f : 1.0f) * -1e9f; }
-                else v = -INFINITY;
+                // clamped, branch-free byte load (a test around it costs a branch + wait per key)
+                const uint8_t mk = (key_mask != nullptr) ? key_mask[(size_t)b * L + min(key, L - 1)] : (uint8_t)1;
+                const float v = (key < L) ? st[j][r] * scale_mul + (mk ? 0.0f : 1.0f) * -1e9f : -INFINITY;
                 st[j][r] = v;
                 mx = fmaxf(mx, v);
             }
