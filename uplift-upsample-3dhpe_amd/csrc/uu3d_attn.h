@@ -53,6 +53,7 @@ attn_f32_kernel(const float* __restrict__ qkv, const int ld, const int D, const 
     constexpr int NS = (16 * F4 + 63) / 64; // staging float4 per thread and matrix
     __shared__ __attribute__((aligned(16))) float Ks[NT * 16 * LD];
     __shared__ __attribute__((aligned(16))) float Vs[NT * 16 * LD];
+    __shared__ __attribute__((aligned(16))) _Float16 Os[SPLIT ? NT : 1][SPLIT ? 2 * 16 * DH : 8];     // per-wave output tile, f16 planes
 
     const int tid = threadIdx.x;
     const int lane = tid & 63, w = tid >> 6;
@@ -165,6 +166,7 @@ attn_f32_kernel(const float* __restrict__ qkv, const int ld, const int D, const 
 
     ATTN_STAMP(asm volatile("s_nop 0" :: "v"(st[NT - 1][3])); const long long c3 = clock64();)
     // O = P V : tile t covers head channels 16t .. 16t+15
+    f32x4 ot[KT];
 #pragma unroll
     for (int t = 0; t < KT; ++t) {
         f32x4 o = (f32x4){0.f, 0.f, 0.f, 0.f};
@@ -175,29 +177,49 @@ attn_f32_kernel(const float* __restrict__ qkv, const int ld, const int D, const 
                 const float vv = Vs[(16 * j + 4 * g + s) * LD + 16 * t + qi];
                 o = __builtin_amdgcn_mfma_f32_16x16x4f32(st[j][s], vv, o, 0, 0, 0);
             }
-        // C/D map: col = lane & 15 -> channel, row = 4g + r -> query
+        ot[t] = o;
+    }
+    // C/D map: col = lane & 15 -> channel, row = 4g + r -> query
+    if constexpr (SPLIT) {
+        // the wave's 16 x DH tile as two f16 planes through LDS, out as 16-byte pieces (see attn_head_wave_kernel)
+        _Float16* Ow = Os[w];
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int q = 16 * w + 4 * g + r;
-            if (q < L) {
-                const size_t at = ((size_t)b * L + q) * ldo + h * DH + 16 * t + qi;
-                if (SPLIT) {
-                    _Float16* oh = reinterpret_cast<_Float16*>(out);
-                    const _Float16 hv = (fabsf(o[r]) < 6.103515625e-05f) ? (_Float16)0.f : (_Float16)o[r];   // = h3_hi (uu3d_gemm_h3.h), explicit: this kernel keeps f16 denormals on
-                    const _Float16 lv = (_Float16)((o[r] - (float)hv) * 2048.0f);
-                    if (lo_off == ATTN_FRAG_ORDER) {
-                        const int row = b * L + q, k = h * DH + 16 * t + qi;
-                        const size_t fi = ((((size_t)(row >> 5) * (D >> 4) + (k >> 4)) * 2) * 64 + ((k >> 3) & 1) * 32 + (row & 31)) * 8 + (k & 7);
-                        oh[fi] = hv; oh[fi + 512] = lv;
-                        continue;
-                    }
-                    oh[at] = hv;
-                    oh[lo_off + at] = lv;
-                } else {
-                    out[at] = o[r];
-                }
+        for (int t = 0; t < KT; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const _Float16 hv = (fabsf(ot[t][r]) < 6.103515625e-05f) ? (_Float16)0.f : (_Float16)ot[t][r];   // = h3_hi (uu3d_gemm_h3.h), explicit: this kernel keeps f16 denormals on
+                const _Float16 lv = (_Float16)((ot[t][r] - (float)hv) * 2048.0f);
+                Ow[(4 * g + r) * DH + 16 * t + qi] = hv;
+                Ow[(16 + 4 * g + r) * DH + 16 * t + qi] = lv;
+            }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        constexpr int PPR = DH / 8, PIECES = 2 * 16 * PPR;
+        _Float16* oh = reinterpret_cast<_Float16*>(out);
+#pragma unroll
+        for (int i = 0; i < (PIECES + 63) / 64; ++i) {
+            const int pc = lane + 64 * i;
+            const int plane = pc / (16 * PPR), rem = pc - plane * 16 * PPR, row = rem / PPR, c8 = rem - row * PPR;
+            const int q = 16 * w + row;
+            if (pc < PIECES && q < L) {
+                const h16x8v piece = *reinterpret_cast<const h16x8v*>(&Ow[(plane * 16 + row) * DH + 8 * c8]);
+                const int grow = b * L + q, k = h * DH + 8 * c8;
+                size_t at;
+                if (lo_off == ATTN_FRAG_ORDER)
+                    at = ((((size_t)(grow >> 5) * (D >> 4) + (k >> 4)) * 2 + plane) * 64 + ((k >> 3) & 1) * 32 + (grow & 31)) * 8;
+                else
+                    at = (size_t)plane * lo_off + (size_t)grow * ldo + k;
+                *reinterpret_cast<h16x8v*>(oh + at) = piece;
             }
         }
+    } else {
+#pragma unroll
+        for (int t = 0; t < KT; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int q = 16 * w + 4 * g + r;
+                if (q < L) out[((size_t)b * L + q) * ldo + h * DH + 16 * t + qi] = ot[t][r];
+            }
     }
     ATTN_STAMP(asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); if (tid == 0) { const long long c4 = clock64();
         atomicAdd(&attn_clk[0], (unsigned long long)(c1 - c0)); atomicAdd(&attn_clk[1], (unsigned long long)(c2 - c1));
