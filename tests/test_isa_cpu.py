@@ -19,7 +19,15 @@ CSRC = os.path.join(util.ROOT, "uplift-upsample-3dhpe_amd", "csrc")
 SRC = r'''
 #include "uu3d_gemm_h3.h"
 #include "uu3d_gemm_panel.h"
+#include "uu3d_attn.h"
+#include "uu3d_bwd.h"
+#include "uu3d_spatial_h3.h"
 using namespace uu3d;
+template __global__ void uu3d::attn_head_wave_kernel<5, 48, true>(const float*, int, int, int, int, const uint8_t*, float*, int, size_t, int);
+template __global__ void uu3d::attn_f32_kernel<3, 48, true>(const float*, int, int, int, int, const uint8_t*, float*, int, size_t, int);
+template __global__ void uu3d::gemm_tn_h3_kernel<TnLoadLayerNorm, EpSlab>(const TnLoadLayerNorm, const float*, int, int, int, int, int, int, int, const EpSlab);
+template __global__ void uu3d::gemm_tn_kernel<TnLoadLayerNorm, EpSlab>(const TnLoadLayerNorm, const float*, int, int, int, int, int, int, int, const EpSlab);
+template __global__ void uu3d::spatial_stack_h3_kernel<17, 3>(const float*, const SpatialParams, const _Float16*, float*, _Float16*, _Float16*);
 template __global__ void uu3d::gemm_h3_panel_kernel<24, PanelEpBias>(const _Float16*, const _Float16*, const float*, int, int, int, int, const PanelEpBias, int, float);
 template __global__ void uu3d::gemm_h3_panel_kernel<24, PanelEpBias, true>(const _Float16*, const _Float16*, const float*, int, int, int, int, const PanelEpBias, int, float);
 template __global__ void uu3d::gemm_h3_panel_kernel<24, PanelEpBiasReluSplit>(const _Float16*, const _Float16*, const float*, int, int, int, int, const PanelEpBiasReluSplit, int, float);
@@ -87,3 +95,64 @@ def test_row_panel_gemm_code_shape(asm):
 def test_no_packed_fp32_valu_ops(asm):
     assert re.search(r"v_pk_(mul|fma|add)_f32", asm) is None
     assert "v_mfma_f32_32x32x16_f16" in asm
+
+
+def _exec_guarded_loads(body):
+    """Loads that hipcc put inside a divergent branch together with the wait for their data (source: `if (ok) x = *p;`):
+    each one is a serial memory round trip.  Counts s_cbranch_execz -> global_load -> s_waitcnt vmcnt within one block."""
+    lines, n = body.split("\n"), 0
+    for i, l in enumerate(lines):
+        if "s_cbranch_execz" not in l:
+            continue
+        seg = lines[i + 1:i + 25]
+        gl = [j for j, x in enumerate(seg) if "global_load" in x]
+        if gl and not any(".LBB" in x for x in seg[:gl[0]]) and any("s_waitcnt vmcnt" in x for x in seg[gl[0]:gl[0] + 12]):
+            n += 1
+    return n
+
+
+def test_attention_kernels_code_shape(asm):
+    """uu3d_attn.h: no scratch, no branch-guarded loads (mask bytes, K / V / Q rows are clamped and selected instead), the
+    V operand reads of the wave-per-item kernel stay the by-name ds_read_b32 batches issued ahead of their MFMAs, and the
+    f16 planes leave as 16-byte stores."""
+    ks = _kernels(asm)
+    hw = next(v for k, v in ks.items() if "attn_head_wave_kernel" in k)
+    wg = next(v for k, v in ks.items() if "attn_f32_kernel" in k)
+    for body in (hw, wg):
+        assert "scratch_" not in body
+        assert _exec_guarded_loads(body) == 0
+        assert "global_store_dwordx4" in body and "global_store_short" not in body
+    assert hw.count("s_barrier") == 0
+    code = [l.strip() for l in hw.split("\n") if l.strip() and not l.strip().startswith(";")]
+    run = best = 0
+    for l in code:
+        run = run + 1 if l.startswith("ds_read_b32") else 0
+        best = max(best, run)
+    assert best >= 24, best                                  # two key tiles' V values (2 x 12) issued back to back, ahead of the MFMAs
+    assert "s_waitcnt lgkmcnt(15)" in hw and "s_waitcnt lgkmcnt(12)" in hw
+
+
+def test_weight_gradient_gemm_code_shape(asm):
+    """uu3d_bwd.h: the f16x3 weight-gradient GEMM reads its fragments with ds_read_b64_tr_b16 (32 per k-step: 8 fragments x 2
+    planes x 2 reads) for 24 MFMAs, fits two workgroups per CU (<= 256 registers), and neither it nor the f32 kernel waits for a
+    load inside a divergent branch (TnLoad*::fetch / finish)."""
+    ks = _kernels(asm)
+    h3 = next(v for k, v in ks.items() if "gemm_tn_h3_kernel" in k)
+    f32 = next(v for k, v in ks.items() if "gemm_tn_kernel" in k)
+    assert "scratch_" not in h3 and "scratch_" not in f32
+    assert h3.count("ds_read_b64_tr_b16") == 32
+    assert h3.count("v_mfma_f32_32x32x16_f16") == 24
+    assert _exec_guarded_loads(h3) == 0 and _exec_guarded_loads(f32) == 0
+    m = re.search(r"gemm_tn_h3_kernel\w*\n(?:.*\n)*?\s*\.vgpr_count:\s+(\d+)", asm)
+    assert m and int(m.group(1)) <= 256, m and m.group(1)
+
+
+def test_spatial_stack_weight_fragments_are_prefetched(asm):
+    """uu3d_spatial_h3.h: the weight fragments of a product are loaded by name ahead of it (12 loads in one batch at the top of
+    a block for q / k / v) with counted waits; hipcc had sunk every pair of loads to its MFMAs."""
+    ks = _kernels(asm)
+    sp = next(v for k, v in ks.items() if "spatial_stack_h3_kernel" in k)
+    assert "scratch_" not in sp
+    assert re.search(r"(global_load_dwordx4 v\[\d+:\d+\], v\[\d+:\d+\], off\n(?:\t[sv]_\w+.*\n){0,6}?\t?){12}", sp) or sp.count("global_load_dwordx4") >= 32
+    for n in (8, 4, 0):
+        assert f"s_waitcnt vmcnt({n})" in sp
