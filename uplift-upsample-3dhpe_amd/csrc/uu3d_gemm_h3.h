@@ -21,6 +21,9 @@
 #include <stdint.h>
 #include "uu3d_gemm.h"
 
+#ifndef UU3D_H3G_PIPE12
+#define UU3D_H3G_PIPE12 0      // -DUU3D_H3G_PIPE12=1: by-name fragment reads for the 64 x 128 / 64 x 64 tiles too (measured: no gain, see the kernel)
+#endif
 namespace uu3d {
 
 typedef _Float16 h16x8 __attribute__((ext_vector_type(8)));
@@ -529,7 +532,10 @@ gemm_h3g_kernel(const GL gl, const _Float16* __restrict__ Bh, const _Float16* __
     // 128 x 128 tiles leave one workgroup per CU = one wave per SIMD: nothing hides an LDS read that hipcc sinks to its
     // use, so this form issues all 16 fragment reads of a k-tile up front by asm (counted lgkmcnt waits, LDS returns in
     // order) and spreads the next tile's 8 DMAs between the MFMAs instead of issuing them in front of them.
-    constexpr bool PIPE = (TM == 2 && TN == 2 && NBUF == 3);
+    // The 64 x 128 and 64 x 64 tiles can take the same form (-DUU3D_H3G_PIPE12=1): hipcc reads 6 fragments, waits, runs 6 MFMAs,
+    // reads the other 6, waits again.  Measured with all 12 reads up front: fc2 31.0 vs 30.5 us, projection 21.4 vs 20.6 us --
+    // with two workgroups per CU the other workgroup's MFMAs already cover the reads; left off.
+    constexpr bool PIPE = (NBUF == 3) && ((TM == 2 && TN == 2) || (UU3D_H3G_PIPE12 && TM == 1 && (TN == 2 || TN == 1)));
     if (PIPE) {
         unsigned aoff[2][TM][2], boff[2][TN][2];           // byte offsets inside a stage: [kk][fragment][plane]
 #pragma unroll
@@ -564,8 +570,17 @@ gemm_h3g_kernel(const GL gl, const _Float16* __restrict__ Bh, const _Float16* __
             int piece = 0;
 #pragma unroll
             for (int kk = 0; kk < 2; ++kk) {
-                if (kk == 0) asm volatile("s_waitcnt lgkmcnt(8)" : "+v"(fa[0][0][0]), "+v"(fa[0][0][1]), "+v"(fa[0][1][0]), "+v"(fa[0][1][1]), "+v"(fb[0][0][0]), "+v"(fb[0][0][1]), "+v"(fb[0][1][0]), "+v"(fb[0][1][1]));
-                else asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(fa[1][0][0]), "+v"(fa[1][0][1]), "+v"(fa[1][1][0]), "+v"(fa[1][1][1]), "+v"(fb[1][0][0]), "+v"(fb[1][0][1]), "+v"(fb[1][1][0]), "+v"(fb[1][1][1]));
+                // the reads of kk = 1 (2 (TM + TN) of them) may stay in flight over the MFMAs of kk = 0
+                if constexpr (TM == 2 && TN == 2) {
+                    if (kk == 0) asm volatile("s_waitcnt lgkmcnt(8)" : "+v"(fa[0][0][0]), "+v"(fa[0][0][1]), "+v"(fa[0][TM - 1][0]), "+v"(fa[0][TM - 1][1]), "+v"(fb[0][0][0]), "+v"(fb[0][0][1]), "+v"(fb[0][TN - 1][0]), "+v"(fb[0][TN - 1][1]));
+                    else asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(fa[1][0][0]), "+v"(fa[1][0][1]), "+v"(fa[1][TM - 1][0]), "+v"(fa[1][TM - 1][1]), "+v"(fb[1][0][0]), "+v"(fb[1][0][1]), "+v"(fb[1][TN - 1][0]), "+v"(fb[1][TN - 1][1]));
+                } else if constexpr (TN == 2) {
+                    if (kk == 0) asm volatile("s_waitcnt lgkmcnt(6)" : "+v"(fa[0][0][0]), "+v"(fa[0][0][1]), "+v"(fb[0][0][0]), "+v"(fb[0][0][1]), "+v"(fb[0][TN - 1][0]), "+v"(fb[0][TN - 1][1]));
+                    else asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(fa[1][0][0]), "+v"(fa[1][0][1]), "+v"(fb[1][0][0]), "+v"(fb[1][0][1]), "+v"(fb[1][TN - 1][0]), "+v"(fb[1][TN - 1][1]));
+                } else {
+                    if (kk == 0) asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(fa[0][0][0]), "+v"(fa[0][0][1]), "+v"(fb[0][0][0]), "+v"(fb[0][0][1]));
+                    else asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(fa[1][0][0]), "+v"(fa[1][0][1]), "+v"(fb[1][0][0]), "+v"(fb[1][0][1]));
+                }
 #pragma unroll
                 for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -573,7 +588,12 @@ gemm_h3g_kernel(const GL gl, const _Float16* __restrict__ Bh, const _Float16* __
                         acc0[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[kk][i][0], fb[kk][j][0], acc0[i][j], 0, 0, 0);
                         acc1[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[kk][i][0], fb[kk][j][1], acc1[i][j], 0, 0, 0);
                         acc1[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[kk][i][1], fb[kk][j][0], acc1[i][j], 0, 0, 0);
-                        dma_piece(kt + 2, wbuf, piece); ++piece;     // NP = 8 pieces over the 8 (kk, i, j) groups
+                        // the NP DMA pieces of tile kt + 2 spread over the 2 TM TN MFMA groups
+                        constexpr int GROUPS = 2 * TM * TN;
+                        const int gi = (kk * TM + i) * TN + j;
+#pragma unroll
+                        for (int q = 0; q < (NP + GROUPS - 1) / GROUPS; ++q)
+                            if (piece < NP && piece * GROUPS < (gi + 1) * NP) { dma_piece(kt + 2, wbuf, piece); ++piece; }
                     }
             }
             asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" :: "i"(NP) : "memory");
