@@ -268,25 +268,39 @@ attn_head_wave_kernel(const float* __restrict__ qkv, const int ld, const int D, 
     {
         // branch-free (row clamped, zeroed afterwards): a test around a load costs a divergent branch with the wait for the data
         // inside it, i.e. one memory round trip per load instead of one for all of them
-        // two register groups (one array of all NS float4 per matrix ended up in scratch memory)
-        constexpr int NA = (NS + 1) / 2, NB = NS - NA;
-        f32x4 ka[NA], va[NA], kb[NB > 0 ? NB : 1], vb2[NB > 0 ? NB : 1];      // (vector types: a ?: on the float4 struct goes through a stack array)
-        auto src = [&](const int s) { const int idx = lane + s * 64; const int row = idx / F4; return base + (size_t)min(row, L - 1) * ld + (idx - row * F4) * 4; };
-        auto put = [&](const int s, const f32x4 k4, const f32x4 v4) {
+        // All 2 NS loads in flight at once, by name: K rows then V rows (scalar base of this wave's head + one 32-bit lane
+        // offset per pass, shared by K and V); hipcc kept ~16 in flight and paid the memory round trip twice.
+        static_assert(NS <= 15, "the counted waits list at most 15 registers");
+        f32x4 kx[15], vx[15];
+        auto scalar_ptr = [](const float* q) {                   // wave-uniform by construction (one head per wave): into SGPRs
+            const unsigned long long a = (unsigned long long)q;
+            const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)a), hi = __builtin_amdgcn_readfirstlane((unsigned)(a >> 32));
+            return (const float*)(((unsigned long long)hi << 32) | lo);
+        };
+        const float* kbase = scalar_ptr(base + D);
+        const float* vbase = scalar_ptr(base + 2 * D);
+        unsigned off[NS];
+#pragma unroll
+        for (int s = 0; s < NS; ++s) { const int idx = lane + s * 64; const int row = idx / F4; off[s] = (unsigned)((min(row, L - 1) * ld + (idx - row * F4) * 4) * 4); }
+#pragma unroll
+        for (int s = 0; s < NS; ++s) asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(kx[s]) : "v"(off[s]), "s"(kbase) : "memory");
+#pragma unroll
+        for (int s = 0; s < NS; ++s) asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(vx[s]) : "v"(off[s]), "s"(vbase) : "memory");
+#pragma unroll
+        for (int s = NS; s < 15; ++s) { kx[s] = (f32x4){0.f, 0.f, 0.f, 0.f}; vx[s] = kx[s]; }
+        auto put = [&](float* T, const int s, const f32x4 x4) {
             const int idx = lane + s * 64;
             const int row = idx / F4, c4 = (idx - row * F4) * 4;
-            const float keep = row < L ? 1.0f : 0.0f;                       // finite inputs: x * 0 = 0
-            *reinterpret_cast<f32x4*>(&Ks[row * LD + c4]) = k4 * keep;
-            *reinterpret_cast<f32x4*>(&Vs[row * LD + c4]) = v4 * keep;
+            *reinterpret_cast<f32x4*>(&T[row * LD + c4]) = x4 * (row < L ? 1.0f : 0.0f);      // finite inputs: x * 0 = 0
         };
+#define UU3D_ATTN_W15(x) "+v"(x[0]), "+v"(x[1]), "+v"(x[2]), "+v"(x[3]), "+v"(x[4]), "+v"(x[5]), "+v"(x[6]), "+v"(x[7]), "+v"(x[8]), "+v"(x[9]), "+v"(x[10]), "+v"(x[11]), "+v"(x[12]), "+v"(x[13]), "+v"(x[14])
+        asm volatile("s_waitcnt vmcnt(%15)" : UU3D_ATTN_W15(kx) : "i"(NS));       // the K rows are here, the V rows still in flight
 #pragma unroll
-        for (int s = 0; s < NA; ++s) { const float* p = src(s); ka[s] = *reinterpret_cast<const f32x4*>(p + D); va[s] = *reinterpret_cast<const f32x4*>(p + 2 * D); }
+        for (int s = 0; s < NS; ++s) put(Ks, s, kx[s]);
+        asm volatile("s_waitcnt vmcnt(0)" : UU3D_ATTN_W15(vx));
 #pragma unroll
-        for (int s = 0; s < NB; ++s) { const float* p = src(NA + s); kb[s] = *reinterpret_cast<const f32x4*>(p + D); vb2[s] = *reinterpret_cast<const f32x4*>(p + 2 * D); }
-#pragma unroll
-        for (int s = 0; s < NA; ++s) put(s, ka[s], va[s]);
-#pragma unroll
-        for (int s = 0; s < NB; ++s) put(NA + s, kb[s], vb2[s]);
+        for (int s = 0; s < NS; ++s) put(Vs, s, vx[s]);
+#undef UU3D_ATTN_W15
     }
     f32x4 qnext[KT];
     auto issue_q = [&](const int tile) {
