@@ -130,6 +130,14 @@ def test_attention_kernels_code_shape(asm):
         best = max(best, run)
     assert best >= 24, best                                  # two key tiles' V values (2 x 12) issued back to back, ahead of the MFMAs
     assert "s_waitcnt lgkmcnt(15)" in hw and "s_waitcnt lgkmcnt(12)" in hw
+    # no scalar load between the first by-name V read and the last counted wait (scalar loads return out of order: a counted
+    # lgkmcnt would then not mean "the oldest reads are back")
+    first = next(i for i, l in enumerate(code) if l.startswith("ds_read_b32"))
+    last = max(i for i, l in enumerate(code) if l.startswith("s_waitcnt lgkmcnt(12)") or l.startswith("s_waitcnt lgkmcnt(15)"))
+    assert not any(l.startswith(("s_load", "s_buffer_load")) for l in code[first:last + 1])
+    back = code[max(0, first - 40):first]
+    z = max(i for i, l in enumerate(back) if l.startswith("s_waitcnt lgkmcnt(0)"))             # the reads start from an empty counter ...
+    assert not any(l.startswith(("ds_", "s_load", "s_buffer_load")) for l in back[z + 1:])      # ... and nothing else is issued on it in between
 
 
 def test_weight_gradient_gemm_code_shape(asm):

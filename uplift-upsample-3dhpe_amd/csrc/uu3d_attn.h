@@ -389,7 +389,11 @@ attn_head_wave_kernel(const float* __restrict__ qkv, const int ld, const int D, 
 #define UU3D_ATTN_VREAD(buf, jj) \
             _Pragma("unroll") for (int s = 0; s < 4; ++s) \
             _Pragma("unroll") for (int t = 0; t < KT; ++t) \
-                asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(vv[buf][s * KT + t]) : "v"(vb), "i"(((16 * (jj) + s) * LD + 16 * t) * 4));
+                asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(vv[buf][s * KT + t]) : "v"(vb), "i"(((16 * (jj) + s) * LD + 16 * t) * 4) : "memory");
+            // The counted waits below are only right while nothing but these reads is outstanding on lgkmcnt: scalar loads
+            // return out of order.  Start from zero; the "memory" clobbers keep the compiler's own memory operations (a lazily
+            // placed kernel-argument s_load included) from being scheduled in between.  (tests/test_isa_cpu.py checks.)
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             UU3D_ATTN_VREAD(0, 0)
             if (NT > 1) { UU3D_ATTN_VREAD(1, 1) }
 #pragma unroll
@@ -397,9 +401,9 @@ attn_head_wave_kernel(const float* __restrict__ qkv, const int ld, const int D, 
                 if (j + 2 < NT) { UU3D_ATTN_VREAD((j + 2) % 3, j + 2) }
                 static_assert(KT == 3, "the counted wait below lists 4 * KT = 12 registers");
                 float (&c)[4 * KT] = vv[j % 3];
-                if (j + 2 < NT)      asm volatile("s_waitcnt lgkmcnt(15)" : "+v"(c[0]), "+v"(c[1]), "+v"(c[2]), "+v"(c[3]), "+v"(c[4]), "+v"(c[5]), "+v"(c[6]), "+v"(c[7]), "+v"(c[8]), "+v"(c[9]), "+v"(c[10]), "+v"(c[11]));
-                else if (j + 1 < NT) asm volatile("s_waitcnt lgkmcnt(12)" : "+v"(c[0]), "+v"(c[1]), "+v"(c[2]), "+v"(c[3]), "+v"(c[4]), "+v"(c[5]), "+v"(c[6]), "+v"(c[7]), "+v"(c[8]), "+v"(c[9]), "+v"(c[10]), "+v"(c[11]));
-                else                 asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(c[0]), "+v"(c[1]), "+v"(c[2]), "+v"(c[3]), "+v"(c[4]), "+v"(c[5]), "+v"(c[6]), "+v"(c[7]), "+v"(c[8]), "+v"(c[9]), "+v"(c[10]), "+v"(c[11]));
+                if (j + 2 < NT)      asm volatile("s_waitcnt lgkmcnt(15)" : "+v"(c[0]), "+v"(c[1]), "+v"(c[2]), "+v"(c[3]), "+v"(c[4]), "+v"(c[5]), "+v"(c[6]), "+v"(c[7]), "+v"(c[8]), "+v"(c[9]), "+v"(c[10]), "+v"(c[11]) :: "memory");
+                else if (j + 1 < NT) asm volatile("s_waitcnt lgkmcnt(12)" : "+v"(c[0]), "+v"(c[1]), "+v"(c[2]), "+v"(c[3]), "+v"(c[4]), "+v"(c[5]), "+v"(c[6]), "+v"(c[7]), "+v"(c[8]), "+v"(c[9]), "+v"(c[10]), "+v"(c[11]) :: "memory");
+                else                 asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(c[0]), "+v"(c[1]), "+v"(c[2]), "+v"(c[3]), "+v"(c[4]), "+v"(c[5]), "+v"(c[6]), "+v"(c[7]), "+v"(c[8]), "+v"(c[9]), "+v"(c[10]), "+v"(c[11]) :: "memory");
 #pragma unroll
                 for (int s = 0; s < 4; ++s)
 #pragma unroll
