@@ -83,3 +83,28 @@ def test_row_panel_gemm_path_matches_oracle(cfgname, batch, monkeypatch):
     assert dev > 0.0, "UU3D_NO_PANEL=1 did not change the path: the panel kernels were not exercised"
     full2, central2, _ = _run_hip(cfg, w, x, m, "f16x3")
     assert np.array_equal(full, full2) and np.array_equal(central, central2)      # run-to-run bitwise
+
+
+@pytest.mark.parametrize("n_frames,strides,batch", [(75, [3, 5, 5], 6), (63, [3, 3, 7], 8), (80, [4, 4, 5], 5), (49, [3, 4, 4], 8), (63, [3, 3, 7], 6), (75, [3, 5, 5], 8)])
+def test_wave_per_head_attention_on_other_lengths(n_frames, strides, batch, monkeypatch):
+    """attn_head_wave_kernel (uu3d_attn.h) serves every sequence of 5 query tiles (65..80 tokens); the shipped configs only
+    have 71.  Other lengths (ragged and full last tiles, grids that are and are not a multiple of 8 workgroups) against the
+    oracle and against the workgroup-per-item kernel (UU3D_ATTN_WG=1), masked block included; the 4-tile lengths (49, 63) run
+    on the workgroup-per-item kernel -- the wave-per-head instantiation for 4 tiles faulted in this test and is gated off."""
+    from oracle import uplift_oracle as O
+    cfg = util.load_config("h36m_351")
+    cfg.SEQUENCE_LENGTH = n_frames
+    cfg.STRIDES = list(strides)
+    cfg.PADDINGS = [[0, 0]] * 3
+    arch = pkg.arch_from_config(cfg)
+    w = pkg.init_weights(arch, seed=5, perturb=0.1)
+    x, m = util.synthetic_batch(cfg, batch=batch, seed=5)
+    full, central, xm = _run_hip(cfg, w, x, m, "f16x3")
+    f32, c32 = O.forward(util.hp_from_arch(arch), w, xm, m, torch.float32)
+    err = max(np.abs(full - f32).max(), np.abs(central - c32).max())
+    monkeypatch.setenv("UU3D_ATTN_WG", "1")
+    full_wg, central_wg, _ = _run_hip(cfg, w, x, m, "f16x3")
+    dev = max(np.abs(full - full_wg).max(), np.abs(central - central_wg).max())
+    print(f"N={n_frames} strides {strides} batch {batch}: max-abs vs oracle f32 {err:.3e}, vs the workgroup-per-item kernel {dev:.3e}")
+    assert np.isfinite(full).all() and err <= util.TOL_MAX_ABS
+    assert dev <= 2e-5
