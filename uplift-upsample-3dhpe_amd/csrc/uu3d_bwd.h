@@ -461,7 +461,7 @@ ln_bwd_narrow_kernel(const float* __restrict__ x, const float* __restrict__ dy, 
     const f32x4 gm = *reinterpret_cast<const f32x4*>(gamma + 4 * l);
     f32x4 dg = (f32x4){0.f, 0.f, 0.f, 0.f}, db = dg;
     const int base = blockIdx.x * RG * rows_per_group + rg;
-#pragma unroll 2
+
     for (int rr = 0; rr < rows_per_group; ++rr) {
         const int row = base + rr * RG;
         const bool ok = row < M;
