@@ -123,6 +123,12 @@ def test_attention_kernels_code_shape(asm):
         assert _exec_guarded_loads(body) == 0
         assert "global_store_dwordx4" in body and "global_store_short" not in body
     assert hw.count("s_barrier") == 0
+    # inline-asm loads with a scalar base: the compiler cannot pad the VALU-writes-SGPR -> VMEM-reads-SGPR hazard (5 wait
+    # states) for them; an s_nop 4 must stand between the last v_readfirstlane and the first such load
+    code0 = [l.strip() for l in hw.split("\n") if l.strip() and not l.strip().startswith(";")]
+    first_s = next(i for i, l in enumerate(code0) if re.match(r"global_load_dwordx4 v\[\d+:\d+\], v\d+, s\[", l))
+    last_rfl = max(i for i, l in enumerate(code0[:first_s]) if l.startswith("v_readfirstlane_b32"))
+    assert any(l.startswith("s_nop 4") for l in code0[last_rfl + 1:first_s])
     code = [l.strip() for l in hw.split("\n") if l.strip() and not l.strip().startswith(";")]
     run = best = 0
     for l in code:

@@ -87,10 +87,10 @@ def test_row_panel_gemm_path_matches_oracle(cfgname, batch, monkeypatch):
 
 @pytest.mark.parametrize("n_frames,strides,batch", [(75, [3, 5, 5], 6), (63, [3, 3, 7], 8), (80, [4, 4, 5], 5), (49, [3, 4, 4], 8), (63, [3, 3, 7], 6), (75, [3, 5, 5], 8)])
 def test_wave_per_head_attention_on_other_lengths(n_frames, strides, batch, monkeypatch):
-    """attn_head_wave_kernel (uu3d_attn.h) serves every sequence of 5 query tiles (65..80 tokens); the shipped configs only
-    have 71.  Other lengths (ragged and full last tiles, grids that are and are not a multiple of 8 workgroups) against the
-    oracle and against the workgroup-per-item kernel (UU3D_ATTN_WG=1), masked block included; the 4-tile lengths (49, 63) run
-    on the workgroup-per-item kernel -- the wave-per-head instantiation for 4 tiles faulted in this test and is gated off."""
+    """attn_head_wave_kernel (uu3d_attn.h) serves every sequence of 4-5 query tiles (49..80 tokens); the shipped configs only
+    have 71.  Other lengths (ragged and full last tiles, 4 and 5 tiles, grids that are and are not a multiple of 8 workgroups)
+    against the oracle and against the workgroup-per-item kernel (UU3D_ATTN_WG=1), masked block included.  (This test found a
+    GPU memory fault of the 4-tile instantiation: an SGPR hazard behind inline asm, see the kernel.)"""
     from oracle import uplift_oracle as O
     cfg = util.load_config("h36m_351")
     cfg.SEQUENCE_LENGTH = n_frames

@@ -920,10 +920,8 @@ struct Launcher {
         const dim3 grid((items >= 1024 && !m->no_attn_pipe) ? (items + 1) / 2 : items);
         // one wave per (sequence, head), four heads per workgroup (attn_head_wave_kernel): whenever the heads come in fours and the
         // K / V tiles of four heads fit the LDS; UU3D_ATTN_WG=1 keeps the workgroup-per-item kernel
-        // NT <= 3: more, smaller workgroups hide latency better (measured).  NT == 4 (49..64 tokens, no shipped config): the
-        // instantiation raises a GPU memory fault that NT == 5 does not (tests/test_parity_gpu.py found it; cause not yet
-        // found) -- it stays on the workgroup-per-item kernel.
-        if (!m->attn_wg && H % 4 == 0 && NT == 5) {
+        // NT <= 3: more, smaller workgroups hide latency better (measured)
+        if (!m->attn_wg && H % 4 == 0 && NT >= 4 && NT <= 5) {
             const dim3 hgrid((items + 3) / 4);
 #define UU3D_ATTN_HW(nt) case nt: { \
             constexpr size_t lds = attn_head_wave_lds_bytes<nt, kDH>(); \
@@ -932,7 +930,7 @@ struct Launcher {
             else { auto k = attn_head_wave_kernel<nt, kDH, false>; static const bool once = (hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) == hipSuccess); (void)once; \
                 hipLaunchKernelGGL(k, hgrid, dim3(256), lds, stream, qkv, 3 * D, D, L, H, mask, out, D, (size_t)0, items); } \
             } break;
-            switch (NT) { UU3D_ATTN_HW(5) default: break; }
+            switch (NT) { UU3D_ATTN_HW(4) UU3D_ATTN_HW(5) default: break; }
 #undef UU3D_ATTN_HW
             end();
             return;
