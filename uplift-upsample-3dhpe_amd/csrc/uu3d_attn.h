@@ -335,7 +335,7 @@ attn_head_wave_kernel(const float* __restrict__ qkv, const int ld, const int D, 
     const float scale_mul = 1.0f / sqrtf((float)DH);
     ATTN_STAMP(asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); const long long c1 = clock64();)
 
-#pragma unroll 1
+#pragma unroll
     for (int tile = 0; tile < NT; ++tile) {
         ATTN_STAMP(const long long t0 = clock64();)
         f32x4 qf[KT];
