@@ -170,3 +170,11 @@ def test_spatial_stack_weight_fragments_are_prefetched(asm):
     assert re.search(r"(global_load_dwordx4 v\[\d+:\d+\], v\[\d+:\d+\], off\n(?:\t[sv]_\w+.*\n){0,6}?\t?){12}", sp) or sp.count("global_load_dwordx4") >= 32
     for n in (8, 4, 0):
         assert f"s_waitcnt vmcnt({n})" in sp
+    # the per-head attention reads its 17 key rows (then its 17 value rows) in one by-name batch
+    code = [l.strip() for l in sp.split("\n") if l.strip() and not l.strip().startswith(";")]
+    run = best = 0
+    for l in code:
+        run = run + 1 if l.startswith("ds_read_b128") else 0
+        best = max(best, run)
+    assert best >= 17, best
+    assert "s_waitcnt lgkmcnt(8)" in sp

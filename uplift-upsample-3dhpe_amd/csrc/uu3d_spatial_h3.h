@@ -205,6 +205,9 @@ __device__ __forceinline__ void store_planes(_Float16* Th, _Float16* Tl, const i
 
 // One (token, head): softmax(q k^T / sqrt(d_h)) v over the J keys of the token's frame; Kp / Vp point at the head's 4
 // channels of the frame's first key row.
+#ifndef UU3D_SPATIAL_ATTN_BYNAME
+#define UU3D_SPATIAL_ATTN_BYNAME 1
+#endif
 template <int J>
 __device__ __forceinline__ f32x4 head_attention(const f32x4 q4, const float* Kp, const float* Vp) {
     // softmax(x) with x = q.k / 2: exp(x - max) = exp2((q * log2e / 2).k - max'), so the scale and the base change are
@@ -213,6 +216,48 @@ __device__ __forceinline__ f32x4 head_attention(const f32x4 q4, const float* Kp,
                       q4[2] * 0.72134752044448170368f, q4[3] * 0.72134752044448170368f};
     float s[J];
     float mx = -INFINITY;
+    if constexpr (J == 17 && UU3D_SPATIAL_ATTN_BYNAME) {
+        // The 17 key rows and then the 17 value rows of this head by name, all in flight at once, with counted waits (LDS returns
+        // in order; the counter starts from zero and the "memory" clobbers keep other memory operations out, see uu3d_attn.h).
+        // hipcc had emitted read -> wait -> use for every row: 34 exposed LDS round trips per (token, head), 272 per block.
+        f32x4 kv[17];
+        const unsigned ka = (unsigned)(uintptr_t)(__attribute__((address_space(3))) const void*)Kp;
+        const unsigned va = (unsigned)(uintptr_t)(__attribute__((address_space(3))) const void*)Vp;
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+        for (int j = 0; j < 17; ++j) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(kv[j]) : "v"(ka), "i"(j * KLD * 4) : "memory");
+#define UU3D_SP_W9(x, o) "+v"(x[o]), "+v"(x[o + 1]), "+v"(x[o + 2]), "+v"(x[o + 3]), "+v"(x[o + 4]), "+v"(x[o + 5]), "+v"(x[o + 6]), "+v"(x[o + 7]), "+v"(x[o + 8])
+        asm volatile("s_waitcnt lgkmcnt(8)" : UU3D_SP_W9(kv, 0) :: "memory");
+#pragma unroll
+        for (int j = 0; j < 9; ++j) {
+            float d = qs[0] * kv[j][0];
+            d = fmaf(qs[1], kv[j][1], d); d = fmaf(qs[2], kv[j][2], d); d = fmaf(qs[3], kv[j][3], d);
+            s[j] = d; mx = fmaxf(mx, d);
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" : UU3D_SP_W9(kv, 8) :: "memory");
+#pragma unroll
+        for (int j = 9; j < 17; ++j) {
+            float d = qs[0] * kv[j][0];
+            d = fmaf(qs[1], kv[j][1], d); d = fmaf(qs[2], kv[j][2], d); d = fmaf(qs[3], kv[j][3], d);
+            s[j] = d; mx = fmaxf(mx, d);
+        }
+#pragma unroll
+        for (int j = 0; j < 17; ++j) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(kv[j]) : "v"(va), "i"(j * KLD * 4) : "memory");
+        float sum = 0.f;
+#pragma unroll
+        for (int j = 0; j < 17; ++j) { s[j] = __builtin_amdgcn_exp2f(s[j] - mx); sum += s[j]; }     // the value rows arrive meanwhile
+        f32x4 o = {0.f, 0.f, 0.f, 0.f};
+        asm volatile("s_waitcnt lgkmcnt(8)" : UU3D_SP_W9(kv, 0) :: "memory");
+#pragma unroll
+        for (int j = 0; j < 9; ++j) { o[0] = fmaf(s[j], kv[j][0], o[0]); o[1] = fmaf(s[j], kv[j][1], o[1]); o[2] = fmaf(s[j], kv[j][2], o[2]); o[3] = fmaf(s[j], kv[j][3], o[3]); }
+        asm volatile("s_waitcnt lgkmcnt(0)" : UU3D_SP_W9(kv, 8) :: "memory");
+#pragma unroll
+        for (int j = 9; j < 17; ++j) { o[0] = fmaf(s[j], kv[j][0], o[0]); o[1] = fmaf(s[j], kv[j][1], o[1]); o[2] = fmaf(s[j], kv[j][2], o[2]); o[3] = fmaf(s[j], kv[j][3], o[3]); }
+#undef UU3D_SP_W9
+        const float rsum = 1.0f / sum;
+        o[0] *= rsum; o[1] *= rsum; o[2] *= rsum; o[3] *= rsum;
+        return o;
+    } else {
 #pragma unroll
     for (int j = 0; j < J; ++j) {
         const f32x4 k4 = *reinterpret_cast<const f32x4*>(Kp + j * KLD);
@@ -233,6 +278,7 @@ __device__ __forceinline__ f32x4 head_attention(const f32x4 q4, const float* Kp,
     const float rsum = 1.0f / sum;
     o[0] *= rsum; o[1] *= rsum; o[2] *= rsum; o[3] *= rsum;
     return o;
+    }
 }
 }  // namespace sh3
 
