@@ -28,6 +28,9 @@ namespace uu3d {
 // see uu3d_gemm_h3.h) that the f16x3 projection GEMM reads, instead of f32.  lo_off == ATTN_FRAG_ORDER: the planes go
 // out in the row-panel GEMM's A-fragment order instead ([32-row panel][16-deep k-slice][plane][lane][8 halfs],
 // uu3d_gemm_panel.h) for a contraction length of D.
+#ifndef UU3D_ATTN_WG_BYNAME
+#define UU3D_ATTN_WG_BYNAME 0
+#endif
 static constexpr size_t ATTN_FRAG_ORDER = ~(size_t)0;
 typedef _Float16 h16x8v __attribute__((ext_vector_type(8)));
 #ifdef UU3D_ATTN_STAMP
@@ -168,16 +171,43 @@ attn_f32_kernel(const float* __restrict__ qkv, const int ld, const int D, const 
     // O = P V : tile t covers head channels 16t .. 16t+15
     f32x4 ot[KT];
 #pragma unroll
-    for (int t = 0; t < KT; ++t) {
-        f32x4 o = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int t = 0; t < KT; ++t) ot[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    if constexpr (KT == 3 && UU3D_ATTN_WG_BYNAME) {
+        // V values by name, two key tiles ahead of their MFMAs, counted waits (see attn_head_wave_kernel: hipcc placed one
+        // ds_read2_b32 directly in front of every two MFMAs)
+        float vv[3][4 * KT];
+        const unsigned vb = (unsigned)(uintptr_t)(__attribute__((address_space(3))) void*)(Vs + (4 * g) * LD + qi);
+#define UU3D_ATTN_VREAD(buf, jj) \
+        _Pragma("unroll") for (int s = 0; s < 4; ++s) \
+        _Pragma("unroll") for (int t = 0; t < KT; ++t) \
+            asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(vv[buf][s * KT + t]) : "v"(vb), "i"(((16 * (jj) + s) * LD + 16 * t) * 4) : "memory");
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        UU3D_ATTN_VREAD(0, 0)
+        if (NT > 1) { UU3D_ATTN_VREAD(1, 1) }
 #pragma unroll
-        for (int j = 0; j < NT; ++j)
+        for (int j = 0; j < NT; ++j) {
+            if (j + 2 < NT) { UU3D_ATTN_VREAD((j + 2) % 3, j + 2) }
+            float (&c)[4 * KT] = vv[j % 3];
+            if (j + 2 < NT)      asm volatile("s_waitcnt lgkmcnt(15)" : "+v"(c[0]), "+v"(c[1]), "+v"(c[2]), "+v"(c[3]), "+v"(c[4]), "+v"(c[5]), "+v"(c[6]), "+v"(c[7]), "+v"(c[8]), "+v"(c[9]), "+v"(c[10]), "+v"(c[11]) :: "memory");
+            else if (j + 1 < NT) asm volatile("s_waitcnt lgkmcnt(12)" : "+v"(c[0]), "+v"(c[1]), "+v"(c[2]), "+v"(c[3]), "+v"(c[4]), "+v"(c[5]), "+v"(c[6]), "+v"(c[7]), "+v"(c[8]), "+v"(c[9]), "+v"(c[10]), "+v"(c[11]) :: "memory");
+            else                 asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(c[0]), "+v"(c[1]), "+v"(c[2]), "+v"(c[3]), "+v"(c[4]), "+v"(c[5]), "+v"(c[6]), "+v"(c[7]), "+v"(c[8]), "+v"(c[9]), "+v"(c[10]), "+v"(c[11]) :: "memory");
 #pragma unroll
-            for (int s = 0; s < 4; ++s) {
-                const float vv = Vs[(16 * j + 4 * g + s) * LD + 16 * t + qi];
-                o = __builtin_amdgcn_mfma_f32_16x16x4f32(st[j][s], vv, o, 0, 0, 0);
-            }
-        ot[t] = o;
+            for (int s = 0; s < 4; ++s)
+#pragma unroll
+                for (int t = 0; t < KT; ++t)
+                    ot[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(st[j][s], c[s * KT + t], ot[t], 0, 0, 0);
+        }
+#undef UU3D_ATTN_VREAD
+    } else {
+#pragma unroll
+        for (int t = 0; t < KT; ++t)
+#pragma unroll
+            for (int j = 0; j < NT; ++j)
+#pragma unroll
+                for (int s = 0; s < 4; ++s) {
+                    const float vv = Vs[(16 * j + 4 * g + s) * LD + 16 * t + qi];
+                    ot[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(st[j][s], vv, ot[t], 0, 0, 0);
+                }
     }
     // C/D map: col = lane & 15 -> channel, row = 4g + r -> query
     if constexpr (SPLIT) {
