@@ -317,15 +317,10 @@ attn_head_wave_kernel(const float* __restrict__ qkv, const int ld, const int D, 
         unsigned off[NS];
 #pragma unroll
         for (int s = 0; s < NS; ++s) { const int idx = lane + s * 64; const int row = idx / F4; off[s] = (unsigned)((min(row, L - 1) * ld + (idx - row * F4) * 4) * 4); }
-#if defined(UU3D_ATTN_DBG) && UU3D_ATTN_DBG == 2
-#pragma unroll
-        for (int s = 0; s < NS; ++s) { kx[s] = *reinterpret_cast<const f32x4*>((const char*)kbase + off[s]); vx[s] = *reinterpret_cast<const f32x4*>((const char*)vbase + off[s]); }
-#else
 #pragma unroll
         for (int s = 0; s < NS; ++s) asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(kx[s]) : "v"(off[s]), "s"(kbase) : "memory");
 #pragma unroll
         for (int s = 0; s < NS; ++s) asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(vx[s]) : "v"(off[s]), "s"(vbase) : "memory");
-#endif
 #pragma unroll
         for (int s = NS; s < 15; ++s) { kx[s] = (f32x4){0.f, 0.f, 0.f, 0.f}; vx[s] = kx[s]; }
         auto put = [&](float* T, const int s, const f32x4 x4) {
@@ -481,11 +476,7 @@ attn_head_wave_kernel(const float* __restrict__ qkv, const int ld, const int D, 
                         at = ((((size_t)(grow >> 5) * (D >> 4) + (k >> 4)) * 2 + plane) * 64 + ((k >> 3) & 1) * 32 + (grow & 31)) * 8;
                     else
                         at = (size_t)plane * lo_off + (size_t)grow * ldo + k;
-                    
-#if !defined(UU3D_ATTN_DBG) || UU3D_ATTN_DBG != 1
                     *reinterpret_cast<h16x8v*>(oh + at) = piece;
-#endif
-
                 }
             }
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
