@@ -1,7 +1,9 @@
 """Throughput of the uplift/upsample transformer forward on synthetic (B, N, 17, 2) windows.
 
     python bench.py --gpus 1 --steps 50 --warmup 10
-    python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
+    python bench.py --gpus N ...                 # starts its own N ranks (child processes, before the parent touches a GPU)
+    python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...     # or under a launcher
+    python bench.py --config dense_351 --batch 32        # SURVEY 8(d)'s stress shape: temporal attention over 351 tokens
 
 One step = one forward of `--batch` sequences per rank (inputs resident in HBM) + the
 per-joint MPJPE kernel; with N > 1 ranks the batch is sharded (weak scaling: every rank
@@ -22,26 +24,37 @@ PEAK_F32_MFMA_TFLOPS = 157.3   # /opt/skills/guides/MI355X_MICROARCH.md "Peak FP
 PEAK_F16_MFMA_TFLOPS = 2500.0  # same table, "Peak BF16/FP16 MFMA ~2.5 PF dense"
 
 
-def cpu_baseline(cfg, arch, weights, x, m, budget_s=12.0):
-    """Oracle ("port": PyTorch-CPU fp32 restatement) timed on the host cores on a bounded sample."""
-    import numpy as np
+def cpu_baseline(cfg, arch, weights, x, m, budget_s=75.0):
+    """Oracle ("port": PyTorch-CPU fp32 restatement) timed on the host cores at the BENCH batch (BASELINE.md section 4:
+    same synthetic batch, 3 warm-ups, median of >= 10 forwards).  The thread count is swept first on one forward each
+    (eager PyTorch on many-core hosts is not fastest with every core) and stated in the result; `budget_s` bounds the
+    whole measurement, the counts actually reached are in `sample`."""
+    import statistics
     import torch
     from oracle import uplift_oracle as O
-    from tests import util
-    hp = util.hp_from_arch(arch)
-    nb = min(8, x.shape[0])
-    xs, ms = x[:nb], m[:nb]
-    O.forward(hp, weights, xs, ms, torch.float32)    # warm-up
-    t0 = time.time()
-    n = 0
-    while True:
-        O.forward(hp, weights, xs, ms, torch.float32)
-        n += 1
-        if time.time() - t0 > budget_s or n >= 20:
+    hp = O.hp_from_arch(arch)
+    t_start = time.time()
+    ncpu = os.cpu_count() or 1
+    cand = sorted({t for t in (ncpu, ncpu // 2, ncpu // 4, 32, 16) if 1 <= t <= ncpu}, reverse=True)
+    sweep = {}
+    for t in cand:
+        torch.set_num_threads(t)
+        O.forward(hp, weights, x[:16], m[:16], torch.float32)                  # page in / thread-pool start
+        t0 = time.time(); O.forward(hp, weights, x, m, torch.float32); sweep[t] = time.time() - t0
+        if time.time() - t_start > budget_s / 3:
             break
-    dt = time.time() - t0
-    return {"value": round(nb * n / dt, 2), "unit": "pose-sequences/s", "cores": int(torch.get_num_threads()),
-            "kind": "port", "sample": f"{n} forwards of {nb} sequences, PyTorch-CPU fp32 oracle (oracle/uplift_oracle.py)"}
+    best = min(sweep, key=sweep.get)
+    torch.set_num_threads(best)
+    warm, times = 0, []
+    while warm < 3 and time.time() - t_start < budget_s * 0.5:
+        O.forward(hp, weights, x, m, torch.float32); warm += 1
+    while len(times) < 10 and (len(times) < 3 or time.time() - t_start < budget_s):
+        t0 = time.time(); O.forward(hp, weights, x, m, torch.float32); times.append(time.time() - t0)
+    med = statistics.median(times)
+    return {"value": round(x.shape[0] / med, 2), "unit": "pose-sequences/s", "cores": int(best), "kind": "port",
+            "host_cores": int(ncpu), "thread_sweep_s_per_forward": {str(k): round(v, 3) for k, v in sweep.items()},
+            "sample": f"median of {len(times)} forwards of the bench batch ({x.shape[0]} sequences) after {warm} warm-ups, "
+                      f"PyTorch-CPU fp32 oracle (oracle/uplift_oracle.py) on {best} threads"}
 
 
 def train_bench(args, world, rank, local_rank, use_dist):
@@ -50,7 +63,7 @@ def train_bench(args, world, rank, local_rank, use_dist):
     import torch
     import torch.distributed as dist
     import uplift_upsample_3dhpe_amd as pkg
-    from tests import util
+    from uplift_upsample_3dhpe_amd import synthetic as util
     from uplift_upsample_3dhpe_amd import harness
     from uplift_upsample_3dhpe_amd.trainer import Trainer
     cfgname = args.config if args.config != "h36m_351" else "h36m_351_pt"
@@ -92,7 +105,8 @@ def train_bench(args, world, rank, local_rank, use_dist):
             "metric": "train-sequences/sec", "value": round(seqs / elapsed, 2), "unit": "pose-sequences/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f16x3 forward / input-gradient GEMMs, f32 weight-gradient GEMMs, attention, optimizer" if args.precision == "f16x3" else "f32",
+            "dtype": ("f16x3 forward / input-gradient / weight-gradient GEMMs (UU3D_TN_F32=1: f32 weight gradients), f32 attention, loss, optimizer"
+                      if args.precision == "f16x3" and not os.environ.get("UU3D_TRAIN_F32") else "f32"),
             "data": "synthetic",
             "config": {"workload": f"config/{cfgname}.json train step (fwd+bwd+AdamW), N={N}, J={J}, batch {B}/GPU, "
                                    f"per-sample mask stride from {cfg.MASK_STRIDE}, DropPath {cfg.DROP_PATH_RATE}",
@@ -141,6 +155,19 @@ def attention_roofline(agg):
             "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 4), "avg_launch_ms": round(a["ms"] / a["n"], 5)}
 
 
+def spawn_ranks(n, argv):
+    """One process per GPU under torch.distributed.run on 127.0.0.1 (the container hostname may not resolve)."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+    return subprocess.call(cmd, env=env)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -156,19 +183,28 @@ def main():
     ap.add_argument("--halves", action="store_true", help="two concurrent half-batch chains on two streams instead of one chain of kernels per batch")
     ap.add_argument("--no-halves", action="store_true", help="(default since the row-panel GEMM; accepted for older scripts)")
     ap.add_argument("--force-dist", action="store_true", help="initialise the process group even at world size 1 (exercises the RCCL path)")
+    ap.add_argument("--spawn-check", action="store_true", help="ranks print their rank / world size and exit (no GPU): checks the self-spawn path")
     args = ap.parse_args()
+
+    # `python bench.py --gpus N` without a launcher: start N ranks as CHILD processes here, before this process has
+    # touched the GPU (no exec from a GPU-initialised process), and return their exit code.
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(spawn_ranks(args.gpus, sys.argv[1:]))
+    if args.spawn_check:
+        print(f"rank {os.environ.get('RANK', '0')}/{os.environ.get('WORLD_SIZE', '1')} local {os.environ.get('LOCAL_RANK', '0')}", flush=True)
+        return
 
     import numpy as np
     import torch
     import torch.distributed as dist
     import uplift_upsample_3dhpe_amd as pkg
-    from tests import util
+    from uplift_upsample_3dhpe_amd import synthetic as util
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     torch.cuda.set_device(local_rank)
     use_dist = world > 1 or args.force_dist
     if use_dist:

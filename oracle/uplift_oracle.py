@@ -144,6 +144,16 @@ def strided_transformer_block(p, prefix, x, pe, num_heads, stride, pad):
 # --------------------------------------------------------------------------------------
 # the model forward
 # --------------------------------------------------------------------------------------
+def hp_from_arch(a):
+    """The hyper-parameter dict of this oracle from the product's UpliftArch (plain attribute reads; test-side glue)."""
+    return dict(num_frames=a.num_frames, num_keypoints=a.num_keypoints, d_spatial=a.d_spatial,
+                d_temporal=a.d_temporal, spatial_depth=a.spatial_depth, temporal_depth=a.temporal_depth,
+                strides=tuple(a.strides), paddings=tuple(a.paddings), num_heads=a.num_heads,
+                has_strided_input=a.has_strided_input,
+                first_strided_token_attention_layer=a.first_strided_token_attention_layer,
+                full_output=a.full_output)
+
+
 def forward(hp, weights, x, stride_mask=None, dtype=torch.float32, return_attention=False):
     """``UpliftUpsampleTransformer.call`` (u_u_t.py:388-421), ``training=False``; numpy in, numpy out."""
     p = {k: _t(v, dtype) for k, v in weights.items()}

@@ -194,11 +194,12 @@ def test_concurrent_half_batches_option(cfgname, batch):
     assert np.abs(f1 - f2).max() <= 2e-5 and np.abs(c1 - c2).max() <= 2e-5
 
 
-@pytest.mark.parametrize("env", ["UU3D_ATTN_PIPE", "UU3D_S2T_PLANES", "UU3D_G_TILE22", "UU3D_LNFOLD", "UU3D_LN_PLANES",
-                                 "UU3D_LNFUSE", "UU3D_PANEL_ACC", "UU3D_NO_PANEL", "UU3D_NO_PLANES"])
+@pytest.mark.parametrize("env", ["UU3D_NO_PANEL", "UU3D_NO_PLANES", "UU3D_ATTN_WG"])
 def test_optional_kernel_paths_agree(env, monkeypatch):
-    """The opt-in / opt-out kernel variants kept for A/B measurements at the full
-    h36m_351 batch, where every one of them is actually taken: same results as the product path to rounding."""
+    """The opt-out switches kept for A/B measurements at the full h36m_351 batch, where every one of them
+    changes the kernels that run: same results as the product path to rounding.  (The round-1 experiments that measured
+    neutral or slower -- LNFUSE, PANEL_ACC, LNFOLD, LN_PLANES, ATTN_PIPE, S2T_PLANES, G_TILE22 -- left the library for
+    tools/r01_variants/.)"""
     cfg = util.load_config("h36m_351")
     arch = pkg.arch_from_config(cfg)
     w = pkg.init_weights(arch, seed=5, perturb=0.1)
@@ -206,17 +207,13 @@ def test_optional_kernel_paths_agree(env, monkeypatch):
     x = x * m[:, :, None, None]
     f0, c0 = _call(pkg.build_uplift_upsample_transformer(cfg, weights=w), x, m)
     monkeypatch.setenv(env, "1")
-    if env in ("UU3D_LNFOLD", "UU3D_LN_PLANES"):          # variants of the tiled LayerNorm-fed GEMMs: only reachable without the panel GEMM
-        monkeypatch.setenv("UU3D_NO_PANEL", "1")
     f1, c1 = _call(pkg.build_uplift_upsample_transformer(cfg, weights=w), x, m)
     monkeypatch.delenv(env)
-    monkeypatch.delenv("UU3D_NO_PANEL", raising=False)
     d = max(np.abs(f0 - f1).max(), np.abs(c0 - c1).max())
     print(f"{env}=1: max deviation from the product path {d:.3e}")
     assert np.isfinite(f1).all() and np.isfinite(c1).all()
     assert d <= 3e-5, d
-    if env not in ("UU3D_ATTN_PIPE", "UU3D_G_TILE22", "UU3D_S2T_PLANES"):      # those only reschedule / re-tile the same products (bit-identical is fine)
-        assert d > 0.0, "the switch did not change the path"
+    assert d > 0.0, "the switch did not change the path"
 
 
 def test_mpjpe_kernel_matches_the_reference_metric():

@@ -24,13 +24,12 @@ SRC = r'''
 #include "uu3d_spatial_h3.h"
 using namespace uu3d;
 template __global__ void uu3d::attn_head_wave_kernel<5, 48, true>(const float*, int, int, int, int, const uint8_t*, float*, int, size_t, int);
-template __global__ void uu3d::attn_f32_kernel<3, 48, true>(const float*, int, int, int, int, const uint8_t*, float*, int, size_t, int);
+template __global__ void uu3d::attn_f32_kernel<3, 48, true>(const float*, int, int, int, int, const uint8_t*, float*, int, size_t);
 template __global__ void uu3d::gemm_tn_h3_kernel<TnLoadLayerNorm, EpSlab>(const TnLoadLayerNorm, const float*, int, int, int, int, int, int, int, const EpSlab);
 template __global__ void uu3d::gemm_tn_kernel<TnLoadLayerNorm, EpSlab>(const TnLoadLayerNorm, const float*, int, int, int, int, int, int, int, const EpSlab);
 template __global__ void uu3d::spatial_stack_h3_kernel<17, 3>(const float*, const SpatialParams, const _Float16*, float*, _Float16*, _Float16*);
-template __global__ void uu3d::gemm_h3_panel_kernel<24, PanelEpBias>(const _Float16*, const _Float16*, const float*, int, int, int, int, const PanelEpBias, int, float);
-template __global__ void uu3d::gemm_h3_panel_kernel<24, PanelEpBias, true>(const _Float16*, const _Float16*, const float*, int, int, int, int, const PanelEpBias, int, float);
-template __global__ void uu3d::gemm_h3_panel_kernel<24, PanelEpBiasReluSplit>(const _Float16*, const _Float16*, const float*, int, int, int, int, const PanelEpBiasReluSplit, int, float);
+template __global__ void uu3d::gemm_h3_panel_kernel<24, PanelEpBias>(const _Float16*, const _Float16*, const float*, int, int, int, int, const PanelEpBias);
+template __global__ void uu3d::gemm_h3_panel_kernel<24, PanelEpBiasReluSplit>(const _Float16*, const _Float16*, const float*, int, int, int, int, const PanelEpBiasReluSplit);
 template __global__ void uu3d::ln_split_frag_kernel<24, 8>(const float*, int, int, float, const float*, const float*, _Float16*);
 template __global__ void uu3d::gemm_h3g_kernel<1, 1, GLoadConv3, EpSlab, 3>(const GLoadConv3, const _Float16*, const _Float16*, int, int, int, int, int, int, const EpSlab);
 template __global__ void uu3d::gemm_h3g_kernel<1, 2, GLoadPlain, EpBiasResidual, 3>(const GLoadPlain, const _Float16*, const _Float16*, int, int, int, int, int, int, const EpBiasResidual);

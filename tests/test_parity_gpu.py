@@ -56,28 +56,16 @@ def test_row_panel_gemm_path_matches_oracle(cfgname, batch, monkeypatch):
     w = pkg.init_weights(arch, seed=3, perturb=0.1)
     x, m = util.synthetic_batch(cfg, batch=batch, seed=3)
     full, central, xm = _run_hip(cfg, w, x, m, "f16x3")          # the product path: ln_split_frag + panel GEMM for the LayerNorm-fed Dense layers
-    f32_early, c32_early = O.forward(util.hp_from_arch(arch), w, xm, m, torch.float32)
     monkeypatch.setenv("UU3D_NO_PANEL", "1")
     full_t, central_t, _ = _run_hip(cfg, w, x, m, "f16x3")
     monkeypatch.delenv("UU3D_NO_PANEL")
-    monkeypatch.setenv("UU3D_PANEL_ACC", "1")          # opt-in: projection / fc2 on the accumulating row-panel kernel, attention output in fragment order
-    full_a, central_a, _ = _run_hip(cfg, w, x, m, "f16x3")
-    monkeypatch.delenv("UU3D_PANEL_ACC")
-    dev_a = max(np.abs(full - full_a).max(), np.abs(central - central_a).max())
-    assert max(np.abs(full_a - f32_early).max(), np.abs(central_a - c32_early).max()) <= util.TOL_MAX_ABS and dev_a > 0.0
-    monkeypatch.setenv("UU3D_LNFUSE", "1")             # opt-in: producer-side split + LayerNorm folded into the panel GEMM (LNF)
-    full_u, central_u, _ = _run_hip(cfg, w, x, m, "f16x3")
-    monkeypatch.delenv("UU3D_LNFUSE")
     hp = util.hp_from_arch(arch)
     f32, c32 = O.forward(hp, w, xm, m, torch.float32)
     err = max(np.abs(full - f32).max(), np.abs(central - c32).max())
     err_t = max(np.abs(full_t - f32).max(), np.abs(central_t - c32).max())
     dev = max(np.abs(full - full_t).max(), np.abs(central - central_t).max())
-    err_u = max(np.abs(full_u - f32).max(), np.abs(central_u - c32).max())
-    dev_u = max(np.abs(full - full_u).max(), np.abs(central - central_u).max())
-    print(f"{cfgname} batch {batch}: panel vs oracle {err:.3e}, fused-LN panel vs oracle {err_u:.3e}, tiled vs oracle {err_t:.3e}, "
-          f"panel vs tiled {dev:.3e}, panel vs fused-LN panel {dev_u:.3e}")
-    assert err_u <= util.TOL_MAX_ABS and dev_u > 0.0
+    print(f"{cfgname} batch {batch}: panel vs oracle {err:.3e}, tiled vs oracle {err_t:.3e}, panel vs tiled {dev:.3e}")
+    assert err_t <= util.TOL_MAX_ABS
     assert np.isfinite(full).all() and np.isfinite(central).all()
     assert err <= util.TOL_MAX_ABS
     assert dev > 0.0, "UU3D_NO_PANEL=1 did not change the path: the panel kernels were not exercised"

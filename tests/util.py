@@ -1,52 +1,4 @@
-"""Shared helpers for the tests: config -> oracle hyper-parameter dict, synthetic inputs."""
-import os
-
-import numpy as np
-
-import uplift_upsample_3dhpe_amd as pkg
-
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-CONFIGS = {"h36m_351": "config/h36m_351.json", "h36m_81": "config/h36m_81.json",
-           "h36m_351_pt": "config/h36m_351_pt.json", "amass_351": "config/amass_351.json"}
-
-# max-abs tolerance on fp32 3D joints stated by BASELINE.json's north_star
-TOL_MAX_ABS = 1e-4
-# |delta MPJPE| budget in millimetres stated by the north_star
-TOL_MPJPE_MM = 0.05
-
-
-def load_config(name):
-    return pkg.UpliftUpsampleConfig(os.path.join(ROOT, CONFIGS[name]))
-
-
-def hp_from_arch(a):
-    return dict(num_frames=a.num_frames, num_keypoints=a.num_keypoints, d_spatial=a.d_spatial,
-                d_temporal=a.d_temporal, spatial_depth=a.spatial_depth, temporal_depth=a.temporal_depth,
-                strides=tuple(a.strides), paddings=tuple(a.paddings), num_heads=a.num_heads,
-                has_strided_input=a.has_strided_input,
-                first_strided_token_attention_layer=a.first_strided_token_attention_layer,
-                full_output=a.full_output)
-
-
-def eval_stride_mask(num_frames, seq_stride, mask_stride, frame_index):
-    """Global-aligned stride mask; 1 = real input present."""
-    idx = (np.arange(num_frames) - num_frames // 2) * seq_stride + frame_index
-    return np.equal(idx % mask_stride, 0)
-
-
-def synthetic_batch(cfg, batch, seed=0, mask_specs=None):
-    """2D keypoints ~ U(-1,1) and eval-style stride masks.
-
-    mask_specs: list of (mask_stride, frame_index) cycled over the batch; default exercises
-    keyframe-aligned, centre-masked and all-masked rows.
-    """
-    rng = np.random.default_rng(seed)
-    N, J = cfg.SEQUENCE_LENGTH, cfg.NUM_KEYPOINTS
-    x = rng.uniform(-1.0, 1.0, size=(batch, N, J, 2)).astype(np.float32)
-    s_out = cfg.SEQUENCE_STRIDE
-    strides = cfg.MASK_STRIDE if isinstance(cfg.MASK_STRIDE, list) else [cfg.MASK_STRIDE]
-    if mask_specs is None:
-        mask_specs = [(strides[0], 0), (strides[1], 0), (strides[2], s_out), (strides[1], s_out),
-                      (strides[0], 1 if s_out > 1 else 0), (strides[2], 0)]
-    m = np.stack([eval_stride_mask(N, s_out, *mask_specs[i % len(mask_specs)]) for i in range(batch)])
-    return x, m
+"""Shared helpers for the tests: the product's synthetic-workload module plus the oracle-side config mapping."""
+from uplift_upsample_3dhpe_amd.synthetic import (ROOT, CONFIGS, TOL_MAX_ABS, TOL_MPJPE_MM, load_config,   # noqa: F401
+                                                 eval_stride_mask, synthetic_batch)
+from oracle.uplift_oracle import hp_from_arch                                                                # noqa: F401

@@ -62,8 +62,13 @@ struct WeightRec {
 struct BlockDev {
     const float *ln1_g, *ln1_b, *wqkv_t, *bqkv, *wp_t, *bp, *ln2_g, *ln2_b, *w1_t, *b1, *w2_t, *b2;
     const float* pe;   // strided blocks: (L_i, d_t)
+    // LayerNorm folded into the following Dense (f16x3 forward, uu3d_gemm_h3.h gemm_h3_lnfold_kernel):
+    //   LN(x) W + b = rstd (x (gamma o W)) - rstd mean (gamma^T W) + (beta^T W + b)
+    const float *wqkv_f, *gqkv, *bqkv_f, *w1_f, *g1, *b1_f;
     // fragment-ordered f16 planes of wqkv / w1 for the row-panel GEMM (uu3d_gemm_panel.h); offsets in harena, 0 = none
     size_t wqkv_pf = 0, w1_pf = 0;
+    size_t wqkv_fpf = 0, w1_fpf = 0;   // the same for the LayerNorm-folded operands gamma o W (LNF panel kernel)
+    size_t wp_pf = 0, w2_pf = 0;       // projection (K = d) and fc2 (K = h, Dense blocks only) for gemm_h3_panel_acc_kernel
 };
 
 struct ProfRec {
@@ -85,9 +90,16 @@ struct uu3d_model {
     bool committed = false;
     float* arena = nullptr;        // packed device weights
     size_t arena_floats = 0;
-    bool attn_wg = false;          // UU3D_ATTN_WG=1: attention with one workgroup per (sequence, head) (attn_f32_kernel) instead of one wave per item (A/B measurements, tests)
-    bool no_panel = false;         // UU3D_NO_PANEL=1: LayerNorm-fed GEMMs stay on the tiled kernels (A/B measurements, tests)
-    bool no_planes = false;        // UU3D_NO_PLANES=1: keep the on-the-fly split GEMMs in f16x3 mode (A/B measurements, tests)
+    bool no_lnfuse = true;         // UU3D_LNFUSE=1: producer-side split + LayerNorm folded into the panel GEMMs (LNF) instead of the ln_split_frag pass; measured +-0.6 %, off
+    bool attn_wg = false;          // UU3D_ATTN_WG=1: attention with one workgroup per (sequence, head) (attn_f32_kernel) instead of one wave per item
+    bool no_attn_pipe = true;      // UU3D_ATTN_PIPE=1: two (sequence, head) items per attention workgroup, the second one's loads in flight while the first is computed (+1 % h36m_351, -1.3 % h36m_81: off)
+    bool no_panel_acc = true;      // UU3D_PANEL_ACC=1: projection / fc2 on gemm_h3_panel_acc_kernel instead of the tiled LDS-DMA kernel (measured slower: DESIGN section 11)
+    bool g_tile22 = false;         // UU3D_G_TILE22=1: 128 x 128 tiles for the large LDS-DMA GEMMs (experiment)
+    bool s2t_planes = false;       // UU3D_S2T_PLANES=1 (see uu3d_forward)
+    bool no_panel = false;         // UU3D_NO_PANEL=1: LayerNorm-fed GEMMs stay on the tiled kernels (A/B measurements)
+    bool no_lnfold = true;         // UU3D_LNFOLD=1 folds LayerNorm into the next Dense (gemm_h3_lnfold_kernel); measured neutral, off by default
+    bool ln_planes = false;        // UU3D_LN_PLANES=1: LayerNorm as a separate pass that writes planes (ln_split) instead of inside the GEMM loader
+    bool no_planes = false;        // UU3D_NO_PLANES=1: keep the on-the-fly split GEMMs in f16x3 mode (A/B measurements)
     _Float16* harena = nullptr;    // f16 hi/lo planes of every GEMM operand (f16x3 mode)
     size_t harena_halfs = 0;
     std::map<size_t, std::pair<size_t, size_t>> hplanes;   // Bt float offset -> (hi offset, lo offset) in harena
@@ -219,7 +231,7 @@ void pack_dense_t(std::vector<float>& buf, size_t off, const float* w, int K, in
 // =========================================================================================
 // Definitions below take C linkage from their extern "C" declarations in include/uu3d.h.
 
-const char* uu3d_version(void) { return "uu3d 0.2.0 gfx950 f16x3+f32-mfma"; }
+const char* uu3d_version(void) { return "uu3d 0.1.0 gfx950 f32-mfma"; }
 
 const char* uu3d_status_string(int s) {
     switch (s) {
@@ -292,8 +304,15 @@ int uu3d_create(const uu3d_config* c, int device, uu3d_model** out) {
     { const char* e = getenv("UU3D_SPATIAL"); m->spatial_valu = (e != nullptr && std::string(e) == "valu");
       m->spatial_f32 = (e != nullptr && std::string(e) == "f32"); m->spatial_h3_always = (e != nullptr && std::string(e) == "h3"); }
     { const char* e = getenv("UU3D_NO_PLANES"); m->no_planes = (e != nullptr && e[0] == '1'); }
+    { const char* e = getenv("UU3D_LN_PLANES"); m->ln_planes = (e != nullptr && e[0] == '1'); }
+    { const char* e = getenv("UU3D_LNFUSE"); m->no_lnfuse = !(e != nullptr && e[0] == '1'); }
     { const char* e = getenv("UU3D_ATTN_WG"); m->attn_wg = (e != nullptr && e[0] == '1'); }
+    { const char* e = getenv("UU3D_ATTN_PIPE"); m->no_attn_pipe = !(e != nullptr && e[0] == '1'); }
+    { const char* e = getenv("UU3D_PANEL_ACC"); m->no_panel_acc = !(e != nullptr && e[0] == '1'); }
+    { const char* e = getenv("UU3D_G_TILE22"); m->g_tile22 = (e != nullptr && e[0] == '1'); }
+    { const char* e = getenv("UU3D_S2T_PLANES"); m->s2t_planes = (e != nullptr && e[0] == '1'); }
     { const char* e = getenv("UU3D_NO_PANEL"); m->no_panel = (e != nullptr && e[0] == '1'); }
+    { const char* e = getenv("UU3D_LNFOLD"); m->no_lnfold = !(e != nullptr && e[0] == '1'); }
     *out = m;
     return UU3D_OK;
 }
@@ -425,7 +444,7 @@ int uu3d_commit_weights(uu3d_model* m, void* stream_) {
     std::copy_n(W(m, "temporal_pe/positional_encoding_weights"), (size_t)N * dt, P.buf.begin() + o_pet);
 
     // ---- transformer blocks ----
-    struct BlockOff { size_t ln1_g, ln1_b, wqkv, bqkv, wp, bp, ln2_g, ln2_b, w1, b1, w2, b2, pe; };
+    struct BlockOff { size_t ln1_g, ln1_b, wqkv, bqkv, wp, bp, ln2_g, ln2_b, w1, b1, w2, b2, pe, wqkv_f, gqkv, bqkv_f, w1_f, g1, b1_f; };
     auto pack_block = [&](const std::string& p, bool strided, int peL, const std::string& pe_name) {
         BlockOff o{};
         o.ln1_g = P.alloc(dt); o.ln1_b = P.alloc(dt);
@@ -450,6 +469,21 @@ int uu3d_commit_weights(uu3d_model* m, void* stream_) {
         o.w1 = P.alloc_dense((size_t)Nph * Kdt); o.b1 = P.alloc(Nph);
         pack_dense_t(P.buf, o.w1, W(m, p + "/mlp/fc1/kernel"), dt, ht, Kdt, 0);   // Conv1D k=1 (1,dt,ht) has the same flat layout
         std::copy_n(W(m, p + "/mlp/fc1/bias"), ht, P.buf.begin() + o.b1);
+        // folded operands: Bt'[n][k] = Bt[n][k] gamma[k]; g[n] = sum_k gamma[k] Bt[n][k]; b'[n] = sum_k beta[k] Bt[n][k] + b[n]
+        auto fold = [&](size_t src, size_t bias, size_t gam, size_t bet, int Nrows, int Nreal, size_t& wf, size_t& gf, size_t& bf) {
+            wf = P.alloc_dense((size_t)Nrows * Kdt); gf = P.alloc(Nrows); bf = P.alloc(Nrows);
+            for (int n = 0; n < Nreal; ++n) {
+                double gs = 0.0, bs = 0.0;
+                for (int k = 0; k < dt; ++k) {
+                    const float wv = P.buf[src + (size_t)n * Kdt + k];
+                    P.buf[wf + (size_t)n * Kdt + k] = wv * P.buf[gam + k];
+                    gs += (double)P.buf[gam + k] * wv; bs += (double)P.buf[bet + k] * wv;
+                }
+                P.buf[gf + n] = (float)gs; P.buf[bf + n] = (float)(bs + (double)P.buf[bias + n]);
+            }
+        };
+        fold(o.wqkv, o.bqkv, o.ln1_g, o.ln1_b, Npq, 3 * dt, o.wqkv_f, o.gqkv, o.bqkv_f);
+        fold(o.w1, o.b1, o.ln2_g, o.ln2_b, Nph, ht, o.w1_f, o.g1, o.b1_f);
         if (strided) {
             const int Kc = round_up(3 * ht, 32);
             o.w2 = P.alloc_dense((size_t)Npdt * Kc); o.b2 = P.alloc(Npdt);
@@ -545,8 +579,10 @@ int uu3d_commit_weights(uu3d_model* m, void* stream_) {
                 panel_pack_operand(hb.data() + it->second.first, hb.data() + it->second.second, Nn, K, Kp, hb.data() + at);
                 m->panel_off[bt_off] = at;
             };
-            for (auto& o : toff) { add_panel(o.wqkv, 3 * dt); add_panel(o.w1, ht); }
-            for (auto& o : soff) { add_panel(o.wqkv, 3 * dt); add_panel(o.w1, ht); }
+            for (auto& o : toff) { add_panel(o.wqkv, 3 * dt); add_panel(o.w1, ht); add_panel(o.wqkv_f, 3 * dt); add_panel(o.w1_f, ht);
+                                   if (dt % 32 == 0) { add_panel(o.wp, dt); add_panel(o.w2, dt, ht, Kht); } }
+            for (auto& o : soff) { add_panel(o.wqkv, 3 * dt); add_panel(o.w1, ht); add_panel(o.wqkv_f, 3 * dt); add_panel(o.w1_f, ht);
+                                   if (dt % 32 == 0) add_panel(o.wp, dt); }
         }
         if (m->harena_halfs < hb.size()) {
             if (m->harena) HIPCHK(m, hipFree(m->harena));
@@ -571,6 +607,11 @@ int uu3d_commit_weights(uu3d_model* m, void* stream_) {
         b.pe = strided ? A + o.pe : nullptr;
         { const auto it = m->panel_off.find(o.wqkv); b.wqkv_pf = (it != m->panel_off.end()) ? it->second : 0; }
         { const auto it = m->panel_off.find(o.w1); b.w1_pf = (it != m->panel_off.end()) ? it->second : 0; }
+        { const auto it = m->panel_off.find(o.wp); b.wp_pf = (it != m->panel_off.end()) ? it->second : 0; }
+        { const auto it = m->panel_off.find(o.w2); b.w2_pf = (!strided && it != m->panel_off.end()) ? it->second : 0; }
+        { const auto it = m->panel_off.find(o.wqkv_f); b.wqkv_fpf = (it != m->panel_off.end()) ? it->second : 0; }
+        { const auto it = m->panel_off.find(o.w1_f); b.w1_fpf = (it != m->panel_off.end()) ? it->second : 0; }
+        b.wqkv_f = A + o.wqkv_f; b.gqkv = A + o.gqkv; b.bqkv_f = A + o.bqkv_f; b.w1_f = A + o.w1_f; b.g1 = A + o.g1; b.b1_f = A + o.b1_f;
         return b;
     };
     m->tblocks.clear(); m->sblocks.clear();
@@ -585,7 +626,7 @@ int uu3d_commit_weights(uu3d_model* m, void* stream_) {
 // ---- workspace --------------------------------------------------------------------------
 namespace {
 struct Workspace {
-    float *S, *X, *QKV, *O, *Hb, *XA, *XB, *slab;
+    float *S, *X, *QKV, *O, *Hb, *XA, *XB, *slab, *F;
     int* frame_list;
     float2* stats;
     size_t slab_floats;
@@ -609,11 +650,12 @@ Workspace carve(const uu3d_model* m, int B, char* base) {
     w.slab_floats = (size_t)1536 * 4096;            // >= slices * M * N of any split GEMM (slices * tiles <= ~1150)
     const size_t oSl = take(w.slab_floats * 4);
     const size_t oFl = take((rows + 1) * sizeof(int));
+    const size_t oF = take((rows + 32) * c.d_temporal * 4);     // second A-fragment buffer (LN2 input planes written by the projection epilogue)
     w.bytes = off;
     if (base) {
         w.S = (float*)(base + oS); w.X = (float*)(base + oX); w.QKV = (float*)(base + oQ);
         w.O = (float*)(base + oO); w.Hb = (float*)(base + oH); w.XA = (float*)(base + oA);
-        w.XB = (float*)(base + oB); w.stats = (float2*)(base + oT); w.slab = (float*)(base + oSl); w.frame_list = (int*)(base + oFl);
+        w.XB = (float*)(base + oB); w.stats = (float2*)(base + oT); w.slab = (float*)(base + oSl); w.frame_list = (int*)(base + oFl); w.F = (float*)(base + oF);
     }
     return w;
 }
@@ -716,7 +758,8 @@ struct Launcher {
         const _Float16* Bh = m->harena + it->second.first; const _Float16* Bl = m->harena + it->second.second;
         if (slices == 1) {
             // measured (tools/gemm_bench, M = 4544 / 1472 rows): 64x128 is the fastest LDS-DMA tile down to ~200 tiles
-            if (N % 128 == 0 && tiles >= 256) gemm_h3g_tile<1, 2>(gl, Bh, Bl, M, N, K, 1, KT, ep);
+            if (m->g_tile22 && N % 128 == 0 && tiles >= 512) gemm_h3g_tile<2, 2>(gl, Bh, Bl, M, N, K, 1, KT, ep);     // UU3D_G_TILE22=1 (experiment)
+            else if (N % 128 == 0 && tiles >= 256) gemm_h3g_tile<1, 2>(gl, Bh, Bl, M, N, K, 1, KT, ep);
             else gemm_h3g_tile<1, 1>(gl, Bh, Bl, M, N, K, 1, KT, ep);
         } else {
             EpSlab es{slab, ldslab, (size_t)M * ldslab};
@@ -725,6 +768,33 @@ struct Launcher {
                                slab, slices, (size_t)M * ldslab, M, N, ldslab, ep);
         }
         end();
+    }
+
+    // LayerNorm folded into the GEMM (gemm_h3_lnfold_kernel): X raw rows [M][K], Wf the folded operand.  Only for
+    // launches that are not split along K (the workgroup must see whole rows); returns false otherwise.
+    template <class EPL>
+    bool gemm_lnfold(const char* name, const float* X, const float* Wf, int M, int N, int K, const EPL& ep) {
+        const int tiles = ((M + 63) / 64) * ((N + 63) / 64);
+        if ((K % 32) != 0 || (tiles < 384 && K / 32 >= 8) || m->no_lnfold) return false;       // gemm() would split this one
+        const auto it = m->hplanes.find((size_t)(Wf - m->arena));
+        if (it == m->hplanes.end()) return false;
+        const _Float16* Bh = m->harena + it->second.first; const _Float16* Bl = m->harena + it->second.second;
+        begin(name, "gemm_h3", 2.0 * M * (double)N * K, 4.0 * ((double)M * K + (double)N * K + (double)M * N));
+        if (N % 128 == 0 && tiles >= 512) {
+            auto kern = gemm_h3_lnfold_kernel<1, 2, EPL>;
+            constexpr size_t lds = gemm_h3_lds_bytes(64, 128);
+            static bool attr_done = false;
+            if (!attr_done) { (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr_done = true; }
+            const int mt = (M + 63) / 64, nt = N / 128;
+            hipLaunchKernelGGL(kern, dim3(round_up(mt, 8) * nt), dim3(256), lds, stream, X, K, Bh, Bl, M, N, K, 1e-5f, mt, nt, ep);
+        } else {
+            auto kern = gemm_h3_lnfold_kernel<1, 1, EPL>;
+            constexpr size_t lds = gemm_h3_lds_bytes(64, 64);
+            const int mt = (M + 63) / 64, nt = (N + 63) / 64;
+            hipLaunchKernelGGL(kern, dim3(round_up(mt, 8) * nt), dim3(256), lds, stream, X, K, Bh, Bl, M, N, K, 1e-5f, mt, nt, ep);
+        }
+        end();
+        return true;
     }
 
     // Row-panel GEMM (uu3d_gemm_panel.h): C = A B + colv with A the fragment-ordered planes written by ln_split_frag and
@@ -752,13 +822,46 @@ struct Launcher {
         auto kern = gemm_h3_panel_kernel<24, EP>;
         static bool attr_done = false;
         if (!attr_done) { (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)PANEL_LDS_TOTAL); attr_done = true; }
-        hipLaunchKernelGGL(kern, dim3(8 * S, ((mt * S + 7) / 8 + S - 1) / S), dim3(256), PANEL_LDS_TOTAL, stream, Af, m->harena + pf, colv, M, mt, S, (N / 32) / S, ep);
+        hipLaunchKernelGGL(kern, dim3(8 * S, ((mt * S + 7) / 8 + S - 1) / S), dim3(256), PANEL_LDS_TOTAL, stream, Af, m->harena + pf, colv, M, mt, S, (N / 32) / S, ep, 0, 0.f);
+        end();
+    }
+    // The residual Dense layers on gemm_h3_panel_acc_kernel: x += A B + bias, N = 384 output columns in 3 ranges of 4 chunks,
+    // A = fragment-ordered planes of contraction length 384 NH (attention output / hidden), B at harena + pf.
+    bool panel_acc_ok(int M, int N, size_t pf) const { return !m->no_panel && !m->no_panel_acc && pf != 0 && N == 384 && M >= 1024; }
+    template <int NH>
+    void gemm_panel_acc(const char* name, const _Float16* Af, size_t pf, const float* bias, int M, const PanelEpResidual& ep) {
+        const int N = 384, K = 384 * NH, S = 3, mt = (M + 127) / 128;
+        begin(name, "gemm_panel", 2.0 * M * (double)N * K, 4.0 * ((double)M * K + (double)N * K + 2.0 * M * N));
+        auto kern = gemm_h3_panel_acc_kernel<NH, 4, PanelEpResidual>;
+        static bool attr_done = false;
+        if (!attr_done) { (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)PANEL_LDS_TOTAL); attr_done = true; }
+        hipLaunchKernelGGL(kern, dim3(8 * S, ((mt * S + 7) / 8 + S - 1) / S), dim3(256), PANEL_LDS_TOTAL, stream, Af, m->harena + pf, bias, M, mt, S, ep);
+        end();
+    }
+    // The same with LayerNorm folded in (LNF): Af = raw split rows written by the producer of the residual stream,
+    // pf = planes of gamma o W, gb = g | b' (N floats each, contiguous: gemm_lnfold's per-column vectors)
+    template <class EP>
+    void gemm_panel_ln(const char* name, const _Float16* Af, size_t pf, const float* g, const float* bprime, int M, int N, const EP& ep) {
+        const int K = 384, S = panel_splits(M, N), mt = (M + 127) / 128;
+        begin(name, "gemm_panel", 2.0 * M * (double)N * K, 4.0 * ((double)M * K + (double)N * K + (double)M * N));
+        auto kern = gemm_h3_panel_kernel<24, EP, true>;
+        static bool attr_done = false;
+        if (!attr_done) { (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)PANEL_LDS_TOTAL); attr_done = true; }
+        hipLaunchKernelGGL(kern, dim3(8 * S, ((mt * S + 7) / 8 + S - 1) / S), dim3(256), PANEL_LDS_TOTAL, stream, Af, m->harena + pf, g, M, mt, S, (N / 32) / S, ep,
+                           (int)(bprime - g), 1e-5f);
         end();
     }
     // LayerNorm (eps 1e-5) of M rows of 384 floats, written as the fragment-ordered planes of the panel GEMM's A operand
     void ln_split_frag(const char* name, const float* x, int M, const float* g, const float* b, _Float16* Af) {
         begin(name, "ln_split_frag", 0.0, 8.0 * (double)M * 384);
         hipLaunchKernelGGL((ln_split_frag_kernel<24, 8>), dim3((M + 7) / 8), dim3(128), 0, stream, x, 384, M, 1e-5f, g, b, Af);   // 8 rows per workgroup: 6.6 us at 9088 rows (16: 7.0, 32: 7.9, 4: 6.6)
+        end();
+    }
+
+    // LayerNorm (eps 1e-5) of M rows of D floats, written as the hi / lo planes [M][D] of the next GEMM's A operand
+    void ln_split(const char* name, const float* x, int D, int M, const float* g, const float* b, _Float16* Ph, _Float16* Pl) {
+        begin(name, "ln_split", 0.0, 8.0 * (double)M * D);
+        hipLaunchKernelGGL(ln_split_kernel<4>, dim3((M + 3) / 4), dim3(256), 0, stream, x, D, D, M, 1e-5f, g, b, Ph, Pl, D);
         end();
     }
 
@@ -815,8 +918,9 @@ struct Launcher {
         const int D = m->cfg.d_temporal, H = m->cfg.num_heads;
         const int NT = (L + 15) / 16;
         begin(name, "attn_f32", 4.0 * B * (double)H * L * L * kDH, 4.0 * 4.0 * B * (double)L * D);
+        // opt-in (UU3D_ATTN_PIPE=1), >= 1024 (sequence, head) items: two per workgroup, the second one's loads in flight while the first is computed
         const int items = B * H;
-        const dim3 grid(items);
+        const dim3 grid((items >= 1024 && !m->no_attn_pipe) ? (items + 1) / 2 : items);
         // one wave per (sequence, head), four heads per workgroup (attn_head_wave_kernel): whenever the heads come in fours and the
         // K / V tiles of four heads fit the LDS; UU3D_ATTN_WG=1 keeps the workgroup-per-item kernel
         // NT <= 3: more, smaller workgroups hide latency better (measured)
@@ -835,8 +939,8 @@ struct Launcher {
             return;
         }
 #define UU3D_ATTN_CASE(nt) case nt: \
-        if (split_lo_off) hipLaunchKernelGGL((attn_f32_kernel<nt, kDH, true>), grid, dim3(64 * nt), 0, stream, qkv, 3 * D, D, L, H, mask, out, D, split_lo_off); \
-        else hipLaunchKernelGGL((attn_f32_kernel<nt, kDH, false>), grid, dim3(64 * nt), 0, stream, qkv, 3 * D, D, L, H, mask, out, D, (size_t)0); \
+        if (split_lo_off) hipLaunchKernelGGL((attn_f32_kernel<nt, kDH, true>), grid, dim3(64 * nt), 0, stream, qkv, 3 * D, D, L, H, mask, out, D, split_lo_off, items); \
+        else hipLaunchKernelGGL((attn_f32_kernel<nt, kDH, false>), grid, dim3(64 * nt), 0, stream, qkv, 3 * D, D, L, H, mask, out, D, (size_t)0, items); \
         break;
         switch (NT) {
             UU3D_ATTN_CASE(1) UU3D_ATTN_CASE(2) UU3D_ATTN_CASE(3) UU3D_ATTN_CASE(4)
@@ -873,6 +977,7 @@ int uu3d_forward(uu3d_model* m, const float* kp2d, const uint8_t* mask, int32_t 
     char nm[48];
 
     // 1. spatial stack
+    bool s_planes = false;
     {
         SpatialParams sp = m->sp;
         sp.total_frames = M;
@@ -897,8 +1002,12 @@ int uu3d_forward(uu3d_model* m, const float* kp2d, const uint8_t* mask, int32_t 
             sp.blocks = m->sp_blocks_v2;             // LayerNorm parameters and biases
             auto kern = spatial_stack_h3_kernel<kJ, kFR>;
             Lh.begin("spatial_stack", "spatial_h3", fl, 4.0 * M * J * (2.0 + ds));
+            // UU3D_S2T_PLANES=1: the spatial stack writes its output as f16 hi / lo planes and spatial_to_temporal_fc runs on the
+            // LDS-DMA kernel (A/B measurement)
+            s_planes = m->s2t_planes && (J * ds) % 32 == 0 && m->hplanes.count((size_t)(m->s2t_wt - m->arena)) != 0;
+            _Float16* const Sh = reinterpret_cast<_Float16*>(w.S);
             hipLaunchKernelGGL(kern, dim3((M + kFR - 1) / kFR), dim3(64), sh3::lds_bytes(), Lh.stream, kp2d, sp,
-                               m->harena + m->sp_frag_off, w.S, (_Float16*)nullptr, (_Float16*)nullptr);
+                               m->harena + m->sp_frag_off, w.S, s_planes ? Sh : (_Float16*)nullptr, s_planes ? Sh + (size_t)M * J * ds : (_Float16*)nullptr);
             Lh.end();
         } else {
             sp.blocks = m->sp_blocks_v2;
@@ -908,62 +1017,101 @@ int uu3d_forward(uu3d_model* m, const float* kp2d, const uint8_t* mask, int32_t 
             Lh.end();
         }
     }
+    // LayerNorm fused away (f16x3, >= 1024 token rows): every producer of the residual stream (s2t, projection, fc2) also
+    // writes the raw split rows in the panel GEMM's A-fragment order (Fa for the next LN1, Fb for LN2), and the LayerNorm-fed
+    // Dense layers run as the LNF panel kernel on the folded operands -- no row-statistics / LayerNorm launch at all.
+    bool lnfuse = (c.precision == UU3D_PREC_F16X3) && (dt % 32 == 0) && (ht % 32 == 0) && !m->no_planes && !m->no_lnfuse && c.temporal_depth >= 1;
+    for (const BlockDev& b : m->tblocks) lnfuse = lnfuse && Lh.panel_ok(M, 3 * dt, dt, b.wqkv_fpf) && Lh.panel_ok(M, ht, dt, b.w1_fpf);
+    lnfuse = lnfuse && c.num_strided >= 1 && m->sblocks[0].wqkv_fpf != 0 && m->sblocks[0].w1_fpf != 0;
+    // projection / fc2 on gemm_h3_panel_acc_kernel: the attention output and the hidden activations travel as fragment-ordered planes
+    const bool acc_path = (c.precision == UU3D_PREC_F16X3) && (dt % 32 == 0) && (ht % 32 == 0) && !m->no_planes && !lnfuse;
+    _Float16* const Fa = reinterpret_cast<_Float16*>(w.O);       // raw split rows for the next LN1 (the bytes of O: dead between projection and attention)
+    _Float16* const Fb = reinterpret_cast<_Float16*>(w.F);       // raw split rows for LN2
     // 2. spatial_to_temporal_fc + token blend + temporal PE
     {
         ALoadPlain al{w.S, J * ds, M, J * ds};
         EpSpatialToTemporal ep{w.X, m->s2t_b, dt, mask, m->token, m->pe_t, N};
+        if (lnfuse) { ep.frag = reinterpret_cast<_Float16*>(w.O); ep.frag_ks = dt / 16; }
+        if (s_planes) {
+            const _Float16* Sh = reinterpret_cast<const _Float16*>(w.S);
+            GLoadPlain gl{Sh, Sh + (size_t)M * J * ds, J * ds, M};
+            Lh.gemm_g("s2t", gl, m->s2t_wt, M, dt, J * ds, ep);
+        } else
         Lh.gemm("s2t", al, m->s2t_wt, M, dt, J * ds, ep);
     }
     // f16x3 with K % 32 == 0 everywhere: activations that feed a GEMM travel as f16 hi/lo planes (same bytes as the
     // f32 tensors they replace: O and Hb are reused) and the GEMMs are the LDS-DMA kernel gemm_h3g_kernel
     const bool planes = (c.precision == UU3D_PREC_F16X3) && (dt % 32 == 0) && (ht % 32 == 0) && !m->no_planes;
-    _Float16* const Ph = reinterpret_cast<_Float16*>(w.O);       // LayerNorm output (fragment order), then attention output (planes)
+    _Float16* const Ph = reinterpret_cast<_Float16*>(w.O);       // LayerNorm output, then attention output
     _Float16* const Hh = reinterpret_cast<_Float16*>(w.Hb);      // relu(fc1)
     const _Float16* const hzero = m->harena;                     // 64 zero halfs (uu3d_commit_weights)
-
-    // The first five launches of a transformer block (temporal: vit.py:176-188, strided: u_u_t.py:126-135), on the residual
-    // stream x of Mr = B * L rows:  x += proj(MHA(LN1(x)));  Hb = relu(fc1(LN2(x)))  -- Hb as f16 planes when `planes`.
-    //   LayerNorm-fed Dense layers: ln_split_frag + the row-panel GEMM (>= 1024 rows), else row_stats + the tiled GEMM
-    //   with LayerNorm in its loader.
-    auto block_head = [&](const char* tag, int i, const BlockDev& b, float* x, int L, const uint8_t* kmask) {
-        const int Mr = B * L;
-        auto name = [&](const char* what) { snprintf(nm, sizeof nm, "%s%d.%s", tag, i + 1, what); return nm; };
-        _Float16* const Pl = Ph + (size_t)Mr * dt; _Float16* const Hl = Hh + (size_t)Mr * ht;
-        if (planes && Lh.panel_ok(Mr, 3 * dt, dt, b.wqkv_pf)) {
-            Lh.ln_split_frag(name("ln1_split"), x, Mr, b.ln1_g, b.ln1_b, Ph);
-            Lh.gemm_panel(name("ln_qkv"), Ph, b.wqkv_pf, b.bqkv, Mr, 3 * dt, PanelEpBias{w.QKV, 3 * dt});
-        } else {
-            Lh.row_stats(name("stats1"), x, dt, Mr, w.stats);
-            ALoadLayerNorm al{x, w.stats, b.ln1_g, b.ln1_b, dt, Mr, dt}; EpBias ep{w.QKV, b.bqkv, 3 * dt};
-            Lh.gemm(name("ln_qkv"), al, b.wqkv_t, Mr, 3 * dt, dt, ep);
-        }
-        Lh.attn(name("attn"), w.QKV, B, L, kmask, w.O, planes ? (size_t)Mr * dt : 0);
-        {
-            EpBiasResidual ep{x, b.bp, dt, nullptr, nullptr, 1};
-            if (planes) { GLoadPlain gl{Ph, Pl, dt, Mr}; Lh.gemm_g(name("proj_res"), gl, b.wp_t, Mr, dt, dt, ep, 4.0 * Mr * dt); }
-            else { ALoadPlain al{w.O, dt, Mr, dt}; Lh.gemm(name("proj_res"), al, b.wp_t, Mr, dt, dt, ep, 4.0 * Mr * dt); }
-        }
-        if (planes && Lh.panel_ok(Mr, ht, dt, b.w1_pf)) {
-            Lh.ln_split_frag(name("ln2_split"), x, Mr, b.ln2_g, b.ln2_b, Ph);
-            Lh.gemm_panel(name("ln_fc1"), Ph, b.w1_pf, b.b1, Mr, ht, PanelEpBiasReluSplit{Hh, Hl, ht});
-        } else {
-            Lh.row_stats(name("stats2"), x, dt, Mr, w.stats);
-            ALoadLayerNorm al{x, w.stats, b.ln2_g, b.ln2_b, dt, Mr, dt};
-            if (planes) { EpBiasReluSplit ep{Hh, Hl, b.b1, ht}; Lh.gemm(name("ln_fc1"), al, b.w1_t, Mr, ht, dt, ep); }
-            else { EpBiasRelu ep{w.Hb, b.b1, ht}; Lh.gemm(name("ln_fc1"), al, b.w1_t, Mr, ht, dt, ep); }
-        }
-    };
-
     // 3. temporal blocks
     for (int i = 0; i < c.temporal_depth; ++i) {
         const BlockDev& b = m->tblocks[i];
         const bool masked = c.has_strided_input && i < c.first_strided_token_attention_layer;
         const bool last = (i + 1 == c.temporal_depth);
-        block_head("t", i, b, w.X, N, masked ? mask : nullptr);
         EpBiasResidual ep_fc2{w.X, b.b2, dt, last ? w.XA : nullptr, last ? m->sblocks[0].pe : nullptr, N};
-        snprintf(nm, sizeof nm, "t%d.fc2_res", i + 1);
-        if (planes) { GLoadPlain gl{Hh, Hh + (size_t)M * ht, ht, M}; Lh.gemm_g(nm, gl, b.w2_t, M, dt, ht, ep_fc2, 4.0 * M * dt); }
-        else { ALoadPlain al{w.Hb, ht, M, ht}; Lh.gemm(nm, al, b.w2_t, M, dt, ht, ep_fc2, 4.0 * M * dt); }
+        if (lnfuse) { ep_fc2.frag = Fa; ep_fc2.frag_ks = dt / 16; }
+        if (planes) {
+            _Float16* const Pl = Ph + (size_t)M * dt; _Float16* const Hl = Hh + (size_t)M * ht;
+            if (lnfuse) {
+                snprintf(nm, sizeof nm, "t%d.ln_qkv", i + 1); Lh.gemm_panel_ln(nm, Fa, b.wqkv_fpf, b.gqkv, b.bqkv_f, M, 3 * dt, PanelEpBias{w.QKV, 3 * dt});
+            } else if (Lh.panel_ok(M, 3 * dt, dt, b.wqkv_pf)) {
+                snprintf(nm, sizeof nm, "t%d.ln1_split", i + 1); Lh.ln_split_frag(nm, w.X, M, b.ln1_g, b.ln1_b, Ph);
+                snprintf(nm, sizeof nm, "t%d.ln_qkv", i + 1); Lh.gemm_panel(nm, Ph, b.wqkv_pf, b.bqkv, M, 3 * dt, PanelEpBias{w.QKV, 3 * dt});
+            } else if (m->ln_planes) {
+                snprintf(nm, sizeof nm, "t%d.ln1_split", i + 1); Lh.ln_split(nm, w.X, dt, M, b.ln1_g, b.ln1_b, Ph, Pl);
+                GLoadPlain gl{Ph, Pl, dt, M}; EpBias ep{w.QKV, b.bqkv, 3 * dt};
+                snprintf(nm, sizeof nm, "t%d.ln_qkv", i + 1); Lh.gemm_g(nm, gl, b.wqkv_t, M, 3 * dt, dt, ep);
+            } else if (snprintf(nm, sizeof nm, "t%d.ln_qkv", i + 1), !Lh.gemm_lnfold(nm, w.X, b.wqkv_f, M, 3 * dt, dt, EpLnBias{w.QKV, b.gqkv, b.bqkv_f, 3 * dt})) {
+                snprintf(nm, sizeof nm, "t%d.stats1", i + 1); Lh.row_stats(nm, w.X, dt, M, w.stats);
+                ALoadLayerNorm al{w.X, w.stats, b.ln1_g, b.ln1_b, dt, M, dt}; EpBias ep{w.QKV, b.bqkv, 3 * dt};
+                snprintf(nm, sizeof nm, "t%d.ln_qkv", i + 1); Lh.gemm(nm, al, b.wqkv_t, M, 3 * dt, dt, ep);
+            }
+            const bool acc_p = acc_path && Lh.panel_acc_ok(M, dt, b.wp_pf);
+            const bool acc_f = acc_path && Lh.panel_acc_ok(M, dt, b.w2_pf) && Lh.panel_ok(M, ht, dt, b.w1_pf);
+            snprintf(nm, sizeof nm, "t%d.attn", i + 1); Lh.attn(nm, w.QKV, B, N, masked ? mask : nullptr, w.O, acc_p ? ATTN_FRAG_ORDER : (size_t)M * dt);
+            if (acc_p) {
+                snprintf(nm, sizeof nm, "t%d.proj_res", i + 1); Lh.gemm_panel_acc<1>(nm, Ph, b.wp_pf, b.bp, M, PanelEpResidual{w.X, dt, nullptr, nullptr, 1});
+            } else {
+              GLoadPlain gl{Ph, Pl, dt, M}; EpBiasResidual ep{w.X, b.bp, dt, nullptr, nullptr, 1};
+              if (lnfuse) { ep.frag = Fb; ep.frag_ks = dt / 16; }
+              snprintf(nm, sizeof nm, "t%d.proj_res", i + 1); Lh.gemm_g(nm, gl, b.wp_t, M, dt, dt, ep, 4.0 * M * dt); }
+            if (lnfuse) {
+                snprintf(nm, sizeof nm, "t%d.ln_fc1", i + 1); Lh.gemm_panel_ln(nm, Fb, b.w1_fpf, b.g1, b.b1_f, M, ht, PanelEpBiasReluSplit{Hh, Hl, ht});
+            } else if (Lh.panel_ok(M, ht, dt, b.w1_pf)) {
+                snprintf(nm, sizeof nm, "t%d.ln2_split", i + 1); Lh.ln_split_frag(nm, w.X, M, b.ln2_g, b.ln2_b, Ph);
+                snprintf(nm, sizeof nm, "t%d.ln_fc1", i + 1);
+                if (acc_f) Lh.gemm_panel(nm, Ph, b.w1_pf, b.b1, M, ht, PanelEpBiasReluFrag{Hh, ht});
+                else Lh.gemm_panel(nm, Ph, b.w1_pf, b.b1, M, ht, PanelEpBiasReluSplit{Hh, Hl, ht});
+            } else if (m->ln_planes) {
+                snprintf(nm, sizeof nm, "t%d.ln2_split", i + 1); Lh.ln_split(nm, w.X, dt, M, b.ln2_g, b.ln2_b, Ph, Pl);
+                GLoadPlain gl{Ph, Pl, dt, M}; EpBiasReluSplit ep{Hh, Hl, b.b1, ht};
+                snprintf(nm, sizeof nm, "t%d.ln_fc1", i + 1); Lh.gemm_g(nm, gl, b.w1_t, M, ht, dt, ep);
+            } else if (snprintf(nm, sizeof nm, "t%d.ln_fc1", i + 1), !Lh.gemm_lnfold(nm, w.X, b.w1_f, M, ht, dt, EpLnBiasReluSplit{Hh, Hl, b.g1, b.b1_f, ht})) {
+                snprintf(nm, sizeof nm, "t%d.stats2", i + 1); Lh.row_stats(nm, w.X, dt, M, w.stats);
+                ALoadLayerNorm al{w.X, w.stats, b.ln2_g, b.ln2_b, dt, M, dt}; EpBiasReluSplit ep{Hh, Hl, b.b1, ht};
+                snprintf(nm, sizeof nm, "t%d.ln_fc1", i + 1); Lh.gemm(nm, al, b.w1_t, M, ht, dt, ep);
+            }
+            if (acc_f) {
+                snprintf(nm, sizeof nm, "t%d.fc2_res", i + 1);
+                Lh.gemm_panel_acc<2>(nm, Hh, b.w2_pf, b.b2, M, PanelEpResidual{w.X, dt, last ? w.XA : nullptr, last ? m->sblocks[0].pe : nullptr, N});
+            } else {
+              GLoadPlain gl{Hh, Hl, ht, M};
+              snprintf(nm, sizeof nm, "t%d.fc2_res", i + 1); Lh.gemm_g(nm, gl, b.w2_t, M, dt, ht, ep_fc2, 4.0 * M * dt); }
+            continue;
+        }
+        snprintf(nm, sizeof nm, "t%d.stats1", i + 1); Lh.row_stats(nm, w.X, dt, M, w.stats);
+        { ALoadLayerNorm al{w.X, w.stats, b.ln1_g, b.ln1_b, dt, M, dt}; EpBias ep{w.QKV, b.bqkv, 3 * dt};
+          snprintf(nm, sizeof nm, "t%d.ln_qkv", i + 1); Lh.gemm(nm, al, b.wqkv_t, M, 3 * dt, dt, ep); }
+        snprintf(nm, sizeof nm, "t%d.attn", i + 1); Lh.attn(nm, w.QKV, B, N, masked ? mask : nullptr, w.O);
+        { ALoadPlain al{w.O, dt, M, dt}; EpBiasResidual ep{w.X, b.bp, dt, nullptr, nullptr, 1};
+          snprintf(nm, sizeof nm, "t%d.proj_res", i + 1); Lh.gemm(nm, al, b.wp_t, M, dt, dt, ep, 4.0 * M * dt); }
+        snprintf(nm, sizeof nm, "t%d.stats2", i + 1); Lh.row_stats(nm, w.X, dt, M, w.stats);
+        { ALoadLayerNorm al{w.X, w.stats, b.ln2_g, b.ln2_b, dt, M, dt}; EpBiasRelu ep{w.Hb, b.b1, ht};
+          snprintf(nm, sizeof nm, "t%d.ln_fc1", i + 1); Lh.gemm(nm, al, b.w1_t, M, ht, dt, ep); }
+        { ALoadPlain al{w.Hb, ht, M, ht};
+          snprintf(nm, sizeof nm, "t%d.fc2_res", i + 1); Lh.gemm(nm, al, b.w2_t, M, dt, ht, ep_fc2, 4.0 * M * dt); }
     }
     // 4. head1
     if (has_h1) {
@@ -979,12 +1127,60 @@ int uu3d_forward(uu3d_model* m, const float* kp2d, const uint8_t* mask, int32_t 
         const int lo = (c.strides[i] > 1 && c.pad_left[i] == 0) ? 1 : 0;
         const EpConvResidual ep_conv{xb, b.b2, dt, xa, Li, Lo, c.strides[i], lo,
                                      (i + 1 < c.num_strided) ? m->sblocks[i + 1].pe : nullptr};
-        block_head("s", i, b, xa, Li, nullptr);
-        snprintf(nm, sizeof nm, "s%d.conv_res", i + 1);
-        if (planes) { GLoadConv3 gl{Hh, Hh + (size_t)Mi * ht, hzero, ht, Li, Lo, c.strides[i], c.pad_left[i], Mo};
-                      Lh.gemm_g(nm, gl, b.w2_t, Mo, dt, 3 * ht, ep_conv, 4.0 * Mo * dt); }
-        else { ALoadConv3 al{w.Hb, ht, Li, Lo, c.strides[i], c.pad_left[i], Mo, 3 * ht};
-               Lh.gemm(nm, al, b.w2_t, Mo, dt, 3 * ht, ep_conv, 4.0 * Mo * dt); }
+        if (planes) {
+            _Float16* const Pl = Ph + (size_t)Mi * dt; _Float16* const Hl = Hh + (size_t)Mi * ht;
+            const bool fuse1 = lnfuse && i == 0;      // the first strided block reads the rows the last temporal fc2 left in Fa
+            if (fuse1) {
+                snprintf(nm, sizeof nm, "s%d.ln_qkv", i + 1); Lh.gemm_panel_ln(nm, Fa, b.wqkv_fpf, b.gqkv, b.bqkv_f, Mi, 3 * dt, PanelEpBias{w.QKV, 3 * dt});
+            } else if (Lh.panel_ok(Mi, 3 * dt, dt, b.wqkv_pf)) {
+                snprintf(nm, sizeof nm, "s%d.ln1_split", i + 1); Lh.ln_split_frag(nm, xa, Mi, b.ln1_g, b.ln1_b, Ph);
+                snprintf(nm, sizeof nm, "s%d.ln_qkv", i + 1); Lh.gemm_panel(nm, Ph, b.wqkv_pf, b.bqkv, Mi, 3 * dt, PanelEpBias{w.QKV, 3 * dt});
+            } else if (m->ln_planes) {
+                snprintf(nm, sizeof nm, "s%d.ln1_split", i + 1); Lh.ln_split(nm, xa, dt, Mi, b.ln1_g, b.ln1_b, Ph, Pl);
+                GLoadPlain gl{Ph, Pl, dt, Mi}; EpBias ep{w.QKV, b.bqkv, 3 * dt};
+                snprintf(nm, sizeof nm, "s%d.ln_qkv", i + 1); Lh.gemm_g(nm, gl, b.wqkv_t, Mi, 3 * dt, dt, ep);
+            } else if (snprintf(nm, sizeof nm, "s%d.ln_qkv", i + 1), !Lh.gemm_lnfold(nm, xa, b.wqkv_f, Mi, 3 * dt, dt, EpLnBias{w.QKV, b.gqkv, b.bqkv_f, 3 * dt})) {
+                snprintf(nm, sizeof nm, "s%d.stats1", i + 1); Lh.row_stats(nm, xa, dt, Mi, w.stats);
+                ALoadLayerNorm al{xa, w.stats, b.ln1_g, b.ln1_b, dt, Mi, dt}; EpBias ep{w.QKV, b.bqkv, 3 * dt};
+                snprintf(nm, sizeof nm, "s%d.ln_qkv", i + 1); Lh.gemm(nm, al, b.wqkv_t, Mi, 3 * dt, dt, ep);
+            }
+            const bool acc_p = acc_path && Lh.panel_acc_ok(Mi, dt, b.wp_pf);
+            snprintf(nm, sizeof nm, "s%d.attn", i + 1); Lh.attn(nm, w.QKV, B, Li, nullptr, w.O, acc_p ? ATTN_FRAG_ORDER : (size_t)Mi * dt);
+            if (acc_p) {
+                snprintf(nm, sizeof nm, "s%d.proj_res", i + 1); Lh.gemm_panel_acc<1>(nm, Ph, b.wp_pf, b.bp, Mi, PanelEpResidual{xa, dt, nullptr, nullptr, 1});
+            } else {
+              GLoadPlain gl{Ph, Pl, dt, Mi}; EpBiasResidual ep{xa, b.bp, dt, nullptr, nullptr, 1};
+              if (fuse1) { ep.frag = Fb; ep.frag_ks = dt / 16; }
+              snprintf(nm, sizeof nm, "s%d.proj_res", i + 1); Lh.gemm_g(nm, gl, b.wp_t, Mi, dt, dt, ep, 4.0 * Mi * dt); }
+            if (fuse1) {
+                snprintf(nm, sizeof nm, "s%d.ln_fc1", i + 1); Lh.gemm_panel_ln(nm, Fb, b.w1_fpf, b.g1, b.b1_f, Mi, ht, PanelEpBiasReluSplit{Hh, Hl, ht});
+            } else if (Lh.panel_ok(Mi, ht, dt, b.w1_pf)) {
+                snprintf(nm, sizeof nm, "s%d.ln2_split", i + 1); Lh.ln_split_frag(nm, xa, Mi, b.ln2_g, b.ln2_b, Ph);
+                snprintf(nm, sizeof nm, "s%d.ln_fc1", i + 1); Lh.gemm_panel(nm, Ph, b.w1_pf, b.b1, Mi, ht, PanelEpBiasReluSplit{Hh, Hl, ht});
+            } else if (m->ln_planes) {
+                snprintf(nm, sizeof nm, "s%d.ln2_split", i + 1); Lh.ln_split(nm, xa, dt, Mi, b.ln2_g, b.ln2_b, Ph, Pl);
+                GLoadPlain gl{Ph, Pl, dt, Mi}; EpBiasReluSplit ep{Hh, Hl, b.b1, ht};
+                snprintf(nm, sizeof nm, "s%d.ln_fc1", i + 1); Lh.gemm_g(nm, gl, b.w1_t, Mi, ht, dt, ep);
+            } else if (snprintf(nm, sizeof nm, "s%d.ln_fc1", i + 1), !Lh.gemm_lnfold(nm, xa, b.w1_f, Mi, ht, dt, EpLnBiasReluSplit{Hh, Hl, b.g1, b.b1_f, ht})) {
+                snprintf(nm, sizeof nm, "s%d.stats2", i + 1); Lh.row_stats(nm, xa, dt, Mi, w.stats);
+                ALoadLayerNorm al{xa, w.stats, b.ln2_g, b.ln2_b, dt, Mi, dt}; EpBiasReluSplit ep{Hh, Hl, b.b1, ht};
+                snprintf(nm, sizeof nm, "s%d.ln_fc1", i + 1); Lh.gemm(nm, al, b.w1_t, Mi, ht, dt, ep);
+            }
+            { GLoadConv3 gl{Hh, Hl, hzero, ht, Li, Lo, c.strides[i], c.pad_left[i], Mo};
+              snprintf(nm, sizeof nm, "s%d.conv_res", i + 1); Lh.gemm_g(nm, gl, b.w2_t, Mo, dt, 3 * ht, ep_conv, 4.0 * Mo * dt); }
+        } else {
+            snprintf(nm, sizeof nm, "s%d.stats1", i + 1); Lh.row_stats(nm, xa, dt, Mi, w.stats);
+            { ALoadLayerNorm al{xa, w.stats, b.ln1_g, b.ln1_b, dt, Mi, dt}; EpBias ep{w.QKV, b.bqkv, 3 * dt};
+              snprintf(nm, sizeof nm, "s%d.ln_qkv", i + 1); Lh.gemm(nm, al, b.wqkv_t, Mi, 3 * dt, dt, ep); }
+            snprintf(nm, sizeof nm, "s%d.attn", i + 1); Lh.attn(nm, w.QKV, B, Li, nullptr, w.O);
+            { ALoadPlain al{w.O, dt, Mi, dt}; EpBiasResidual ep{xa, b.bp, dt, nullptr, nullptr, 1};
+              snprintf(nm, sizeof nm, "s%d.proj_res", i + 1); Lh.gemm(nm, al, b.wp_t, Mi, dt, dt, ep, 4.0 * Mi * dt); }
+            snprintf(nm, sizeof nm, "s%d.stats2", i + 1); Lh.row_stats(nm, xa, dt, Mi, w.stats);
+            { ALoadLayerNorm al{xa, w.stats, b.ln2_g, b.ln2_b, dt, Mi, dt}; EpBiasRelu ep{w.Hb, b.b1, ht};
+              snprintf(nm, sizeof nm, "s%d.ln_fc1", i + 1); Lh.gemm(nm, al, b.w1_t, Mi, ht, dt, ep); }
+            { ALoadConv3 al{w.Hb, ht, Li, Lo, c.strides[i], c.pad_left[i], Mo, 3 * ht};
+              snprintf(nm, sizeof nm, "s%d.conv_res", i + 1); Lh.gemm(nm, al, b.w2_t, Mo, dt, 3 * ht, ep_conv, 4.0 * Mo * dt); }
+        }
         std::swap(xa, xb);
         if (i == 0) xb = w.XA;   // XA (B*N rows) is free again; XB only needs B*L_1 rows
     }

@@ -25,7 +25,13 @@
 namespace uu3d {
 
 // SPLIT: the context rows are written as the two f16 planes (hi at out, lo at out + lo_off halfs; x ~= hi + lo / 2048,
-// see uu3d_gemm_h3.h) that the f16x3 projection GEMM reads, instead of f32.
+// see uu3d_gemm_h3.h) that the f16x3 projection GEMM reads, instead of f32.  lo_off == ATTN_FRAG_ORDER: the planes go
+// out in the row-panel GEMM's A-fragment order instead ([32-row panel][16-deep k-slice][plane][lane][8 halfs],
+// uu3d_gemm_panel.h) for a contraction length of D.
+#ifndef UU3D_ATTN_WG_BYNAME
+#define UU3D_ATTN_WG_BYNAME 0
+#endif
+static constexpr size_t ATTN_FRAG_ORDER = ~(size_t)0;
 typedef _Float16 h16x8v __attribute__((ext_vector_type(8)));
 #ifdef UU3D_ATTN_STAMP
 __device__ unsigned long long attn_clk[8];     // tools/attn_stamp_exp: s_memtime ticks per phase, summed over workgroups (wave 0)
@@ -33,11 +39,15 @@ __device__ unsigned long long attn_clk[8];     // tools/attn_stamp_exp: s_memtim
 #else
 #define ATTN_STAMP(...)
 #endif
+// A workgroup handles the items bh = blockIdx.x, blockIdx.x + gridDim.x, ... (n_items = B * H in all): with fewer
+// workgroups than items the K / V / Q loads of the NEXT item are issued into registers before the current one is computed
+// (one workgroup per item, all 1024 resident at once, ran load -> compute -> store in lockstep on every CU: 31 us of which
+// ~9 is the memory floor of the 42 MB QKV tensor and ~14 the MFMA + softmax work).
 template <int NT, int DH, bool SPLIT = false>
 __global__ void __launch_bounds__(64 * NT)
 attn_f32_kernel(const float* __restrict__ qkv, const int ld, const int D, const int L, const int H,
                 const uint8_t* __restrict__ key_mask,   // (B, L) 1 = attend; nullptr = no mask
-                float* __restrict__ out, const int ldo, const size_t lo_off = 0)
+                float* __restrict__ out, const int ldo, const size_t lo_off = 0, const int n_items = 0)
 {
     static_assert(DH % 16 == 0, "head dim must be a multiple of 16");
     constexpr int LD = DH + 4;
@@ -52,43 +62,54 @@ attn_f32_kernel(const float* __restrict__ qkv, const int ld, const int D, const 
     const int lane = tid & 63, w = tid >> 6;
     const int qi = lane & 15, g = lane >> 4;
     const int qrow = 16 * w + qi;
+    const int items = n_items > 0 ? n_items : (int)gridDim.x;
     // Workgroups go round-robin over the 8 XCDs; remapped so that CONSECUTIVE items (the H heads of one sequence) run on the
     // SAME XCD: a head's 192-byte q / k / v slices straddle 128-byte lines that the neighbouring head also needs, and the heads'
     // partial-line output writes meet in one L2 instead of eight.
-    const int bh = ((int)gridDim.x & 7) == 0 ? ((int)blockIdx.x & 7) * ((int)gridDim.x >> 3) + ((int)blockIdx.x >> 3) : (int)blockIdx.x;
+    const int first = ((int)gridDim.x & 7) == 0 ? ((int)blockIdx.x & 7) * ((int)gridDim.x >> 3) + ((int)blockIdx.x >> 3) : (int)blockIdx.x;
 
-    const int b = bh / H, h = bh - b * H;
     float4 kreg[NS], vreg[NS];
-    f32x4 qf[KT];
-    {
+    f32x4 qnext[KT];
+    auto issue = [&](const int bh) {
+        const int b = bh / H, h = bh - b * H;
         const float* base = qkv + (size_t)b * L * ld + h * DH;
 #pragma unroll
         for (int s = 0; s < NS; ++s) {
             const int idx = tid + s * 64 * NT;
             const int row = idx / F4, c4 = (idx - row * F4) * 4;
-            // branch-free: clamped row, zeroed afterwards (a test around a load = a divergent branch with the wait inside it)
-            const float* p = base + (size_t)min(row, L - 1) * ld + c4;
-            const float keep = (row < L) ? 1.0f : 0.0f;
-            const float4 kv = *reinterpret_cast<const float4*>(p + D), vv = *reinterpret_cast<const float4*>(p + 2 * D);
-            kreg[s] = make_float4(kv.x * keep, kv.y * keep, kv.z * keep, kv.w * keep);
-            vreg[s] = make_float4(vv.x * keep, vv.y * keep, vv.z * keep, vv.w * keep);
+            kreg[s] = make_float4(0.f, 0.f, 0.f, 0.f); vreg[s] = kreg[s];
+            if (idx < NT * 16 * F4 && row < L) {
+                const float* p = base + (size_t)row * ld + c4;
+                kreg[s] = *reinterpret_cast<const float4*>(p + D);
+                vreg[s] = *reinterpret_cast<const float4*>(p + 2 * D);
+            }
         }
 #pragma unroll
-        for (int t = 0; t < KT; ++t)      // query rows above L: a copy of the last row, never stored
-            qf[t] = *reinterpret_cast<const f32x4*>(base + (size_t)min(qrow, L - 1) * ld + 16 * t + 4 * g);
-    }
+        for (int t = 0; t < KT; ++t) {
+            qnext[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            if (qrow < L) qnext[t] = *reinterpret_cast<const f32x4*>(base + (size_t)qrow * ld + 16 * t + 4 * g);
+        }
+    };
     ATTN_STAMP(const long long c0 = clock64();)
+    issue(first);
+    for (int bh = first; ; ) {
+    const int b = bh / H, h = bh - b * H;
 #pragma unroll
     for (int s = 0; s < NS; ++s) {
         const int idx = tid + s * 64 * NT;
         const int row = idx / F4, c4 = (idx - row * F4) * 4;
-        if ((16 * F4) % 64 == 0 || idx < NT * 16 * F4) {          // whole staging passes (d_h = 48): no guard for hipcc to sink the loads into
+        if (idx < NT * 16 * F4) {
             *reinterpret_cast<float4*>(&Ks[row * LD + c4]) = kreg[s];
             *reinterpret_cast<float4*>(&Vs[row * LD + c4]) = vreg[s];
         }
     }
+    f32x4 qf[KT];
+#pragma unroll
+    for (int t = 0; t < KT; ++t) qf[t] = qnext[t];
     __syncthreads();
     ATTN_STAMP(const long long c1 = clock64();)
+    const int bh_next = bh + (int)gridDim.x;
+    if (bh_next < items) issue(bh_next);               // in flight while this item is computed
 
     // S^T tiles: st[j][r] = <Q[qrow], K[16j + 4g + r]>
     f32x4 st[NT];
@@ -151,6 +172,33 @@ attn_f32_kernel(const float* __restrict__ qkv, const int ld, const int D, const 
     f32x4 ot[KT];
 #pragma unroll
     for (int t = 0; t < KT; ++t) ot[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    if constexpr (KT == 3 && UU3D_ATTN_WG_BYNAME) {
+        // V values by name, two key tiles ahead of their MFMAs, counted waits (see attn_head_wave_kernel: hipcc placed one
+        // ds_read2_b32 directly in front of every two MFMAs)
+        float vv[3][4 * KT];
+        const unsigned vb = (unsigned)(uintptr_t)(__attribute__((address_space(3))) void*)(Vs + (4 * g) * LD + qi);
+#define UU3D_ATTN_VREAD(buf, jj) \
+        _Pragma("unroll") for (int s = 0; s < 4; ++s) \
+        _Pragma("unroll") for (int t = 0; t < KT; ++t) \
+            asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(vv[buf][s * KT + t]) : "v"(vb), "i"(((16 * (jj) + s) * LD + 16 * t) * 4) : "memory");
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        UU3D_ATTN_VREAD(0, 0)
+        if (NT > 1) { UU3D_ATTN_VREAD(1, 1) }
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+            if (j + 2 < NT) { UU3D_ATTN_VREAD((j + 2) % 3, j + 2) }
+            float (&c)[4 * KT] = vv[j % 3];
+            if (j + 2 < NT)      asm volatile("s_waitcnt lgkmcnt(15)" : "+v"(c[0]), "+v"(c[1]), "+v"(c[2]), "+v"(c[3]), "+v"(c[4]), "+v"(c[5]), "+v"(c[6]), "+v"(c[7]), "+v"(c[8]), "+v"(c[9]), "+v"(c[10]), "+v"(c[11]) :: "memory");
+            else if (j + 1 < NT) asm volatile("s_waitcnt lgkmcnt(12)" : "+v"(c[0]), "+v"(c[1]), "+v"(c[2]), "+v"(c[3]), "+v"(c[4]), "+v"(c[5]), "+v"(c[6]), "+v"(c[7]), "+v"(c[8]), "+v"(c[9]), "+v"(c[10]), "+v"(c[11]) :: "memory");
+            else                 asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(c[0]), "+v"(c[1]), "+v"(c[2]), "+v"(c[3]), "+v"(c[4]), "+v"(c[5]), "+v"(c[6]), "+v"(c[7]), "+v"(c[8]), "+v"(c[9]), "+v"(c[10]), "+v"(c[11]) :: "memory");
+#pragma unroll
+            for (int s = 0; s < 4; ++s)
+#pragma unroll
+                for (int t = 0; t < KT; ++t)
+                    ot[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(st[j][s], c[s * KT + t], ot[t], 0, 0, 0);
+        }
+#undef UU3D_ATTN_VREAD
+    } else {
 #pragma unroll
         for (int t = 0; t < KT; ++t)
 #pragma unroll
@@ -160,6 +208,7 @@ attn_f32_kernel(const float* __restrict__ qkv, const int ld, const int D, const 
                     const float vv = Vs[(16 * j + 4 * g + s) * LD + 16 * t + qi];
                     ot[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(st[j][s], vv, ot[t], 0, 0, 0);
                 }
+    }
     // C/D map: col = lane & 15 -> channel, row = 4g + r -> query
     if constexpr (SPLIT) {
         // the wave's 16 x DH tile as two f16 planes through LDS, out as 16-byte pieces (see attn_head_wave_kernel)
@@ -185,7 +234,12 @@ attn_f32_kernel(const float* __restrict__ qkv, const int ld, const int D, const 
             if (pc < PIECES && q < L) {
                 const h16x8v piece = *reinterpret_cast<const h16x8v*>(&Ow[(plane * 16 + row) * DH + 8 * c8]);
                 const int grow = b * L + q, k = h * DH + 8 * c8;
-                *reinterpret_cast<h16x8v*>(oh + (size_t)plane * lo_off + (size_t)grow * ldo + k) = piece;
+                size_t at;
+                if (lo_off == ATTN_FRAG_ORDER)
+                    at = ((((size_t)(grow >> 5) * (D >> 4) + (k >> 4)) * 2 + plane) * 64 + ((k >> 3) & 1) * 32 + (grow & 31)) * 8;
+                else
+                    at = (size_t)plane * lo_off + (size_t)grow * ldo + k;
+                *reinterpret_cast<h16x8v*>(oh + at) = piece;
             }
         }
     } else {
@@ -200,6 +254,10 @@ attn_f32_kernel(const float* __restrict__ qkv, const int ld, const int D, const 
     ATTN_STAMP(asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); if (tid == 0) { const long long c4 = clock64();
         atomicAdd(&attn_clk[0], (unsigned long long)(c1 - c0)); atomicAdd(&attn_clk[1], (unsigned long long)(c2 - c1));
         atomicAdd(&attn_clk[2], (unsigned long long)(c3 - c2)); atomicAdd(&attn_clk[3], (unsigned long long)(c4 - c3)); atomicAdd(&attn_clk[4], 1ull); })
+    if (bh_next >= items) break;
+    __syncthreads();                                    // every wave is done with this item's K / V tiles
+    bh = bh_next;
+    }
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -231,10 +289,6 @@ attn_head_wave_kernel(const float* __restrict__ qkv, const int ld, const int D, 
     const int wg = ((int)gridDim.x & 7) == 0 ? ((int)blockIdx.x & 7) * ((int)gridDim.x >> 3) + ((int)blockIdx.x >> 3) : (int)blockIdx.x;
     const int bh = wg * 4 + w;
     if (bh >= items) return;                               // whole waves only: no barrier anywhere below
-    // kernel arguments of the store path, loaded NOW: a lazily placed s_load between a tile's by-name V reads and their counted
-    // lgkmcnt waits would break the count (scalar loads return out of order; tests/test_isa_cpu.py checks the placement)
-    size_t lo_off_s = lo_off; int ldo_s = ldo;
-    asm volatile("" : "+s"(lo_off_s), "+s"(ldo_s));
     const int b = bh / H, h = bh - b * H;
     const float* base = qkv + (size_t)b * L * ld + h * DH;
     ATTN_STAMP(const long long c0 = clock64(); long long tqk = 0, tsm = 0, tpv = 0;)
@@ -417,7 +471,12 @@ attn_head_wave_kernel(const float* __restrict__ qkv, const int ld, const int D, 
                 if (pc < PIECES && q < L) {
                     const h16x8v piece = *reinterpret_cast<const h16x8v*>(&Os[(plane * 16 + row) * DH + 8 * c8]);
                     const int grow = b * L + q, k = h * DH + 8 * c8;
-                    *reinterpret_cast<h16x8v*>(oh + (size_t)plane * lo_off_s + (size_t)grow * ldo_s + k) = piece;
+                    size_t at;
+                    if (lo_off == ATTN_FRAG_ORDER)
+                        at = ((((size_t)(grow >> 5) * (D >> 4) + (k >> 4)) * 2 + plane) * 64 + ((k >> 3) & 1) * 32 + (grow & 31)) * 8;
+                    else
+                        at = (size_t)plane * lo_off + (size_t)grow * ldo + k;
+                    *reinterpret_cast<h16x8v*>(oh + at) = piece;
                 }
             }
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -428,7 +487,7 @@ attn_head_wave_kernel(const float* __restrict__ qkv, const int ld, const int D, 
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const int q = 16 * tile + 4 * g + r;
-                    if (q < L) out[((size_t)b * L + q) * ldo_s + h * DH + 16 * t + qi] = o[t][r];
+                    if (q < L) out[((size_t)b * L + q) * ldo + h * DH + 16 * t + qi] = o[t][r];
                 }
         }
         ATTN_STAMP(asm volatile("s_nop 0" :: "v"(o[KT - 1])); const long long t3 = clock64(); tqk += t1 - t0; tsm += t2 - t1; tpv += t3 - t2;)

@@ -151,9 +151,22 @@ struct EpBiasRelu {        // out = max(acc + bias, 0)
 };
 // x = x + (acc + bias), in place; optionally a second stream out2 = x_new + pe2[row % period]
 // (the next strided block's positional encoding, folded in here).
+// The value a residual-stream producer hands to the next LayerNorm-fed row-panel GEMM (uu3d_gemm_panel.h, LNF): the raw
+// f32 value split into f16 hi / lo (x ~= hi + lo / 2048, uu3d_gemm_h3.h) and stored in that GEMM's A-fragment order
+// [32-row panel][16-deep k-slice][plane][lane][8 halfs] for a contraction length of 16 ks.  The calling kernel has
+// switched the wave's f16 denormal mode to flush (v_cvt_f16_f32 then returns 0 below 2^-14, as the MFMA reads it).
+__device__ __forceinline__ void frag_store_split(_Float16* __restrict__ f, const int ks, const int row, const int col, const float y) {
+    _Float16 h;
+    asm("v_cvt_f16_f32 %0, %1" : "=v"(h) : "v"(y));
+    const size_t i = ((((size_t)(row >> 5) * ks + (col >> 4)) * 2) * 64 + ((col >> 3) & 1) * 32 + (row & 31)) * 8 + (col & 7);
+    f[i] = h;
+    f[i + 512] = (_Float16)((y - (float)h) * 2048.0f);
+}
+
 struct EpBiasResidual {
     float* x; const float* __restrict__ bias; int ld;
     float* out2; const float* __restrict__ pe2; int period;
+    _Float16* frag = nullptr; int frag_ks = 0;      // optional: also the split planes of the result (of out2's value when given)
     __device__ __forceinline__ float2 colv(int col) const { return make_float2(bias[col], 0.f); }
     __device__ __forceinline__ float2 pre(int rowc, int col) const {
         float2 p; p.x = x[(size_t)rowc * ld + col];
@@ -165,6 +178,7 @@ struct EpBiasResidual {
         const float y = p.x + (v + cv.x);
         x[o] = y;
         if (out2 != nullptr) out2[o] = y + p.y;
+        if (frag != nullptr) frag_store_split(frag, frag_ks, row, col, (out2 != nullptr) ? y + p.y : y);
     }
 };
 // spatial_to_temporal_fc + strided-input token blend + temporal PE (u_u_t.py:332,344-352):
@@ -173,6 +187,7 @@ struct EpSpatialToTemporal {
     float* __restrict__ x; const float* __restrict__ bias; int ld;
     const uint8_t* __restrict__ mask;     // per row (B*N), nullptr when no strided input
     const float* __restrict__ token; const float* __restrict__ pe; int period;
+    _Float16* frag = nullptr; int frag_ks = 0;      // optional: also the split planes of the result (frag_store_split)
     __device__ __forceinline__ float2 colv(int col) const {
         return make_float2(bias[col], mask != nullptr ? token[col] : 0.f);
     }
@@ -184,6 +199,7 @@ struct EpSpatialToTemporal {
     __device__ __forceinline__ void store(int row, int col, float v, float2 cv, float2 p) const {
         const float t = (p.y != 0.f) ? (v + cv.x) : cv.y;
         x[(size_t)row * ld + col] = t + p.x;
+        if (frag != nullptr) frag_store_split(frag, frag_ks, row, col, t + p.x);
     }
 };
 // strided block tail (u_u_t.py:138-156): out = identity + (acc + bias) (+ next block's PE)

@@ -21,6 +21,9 @@
 #include <stdint.h>
 #include "uu3d_gemm.h"
 
+#ifndef UU3D_H3G_PIPE12
+#define UU3D_H3G_PIPE12 0      // -DUU3D_H3G_PIPE12=1: by-name fragment reads for the 64 x 128 / 64 x 64 tiles too (measured: no gain, see the kernel)
+#endif
 namespace uu3d {
 
 typedef _Float16 h16x8 __attribute__((ext_vector_type(8)));
@@ -209,6 +212,182 @@ gemm_h3_kernel(const AL al, const _Float16* __restrict__ Bh, const _Float16* __r
 }
 
 // ------------------------------------------------------------------------------------------------
+// LayerNorm folded into the Dense that follows it:
+//     LN(x) W + b = rstd (x (gamma o W)) - rstd mean (gamma^T W) + (beta^T W + b)          (row-wise mean, rstd)
+// The GEMM runs on the RAW rows x against the folded operand W' = gamma o W (planes made at commit time); every
+// workgroup sees its 64 rows over their full length (K = d, no split-K), so it accumulates sum x and sum x^2 of the
+// rows while it stages them and the epilogue applies rstd / mean with two per-column vectors g = gamma^T W and
+// b' = beta^T W + b.  Removes the row-statistics launch in front of every LayerNorm-fed GEMM and the LayerNorm
+// arithmetic from the staging loop.  The variance is the one-pass E[x^2] - mean^2 in f32 (the separate kernel is
+// two-pass): measured on the whole model the outputs move by ~1e-6, parity stays at the 1e-5 level.
+struct EpLnBias {            // out = rstd * acc - rstd * mean * g[col] + b'[col]
+    float* __restrict__ out; const float* __restrict__ g; const float* __restrict__ bf; int ldo;
+    __device__ __forceinline__ float2 colv(int col) const { return make_float2(g[col], bf[col]); }
+    __device__ __forceinline__ void store(int row, int col, float acc, float2 cv, float2 ms) const {
+        out[(size_t)row * ldo + col] = fmaf(ms.y, acc, fmaf(-(ms.y * ms.x), cv.x, cv.y));
+    }
+};
+struct EpLnBiasReluSplit {   // ... then ReLU and the f16 hi / lo planes the next GEMM reads
+    _Float16* __restrict__ Oh; _Float16* __restrict__ Ol; const float* __restrict__ g; const float* __restrict__ bf; int ldo;
+    __device__ __forceinline__ float2 colv(int col) const { return make_float2(g[col], bf[col]); }
+    __device__ __forceinline__ void store(int row, int col, float acc, float2 cv, float2 ms) const {
+        const float v = fmaxf(fmaf(ms.y, acc, fmaf(-(ms.y * ms.x), cv.x, cv.y)), 0.f);
+        const _Float16 h = h3_hi(v);
+        Oh[(size_t)row * ldo + col] = h;
+        Ol[(size_t)row * ldo + col] = (_Float16)((v - (float)h) * H3_SCALE);
+    }
+};
+
+template <int TM, int TN, class EPL>
+__global__ void __launch_bounds__(256)
+gemm_h3_lnfold_kernel(const float* __restrict__ X, const int ldx, const _Float16* __restrict__ Bh, const _Float16* __restrict__ Bl,
+                      const int M, const int N, const int K, const float eps, const int m_tiles, const int n_tiles, const EPL ep)
+{
+    h3_flush_f16_denormals();
+    constexpr int BM = 64 * TM, BN = 64 * TN, LD = H3_LD;
+    constexpr int AI = BM / 32, BI = BN / 64;
+    extern __shared__ __attribute__((aligned(16))) _Float16 hsm[];
+    constexpr int STAGE = 2 * (BM + BN) * LD;
+
+    const int id = blockIdx.x;
+    const int xcd = id & 7, slot = id >> 3;
+    const int bn = slot % n_tiles;
+    const int bm = (slot / n_tiles) * 8 + xcd;
+    if (bm >= m_tiles) return;
+    const int bm0 = bm * BM, bn0 = bn * BN;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wm = wave >> 1, wn = wave & 1;
+    const int arow = tid >> 3, acol = (tid & 7) * 4;
+    const int brow = tid >> 2, bcol = (tid & 3) * 8;
+
+    const float* ap[AI];
+#pragma unroll
+    for (int i = 0; i < AI; ++i) ap[i] = X + (size_t)min(bm0 + arow + 32 * i, M - 1) * ldx + acol;
+    const _Float16* bhp[BI]; const _Float16* blp[BI];
+#pragma unroll
+    for (int i = 0; i < BI; ++i) {
+        const size_t o = (size_t)(bn0 + brow + 64 * i) * K + bcol;
+        bhp[i] = Bh + o; blp[i] = Bl + o;
+    }
+    f32x4 ra[AI];
+    h16x8 rbh[BI], rbl[BI];
+    float s1[AI], s2[AI];
+#pragma unroll
+    for (int i = 0; i < AI; ++i) { s1[i] = 0.f; s2[i] = 0.f; }
+    f32x16 acc0[TM][TN], acc1[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { acc0[i][j][r] = 0.f; acc1[i][j][r] = 0.f; }
+
+    const int KT = K / GEMM_BK;
+    auto issue = [&](int kt) {
+        const int k0 = kt * GEMM_BK;
+#pragma unroll
+        for (int i = 0; i < AI; ++i) ra[i] = *reinterpret_cast<const f32x4*>(ap[i] + k0);
+#pragma unroll
+        for (int i = 0; i < BI; ++i) {
+            rbh[i] = *reinterpret_cast<const h16x8*>(bhp[i] + k0);
+            rbl[i] = *reinterpret_cast<const h16x8*>(blp[i] + k0);
+        }
+    };
+    auto stage = [&](int buf, bool count) {
+        _Float16* S = hsm + buf * STAGE;
+#pragma unroll
+        for (int i = 0; i < AI; ++i) {
+            const f32x4 x = ra[i];
+            if (count) {
+                s1[i] += (x[0] + x[1]) + (x[2] + x[3]);
+                s2[i] = fmaf(x[0], x[0], fmaf(x[1], x[1], fmaf(x[2], x[2], fmaf(x[3], x[3], s2[i]))));
+            }
+            h16x4 hi, lo;
+            h3_split(x, hi, lo);
+            *reinterpret_cast<h16x4*>(&S[(arow + 32 * i) * LD + acol]) = hi;
+            *reinterpret_cast<h16x4*>(&S[BM * LD + (arow + 32 * i) * LD + acol]) = lo;
+        }
+#pragma unroll
+        for (int i = 0; i < BI; ++i) {
+            *reinterpret_cast<h16x8*>(&S[2 * BM * LD + (brow + 64 * i) * LD + bcol]) = rbh[i];
+            *reinterpret_cast<h16x8*>(&S[2 * BM * LD + BN * LD + (brow + 64 * i) * LD + bcol]) = rbl[i];
+        }
+    };
+
+    issue(0);
+    stage(0, true);
+    __syncthreads();
+    const int fr = lane & 31, fk = (lane >> 5) * 8;
+    for (int kt = 0; kt < KT; ++kt) {
+        const int cur = kt & 1;
+        const bool more = kt + 1 < KT;
+        issue(more ? kt + 1 : kt);
+        const _Float16* S = hsm + cur * STAGE;
+        const _Float16* Ahp = S + (wm * (BM / 2) + fr) * LD + fk;
+        const _Float16* Alp = Ahp + BM * LD;
+        const _Float16* Bhp = S + 2 * BM * LD + (wn * (BN / 2) + fr) * LD + fk;
+        const _Float16* Blp = Bhp + BN * LD;
+#pragma unroll
+        for (int kk = 0; kk < GEMM_BK / 16; ++kk) {
+            h16x8 ah[TM], alo[TM], bh[TN], blo[TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                ah[i] = *reinterpret_cast<const h16x8*>(Ahp + i * 32 * LD + kk * 16);
+                alo[i] = *reinterpret_cast<const h16x8*>(Alp + i * 32 * LD + kk * 16);
+            }
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                bh[j] = *reinterpret_cast<const h16x8*>(Bhp + j * 32 * LD + kk * 16);
+                blo[j] = *reinterpret_cast<const h16x8*>(Blp + j * 32 * LD + kk * 16);
+            }
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                    acc0[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bh[j], acc0[i][j], 0, 0, 0);
+                    acc1[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], blo[j], acc1[i][j], 0, 0, 0);
+                    acc1[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(alo[i], bh[j], acc1[i][j], 0, 0, 0);
+                }
+        }
+        stage(cur ^ 1, more);            // the last iteration restages its own tile (never read): do not count it twice
+        __syncthreads();
+    }
+
+    // row statistics: the 8 threads tid & 7 of a staging row hold its partial sums (one wave, consecutive lanes)
+    float2* rowstat = reinterpret_cast<float2*>(hsm);                 // [BM] (mean, rstd); the stage buffers are dead
+#pragma unroll
+    for (int i = 0; i < AI; ++i) {
+        float a = s1[i], b = s2[i];
+        a += __shfl_xor(a, 1); b += __shfl_xor(b, 1);
+        a += __shfl_xor(a, 2); b += __shfl_xor(b, 2);
+        a += __shfl_xor(a, 4); b += __shfl_xor(b, 4);
+        if ((tid & 7) == 0) {
+            const float mean = a / (float)K;
+            const float var = fmaxf(b / (float)K - mean * mean, 0.f);
+            rowstat[arow + 32 * i] = make_float2(mean, 1.0f / sqrtf(var + eps));
+        }
+    }
+    __syncthreads();
+
+    const int lrow0 = wm * (BM / 2) + 4 * (lane >> 5);
+    const int ccol0 = bn0 + wn * (BN / 2) + (lane & 31);
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int col = ccol0 + j * 32;
+            if (col >= N) continue;
+            const float2 cv = ep.colv(col);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int lrow = lrow0 + i * 32 + (r & 3) + 8 * (r >> 2);
+                const int row = bm0 + lrow;
+                if (row < M) ep.store(row, col, acc0[i][j][r] + acc1[i][j][r] * (1.0f / H3_SCALE), cv, rowstat[lrow]);
+            }
+        }
+}
+
+// ------------------------------------------------------------------------------------------------
 // Pre-split A operand.  The on-the-fly kernel above repeats the hi/lo split of one A tile in every workgroup
 // along N and carries that VALU work in its main loop.  Here the producer of an activation (attention, the ReLU
 // epilogue, optionally a LayerNorm pass) writes the two f16 planes once -- the same 4 bytes per element as the
@@ -323,6 +502,14 @@ gemm_h3g_kernel(const GL gl, const _Float16* __restrict__ Bh, const _Float16* __
         for (int p = 0; p < 2 * NPB; ++p)
             __builtin_amdgcn_global_load_lds((h3_glb_void*)(bsrc[p] + k), (h3_lds_void*)(d + (2 * NPA + p) * 64 * 32), 16, 0, 0);
     };
+    // one piece (0 .. NP-1) of the same transfer: the 128 x 128 form spreads them between its MFMAs
+    auto dma_piece = [&](int kt, int buf, int p) __attribute__((always_inline)) {
+        const int k = min(kt, KT - 1) * GEMM_BK + dk;
+        _Float16* d = hsm + buf * STAGE + 16 * wave * 32;
+        if (p < 2 * NPA) __builtin_amdgcn_global_load_lds((h3_glb_void*)gl.src(actx[p % NPA], k, p / NPA), (h3_lds_void*)(d + p * 64 * 32), 16, 0, 0);
+        else __builtin_amdgcn_global_load_lds((h3_glb_void*)(bsrc[p - 2 * NPA] + k), (h3_lds_void*)(d + p * 64 * 32), 16, 0, 0);
+    };
+
     f32x16 acc0[TM][TN], acc1[TM][TN];
 #pragma unroll
     for (int i = 0; i < TM; ++i)
@@ -342,6 +529,80 @@ gemm_h3g_kernel(const GL gl, const _Float16* __restrict__ Bh, const _Float16* __
 
     const int fr = lane & 31, fkc = lane >> 5;
     int cur = 0;
+    // 128 x 128 tiles leave one workgroup per CU = one wave per SIMD: nothing hides an LDS read that hipcc sinks to its
+    // use, so this form issues all 16 fragment reads of a k-tile up front by asm (counted lgkmcnt waits, LDS returns in
+    // order) and spreads the next tile's 8 DMAs between the MFMAs instead of issuing them in front of them.
+    // The 64 x 128 and 64 x 64 tiles can take the same form (-DUU3D_H3G_PIPE12=1): hipcc reads 6 fragments, waits, runs 6 MFMAs,
+    // reads the other 6, waits again.  Measured with all 12 reads up front: fc2 31.0 vs 30.5 us, projection 21.4 vs 20.6 us --
+    // with two workgroups per CU the other workgroup's MFMAs already cover the reads; left off.
+    constexpr bool PIPE = (NBUF == 3) && ((TM == 2 && TN == 2) || (UU3D_H3G_PIPE12 && TM == 1 && (TN == 2 || TN == 1)));
+    if (PIPE) {
+        unsigned aoff[2][TM][2], boff[2][TN][2];           // byte offsets inside a stage: [kk][fragment][plane]
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                const int r = wm * (BM / 2) + 32 * i + fr, c = (2 * kk + fkc) ^ ((r >> 2) & 3);
+                aoff[kk][i][0] = (unsigned)((r * 32 + c * 8) * 2); aoff[kk][i][1] = (unsigned)(((BM + r) * 32 + c * 8) * 2);
+            }
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                const int r = wn * (BN / 2) + 32 * j + fr, c = (2 * kk + fkc) ^ ((r >> 2) & 3);
+                boff[kk][j][0] = (unsigned)(((2 * BM + r) * 32 + c * 8) * 2); boff[kk][j][1] = (unsigned)(((2 * BM + BN + r) * 32 + c * 8) * 2);
+            }
+        }
+        const unsigned lds0 = (unsigned)(uintptr_t)(h3_lds_void*)hsm;
+        for (int kt = kt_lo; kt < KT; ++kt) {
+            const unsigned sb = lds0 + (unsigned)(cur * STAGE * 2);
+            const int wbuf = cur >= 1 ? cur - 1 : 2;            // buffer (cur + 2) % 3: last read in iteration kt-1, every wave is past that barrier
+            h16x8 fa[2][TM][2], fb[2][TN][2];
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk) {
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int pl = 0; pl < 2; ++pl) asm volatile("ds_read_b128 %0, %1" : "=&v"(fa[kk][i][pl]) : "v"(sb + aoff[kk][i][pl]));
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+#pragma unroll
+                    for (int pl = 0; pl < 2; ++pl) asm volatile("ds_read_b128 %0, %1" : "=&v"(fb[kk][j][pl]) : "v"(sb + boff[kk][j][pl]));
+            }
+            int piece = 0;
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk) {
+                // the reads of kk = 1 (2 (TM + TN) of them) may stay in flight over the MFMAs of kk = 0
+                if constexpr (TM == 2 && TN == 2) {
+                    if (kk == 0) asm volatile("s_waitcnt lgkmcnt(8)" : "+v"(fa[0][0][0]), "+v"(fa[0][0][1]), "+v"(fa[0][TM - 1][0]), "+v"(fa[0][TM - 1][1]), "+v"(fb[0][0][0]), "+v"(fb[0][0][1]), "+v"(fb[0][TN - 1][0]), "+v"(fb[0][TN - 1][1]));
+                    else asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(fa[1][0][0]), "+v"(fa[1][0][1]), "+v"(fa[1][TM - 1][0]), "+v"(fa[1][TM - 1][1]), "+v"(fb[1][0][0]), "+v"(fb[1][0][1]), "+v"(fb[1][TN - 1][0]), "+v"(fb[1][TN - 1][1]));
+                } else if constexpr (TN == 2) {
+                    if (kk == 0) asm volatile("s_waitcnt lgkmcnt(6)" : "+v"(fa[0][0][0]), "+v"(fa[0][0][1]), "+v"(fb[0][0][0]), "+v"(fb[0][0][1]), "+v"(fb[0][TN - 1][0]), "+v"(fb[0][TN - 1][1]));
+                    else asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(fa[1][0][0]), "+v"(fa[1][0][1]), "+v"(fb[1][0][0]), "+v"(fb[1][0][1]), "+v"(fb[1][TN - 1][0]), "+v"(fb[1][TN - 1][1]));
+                } else {
+                    if (kk == 0) asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(fa[0][0][0]), "+v"(fa[0][0][1]), "+v"(fb[0][0][0]), "+v"(fb[0][0][1]));
+                    else asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(fa[1][0][0]), "+v"(fa[1][0][1]), "+v"(fb[1][0][0]), "+v"(fb[1][0][1]));
+                }
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j) {
+                        acc0[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[kk][i][0], fb[kk][j][0], acc0[i][j], 0, 0, 0);
+                        acc1[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[kk][i][0], fb[kk][j][1], acc1[i][j], 0, 0, 0);
+                        acc1[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[kk][i][1], fb[kk][j][0], acc1[i][j], 0, 0, 0);
+                        // the NP DMA pieces of tile kt + 2 spread over the 2 TM TN MFMA groups
+                        constexpr int GROUPS = 2 * TM * TN;
+                        const int gi = (kk * TM + i) * TN + j;
+#pragma unroll
+                        for (int q = 0; q < (NP + GROUPS - 1) / GROUPS; ++q)
+                            if (piece < NP && piece * GROUPS < (gi + 1) * NP) { dma_piece(kt + 2, wbuf, piece); ++piece; }
+                    }
+            }
+            asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" :: "i"(NP) : "memory");
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_sched_barrier(0);
+            cur = (cur == 2 ? 0 : cur + 1);
+        }
+    } else
     for (int kt = kt_lo; kt < KT; ++kt) {
         // buffer (cur + 2) % 3 was last read in iteration kt-1; every wave is past that barrier
         if (NBUF == 3) dma(kt + 2, cur >= 1 ? cur - 1 : 2); else dma(kt + 1, cur ^ 1);
@@ -413,6 +674,64 @@ gemm_h3g_kernel(const GL gl, const _Float16* __restrict__ Bh, const _Float16* __
         }
 }
 __host__ __device__ inline constexpr size_t gemm_h3g_lds_bytes(int BM, int BN, int nbuf = 3) { return (size_t)nbuf * 2 * (BM + BN) * 32 * sizeof(_Float16); }
+
+// LayerNormalization (non-fused Keras path, see ALoadLayerNorm) of one row per wave, written as the two
+// f16 planes the next GEMM reads.  Same arithmetic, in the same order, as row_stats_kernel followed by
+// ALoadLayerNorm::finish and h3_split.  D % 4 == 0, D <= 64 * 4 * MAXV.
+template <int MAXV>
+__global__ void __launch_bounds__(256)
+ln_split_kernel(const float* __restrict__ x, const int ld, const int D, const int M, const float eps,
+                const float* __restrict__ gamma, const float* __restrict__ beta,
+                _Float16* __restrict__ Ph, _Float16* __restrict__ Pl, const int ldp)
+{
+    h3_flush_f16_denormals();
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= M) return;
+    const float* p = x + (size_t)row * ld;
+    f32x4 v[MAXV];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) {
+        const int c = (i * 64 + lane) * 4;
+        v[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        if (c < D) v[i] = *reinterpret_cast<const f32x4*>(p + c);
+        s += (v[i][0] + v[i][1]) + (v[i][2] + v[i][3]);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+    const float mean = s / (float)D;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) {
+        const int c = (i * 64 + lane) * 4;
+        if (c < D) {
+            const float a = v[i][0] - mean, b = v[i][1] - mean, cc = v[i][2] - mean, d = v[i][3] - mean;
+            q += (a * a + b * b) + (cc * cc + d * d);
+        }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) q += __shfl_xor(q, o);
+    const float rstd = 1.0f / sqrtf(q / (float)D + eps);
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) {
+        const int c = (i * 64 + lane) * 4;
+        if (c < D) {
+            const f32x4 g = *reinterpret_cast<const f32x4*>(gamma + c);
+            const f32x4 bt = *reinterpret_cast<const f32x4*>(beta + c);
+            f32x4 y;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float inv = rstd * g[e];
+                y[e] = v[i][e] * inv + (bt[e] - mean * inv);
+            }
+            h16x4 hi, lo;
+            h3_split(y, hi, lo);
+            *reinterpret_cast<h16x4*>(Ph + (size_t)row * ldp + c) = hi;
+            *reinterpret_cast<h16x4*>(Pl + (size_t)row * ldp + c) = lo;
+        }
+    }
+}
 
 // Plain f32 -> planes conversion (operands that have no producer kernel of their own).
 static __global__ void __launch_bounds__(256)

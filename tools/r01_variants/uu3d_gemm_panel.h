@@ -22,9 +22,9 @@
 //     of relying on co-resident waves.
 //
 // Grid: (M / 128) row tiles x S column ranges of N / (32 S) chunks each, launched as (8 S, ceil(ceil(items / 8) / S)).  Measured (tools/gemm_panel_exp): see DESIGN.md.
-// Forms that measured slower and live in tools/ now: LayerNorm statistics + split in the kernel's own prologue
-// (tools/gemm_panel_lnfold_exp.h), LayerNorm folded into the operand with producer-side fragment stores ("LNF") and the
-// accumulating variant for the residual Dense layers (tools/r01_variants/uu3d_gemm_panel.h).
+// An earlier form that loaded f32 rows, computed LayerNorm statistics and split in its own prologue (LayerNorm folded
+// into the operand) is kept in tools/gemm_panel_lnfold_exp.h: its prologue was 14-35 k cycles of serial VALU work and
+// register spills per workgroup; splitting once per row in a separate wide kernel (ln_split_frag_kernel) is cheaper.
 #pragma once
 #include "uu3d_gemm_h3.h"
 #include <type_traits>
@@ -40,7 +40,7 @@ static constexpr int PANEL_SLOTS = 144 / (2 * PANEL_SS); // ring depth (144 KiB)
 static constexpr int PANEL_PIECES = PANEL_SS / 2;        // 1 KiB pieces of a k-step each of the 4 waves moves
 static constexpr size_t PANEL_RING_BYTES = (size_t)PANEL_SLOTS * PANEL_STEP_BYTES;   // 144 KiB
 static constexpr int PANEL_COLV_FLOATS = 1024;           // per-column epilogue vector of this workgroup's columns (<= 32 chunks)
-static constexpr size_t PANEL_LDS_TOTAL = PANEL_RING_BYTES + PANEL_COLV_FLOATS * sizeof(float);
+static constexpr size_t PANEL_LDS_TOTAL = PANEL_RING_BYTES + (PANEL_COLV_FLOATS + 2 * 128) * sizeof(float);   // + (rstd, rstd * mean) of the 128 rows (LNF)
 
 // halfs in the fragment-ordered operands (A is allocated in whole 32-row panels)
 __host__ __device__ inline constexpr size_t panel_b_halfs(int N, int K) { return (size_t)(N / 32) * (K / 16) * 2 * 512; }
@@ -75,6 +75,10 @@ struct PanelEpBias {           // out[row][col] = v
         *reinterpret_cast<float*>(reinterpret_cast<char*>(out) + b) = v;
     }
 };
+struct PanelEpBiasResidual {   // x[row][col] += v  (residual stream, in place)
+    float* __restrict__ x; int ldo;
+    __device__ __forceinline__ void store(int row, int col, float v) const { float* p = x + (size_t)row * ldo + col; *p = *p + v; }
+};
 struct PanelEpBiasReluSplit {  // ReLU(v) as row-major hi / lo planes [M][ldo] (the A operand of the tiled LDS-DMA kernel)
     _Float16* __restrict__ Oh; _Float16* __restrict__ Ol; int ldo;
     __device__ __forceinline__ void store(int row, int col, float x) const {
@@ -85,6 +89,17 @@ struct PanelEpBiasReluSplit {  // ReLU(v) as row-major hi / lo planes [M][ldo] (
         *reinterpret_cast<_Float16*>(reinterpret_cast<char*>(Ol) + b) = (_Float16)((v - (float)h) * H3_SCALE);
     }
 };
+struct PanelEpBiasReluFrag {   // ReLU(v) as fragment-ordered planes of the next GEMM's A operand (contraction length Kn)
+    _Float16* __restrict__ Af; int Kn;
+    __device__ __forceinline__ void store(int row, int col, float x) const {
+        const float v = fmaxf(x, 0.f);
+        const _Float16 h = h3_hi(v);
+        const size_t i = panel_a_index(row, col, Kn);
+        Af[i] = h;
+        Af[i + 512] = (_Float16)((v - (float)h) * H3_SCALE);
+    }
+};
+
 #ifdef UU3D_PANEL_STAMP
 __device__ unsigned long long panel_clk[8];   // tools/gemm_panel_exp: s_memtime ticks in prologue / loop / tail, summed over workgroups
 #define PANEL_STAMP(...) __VA_ARGS__
@@ -92,16 +107,37 @@ __device__ unsigned long long panel_clk[8];   // tools/gemm_panel_exp: s_memtime
 #define PANEL_STAMP(...)
 #endif
 
-// Counted LDS waits of the main loop.  Issue order of a k-step (all asm, in program order): B(0) B(1), then per k-slice g:
-// B(g+2) | wait B(g) | 3 MFMAs, where B(g) = the two fragment reads of slice g.  LDS returns in order, so a wait for an
-// operation = lgkmcnt(number of operations issued after it).
-constexpr int panel_wait_count(const int g) { return g + 2 < PANEL_SS ? 4 : (g + 1 < PANEL_SS ? 2 : 0); }
+// Counted LDS waits of the main loop.  Issue order of a k-step (all asm, in program order): B(0) B(1) [R(0)], then per
+// k-slice g: B(g+2) | wait B(g) | 3 MFMAs | [wait R(g) | emit | R(g+1)], where B(g) = the two fragment reads of slice g and
+// R(g) = the (rstd, rstd * mean) read of output register g (LNF, first 16 slices only).  LDS returns in order, so a wait
+// for an operation = lgkmcnt(number of operations issued after it).
+constexpr int panel_wait_count(const int g_target, const bool target_is_r, const bool with_r) {
+    int cur = 0, end_b[PANEL_SS + 2] = {}, end_r[17] = {};
+    cur += 2; end_b[0] = cur; cur += 2; end_b[1] = cur;
+    if (with_r) { cur += 1; end_r[0] = cur; }
+    for (int g = 0; g < PANEL_SS; ++g) {
+        if (g + 2 < PANEL_SS) { cur += 2; end_b[g + 2] = cur; }
+        if (!target_is_r && g == g_target) return cur - end_b[g];
+        if (with_r && g < 16) {
+            if (target_is_r && g == g_target) return cur - end_r[g];
+            if (g + 1 < 16) { cur += 1; end_r[g + 1] = cur; }
+        }
+    }
+    return 0;
+}
 
 // C[M][N] = A[M][K] B + colv,  K = 16 KS (KS % 24 == 0), A / B fragment ordered (see top).
-template <int KS, class EP>
+// LNF = LayerNorm folded into the Dense:  LN(x) W + b = rstd (x (gamma o W)) - rstd mean (gamma^T W) + (beta^T W + b).
+//   A holds the RAW rows x (split by the kernel that produced the residual stream), B = gamma o W, colv = g | b' (N each);
+//   the row sums of x and x^2 are taken from the resident fragments with v_dot2_f32_f16 (hi and lo planes and their
+//   cross term: 5 dot2 per pair of elements, ~500 instructions per lane) and the epilogue applies rstd / mean.
+//   One-pass variance E[x^2] - mean^2 in f32: relative error ~1e-7 (1 + mean^2 / var) -- rows would need |mean| > 30 sigma
+//   to reach the 1e-4 parity bar.
+template <int KS, class EP, bool LNF = false>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1)))
 gemm_h3_panel_kernel(const _Float16* __restrict__ Af, const _Float16* __restrict__ Bf, const float* __restrict__ colv,
-                     const int M, const int m_tiles, const int splits, const int chunks_per_wg, const EP ep)
+                     const int M, const int m_tiles, const int splits, const int chunks_per_wg, const EP ep,
+                     const int n_total = 0, const float ln_eps = 0.f)
 {
     constexpr int SPC = KS / PANEL_SS;                           // k-steps per chunk
     h3_flush_f16_denormals();                              // the epilogue may split its result
@@ -155,7 +191,33 @@ gemm_h3_panel_kernel(const _Float16* __restrict__ Af, const _Float16* __restrict
 #pragma unroll
     for (int t = 0; t < PANEL_SLOTS - 1; ++t) dma(t, t);
     float* colv_s = reinterpret_cast<float*>(psm + PANEL_RING_BYTES);
-    for (int i = tid; i < chunks_per_wg * 32; i += 256) colv_s[i] = colv[chunk0 * 32 + i];
+    for (int i = tid; i < chunks_per_wg * 32; i += 256) {
+        colv_s[i] = colv[chunk0 * 32 + i];
+        if (LNF) colv_s[512 + i] = colv[n_total + chunk0 * 32 + i];
+    }
+    float2* rstat_s = reinterpret_cast<float2*>(colv_s + PANEL_COLV_FLOATS);
+    if (LNF) {
+        typedef _Float16 h16x2 __attribute__((ext_vector_type(2)));
+        const h16x2 ones = {(_Float16)1.f, (_Float16)1.f};
+        float sh = 0.f, sl = 0.f, qhh = 0.f, qhl = 0.f, qll = 0.f;
+#pragma unroll
+        for (int q = 0; q < KS; ++q)
+#pragma unroll
+            for (int e = 0; e < 8; e += 2) {
+                const h16x2 h2 = {ah[q][e], ah[q][e + 1]}, l2 = {al[q][e], al[q][e + 1]};
+                sh = __builtin_amdgcn_fdot2(h2, ones, sh, false);  sl = __builtin_amdgcn_fdot2(l2, ones, sl, false);
+                qhh = __builtin_amdgcn_fdot2(h2, h2, qhh, false);  qhl = __builtin_amdgcn_fdot2(h2, l2, qhl, false);
+                qll = __builtin_amdgcn_fdot2(l2, l2, qll, false);
+            }
+        float s1 = sh + sl * (1.0f / H3_SCALE);
+        float s2 = qhh + (2.0f / H3_SCALE) * qhl + (1.0f / (H3_SCALE * H3_SCALE)) * qll;
+        s1 += __shfl_xor(s1, 32); s2 += __shfl_xor(s2, 32);                  // lanes l and l ^ 32 hold the two k-halves of a row
+        const float mean = s1 * (1.0f / (16 * KS));
+        const float var = fmaxf(s2 * (1.0f / (16 * KS)) - mean * mean, 0.f);
+        const float rstd = rsqrtf(var + ln_eps);
+        if (lane < 32) rstat_s[wave * 32 + lane] = make_float2(rstd, rstd * mean);
+    }
+
     // ---- main loop ----
     // Every wait is "vmcnt(6 x k-steps left in flight)": k-step t was issued before t+1 .. t+4, whose pieces are the
     // newest loads at that point, and vector memory operations retire in order -- wherever the compiler puts the
@@ -165,15 +227,26 @@ gemm_h3_panel_kernel(const _Float16* __restrict__ Af, const _Float16* __restrict
     const int valid = min(32, M - row0);                   // wave-uniform: rows of this panel that exist (<= 0: none)
     PANEL_STAMP(asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); const long long c_pro = clock64();)
 
-    auto emit = [&](int c, int r, const f32x16& p0, const f32x16& p1, float cv) __attribute__((always_inline)) {
-        ep.store(row0 + 8 * (r >> 2) + crow + (r & 3), (chunk0 + c) * 32 + ccol, p0[r] + p1[r] * (1.0f / H3_SCALE) + cv);
+    auto emit = [&](int c, int r, const f32x16& p0, const f32x16& p1, float cv, float cg) __attribute__((always_inline)) {
+        const float acc = p0[r] + p1[r] * (1.0f / H3_SCALE);
+        float v = acc + cv;
+        if (LNF) { const float2 rs = rstat_s[wave * 32 + 8 * (r >> 2) + crow + (r & 3)]; v = fmaf(rs.x, acc, fmaf(-rs.y, cg, cv)); }   // (rstd, rstd * mean) of the row
+        ep.store(row0 + 8 * (r >> 2) + crow + (r & 3), (chunk0 + c) * 32 + ccol, v);
     };
+    // the interleaved form takes the row statistics from an asm read issued one k-slice earlier (32 registers the loop cannot spare)
+    typedef float f32x2 __attribute__((ext_vector_type(2)));
+    auto emit_rs = [&](int c, int r, const f32x16& p0, const f32x16& p1, float cv, float cg, f32x2 rs) __attribute__((always_inline)) {
+        const float acc = p0[r] + p1[r] * (1.0f / H3_SCALE);
+        ep.store(row0 + 8 * (r >> 2) + crow + (r & 3), (chunk0 + c) * 32 + ccol, fmaf(rs[0], acc, fmaf(-rs[1], cg, cv)));
+    };
+    const unsigned rsb = (unsigned)(uintptr_t)(h3_lds_void*)(rstat_s + wave * 32 + crow);
     // WHOLE = every row of the panel exists: the 16 stores of chunk c-1 are spread over the first 16 k-slices of chunk c
     // (an MFMA holds the vector issue port for 8 of its 32 cycles).  Otherwise they are predicated and issued as a block.
     auto chunk = [&](auto whole_tag, int c, f32x16& acc0, f32x16& acc1, const f32x16& p0, const f32x16& p1) __attribute__((always_inline)) {
         constexpr bool WHOLE = decltype(whole_tag)::value;
         const bool prev = c > 0;
-        const float pcv = colv_s[max(c - 1, 0) * 32 + ccol];                       // the previous chunk's bias
+        const float pcg = colv_s[max(c - 1, 0) * 32 + ccol];                       // LNF: g | plain: the bias
+        const float pcv = LNF ? colv_s[512 + max(c - 1, 0) * 32 + ccol] : pcg;   // LNF: b'
 #pragma unroll
         for (int st = 0; st < SPC; ++st) {
             asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" :: "i"(PANEL_PIECES * (PANEL_SLOTS - 2)) : "memory");   // k-step t landed (this wave's pieces); own reads of t-1 returned
@@ -183,7 +256,7 @@ gemm_h3_panel_kernel(const _Float16* __restrict__ Af, const _Float16* __restrict
             if (!WHOLE && st == 0 && prev) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r)
-                    if (8 * (r >> 2) + crow + (r & 3) < valid) emit(c - 1, r, p0, p1, pcv);
+                    if (8 * (r >> 2) + crow + (r & 3) < valid) emit(c - 1, r, p0, p1, pcv, pcg);
                 __builtin_amdgcn_sched_barrier(0);
             }
             if (st == 0) {
@@ -195,19 +268,31 @@ gemm_h3_panel_kernel(const _Float16* __restrict__ Af, const _Float16* __restrict
 #define UU3D_PANEL_READ(i, kk) \
             asm volatile("ds_read_b128 %0, %2 offset:%3\n\tds_read_b128 %1, %2 offset:%4" \
                          : "=&v"(bh[i]), "=&v"(bl[i]) : "v"(sb), "i"((kk) * 2048), "i"((kk) * 2048 + 1024))
+            constexpr bool WR = LNF && WHOLE && SPC == 1;      // row-statistics reads ride along (counts: panel_wait_count)
+            f32x2 rs[2];
+#define UU3D_PANEL_READ_R(i, r) \
+            asm volatile("ds_read_b64 %0, %1 offset:%2" : "=&v"(rs[i]) : "v"(rsb), "i"((8 * ((r) >> 2) + ((r) & 3)) * 8))
             UU3D_PANEL_READ(0, 0);
             UU3D_PANEL_READ(1, 1);
+            if (WR) UU3D_PANEL_READ_R(0, 0);
 #pragma unroll
             for (int kk = 0; kk < PANEL_SS; ++kk) {
                 if (kk + 2 < PANEL_SS) UU3D_PANEL_READ((kk + 2) % 3, kk + 2);
-                asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(bh[kk % 3]), "+v"(bl[kk % 3]) : "i"(panel_wait_count(kk)));
+                asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(bh[kk % 3]), "+v"(bl[kk % 3]) : "i"(panel_wait_count(kk, false, WR)));
                 acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[st * PANEL_SS + kk], bh[kk % 3], acc0, 0, 0, 0);
                 acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[st * PANEL_SS + kk], bl[kk % 3], acc1, 0, 0, 0);
                 acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[st * PANEL_SS + kk], bh[kk % 3], acc1, 0, 0, 0);
-                if (WHOLE && st * PANEL_SS + kk < 16 && prev) emit(c - 1, st * PANEL_SS + kk, p0, p1, pcv);
+                if (WR) {
+                    if (kk < 16) {
+                        asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(rs[kk & 1]) : "i"(panel_wait_count(kk, true, true)));
+                        if (prev) emit_rs(c - 1, kk, p0, p1, pcv, pcg, rs[kk & 1]);
+                        if (kk + 1 < 16) UU3D_PANEL_READ_R((kk + 1) & 1, kk + 1);
+                    }
+                } else if (WHOLE && st * PANEL_SS + kk < 16 && prev) emit(c - 1, st * PANEL_SS + kk, p0, p1, pcv, pcg);
                 if (kk & 1) dma1(c * SPC + st + PANEL_SLOTS - 1, slot_w, kk >> 1);   // the refill of the slot read in step t-1, spread over the step (-2 %)
             }
 #undef UU3D_PANEL_READ
+#undef UU3D_PANEL_READ_R
             slot_r = slot_r + 1 == PANEL_SLOTS ? 0 : slot_r + 1;
             slot_w = slot_w + 1 == PANEL_SLOTS ? 0 : slot_w + 1;
         }
@@ -225,20 +310,141 @@ gemm_h3_panel_kernel(const _Float16* __restrict__ Af, const _Float16* __restrict
     PANEL_STAMP(const long long c_loop = clock64();)
     {   // last chunk
         const int c = chunks_per_wg - 1;
-        const float cv = colv_s[c * 32 + ccol];
+        const float cg = colv_s[c * 32 + ccol];
+        const float cv = LNF ? colv_s[512 + c * 32 + ccol] : cg;
         if (c & 1) {
 #pragma unroll
             for (int r = 0; r < 16; ++r)
-                if (8 * (r >> 2) + crow + (r & 3) < valid) emit(c, r, b0, b1, cv);
+                if (8 * (r >> 2) + crow + (r & 3) < valid) emit(c, r, b0, b1, cv, cg);
         } else {
 #pragma unroll
             for (int r = 0; r < 16; ++r)
-                if (8 * (r >> 2) + crow + (r & 3) < valid) emit(c, r, a0, a1, cv);
+                if (8 * (r >> 2) + crow + (r & 3) < valid) emit(c, r, a0, a1, cv, cg);
         }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // the clamped tail DMAs must not outlive the LDS allocation
     PANEL_STAMP(if (tid == 0) { atomicAdd(&panel_clk[0], (unsigned long long)(c_pro - c_start)); atomicAdd(&panel_clk[1], (unsigned long long)(c_loop - c_pro));
         atomicAdd(&panel_clk[4], (unsigned long long)(clock64() - c_loop)); atomicAdd(&panel_clk[5], 1ull); })
+}
+
+// ------------------------------------------------------------------------------------------------
+// The residual Dense layers (projection K = 384, fc2 K = 768; N = 384): x[row][:] += A[row][:] B + bias.
+// Same roles as above, but a workgroup keeps the accumulators of ALL its NCH chunks (NCH x 32 registers) and runs the
+// contraction in NH halves of 384: the wave's A fragments of one half are resident (192 registers), the weight stream is
+// ordered (half, chunk), the second half's fragments are loaded over the first's once those are spent.  So K = 768 fits
+// the register file, there is no epilogue inside the loop (nothing between the MFMAs but fragment reads and DMAs), and the
+// residual rows are read once at the very end -- a global load inside the loop would wait behind the DMA ring, vector
+// memory retires in order.  Grid: (M / 128) row tiles x (N / 32 / NCH) column ranges.
+struct PanelEpResidual {       // x[row][col] += v (+ optionally out2 = x + pe2[row % period][col]: the next stack's input)
+    float* __restrict__ x; int ldo; float* __restrict__ out2; const float* __restrict__ pe2; int period;
+    __device__ __forceinline__ float load(int row, int col) const { return x[(size_t)row * ldo + col]; }
+    __device__ __forceinline__ void store(int row, int col, float y) const {        // y = load(row, col) + v
+        const size_t o = (size_t)row * ldo + col;
+        x[o] = y;
+        if (out2 != nullptr) out2[o] = y + pe2[(size_t)(row % period) * ldo + col];
+    }
+};
+
+template <int NH, int NCH, class EP>
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1)))
+gemm_h3_panel_acc_kernel(const _Float16* __restrict__ Af, const _Float16* __restrict__ Bf, const float* __restrict__ bias,
+                         const int M, const int m_tiles, const int splits, const EP ep)
+{
+    static_assert(PANEL_SS == 24, "one k-step = one half (384) of one chunk");
+    constexpr int KSH = 24, T = NH * NCH;                  // k-slices per half; k-steps of this workgroup
+    h3_flush_f16_denormals();
+    extern __shared__ __attribute__((aligned(16))) unsigned char psm[];
+
+    const int id = blockIdx.y * gridDim.x + blockIdx.x;    // balanced contiguous blocks of work items per XCD (see above)
+    const int total = m_tiles * splits, per = (total + 7) >> 3;
+    const int u = (id & 7) * per + (id >> 3);
+    if ((id >> 3) >= per || u >= total) return;
+    const int bm = u / splits, ns = u - bm * splits;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int row0 = bm * 128 + wave * 32;
+    const int chunk0 = ns * NCH;
+
+    // k-step t = half * NCH + c reads chunk (chunk0 + c), k-range half: [chunk][half] in the operand
+    const unsigned char* bsrc = reinterpret_cast<const unsigned char*>(Bf) + (wave * PANEL_PIECES) * 1024 + lane * 16;
+    auto dma1 = [&](int t, int slot, int p) __attribute__((always_inline)) {
+        const int tc = min(t, T - 1), half = tc / NCH, c = tc - half * NCH;
+        const unsigned char* s = bsrc + (size_t)((chunk0 + c) * NH + half) * PANEL_STEP_BYTES;
+        unsigned char* d = psm + slot * PANEL_STEP_BYTES + (wave * PANEL_PIECES) * 1024;
+        __builtin_amdgcn_global_load_lds((h3_glb_void*)(s + p * 1024), (h3_lds_void*)(d + p * 1024), 16, 0, 0);
+    };
+
+    h16x8 ah[KSH], al[KSH];
+    const h16x8* ap = reinterpret_cast<const h16x8*>(Af) + (size_t)(min(row0, M - 1) >> 5) * (KSH * NH) * 2 * 64 + lane;
+    auto load_a = [&](int half) __attribute__((always_inline)) {
+#pragma unroll
+        for (int q = 0; q < KSH; ++q) { ah[q] = ap[((half * KSH + q) * 2 + 0) * 64]; al[q] = ap[((half * KSH + q) * 2 + 1) * 64]; }
+    };
+    load_a(0);
+#pragma unroll
+    for (int t = 0; t < PANEL_SLOTS - 1; ++t)
+#pragma unroll
+        for (int p = 0; p < PANEL_PIECES; ++p) dma1(t, t, p);
+
+    f32x16 acc0[NCH], acc1[NCH];
+#pragma unroll
+    for (int c = 0; c < NCH; ++c)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { acc0[c][r] = 0.f; acc1[c][r] = 0.f; }
+
+#pragma unroll
+    for (int half = 0; half < NH; ++half) {
+        if (half > 0) load_a(half);                        // over the spent fragments of the previous half
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) {
+            const int t = half * NCH + c;
+            const int slot_r = t % PANEL_SLOTS, slot_w = (t + PANEL_SLOTS - 1) % PANEL_SLOTS;
+            asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" :: "i"(PANEL_PIECES * (PANEL_SLOTS - 2)) : "memory");
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_sched_barrier(0);
+            const unsigned sb = (unsigned)(uintptr_t)(h3_lds_void*)(psm + slot_r * PANEL_STEP_BYTES + lane * 16);
+            h16x8 bh[3], bl[3];
+#define UU3D_PANEL_READ(i, kk) \
+            asm volatile("ds_read_b128 %0, %2 offset:%3\n\tds_read_b128 %1, %2 offset:%4" \
+                         : "=&v"(bh[i]), "=&v"(bl[i]) : "v"(sb), "i"((kk) * 2048), "i"((kk) * 2048 + 1024))
+            UU3D_PANEL_READ(0, 0);
+            UU3D_PANEL_READ(1, 1);
+#pragma unroll
+            for (int kk = 0; kk < PANEL_SS; ++kk) {
+                if (kk + 2 < PANEL_SS) UU3D_PANEL_READ((kk + 2) % 3, kk + 2);
+                asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(bh[kk % 3]), "+v"(bl[kk % 3]) : "i"(panel_wait_count(kk, false, false)));
+                acc0[c] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[kk], bh[kk % 3], acc0[c], 0, 0, 0);
+                acc1[c] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[kk], bl[kk % 3], acc1[c], 0, 0, 0);
+                acc1[c] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[kk], bh[kk % 3], acc1[c], 0, 0, 0);
+                if (kk & 1) dma1(t + PANEL_SLOTS - 1, slot_w, kk >> 1);
+            }
+#undef UU3D_PANEL_READ
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // the clamped tail DMAs must not outlive the LDS allocation
+
+    // epilogue: ALL residual values are loaded before the first store (a load-add-store chain per element waits for the
+    // previous store's acknowledgement 64 times: 33 instead of 13 us for the projection)
+    const int crow = (lane >> 5) * 4, ccol = lane & 31;
+    const int valid = min(32, M - row0);
+    float res[NCH][16];
+#pragma unroll
+    for (int c = 0; c < NCH; ++c)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int lr = 8 * (r >> 2) + crow + (r & 3);
+            res[c][r] = ep.load(row0 + min(lr, max(valid, 1) - 1), (chunk0 + c) * 32 + ccol);
+        }
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+        const int col = (chunk0 + c) * 32 + ccol;
+        const float bv = bias[col];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int lr = 8 * (r >> 2) + crow + (r & 3);
+            if (lr < valid) ep.store(row0 + lr, col, res[c][r] + (acc0[c][r] + acc1[c][r] * (1.0f / H3_SCALE) + bv));
+        }
+    }
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -100,14 +100,14 @@ int uu3d_op_ln_dense_panel(const float* x, int32_t ldx, int32_t M, const float* 
     const dim3 grid(8 * S, ((mt * S + 7) / 8 + S - 1) / S);
     const _Float16* Bf = reinterpret_cast<const _Float16*>(operand);
     if (relu) {
-        auto kern = gemm_h3_panel_kernel<24, PanelEpBiasReluSplit, false>;
+        auto kern = gemm_h3_panel_kernel<24, PanelEpBiasReluSplit>;
         (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)PANEL_LDS_TOTAL);
         _Float16* oh = reinterpret_cast<_Float16*>(out);
-        hipLaunchKernelGGL(kern, grid, dim3(256), PANEL_LDS_TOTAL, stream, Af, Bf, bias, M, mt, S, chunks / S, PanelEpBiasReluSplit{oh, oh + (size_t)M * N, N}, 0, 0.f);
+        hipLaunchKernelGGL(kern, grid, dim3(256), PANEL_LDS_TOTAL, stream, Af, Bf, bias, M, mt, S, chunks / S, PanelEpBiasReluSplit{oh, oh + (size_t)M * N, N});
     } else {
-        auto kern = gemm_h3_panel_kernel<24, PanelEpBias, false>;
+        auto kern = gemm_h3_panel_kernel<24, PanelEpBias>;
         (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)PANEL_LDS_TOTAL);
-        hipLaunchKernelGGL(kern, grid, dim3(256), PANEL_LDS_TOTAL, stream, Af, Bf, bias, M, mt, S, chunks / S, PanelEpBias{reinterpret_cast<float*>(out), ldo}, 0, 0.f);
+        hipLaunchKernelGGL(kern, grid, dim3(256), PANEL_LDS_TOTAL, stream, Af, Bf, bias, M, mt, S, chunks / S, PanelEpBias{reinterpret_cast<float*>(out), ldo});
     }
     return hipGetLastError() == hipSuccess ? UU3D_OK : UU3D_ERR_HIP;
 }
