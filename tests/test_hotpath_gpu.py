@@ -213,7 +213,8 @@ def test_optional_kernel_paths_agree(env, monkeypatch):
     print(f"{env}=1: max deviation from the product path {d:.3e}")
     assert np.isfinite(f1).all() and np.isfinite(c1).all()
     assert d <= 3e-5, d
-    assert d > 0.0, "the switch did not change the path"
+    if env != "UU3D_ATTN_WG":          # the two attention kernels schedule the same exact-f32 products: bit-identical is right
+        assert d > 0.0, "the switch did not change the path"
 
 
 def test_mpjpe_kernel_matches_the_reference_metric():
