@@ -47,7 +47,9 @@ typedef enum uu3d_precision {
     UU3D_PREC_F32 = 0,     /* f32-input MFMA (v_mfma_f32_32x32x2_f32 / 16x16x4_f32), exact f32 */
     UU3D_PREC_F16X3 = 1    /* forward GEMMs as 3 f16 MFMA passes on hi/lo-split operands: f32-grade error,
                               f16-rate matrix pipe (csrc/uu3d_gemm_h3.h).  Attention, spatial stack, LayerNorm,
-                              softmax and every epilogue stay f32.  Training always runs UU3D_PREC_F32. */
+                              softmax and every epilogue stay f32.  The training step runs its forward, input-gradient
+                              and weight-gradient GEMMs the same way (loss-scaled, see uu3d_train_forward_backward);
+                              UU3D_TRAIN_F32=1 / UU3D_TN_F32=1 in the environment keep them on the exact-f32 kernels. */
 } uu3d_precision;
 
 /*
@@ -185,8 +187,8 @@ int uu3d_profile_read(uu3d_model* model, uu3d_profile_entry* out_entries, int32_
                       int32_t* out_count);
 
 /* ------------------------------------------------------------------------------------------
- * Training-step arithmetic that does not involve back-propagation through the network
- * (SURVEY.md section 8(a) rows T1, T3, T4).  The backward pass itself (T2) is not built yet.
+ * The training step: loss, optimizer and EMA kernels first, then the
+ * training-mode forward + backward pass (T2, uu3d_train_forward_backward).
  * ------------------------------------------------------------------------------------------ */
 
 /*
@@ -214,10 +216,13 @@ int uu3d_mpjpe_loss(const float* pred_full_dev, const float* pred_central_dev, c
  *   alpha = lr * sqrt(1 - beta2^t) / (1 - beta1^t)              (t = step = iterations + 1)
  *   m += (g - m) * (1 - beta1);  v += (g*g - v) * (1 - beta2)
  *   var -= (m * alpha) / (sqrt(v) + epsilon)
+ * vhat_dev != NULL selects Keras Adam's amsgrad=True form (TF ApplyAdamWithAmsgrad; the config class default
+ * OPTIMIZER_PARAMS {"amsgrad": True}, uplift_upsample_transformer_config.py:88):
+ *   vhat = max(vhat, v);  var -= (m * alpha) / (sqrt(vhat) + epsilon)
  * lr and wd are the schedule values at `iterations` (both ExponentialDecay for the shipped configs).
- * HBM-bound: 28 bytes per parameter (read var, g, m, v; write var, m, v).
+ * HBM-bound: 28 bytes per parameter (read var, g, m, v; write var, m, v), 36 with vhat.
  */
-int uu3d_adamw_update(float* var_dev, float* m_dev, float* v_dev, const float* grad_dev, int64_t n,
+int uu3d_adamw_update(float* var_dev, float* m_dev, float* v_dev, float* vhat_dev, const float* grad_dev, int64_t n,
                       float lr, float wd, float beta1, float beta2, float epsilon, int64_t step,
                       void* stream);
 
@@ -237,7 +242,15 @@ int uu3d_ema_update(float* ema_dev, const float* w_dev, int64_t n, float decay, 
  *       drop_path_uniform_dev: U[0,1) draws, layout [spatial blocks][2][B*N] then [temporal blocks][2][B]
  *                              (two draws per block: attention branch, MLP branch); NULL disables DropPath.
  *       full_out_dev / central_out_dev may be NULL.  loss_out_dev[3] = {loss, central, sequence}.
+ *       gt3d_dev == NULL: training-mode FORWARD ONLY (model(inputs, training=True) outside a tape, train.py:478);
+ *       loss_out_dev / grads_dev may then be NULL.  DROP_PATH_RATE[2] != 0 is UU3D_ERR_UNSUPPORTED.
+ *   uu3d_train_set_grad_callback: `fn(user, first, count, stream)` is called on the calling host thread from inside
+ *       uu3d_train_forward_backward each time the range [first, first + count) of grads_dev is final; every kernel that
+ *       writes it has been enqueued on `stream` before the call (a bucketed all-reduce makes its communication stream wait
+ *       for `stream` and overlaps with the rest of the backward pass).  Ranges are disjoint and cover the buffer.
  */
+typedef void (*uu3d_grad_ready_fn)(void* user, int64_t first, int64_t count, void* stream);
+int uu3d_train_set_grad_callback(uu3d_model* model, uu3d_grad_ready_fn fn, void* user);
 int64_t uu3d_num_params(const uu3d_model* model);
 int uu3d_train_init(uu3d_model* model, float* params_dev, void* stream);
 int uu3d_train_repack(uu3d_model* model, const float* params_dev, void* stream);

@@ -63,16 +63,22 @@ def train_loss(pred_full, pred_central, gt3d, root, w_center, w_seq, batch_size_
     return out
 
 
-def adamw_update(var, m, v, g, lr, wd, beta1, beta2, eps, step):
-    """One tfa-AdamW dense update in float32 numpy (separately rounded ops). Returns (var, m, v)."""
+def adamw_update(var, m, v, g, lr, wd, beta1, beta2, eps, step, vhat=None):
+    """One tfa-AdamW dense update in float32 numpy (separately rounded ops). Returns (var, m, v), or (var, m, v, vhat)
+    when `vhat` is given: Keras Adam(amsgrad=True) -> TF's ApplyAdamWithAmsgrad functor, vhat = max(vhat, v) and
+    sqrt(vhat) in the denominator."""
     var, m, v, g = (np.asarray(a, f32).copy() for a in (var, m, v, g))
     lr, wd, beta1, beta2, eps = f32(lr), f32(wd), f32(beta1), f32(beta2), f32(eps)
     var = var - wd * var
-    b1p = np.power(beta1, f32(step), dtype=f32)
-    b2p = np.power(beta2, f32(step), dtype=f32)
+    b1p = f32(float(beta1) ** float(step))          # beta^t rounded once from double (numpy's float32 power is an ulp off at some t)
+    b2p = f32(float(beta2) ** float(step))
     alpha = f32(lr * np.sqrt(f32(1) - b2p, dtype=f32) / (f32(1) - b1p))
     m = m + (g - m) * (f32(1) - beta1)
     v = v + (g * g - v) * (f32(1) - beta2)
+    if vhat is not None:
+        vhat = np.maximum(np.asarray(vhat, f32), v)
+        var = var - (m * alpha) / (np.sqrt(vhat, dtype=f32) + eps)
+        return var, m, v, vhat
     var = var - (m * alpha) / (np.sqrt(v, dtype=f32) + eps)
     return var, m, v
 

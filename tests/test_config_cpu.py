@@ -125,3 +125,38 @@ def test_config_matches_the_reference_classes(tmp_path):
     with pytest.warns(UserWarning):                   # single quotes: the reference warns and reads them as double quotes
         c = pkg.UpliftUpsampleConfig(str(t))
     same(public(c), exp["__text_mode__"], "text mode")
+
+
+@pytest.mark.parametrize("key,value,where", [
+    ("OUTPUT_BN", True, "build"),
+    ("TOKEN_MASK_RATE", 0.2, "train"),
+    ("DROP_RATE", 0.1, "train"),
+    ("ATTENTION_DROP_RATE", 0.1, "train"),
+    ("DROP_PATH_RATE", [0.1, 0.1, 0.05], "train"),
+])
+def test_unimplemented_options_are_rejected_not_ignored(key, value, where):
+    """A schema-legal config the HIP path does not implement must fail loudly instead of running a different model
+    (u_u_t.py:201,219-220,275-285, vit.py:87-88): OUTPUT_BN changes the inference model and is refused when the model is
+    built; Dropout rates, random token masking and strided-block DropPath only act with training=True and are refused by
+    every training entry point (arch.training_unsupported is what Trainer / model(training=True) raise from)."""
+    from uplift_upsample_3dhpe_amd.arch import training_unsupported
+    cfg = util.load_config("h36m_351")
+    assert training_unsupported(pkg.arch_from_config(cfg)) == []
+    setattr(cfg, key, value)
+    if where == "build":
+        with pytest.raises(NotImplementedError, match=key):
+            pkg.arch_from_config(cfg)
+    else:
+        bad = training_unsupported(pkg.arch_from_config(cfg))      # inference is unaffected: the arch still builds
+        assert len(bad) == 1 and key in bad[0]
+
+
+def test_learnable_masked_token_rule():
+    """LEARNABLE_MASKED_TOKEN alone creates nothing in the reference (the layer exists only with TOKEN_MASK_RATE > 0,
+    u_u_t.py:219-220): accepted; together with a token mask rate it adds a trainable weight this build does not have."""
+    cfg = util.load_config("h36m_351")
+    cfg.LEARNABLE_MASKED_TOKEN = True
+    pkg.arch_from_config(cfg)
+    cfg.TOKEN_MASK_RATE = 0.1
+    with pytest.raises(NotImplementedError, match="LEARNABLE_MASKED_TOKEN"):
+        pkg.arch_from_config(cfg)

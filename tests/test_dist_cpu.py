@@ -78,3 +78,66 @@ def test_allreduce_gradients_gloo_world2():
     for _, g in res:
         assert np.all(g == 3.0)                           # 1 + 2 on every rank, no rescale
     assert ud.allreduce_gradients(torch.ones(3)).sum() == 3    # no process group: identity
+
+
+def _bucket_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    rng = np.random.default_rng(100 + rank)
+    n = 10007
+    g = torch.from_numpy(rng.normal(0, 1e-3, n).astype(np.float32))
+    flat = g.clone()
+    ud.allreduce_gradients(flat)                                   # the one-collective form
+    b = g.clone()
+    br = ud.BucketedAllReduce(b)
+    # ranges in the order the backward pass finishes them: tail of the buffer first, the front last (uu3d_train_step.inc)
+    for first, count in [(7000, 3007), (4000, 3000), (1500, 2500), (0, 1500)]:
+        br.ready(first, count)
+    br.wait()
+    bad = ud.BucketedAllReduce(g.clone())
+    bad.ready(10, n - 10)
+    try:
+        bad.wait(); tiled = True
+    except RuntimeError:
+        tiled = False
+    q.put((rank, flat.numpy().copy(), b.numpy().copy(), tiled))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_bucketed_allreduce_equals_flat_bitwise_gloo_world2():
+    """gradient buckets started in backward order sum to exactly what one flat all-reduce gives, and a set of
+    ranges that does not tile the buffer is an error (a gradient tensor would silently stay rank-local)."""
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_bucket_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    expect = sum(np.random.default_rng(100 + r).normal(0, 1e-3, 10007).astype(np.float32) for r in range(2))
+    for _, flat, bucketed, tiled in res:
+        assert np.array_equal(flat, bucketed)
+        assert np.array_equal(flat, expect.astype(np.float32))
+        assert not tiled
+    # no process group: ready / wait are bookkeeping only
+    t = torch.ones(8)
+    b = ud.BucketedAllReduce(t)
+    b.ready(4, 4); b.ready(0, 4); b.wait()
+    assert t.sum() == 8
+
+
+def test_bench_starts_its_own_ranks():
+    """`python bench.py --gpus 2` without a launcher (what a driver may call): the parent spawns two ranks as child
+    processes before touching a GPU and returns their exit code (--spawn-check: ranks print and exit, no GPU needed)."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--spawn-check"], env=env,
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert "rank 0/2" in r.stdout and "rank 1/2" in r.stdout

@@ -52,7 +52,39 @@ def test_adamw_oracle_first_step_and_decay():
     assert np.allclose(T.ema_update(np.ones(3), np.zeros(3), 0.9), 0.9)
 
 
+def test_adamw_oracle_amsgrad():
+    """Keras Adam(amsgrad=True) (the config CLASS default OPTIMIZER_PARAMS, config.py:88): vhat never decreases and replaces v
+    in the denominator; with a growing |g| it equals v, so the update is the plain one."""
+    w = np.array([1.0, -2.0], np.float32)
+    var, m, v, vh = T.adamw_update(w, np.zeros(2), np.zeros(2), np.array([0.1, -0.2], np.float32), 1e-3, 0.0, 0.9, 0.999, 1e-8, 1, vhat=np.zeros(2))
+    plain = T.adamw_update(w, np.zeros(2), np.zeros(2), np.array([0.1, -0.2], np.float32), 1e-3, 0.0, 0.9, 0.999, 1e-8, 1)
+    assert np.array_equal(vh, v) and np.array_equal(var, plain[0])
+    var2, m2, v2, vh2 = T.adamw_update(var, m, v, np.zeros(2, np.float32), 1e-3, 0.0, 0.9, 0.999, 1e-8, 2, vhat=vh)
+    assert np.all(v2 < v) and np.array_equal(vh2, vh)          # v decays, vhat holds the maximum
+    assert not np.array_equal(var2, T.adamw_update(var, m, v, np.zeros(2, np.float32), 1e-3, 0.0, 0.9, 0.999, 1e-8, 2)[0])
+
+
 # ---------------------------------------------------------------- GPU: kernels through the C ABI
+@pytest.mark.gpu
+def test_adamw_amsgrad_kernel_bit_exact_over_steps():
+    from uplift_upsample_3dhpe_amd import optim
+    rng = np.random.default_rng(4)
+    n = 50001
+    w0 = rng.normal(0, 0.05, n).astype(np.float32)
+    params = torch.from_numpy(w0.copy()).cuda()
+    opt = optim.AdamW(params, weight_decay=1e-6, learning_rate=1e-4, epsilon=1e-8, amsgrad=True)
+    var, m, v, vh = w0.copy(), np.zeros(n, np.float32), np.zeros(n, np.float32), np.zeros(n, np.float32)
+    for it in range(5):
+        g = (rng.normal(0, 1e-2, n) * (1.0 if it % 2 == 0 else 0.1)).astype(np.float32)     # v falls below vhat on odd steps
+        var, m, v, vh = T.adamw_update(var, m, v, g, 1e-4, 1e-6, 0.9, 0.999, 1e-8, it + 1, vhat=vh)
+        opt.apply_gradients(torch.from_numpy(g).cuda())
+    torch.cuda.synchronize()
+    assert np.array_equal(opt.vhat.cpu().numpy(), vh) and np.array_equal(opt.v.cpu().numpy(), v)
+    assert np.array_equal(params.cpu().numpy(), var)
+    assert (vh > v).any()
+
+
+
 @pytest.mark.gpu
 def test_adamw_kernel_bit_exact_over_steps():
     from uplift_upsample_3dhpe_amd import optim

@@ -21,12 +21,23 @@ def _setup(cfgname, B, seed, batch_norm):
     return cfg, arch, w, model, x, m, gt
 
 
-@pytest.mark.parametrize("cfgname,droppath", [("h36m_81", False), ("h36m_351", False), ("h36m_81", True), ("h36m_351", True)])
-def test_gradients_match_autograd(cfgname, droppath):
+# masks without all-masked rows (those differ between fp32 and the float64 oracle by design): the gradient
+# bound below is then asserted for every case
+_MASKS = [(0, 0), (1, 0), (2, 0)]
+
+
+@pytest.mark.parametrize("cfgname,droppath,batch_norm", [("h36m_81", False, 4), ("h36m_351", False, 4), ("h36m_81", True, 4), ("h36m_351", True, 4),
+                                                         ("h36m_351", True, 512), ("h36m_81", False, 512)])
+def test_gradients_match_autograd(cfgname, droppath, batch_norm):
+    """Every gradient tensor against float64 autograd through the oracle, <= 1e-4 of its scale.  batch_norm = 512 is the
+    PRODUCTION loss normaliser (config BATCH_SIZE): d loss / d joint is 8e-7 there, which the f16x3 gradient GEMMs only
+    resolve because the backward pass runs loss-scaled (uu3d_train_step.inc, gscale)."""
     from oracle import train_oracle as T
     from uplift_upsample_3dhpe_amd.trainer import Trainer
     B = 3
-    cfg, arch, w, model, x, m, gt = _setup(cfgname, B, seed=7, batch_norm=4)
+    cfg, arch, w, model, x, m, gt = _setup(cfgname, B, seed=7, batch_norm=batch_norm)
+    ms = cfg.MASK_STRIDE if isinstance(cfg.MASK_STRIDE, list) else [cfg.MASK_STRIDE]
+    m = np.stack([util.eval_stride_mask(arch.num_frames, cfg.SEQUENCE_STRIDE, ms[i], 0) for i, _ in _MASKS])
     tr = Trainer(model, cfg)
     rng = np.random.default_rng(11)
     u = rng.random(tr.drop_path_size(B)).astype(np.float32) if droppath else None
@@ -60,8 +71,8 @@ def test_gradients_match_autograd(cfgname, droppath):
     for e in sorted(errs, reverse=True)[:6]:
         print("   %.2e  %-60s |g|max %.2e" % e)
     print(f"{cfgname} droppath={droppath}: worst relative gradient error {worst[1]:.2e} at {worst[0]}")
-    if rows.all():
-        assert worst[1] <= 2e-3, worst
+    assert rows.all()
+    assert worst[1] <= 1e-4, worst
 
 
 def test_train_step_updates_weights_and_exports():
@@ -162,3 +173,97 @@ def test_side_stream_schedule_is_bit_identical_to_in_order(cfgname, B, monkeypat
         assert torch.equal(l1, l2)
         assert torch.equal(g1, g2), int((g1 != g2).sum())
     assert torch.equal(ref[0][0], ref[-1][0])
+
+
+def test_training_call_of_the_model_object():
+    """model([x, m], training=True) (train.py:478): the training-mode forward with DropPath -- the same outputs as the
+    Trainer's forward for the same draws, different from the inference call; without DropPath draws mattering
+    (rate 0) equal to inference.  model.weights / trainable_variables list name -> array views in inventory order."""
+    from uplift_upsample_3dhpe_amd.trainer import Trainer
+    cfg, arch, w, model, x, m, gt = _setup("h36m_81", 4, seed=3, batch_norm=4)
+    xm = torch.from_numpy(x * m[:, :, None, None]).cuda(); mt = torch.from_numpy(m).cuda()
+    f_inf, c_inf = model([xm, mt], training=False)
+    f_tr, c_tr = model([xm, mt], training=True)                       # the model's own generator (seed 0)
+    assert f_tr.shape == f_inf.shape and torch.isfinite(f_tr).all() and torch.isfinite(c_tr).all()
+    assert (f_tr - f_inf).abs().max() > 1e-3                            # DropPath dropped / rescaled branches
+    model2 = pkg.build_uplift_upsample_transformer(cfg, weights=w)
+    f_tr2, c_tr2 = model2([xm, mt], training=True)
+    assert torch.equal(f_tr, f_tr2) and torch.equal(c_tr, c_tr2)        # same seed, same draws
+    cfg0 = util.load_config("h36m_81"); cfg0.DROP_PATH_RATE = [0.0, 0.0, 0.0]
+    model0 = pkg.build_uplift_upsample_transformer(cfg0, weights=w)
+    f0, c0 = model0([xm, mt], training=True)
+    assert (f0 - f_inf).abs().max() <= 3e-5 and (c0 - c_inf).abs().max() <= 3e-5
+    cfg0.DROP_PATH_RATE = [0.1, 0.1, 0.05]
+    with pytest.raises(NotImplementedError, match=r"DROP_PATH_RATE\[2\]"):
+        pkg.build_uplift_upsample_transformer(cfg0, weights=w)([xm, mt], training=True)
+    names = [v.name for v in model.weights]
+    assert names == model.weight_names and [v.name for v in model.trainable_variables] == names
+    v = model.weights[1]
+    assert np.array_equal(v.numpy(), w[v.name]) and v.shape == w[v.name].shape
+    # with a Trainer attached the call uses the trainer's live weights and generator
+    tr = Trainer(model, cfg, seed=5)
+    tr2 = Trainer(model2, cfg, seed=5)
+    a = model([xm, mt], training=True)
+    u = torch.rand(tr2.drop_path_size(4), generator=tr2._rng, device="cuda", dtype=torch.float32)
+    _, fb, cb = tr2.forward_backward(torch.from_numpy(x).cuda(), torch.from_numpy(gt).cuda(), mt, drop_path_uniform=u)
+    assert torch.equal(a[0], fb) and torch.equal(a[1], cb)
+
+
+def test_model_sees_trained_weights_without_explicit_export(tmp_path):
+    """train.py:393,706,719 validate and checkpoint with the live model: after Trainer.train_step, get_weights / save_weights /
+    model(..., training=False) must use the UPDATED weights (round-1 returned the stale host copy until export_to_model)."""
+    from uplift_upsample_3dhpe_amd.trainer import Trainer
+    cfg, arch, w, model, x, m, gt = _setup("h36m_81", 2, seed=9, batch_norm=2)
+    cfg.EMA_ENABLED = False
+    tr = Trainer(model, cfg)
+    T_ = lambda a: torch.from_numpy(a).cuda()
+    tr.train_step(T_(x), T_(gt), T_(m), drop_path_uniform=None)
+    flat = tr.params.cpu().numpy()
+    got = np.concatenate([a.ravel() for a in model.get_weights()])
+    assert np.array_equal(got, flat) and not np.array_equal(got, np.concatenate([w[k].ravel() for k in w]))
+    tr.train_step(T_(x), T_(gt), T_(m), drop_path_uniform=None)
+    xm = T_(x * m[:, :, None, None])
+    full, central = model([xm, T_(m)], training=False)                  # syncs by itself
+    fresh = pkg.build_uplift_upsample_transformer(cfg, weights=dict(zip(model.weight_names, model.get_weights())))
+    f2, c2 = fresh([xm, T_(m)], training=False)
+    assert torch.equal(full, f2) and torch.equal(central, c2)
+    assert np.array_equal(np.concatenate([a.ravel() for a in fresh.get_weights()]), tr.params.cpu().numpy())
+
+
+def test_train_step_at_the_benchmarked_batch():
+    """BASELINE config 5's per-GPU shape (h36m_351_pt, 64 sequences, normaliser 512, DropPath on): finite, run-to-run
+    bit-identical, the two half batches' gradients add up to the full one, and the bucket callback tiles the buffer."""
+    from uplift_upsample_3dhpe_amd.trainer import Trainer
+    from uplift_upsample_3dhpe_amd import harness
+    cfg = util.load_config("h36m_351_pt")
+    assert cfg.BATCH_SIZE == 512
+    arch = pkg.arch_from_config(cfg)
+    model = pkg.build_uplift_upsample_transformer(cfg, weights=pkg.init_weights(arch, seed=0))
+    rng = np.random.default_rng(6)
+    B, N = 64, arch.num_frames
+    x = torch.from_numpy(rng.uniform(-1, 1, size=(B, N, 17, 2)).astype(np.float32)).cuda()
+    gt = torch.from_numpy(rng.normal(0, 0.3, size=(B, N, 17, 3)).astype(np.float32)).cuda()
+    m = torch.from_numpy(harness.stride_masks_train(N, cfg.SEQUENCE_STRIDE, cfg.MASK_STRIDE, B, rng, cfg.STRIDE_MASK_RAND_SHIFT)).cuda()
+    tr = Trainer(model, cfg, seed=1)
+    seen = []
+    orig = tr._buckets.ready
+    tr._buckets.ready = lambda first, count, stream=None: (seen.append((first, count)), orig(first, count, stream))[1]
+    u = torch.rand(tr.drop_path_size(B), generator=tr._rng, device="cuda", dtype=torch.float32)
+    loss, _, _ = tr.forward_backward(x, gt, m, drop_path_uniform=u)
+    g1, l1 = tr.grads.clone(), loss.clone()
+    tr._buckets.wait()                                                    # checks that the ranges tile the buffer
+    assert len(seen) == 4 and sorted(seen)[0][0] == 0 and sum(c for _, c in seen) == tr.n_params
+    assert seen[0][0] + seen[0][1] == tr.n_params                         # the tail (strided blocks + heads) finishes first
+    assert torch.isfinite(g1).all() and torch.isfinite(l1).all() and float(g1.abs().max()) > 0
+    loss, _, _ = tr.forward_backward(x, gt, m, drop_path_uniform=u)
+    assert torch.equal(tr.grads, g1) and torch.equal(loss, l1)
+    tr._buckets.wait()
+    # halves: DropPath draws are laid out [spatial blocks][2][B*N] then [temporal blocks][2][B]; without DropPath the halves need no re-indexing
+    tr.forward_backward(x, gt, m, drop_path_uniform=None); tr._buckets.wait()
+    gfull = tr.grads.clone()
+    tr.forward_backward(x[:32], gt[:32], m[:32], drop_path_uniform=None); tr._buckets.wait()
+    ga = tr.grads.clone()
+    tr.forward_backward(x[32:], gt[32:], m[32:], drop_path_uniform=None); tr._buckets.wait()
+    assert (ga + tr.grads - gfull).abs().max() <= 2e-5 * gfull.abs().max()
+    tr.apply_gradients()
+    assert torch.isfinite(tr.params).all()

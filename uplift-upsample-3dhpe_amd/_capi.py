@@ -24,7 +24,7 @@ EXPORTED_SYMBOLS = (
     "uu3d_set_profiling", "uu3d_profile_read", "uu3d_gather_windows", "uu3d_world_to_cam_2d",
     "uu3d_mpjpe_loss", "uu3d_adamw_update", "uu3d_ema_update",
     "uu3d_num_params", "uu3d_train_init", "uu3d_train_repack", "uu3d_train_export",
-    "uu3d_train_workspace_bytes", "uu3d_train_forward_backward",
+    "uu3d_train_workspace_bytes", "uu3d_train_forward_backward", "uu3d_train_set_grad_callback",
 )
 # include/uu3d_ops.h
 OPS_SYMBOLS = (
@@ -64,6 +64,9 @@ class Uu3dProfileEntry(C.Structure):
     _fields_ = [("name", C.c_char * 48), ("kernel", C.c_char * 32), ("ms", C.c_float),
                 ("flops", C.c_double), ("bytes", C.c_double)]
 
+
+# void (*uu3d_grad_ready_fn)(void* user, int64_t first, int64_t count, void* stream)
+GRAD_READY_FN = C.CFUNCTYPE(None, C.c_void_p, C.c_int64, C.c_int64, C.c_void_p)
 
 _lib = None
 
@@ -120,7 +123,7 @@ def load_library(path=None):
     lib.uu3d_mpjpe_loss.restype = C.c_int
     lib.uu3d_mpjpe_loss.argtypes = [vp, vp, vp, i32, i32, i32, i32, C.c_float, C.c_float, i32, vp, vp, vp, vp, vp]
     lib.uu3d_adamw_update.restype = C.c_int
-    lib.uu3d_adamw_update.argtypes = [vp, vp, vp, vp, i64, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, i64, vp]
+    lib.uu3d_adamw_update.argtypes = [vp, vp, vp, vp, vp, i64, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, i64, vp]
     lib.uu3d_ema_update.restype = C.c_int
     lib.uu3d_ema_update.argtypes = [vp, vp, i64, C.c_float, vp]
     lib.uu3d_num_params.restype = i64
@@ -136,6 +139,8 @@ def load_library(path=None):
     lib.uu3d_train_forward_backward.restype = C.c_int
     lib.uu3d_train_forward_backward.argtypes = [vp, vp, vp, vp, vp, i32, i32, C.c_float, C.c_float, i32,
                                                 C.POINTER(C.c_float), vp, vp, vp, vp, vp, vp, sz, vp]
+    lib.uu3d_train_set_grad_callback.restype = C.c_int
+    lib.uu3d_train_set_grad_callback.argtypes = [vp, GRAD_READY_FN, vp]
     lib.uu3d_op_scratch_floats.restype = sz
     lib.uu3d_op_scratch_floats.argtypes = []
     lib.uu3d_op_gemm_tn.restype = C.c_int

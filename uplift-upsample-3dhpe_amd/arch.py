@@ -29,6 +29,10 @@ class UpliftArch:
     full_output: bool
     drop_path_rate: Tuple[float, float, float]
     batch_size: int
+    # training-only regularisers (Keras Dropout / random token masking are identities with training=False)
+    drop_rate: float = 0.0
+    attention_drop_rate: float = 0.0
+    token_mask_rate: float = 0.0
     # derived
     strided_lengths: Tuple[int, ...] = field(default=())   # L_0 .. L_len(strides)
 
@@ -61,7 +65,30 @@ def _conv_length_recurrence(n: int, strides, paddings) -> List[int]:
     return out
 
 
+def training_unsupported(a: "UpliftArch"):
+    """Config options that change the TRAINING-mode forward and that this build does not implement; the caller raises.
+    (All are inactive in the shipped configs.)  Reference: Dropout layers u_u_t.py:201, vit.py:87-88,66-67;
+    random_token_masking u_u_t.py:287-311,336-338; strided DropPath u_u_t.py:111,132-137."""
+    out = []
+    if a.drop_rate != 0.0:
+        out.append(f"DROP_RATE = {a.drop_rate} (Dropout after the embedding, in MHA.projection and the MLPs)")
+    if a.attention_drop_rate != 0.0:
+        out.append(f"ATTENTION_DROP_RATE = {a.attention_drop_rate} (Dropout on the attention probabilities)")
+    if a.token_mask_rate > 0.0:
+        out.append(f"TOKEN_MASK_RATE = {a.token_mask_rate} (random token masking in training)")
+    if a.drop_path_rate[2] != 0.0:
+        out.append(f"DROP_PATH_RATE[2] = {a.drop_path_rate[2]} (DropPath inside the strided blocks)")
+    return out
+
+
 def arch_from_config(config) -> UpliftArch:
+    # Options that would build a DIFFERENT model than the one the HIP path computes are rejected, not ignored.
+    if bool(getattr(config, "OUTPUT_BN", False)):
+        raise NotImplementedError("OUTPUT_BN = true (BatchNormalization in front of both heads, u_u_t.py:275-285) is not "
+                                  "implemented by the HIP path; the shipped configs use OUTPUT_BN = false")
+    if float(getattr(config, "TOKEN_MASK_RATE", 0.0)) > 0.0 and bool(getattr(config, "LEARNABLE_MASKED_TOKEN", False)):
+        raise NotImplementedError("TOKEN_MASK_RATE > 0 with LEARNABLE_MASKED_TOKEN = true adds a trainable masked-token "
+                                  "layer (u_u_t.py:219-220) that is not implemented")
     has_strided_input = config.MASK_STRIDE is not None
     if has_strided_input:
         ms = config.MASK_STRIDE
@@ -119,6 +146,9 @@ def arch_from_config(config) -> UpliftArch:
         full_output=not bool(config.USE_REFINE),
         drop_path_rate=dpr3,
         batch_size=int(config.BATCH_SIZE),
+        drop_rate=float(getattr(config, "DROP_RATE", 0.0)),
+        attention_drop_rate=float(getattr(config, "ATTENTION_DROP_RATE", 0.0)),
+        token_mask_rate=float(getattr(config, "TOKEN_MASK_RATE", 0.0)),
         strided_lengths=tuple(conv_len),
     )
 

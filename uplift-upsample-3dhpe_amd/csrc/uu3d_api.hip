@@ -1071,17 +1071,20 @@ int uu3d_mpjpe_loss(const float* pred_full, const float* pred_central, const flo
     return hipGetLastError() == hipSuccess ? UU3D_OK : UU3D_ERR_HIP;
 }
 
-int uu3d_adamw_update(float* var, float* m, float* v, const float* grad, int64_t n, float lr, float wd, float beta1,
+int uu3d_adamw_update(float* var, float* m, float* v, float* vhat, const float* grad, int64_t n, float lr, float wd, float beta1,
                       float beta2, float epsilon, int64_t step, void* stream) {
     if (!var || !m || !v || !grad || n < 1 || step < 1) return UU3D_ERR_INVALID_ARGUMENT;
-    if ((((uintptr_t)var | (uintptr_t)m | (uintptr_t)v | (uintptr_t)grad) & 15) != 0) return UU3D_ERR_INVALID_ARGUMENT;
+    if ((((uintptr_t)var | (uintptr_t)m | (uintptr_t)v | (uintptr_t)vhat | (uintptr_t)grad) & 15) != 0) return UU3D_ERR_INVALID_ARGUMENT;
     // float32 like the TF kernel: alpha = lr * sqrt(1 - beta2^t) / (1 - beta1^t)
-    const float b1p = powf(beta1, (float)step), b2p = powf(beta2, (float)step);
+    // beta^t rounded once from double (libm powf and numpy's float32 power disagree by an ulp at some t, e.g. 0.9^4)
+    const float b1p = (float)pow((double)beta1, (double)step), b2p = (float)pow((double)beta2, (double)step);
     const float alpha = lr * sqrtf(1.0f - b2p) / (1.0f - b1p);
     const long long n4 = n >> 2;
     const int grid = (int)std::min<long long>(std::max<long long>((n4 + 255) / 256, 1), 256 * 32);
-    hipLaunchKernelGGL(adamw_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, var, m, v, grad, (long long)n, wd, alpha,
-                       1.0f - beta1, 1.0f - beta2, epsilon);
+    if (vhat) hipLaunchKernelGGL(adamw_kernel<true>, dim3(grid), dim3(256), 0, (hipStream_t)stream, var, m, v, vhat, grad, (long long)n, wd, alpha,
+                                 1.0f - beta1, 1.0f - beta2, epsilon);
+    else hipLaunchKernelGGL(adamw_kernel<false>, dim3(grid), dim3(256), 0, (hipStream_t)stream, var, m, v, vhat, grad, (long long)n, wd, alpha,
+                            1.0f - beta1, 1.0f - beta2, epsilon);
     return hipGetLastError() == hipSuccess ? UU3D_OK : UU3D_ERR_HIP;
 }
 

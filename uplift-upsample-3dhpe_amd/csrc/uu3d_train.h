@@ -74,18 +74,21 @@ mpjpe_loss_stage2(const float* __restrict__ partial, const float norm_seq, const
 // ---- T3: tfa AdamW dense update on a flat buffer --------------------------------------------------
 // `#pragma clang fp contract(off)` keeps every operation separately rounded (no fma contraction), so
 // the result is bit-identical to the float32 op sequence of TF's ApplyAdam functor after tfa's decay.
-__device__ __forceinline__ void adamw_one(float& var, float& m, float& v, const float g, const float wd,
+template <bool AMS>
+__device__ __forceinline__ void adamw_one(float& var, float& m, float& v, float& vhat, const float g, const float wd,
                                           const float alpha, const float omb1, const float omb2, const float eps)
 {
 #pragma clang fp contract(off)
     var = var - wd * var;
     m = m + (g - m) * omb1;
     v = v + (g * g - v) * omb2;
-    var = var - (m * alpha) / (sqrtf(v) + eps);
+    if (AMS) { vhat = fmaxf(vhat, v); var = var - (m * alpha) / (sqrtf(vhat) + eps); }     // TF ApplyAdamWithAmsgrad
+    else var = var - (m * alpha) / (sqrtf(v) + eps);
 }
 
+template <bool AMS>
 static __global__ void __launch_bounds__(256)
-adamw_kernel(float* __restrict__ var, float* __restrict__ m, float* __restrict__ v, const float* __restrict__ grad,
+adamw_kernel(float* __restrict__ var, float* __restrict__ m, float* __restrict__ v, float* __restrict__ vhat, const float* __restrict__ grad,
              const long long n, const float wd, const float alpha, const float omb1, const float omb2, const float eps)
 {
     const long long n4 = n >> 2;
@@ -93,18 +96,22 @@ adamw_kernel(float* __restrict__ var, float* __restrict__ m, float* __restrict__
     for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n4; i += stride) {
         float4 w4 = reinterpret_cast<float4*>(var)[i], m4 = reinterpret_cast<float4*>(m)[i];
         float4 v4 = reinterpret_cast<float4*>(v)[i];
+        float4 h4 = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (AMS) h4 = reinterpret_cast<float4*>(vhat)[i];
         const float4 g4 = reinterpret_cast<const float4*>(grad)[i];
-        adamw_one(w4.x, m4.x, v4.x, g4.x, wd, alpha, omb1, omb2, eps);
-        adamw_one(w4.y, m4.y, v4.y, g4.y, wd, alpha, omb1, omb2, eps);
-        adamw_one(w4.z, m4.z, v4.z, g4.z, wd, alpha, omb1, omb2, eps);
-        adamw_one(w4.w, m4.w, v4.w, g4.w, wd, alpha, omb1, omb2, eps);
+        adamw_one<AMS>(w4.x, m4.x, v4.x, h4.x, g4.x, wd, alpha, omb1, omb2, eps);
+        adamw_one<AMS>(w4.y, m4.y, v4.y, h4.y, g4.y, wd, alpha, omb1, omb2, eps);
+        adamw_one<AMS>(w4.z, m4.z, v4.z, h4.z, g4.z, wd, alpha, omb1, omb2, eps);
+        adamw_one<AMS>(w4.w, m4.w, v4.w, h4.w, g4.w, wd, alpha, omb1, omb2, eps);
         reinterpret_cast<float4*>(var)[i] = w4; reinterpret_cast<float4*>(m)[i] = m4; reinterpret_cast<float4*>(v)[i] = v4;
+        if (AMS) reinterpret_cast<float4*>(vhat)[i] = h4;
     }
     if (blockIdx.x == 0 && threadIdx.x < (n & 3)) {        // tail
         const long long i = (n4 << 2) + threadIdx.x;
-        float w1 = var[i], m1 = m[i], v1 = v[i];
-        adamw_one(w1, m1, v1, grad[i], wd, alpha, omb1, omb2, eps);
+        float w1 = var[i], m1 = m[i], v1 = v[i], h1 = AMS ? vhat[i] : 0.f;
+        adamw_one<AMS>(w1, m1, v1, h1, grad[i], wd, alpha, omb1, omb2, eps);
         var[i] = w1; m[i] = m1; v[i] = v1;
+        if (AMS) vhat[i] = h1;
     }
 }
 

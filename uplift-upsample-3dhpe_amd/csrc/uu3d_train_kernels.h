@@ -226,4 +226,12 @@ struct TnLoadGelu {
     __device__ __forceinline__ f32x4 load(int r, int p) const { return finish(fetch(r, p), col(p)); }
 };
 
+// x[i] *= s over a range of the flat gradient buffer (s = 1 / loss scale, a power of two: exact)
+static __global__ void __launch_bounds__(256)
+scale_flat_kernel(float* __restrict__ x, const long long n, const float s)
+{
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) x[i] *= s;
+}
+
 }  // namespace uu3d

@@ -7,8 +7,12 @@
 ``x``: (B, N, J, 2) float32 torch tensor on the model's ROCm device (the caller zeroes
 masked frames, eval.py:67); ``stride_mask``: (B, N) bool/uint8, 1 = real input present.
 Returns ``full`` (B, N, J, 3) (``None`` when the reference would return None, :399-404)
-and ``central`` (B, J, 3).  PyTorch is used for device memory and streams only; every
-FLOP runs in ``csrc/libuu3d.so``.  There is no CPU fallback.
+and ``central`` (B, J, 3).  ``training=True`` (train.py:478) runs the training-mode forward:
+DropPath with draws from the model's (or its Trainer's) generator, on the LIVE weights of
+the Trainer when one is attached.  ``model.weights`` / ``model.trainable_variables``
+(train.py:496,503) are name -> array views in the reference's creation order.
+PyTorch is used for device memory and streams only; every FLOP runs in
+``csrc/libuu3d.so``.  There is no CPU fallback.
 """
 import ctypes as C
 
@@ -17,6 +21,25 @@ import numpy as np
 from .. import _capi
 from ..arch import UpliftArch
 from ..weights import init_weights, weight_spec
+
+
+class WeightView(object):
+    """One entry of ``model.weights`` / ``model.trainable_variables``: the role a tf.Variable plays at train.py:496,503
+    (``name``, ``shape``, ``numpy()``, ``assign(value)``) over the model's current weights."""
+
+    def __init__(self, model, name, shape):
+        self._model, self.name, self.shape = model, name, tuple(shape)
+
+    def numpy(self):
+        return self._model.get_weights_dict()[self.name]
+
+    def assign(self, value):
+        d = self._model.get_weights_dict()
+        d[self.name] = np.asarray(value, np.float32).reshape(self.shape)
+        self._model.set_weights_dict(d)
+
+    def __repr__(self):
+        return f"<WeightView {self.name} {self.shape}>"
 
 
 class UpliftUpsampleTransformer(object):
@@ -71,6 +94,12 @@ class UpliftUpsampleTransformer(object):
         _capi.check(self._lib, st, None)
         self._h = handle
         self._ws = {}
+        self._trainer = None              # a trainer.Trainer owns the live weights once attached
+        self._weights_dirty = False       # live (trainer) weights newer than the host / inference copies
+        self._train_params = None         # master buffer of a training-mode forward without a Trainer
+        self._train_ws = None
+        self._seed = seed
+        self._rng = None
         self._profiling = False
         self._halves = bool(concurrent_halves)
         self._side_stream = None
@@ -96,6 +125,21 @@ class UpliftUpsampleTransformer(object):
     def weight_names(self):
         return [n for n, _ in self._spec]
 
+    # ---- live weights of an attached Trainer -------------------------------------------------
+    def _attach_trainer(self, trainer):
+        self._trainer, self._train_params = trainer, None
+
+    def _sync_from_trainer(self):
+        """save_weights / get_weights / inference calls see the trained weights (train.py:393,706,719 use the live model)."""
+        if self._trainer is not None and self._weights_dirty:
+            self._trainer.export_to_model()
+
+    @property
+    def weights(self):
+        return [WeightView(self, n, s) for n, s in self._spec]
+
+    trainable_variables = weights          # every weight of this model is trainable (no BatchNorm statistics: OUTPUT_BN is rejected)
+
     def set_weights_dict(self, weights):
         for name, shape in self._spec:
             if name not in weights:
@@ -106,6 +150,10 @@ class UpliftUpsampleTransformer(object):
             st = self._lib.uu3d_set_weight(self._h, name.encode(), a.ctypes.data_as(C.c_void_p), a.size)
             _capi.check(self._lib, st, self._h)
         self._commit()
+        self._weights_dirty = False
+        if self._trainer is not None:       # the trainer's master buffer follows (Adam moments are kept, like tf.Variable.assign)
+            self._trainer.reload_from_model()
+        self._train_params = None
 
     def set_weights(self, weight_list):
         if len(weight_list) != len(self._spec):
@@ -113,6 +161,7 @@ class UpliftUpsampleTransformer(object):
         self.set_weights_dict({n: w for (n, _), w in zip(self._spec, weight_list)})
 
     def get_weights_dict(self):
+        self._sync_from_trainer()
         out = {}
         for name, shape in self._spec:
             a = np.empty(shape, np.float32)
@@ -161,10 +210,54 @@ class UpliftUpsampleTransformer(object):
                                     C.c_size_t(ws.numel()), C.c_void_p(stream.cuda_stream))
         _capi.check(self._lib, st, self._h)
 
+    def _mask_u8(self, stride_mask):
+        """(B, N) bool / uint8 mask as uint8 bytes on the model's device.  A bool tensor is reinterpreted (torch bools are
+        one byte, 0 / 1): no conversion kernel inside the forward."""
+        torch = self._torch
+        m = stride_mask
+        if m.device != self.device:
+            m = m.to(self.device)
+        if m.dtype == torch.bool:
+            return m.contiguous().view(torch.uint8)
+        if m.dtype == torch.uint8:
+            return m.contiguous()
+        return (m != 0).contiguous().view(torch.uint8)
+
+    def _training_forward(self, x, stride_mask, full, central):
+        """model(inputs, training=True) (train.py:478): DropPath active, live weights.  Without a Trainer the model keeps
+        its own master buffer (uu3d_train_init) and generator."""
+        from ..arch import training_unsupported
+        torch = self._torch
+        bad = training_unsupported(self.arch)
+        if bad:
+            raise NotImplementedError("training=True with " + "; ".join(bad) + " is not implemented")
+        a, B = self.arch, x.shape[0]
+        stream = C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+        if self._trainer is not None:
+            params, rng, rates = self._trainer.params, self._trainer._rng, self._trainer.drop_path_rates
+        else:
+            if self._train_params is None:
+                self._train_params = torch.empty(int(self._lib.uu3d_num_params(self._h)), dtype=torch.float32, device=self.device)
+                _capi.check(self._lib, self._lib.uu3d_train_init(self._h, C.c_void_p(self._train_params.data_ptr()), stream), self._h)
+            if self._rng is None:
+                self._rng = torch.Generator(device=self.device)
+                self._rng.manual_seed(int(self._seed))
+            params, rng, rates = self._train_params, self._rng, np.asarray(a.drop_path_rate, np.float32)
+        n_draws = a.spatial_depth * 2 * B * a.num_frames + a.temporal_depth * 2 * B
+        u = torch.rand(n_draws, generator=rng, device=self.device, dtype=torch.float32)
+        nbytes = int(self._lib.uu3d_train_workspace_bytes(self._h, B))
+        if self._train_ws is None or self._train_ws.numel() < nbytes:
+            self._train_ws = torch.empty(nbytes, dtype=torch.uint8, device=self.device)
+        r3 = (C.c_float * 3)(*[float(r) for r in rates])
+        st = self._lib.uu3d_train_forward_backward(
+            self._h, C.c_void_p(params.data_ptr()), C.c_void_p(x.data_ptr()),
+            C.c_void_p(stride_mask.data_ptr()) if stride_mask is not None else None, None, B, int(a.batch_size), 0.0, 0.0, 0,
+            r3, C.c_void_p(u.data_ptr()), None, C.c_void_p(full.data_ptr()) if full is not None else None,
+            C.c_void_p(central.data_ptr()), None, C.c_void_p(self._train_ws.data_ptr()), self._train_ws.numel(), stream)
+        _capi.check(self._lib, st, self._h)
+
     def __call__(self, inputs, training=None, mask=None):
         torch = self._torch
-        if training:
-            raise NotImplementedError("training=True (DropPath + backward) is not part of this round's path")
         if self.has_strided_input:
             x, stride_mask = inputs[0], inputs[1]
         else:
@@ -179,10 +272,14 @@ class UpliftUpsampleTransformer(object):
         if stride_mask is not None:
             if tuple(stride_mask.shape) != (B, a.num_frames):
                 raise ValueError(f"stride_mask must be (B, {a.num_frames})")
-            stride_mask = stride_mask.to(device=self.device, dtype=torch.uint8).contiguous()
+            stride_mask = self._mask_u8(stride_mask)
         full = torch.empty((B, a.num_frames, a.num_keypoints, 3), dtype=torch.float32, device=self.device) \
             if self._returns_full else None
         central = torch.empty((B, a.num_keypoints, 3), dtype=torch.float32, device=self.device)
+        if training:
+            self._training_forward(x, stride_mask, full, central)
+            return full, central
+        self._sync_from_trainer()
         main = torch.cuda.current_stream(self.device)
         if not (self._halves and B >= self.SPLIT_MIN_BATCH and not self._profiling):
             self._forward(x, stride_mask, full, central, 0, main)

@@ -1,9 +1,8 @@
 """Host-side mirrors of the reference's optimizer / schedule / loss objects for the training step
 (train.py:396-415,464-506), over the C-ABI kernels uu3d_mpjpe_loss / uu3d_adamw_update / uu3d_ema_update.
 
-Back-propagation through the network is not built yet: these are the pieces of
-train_step that do not need it.  All state lives in flat float32 device buffers in the model's
-weight order (Keras layouts), which is what the fused AdamW kernel updates in one launch.
+All state lives in flat float32 device buffers in the model's weight order (Keras layouts), which is
+what the fused AdamW kernel updates in one launch; back-propagation itself is trainer.Trainer.
 """
 import ctypes as C
 import math
@@ -61,7 +60,7 @@ class AdamW(object):
     float32 device tensor of parameters (train.py:404-415).  ``weight_decay`` / ``learning_rate`` may be
     numbers or schedules called with ``iterations`` (0-based), like the Keras optimizer does."""
 
-    def __init__(self, params, weight_decay, learning_rate, beta_1=0.9, beta_2=0.999, epsilon=1e-7):
+    def __init__(self, params, weight_decay, learning_rate, beta_1=0.9, beta_2=0.999, epsilon=1e-7, amsgrad=False):
         import torch
         if params.dtype != torch.float32 or not params.is_cuda or not params.is_contiguous():
             raise ValueError("params must be a contiguous float32 tensor on the ROCm device (no CPU fallback)")
@@ -70,6 +69,9 @@ class AdamW(object):
         self.params = params.view(-1)
         self.m = torch.zeros_like(self.params)
         self.v = torch.zeros_like(self.params)
+        # Keras Adam(amsgrad=True): one more slot, vhat = max(vhat, v) (the config class default, config.py:88)
+        self.amsgrad = bool(amsgrad)
+        self.vhat = torch.zeros_like(self.params) if self.amsgrad else None
         self.weight_decay, self.learning_rate = weight_decay, learning_rate
         self.beta_1, self.beta_2, self.epsilon = beta_1, beta_2, epsilon
         self.iterations = 0
@@ -85,7 +87,8 @@ class AdamW(object):
         lr, wd = self._value(self.learning_rate), self._value(self.weight_decay)
         stream = torch.cuda.current_stream(self.params.device).cuda_stream
         st = self._lib.uu3d_adamw_update(C.c_void_p(self.params.data_ptr()), C.c_void_p(self.m.data_ptr()),
-                                         C.c_void_p(self.v.data_ptr()), C.c_void_p(g.contiguous().data_ptr()),
+                                         C.c_void_p(self.v.data_ptr()),
+                                         C.c_void_p(self.vhat.data_ptr()) if self.amsgrad else None, C.c_void_p(g.contiguous().data_ptr()),
                                          self.params.numel(), lr, wd, self.beta_1, self.beta_2, self.epsilon,
                                          self.iterations + 1, C.c_void_p(stream))
         _capi.check(self._lib, st, None)

@@ -11,6 +11,8 @@ import ctypes as C
 import numpy as np
 
 from . import _capi, optim
+from .arch import training_unsupported
+from .dist import BucketedAllReduce
 
 
 class Trainer(object):
@@ -20,6 +22,10 @@ class Trainer(object):
         self._torch = torch
         self.model, self.config = model, config
         self._lib = model._lib
+        bad = training_unsupported(model.arch)
+        if bad:
+            raise NotImplementedError("training with " + "; ".join(bad) + " is not implemented (the reference would train a "
+                                      "different model than this step computes)")
         lib = self._lib
         self.n_params = int(lib.uu3d_num_params(model._h))
         dev = model.device
@@ -38,8 +44,14 @@ class Trainer(object):
             wd = 0.0
         else:
             raise ValueError(config.OPTIMIZER)
-        extra = {k: v for k, v in dict(config.OPTIMIZER_PARAMS).items() if k != "amsgrad"}
-        extra.setdefault("epsilon", 1e-8)
+        extra = dict(config.OPTIMIZER_PARAMS)                 # amsgrad / beta_1 / beta_2 (/ epsilon for Adam), train.py:412-417
+        unknown = set(extra) - {"amsgrad", "beta_1", "beta_2", "epsilon"}
+        if unknown:
+            raise NotImplementedError(f"OPTIMIZER_PARAMS {sorted(unknown)} are not implemented")
+        if config.OPTIMIZER == "AdamW":
+            if "epsilon" in extra:                            # tfa.optimizers.AdamW(..., epsilon=1e-8, **OPTIMIZER_PARAMS): duplicate keyword
+                raise TypeError("AdamW() got multiple values for keyword argument 'epsilon'")
+            extra["epsilon"] = 1e-8
         self.optimizer = optim.AdamW(self.params, weight_decay=wd, learning_rate=lr, **extra)
         self.ema = self.params.clone() if config.EMA_ENABLED else None
         self.global_step = 0
@@ -47,6 +59,11 @@ class Trainer(object):
         self._rng.manual_seed(seed)
         self.drop_path_rates = np.asarray(config.DROP_PATH_RATE if isinstance(config.DROP_PATH_RATE, list)
                                           else [config.DROP_PATH_RATE] * 3, np.float32)
+        # bucketed gradient all-reduce: the library reports finished ranges of self.grads during the backward pass
+        self._buckets = BucketedAllReduce(self.grads)
+        self._ready_cb = _capi.GRAD_READY_FN(lambda user, first, count, stream: self._buckets.ready(first, count, stream))
+        _capi.check(lib, lib.uu3d_train_set_grad_callback(model._h, self._ready_cb, None), model._h)
+        model._attach_trainer(self)
 
     def _workspace(self, batch):
         if self._ws is None or batch > self._ws_batch:
@@ -70,9 +87,8 @@ class Trainer(object):
         x = keypoints2d.to(device=dev, dtype=torch.float32)
         m_ptr = None
         if self.model.has_strided_input:
-            sm = stride_masks.to(device=dev)
-            x = x * sm[:, :, None, None].to(torch.float32)                 # train.py:474
-            sm8 = sm.to(torch.uint8).contiguous()
+            sm8 = self.model._mask_u8(stride_masks)
+            x = x * sm8[:, :, None, None]                                   # train.py:474 (mask is 0 / 1)
             m_ptr = C.c_void_p(sm8.data_ptr())
         x = x.contiguous()
         gt = keypoints3d.to(device=dev, dtype=torch.float32).contiguous()
@@ -94,24 +110,31 @@ class Trainer(object):
         return self.loss, full, central
 
     def apply_gradients(self):
-        """optimizer.apply_gradients (+ gradient all-reduce over ranks, + EMA), then refresh the operand packs."""
-        from .dist import allreduce_gradients
-        allreduce_gradients(self.grads)                                      # loss normaliser is the GLOBAL batch size
+        """optimizer.apply_gradients (+ EMA), then refresh the operand packs.  With more than one rank the gradient buckets
+        were started by forward_backward while the backward pass ran; here the stream only waits for them."""
+        self._buckets.wait()                                                 # loss normaliser is the GLOBAL batch size: sums, no rescale
         self.optimizer.apply_gradients(self.grads)
         if self.ema is not None:
             optim.ema_update(self.ema, self.params, optim.ema_decay_value(self.config.EMA_DECAY, self.global_step))
         _capi.check(self._lib, self._lib.uu3d_train_repack(self.model._h, C.c_void_p(self.params.data_ptr()), self._stream()), self.model._h)
         self.global_step += 1
+        self.model._weights_dirty = True                                      # the model's host / inference weights are now stale
 
     def train_step(self, keypoints2d, keypoints3d, stride_masks, drop_path_uniform="draw"):
         loss, _, _ = self.forward_backward(keypoints2d, keypoints3d, stride_masks, drop_path_uniform)
         self.apply_gradients()
         return loss
 
+    def reload_from_model(self):
+        """The model's weights were replaced (set_weights / load_weights): take them as the new master weights."""
+        _capi.check(self._lib, self._lib.uu3d_train_init(self.model._h, C.c_void_p(self.params.data_ptr()), self._stream()), self.model._h)
+        _capi.check(self._lib, self._lib.uu3d_train_set_grad_callback(self.model._h, self._ready_cb, None), self.model._h)
+
     def export_to_model(self, use_ema=False):
         """Copy the trained (or EMA) weights back into the inference model (val_model, train.py:400-401)."""
         src = self.ema if (use_ema and self.ema is not None) else self.params
         _capi.check(self._lib, self._lib.uu3d_train_export(self.model._h, C.c_void_p(src.data_ptr()), self._stream()), self.model._h)
+        self.model._weights_dirty = bool(use_ema and self.ema is not None)    # EMA weights in the model: the live ones differ again
 
     # ---- checkpoint / resume (the role of tf.train.Checkpoint(model, optimizer, ema_model) in train.py:420-436) ----
     def state_dict(self):
@@ -122,6 +145,8 @@ class Trainer(object):
               "rng_state": self._rng.get_state().cpu().numpy()}
         if self.ema is not None:
             sd["ema"] = self.ema.cpu().numpy()
+        if self.optimizer.amsgrad:
+            sd["adam_vhat"] = self.optimizer.vhat.cpu().numpy()
         return sd
 
     def load_state_dict(self, sd):
@@ -131,6 +156,10 @@ class Trainer(object):
         self.params.copy_(torch.from_numpy(np.asarray(sd["params"], np.float32)))
         self.optimizer.m.copy_(torch.from_numpy(np.asarray(sd["adam_m"], np.float32)))
         self.optimizer.v.copy_(torch.from_numpy(np.asarray(sd["adam_v"], np.float32)))
+        if self.optimizer.amsgrad:
+            if "adam_vhat" not in sd:
+                raise ValueError("amsgrad is on but the checkpoint has no vhat slot")
+            self.optimizer.vhat.copy_(torch.from_numpy(np.asarray(sd["adam_vhat"], np.float32)))
         self.optimizer.iterations = int(sd["iterations"])
         self.global_step = int(sd["global_step"])
         self._rng.set_state(torch.from_numpy(np.asarray(sd["rng_state"], np.uint8)))
@@ -139,6 +168,7 @@ class Trainer(object):
                 raise ValueError("EMA is enabled but the checkpoint has no EMA weights")
             self.ema.copy_(torch.from_numpy(np.asarray(sd["ema"], np.float32)))
         _capi.check(self._lib, self._lib.uu3d_train_repack(self.model._h, C.c_void_p(self.params.data_ptr()), self._stream()), self.model._h)
+        self.model._weights_dirty = True
 
     def save_checkpoint(self, path):
         np.savez(path, **self.state_dict())
