@@ -122,8 +122,8 @@ def test_weights_roundtrip_and_errors():
         model([torch.as_tensor(x).cuda(), torch.as_tensor(m[:, :-1]).cuda()])
     with pytest.raises(ValueError):
         model([torch.as_tensor(x), torch.as_tensor(m)])                  # host tensors: no CPU fallback
-    with pytest.raises(NotImplementedError):
-        model([torch.as_tensor(x).cuda(), torch.as_tensor(m).cuda()], training=True)
+    ft, ct = model([torch.as_tensor(x).cuda(), torch.as_tensor(m).cuda()], training=True)      # train.py:478 (tests/test_train_step_gpu.py)
+    assert ft.shape == (2, arch.num_frames, 17, 3) and ct.shape == (2, 17, 3)
     bad = dict(w); bad["temporal_fc/bias"] = np.zeros(50, np.float32)
     with pytest.raises(ValueError):
         model.set_weights_dict(bad)

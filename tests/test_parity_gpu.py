@@ -96,3 +96,52 @@ def test_wave_per_head_attention_on_other_lengths(n_frames, strides, batch, monk
     print(f"N={n_frames} strides {strides} batch {batch}: max-abs vs oracle f32 {err:.3e}, vs the workgroup-per-item kernel {dev:.3e}")
     assert np.isfinite(full).all() and err <= util.TOL_MAX_ABS
     assert dev <= 2e-5
+
+
+@pytest.mark.parametrize("n_frames,strides,batch", [(351, [3, 9, 13], 2), (117, [3, 3, 13], 3), (200, [5, 8, 5], 2), (384, [4, 8, 12], 1)])
+def test_long_sequences_match_oracle(n_frames, strides, batch, monkeypatch):
+    """Sequences beyond the 128 tokens the exact-f32 attention kernels hold: SURVEY 8(d)'s "synthetic dense-351"
+    (351 -> 117 -> 13 -> 1, not a shipped config), other lengths, and the largest supported one (384 tokens = 12 key tiles),
+    on attn_h3_kernel (f16x3 products, online softmax over 32-key tiles, uu3d_attn_h3.h).  Stride masks with masked and
+    all-masked rows; the masked first temporal block included."""
+    from oracle import uplift_oracle as O
+    cfg = util.load_config("dense_351")
+    cfg.SEQUENCE_LENGTH = n_frames
+    cfg.STRIDES = list(strides)
+    arch = pkg.arch_from_config(cfg)
+    w = pkg.init_weights(arch, seed=6, perturb=0.1)
+    x, m = util.synthetic_batch(cfg, batch=batch, seed=6)
+    full, central, xm = _run_hip(cfg, w, x, m, "f16x3")
+    f32, c32 = O.forward(util.hp_from_arch(arch), w, xm, m, torch.float32)
+    err = max(np.abs(full - f32).max(), np.abs(central - c32).max())
+    print(f"N={n_frames} strides {strides} batch {batch}: max-abs vs oracle f32 {err:.3e}")
+    assert np.isfinite(full).all() and np.isfinite(central).all()
+    assert err <= util.TOL_MAX_ABS
+    full2, central2, _ = _run_hip(cfg, w, x, m, "f16x3")
+    assert np.array_equal(full, full2) and np.array_equal(central, central2)
+
+
+def test_sequence_length_limits():
+    """385 tokens do not fit the attention kernel's LDS image; precision f32 keeps the 128-token limit of the exact-f32 kernels."""
+    from uplift_upsample_3dhpe_amd import _capi
+    cfg = util.load_config("dense_351")
+    cfg.SEQUENCE_LENGTH, cfg.STRIDES = 385, [4, 8, 12]
+    with pytest.raises(_capi.Uu3dError, match="384"):
+        pkg.build_uplift_upsample_transformer(cfg)
+    cfg = util.load_config("dense_351")
+    with pytest.raises(_capi.Uu3dError, match="128"):
+        pkg.build_uplift_upsample_transformer(cfg, precision="f32")
+
+
+def test_f16x3_attention_agrees_with_the_f32_kernels(monkeypatch):
+    """h36m_351 (71 tokens, masked block included): attn_h3_kernel vs the exact-f32 wave-per-head kernel (UU3D_ATTN_F32=1)."""
+    cfg = util.load_config("h36m_351")
+    arch = pkg.arch_from_config(cfg)
+    w = pkg.init_weights(arch, seed=8, perturb=0.1)
+    x, m = util.synthetic_batch(cfg, batch=12, seed=8)
+    full, central, _ = _run_hip(cfg, w, x, m, "f16x3")
+    monkeypatch.setenv("UU3D_ATTN_F32", "1")
+    full_f, central_f, _ = _run_hip(cfg, w, x, m, "f16x3")
+    dev = max(np.abs(full - full_f).max(), np.abs(central - central_f).max())
+    print(f"f16x3 attention vs exact-f32 attention: {dev:.3e}")
+    assert 0.0 < dev <= 3e-5

@@ -28,6 +28,7 @@
 #include "uu3d_gemm_h3.h"
 #include "uu3d_gemm_panel.h"
 #include "uu3d_attn.h"
+#include "uu3d_attn_h3.h"
 #include "uu3d_spatial.h"
 #include "uu3d_spatial_h3.h"
 #include "uu3d_misc.h"
@@ -85,6 +86,7 @@ struct uu3d_model {
     bool committed = false;
     float* arena = nullptr;        // packed device weights
     size_t arena_floats = 0;
+    bool attn_f32 = false;         // UU3D_ATTN_F32=1: sequences of 49-128 tokens stay on the exact-f32 attention kernels (A/B measurements, tests)
     bool attn_wg = false;          // UU3D_ATTN_WG=1: attention with one workgroup per (sequence, head) (attn_f32_kernel) instead of one wave per item (A/B measurements, tests)
     bool no_panel = false;         // UU3D_NO_PANEL=1: LayerNorm-fed GEMMs stay on the tiled kernels (A/B measurements, tests)
     bool no_planes = false;        // UU3D_NO_PLANES=1: keep the on-the-fly split GEMMs in f16x3 mode (A/B measurements, tests)
@@ -278,9 +280,10 @@ int uu3d_create(const uu3d_config* c, int device, uu3d_model** out) {
             delete m;
             return fail(nullptr, UU3D_ERR_INVALID_ARGUMENT, "strided block reduces the sequence below one token");
         }
-        if (Lin > 128) {
+        // exact-f32 attention holds a query tile's logits in registers (<= 128 keys); the f16x3 kernel tiles the keys
+        if (Lin > (c->precision == UU3D_PREC_F16X3 ? ATTN_H3_MAX_L : 128)) {
             delete m;
-            return fail(nullptr, UU3D_ERR_UNSUPPORTED, "sequence length > 128 tokens");
+            return fail(nullptr, UU3D_ERR_UNSUPPORTED, c->precision == UU3D_PREC_F16X3 ? "sequence length > 384 tokens" : "sequence length > 128 tokens with precision f32");
         }
         m->L.push_back(Lout);
     }
@@ -293,6 +296,7 @@ int uu3d_create(const uu3d_config* c, int device, uu3d_model** out) {
       m->spatial_f32 = (e != nullptr && std::string(e) == "f32"); m->spatial_h3_always = (e != nullptr && std::string(e) == "h3"); }
     { const char* e = getenv("UU3D_NO_PLANES"); m->no_planes = (e != nullptr && e[0] == '1'); }
     { const char* e = getenv("UU3D_ATTN_WG"); m->attn_wg = (e != nullptr && e[0] == '1'); }
+    { const char* e = getenv("UU3D_ATTN_F32"); m->attn_f32 = (e != nullptr && e[0] == '1'); }
     { const char* e = getenv("UU3D_NO_PANEL"); m->no_panel = (e != nullptr && e[0] == '1'); }
     *out = m;
     return UU3D_OK;
@@ -814,9 +818,25 @@ struct Launcher {
     void attn(const char* name, const float* qkv, int B, int L, const uint8_t* mask, float* out, size_t split_lo_off = 0) {
         const int D = m->cfg.d_temporal, H = m->cfg.num_heads;
         const int NT = (L + 15) / 16;
-        begin(name, "attn_f32", 4.0 * B * (double)H * L * L * kDH, 4.0 * 4.0 * B * (double)L * D);
+        const bool h3a = split_lo_off != 0 && L <= ATTN_H3_MAX_L && (L > 128 || (L > 48 && !m->attn_f32));
+        begin(name, h3a ? "attn_h3" : "attn_f32", 4.0 * B * (double)H * L * L * kDH, 4.0 * 4.0 * B * (double)L * D);
         const int items = B * H;
         const dim3 grid(items);
+        // f16x3 products + online softmax over key tiles (uu3d_attn_h3.h): every sequence the f32 kernels cannot hold
+        // (> 128 tokens), and, measured faster, the 49-128 token range as well; needs the f16-plane output
+        if (split_lo_off != 0 && L <= ATTN_H3_MAX_L && (L > 128 || (L > 48 && !m->attn_f32))) {
+            const int nt = (L + 31) / 32;
+            const size_t lds = attn_h3_lds_bytes(L, kDH);
+            _Float16* oh = reinterpret_cast<_Float16*>(out);
+#define UU3D_ATTN_H3(MW, WPE, MASKED, waves) { auto k = attn_h3_kernel<kDH, MW, WPE, MASKED>; \
+                static const bool once = (hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)attn_h3_lds_bytes(ATTN_H3_MAX_L, kDH)) == hipSuccess); (void)once; \
+                hipLaunchKernelGGL(k, grid, dim3(64 * (waves)), lds, stream, qkv, 3 * D, D, L, H, mask, oh, split_lo_off, D); }
+            if (nt <= 3) { if (mask) UU3D_ATTN_H3(3, 3, true, nt) else UU3D_ATTN_H3(3, 3, false, nt) }
+            else { if (mask) UU3D_ATTN_H3(8, 2, true, std::min(nt, 8)) else UU3D_ATTN_H3(8, 2, false, std::min(nt, 8)) }
+#undef UU3D_ATTN_H3
+            end();
+            return;
+        }
         // one wave per (sequence, head), four heads per workgroup (attn_head_wave_kernel): whenever the heads come in fours and the
         // K / V tiles of four heads fit the LDS; UU3D_ATTN_WG=1 keeps the workgroup-per-item kernel
         // NT <= 3: more, smaller workgroups hide latency better (measured)
@@ -841,7 +861,7 @@ struct Launcher {
         switch (NT) {
             UU3D_ATTN_CASE(1) UU3D_ATTN_CASE(2) UU3D_ATTN_CASE(3) UU3D_ATTN_CASE(4)
             UU3D_ATTN_CASE(5) UU3D_ATTN_CASE(6) UU3D_ATTN_CASE(7) UU3D_ATTN_CASE(8)
-            default: status = UU3D_ERR_UNSUPPORTED; m->err = "attention length > 128"; break;
+            default: status = UU3D_ERR_UNSUPPORTED; m->err = "attention over more than 128 tokens needs the f16x3 path (precision f16x3, d_t and h_t multiples of 32)"; break;
         }
 #undef UU3D_ATTN_CASE
         end();
