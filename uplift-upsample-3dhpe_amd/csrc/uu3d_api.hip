@@ -27,6 +27,7 @@
 #include "uu3d_gemm.h"
 #include "uu3d_gemm_h3.h"
 #include "uu3d_gemm_panel.h"
+#include "uu3d_gemm_wt.h"
 #include "uu3d_attn.h"
 #include "uu3d_attn_h3.h"
 #include "uu3d_spatial.h"
@@ -86,6 +87,7 @@ struct uu3d_model {
     bool committed = false;
     float* arena = nullptr;        // packed device weights
     size_t arena_floats = 0;
+    bool no_wt = false;            // UU3D_NO_WT=1: few-row GEMMs stay on the tiled split-K kernels (A/B measurements, tests)
     bool attn_f32 = false;         // UU3D_ATTN_F32=1: sequences of 49-128 tokens stay on the exact-f32 attention kernels (A/B measurements, tests)
     bool attn_wg = false;          // UU3D_ATTN_WG=1: attention with one workgroup per (sequence, head) (attn_f32_kernel) instead of one wave per item (A/B measurements, tests)
     bool no_panel = false;         // UU3D_NO_PANEL=1: LayerNorm-fed GEMMs stay on the tiled kernels (A/B measurements, tests)
@@ -296,6 +298,7 @@ int uu3d_create(const uu3d_config* c, int device, uu3d_model** out) {
       m->spatial_f32 = (e != nullptr && std::string(e) == "f32"); m->spatial_h3_always = (e != nullptr && std::string(e) == "h3"); }
     { const char* e = getenv("UU3D_NO_PLANES"); m->no_planes = (e != nullptr && e[0] == '1'); }
     { const char* e = getenv("UU3D_ATTN_WG"); m->attn_wg = (e != nullptr && e[0] == '1'); }
+    { const char* e = getenv("UU3D_NO_WT"); m->no_wt = (e != nullptr && e[0] == '1'); }
     { const char* e = getenv("UU3D_ATTN_F32"); m->attn_f32 = (e != nullptr && e[0] == '1'); }
     { const char* e = getenv("UU3D_NO_PANEL"); m->no_panel = (e != nullptr && e[0] == '1'); }
     *out = m;
@@ -808,6 +811,25 @@ struct Launcher {
         end();
     }
 
+    // Few rows (strided blocks 2-3, the heads): one workgroup per 32 x 32 tile, split-K over its waves, LayerNorm in the loader
+    // (uu3d_gemm_wt.h) -- one launch where the tiled path needs row_stats + split-K GEMM + splitk_reduce.
+    bool wt_ok(const float* Bt, int K) const {
+        return m->cfg.precision == UU3D_PREC_F16X3 && !m->no_wt && (K % 16) == 0 && m->hplanes.count((size_t)(Bt - m->arena)) != 0;
+    }
+    template <class AL, class EP>
+    void gemm_wt(const char* name, const AL& al, const float* Bt, int M, int N, int K, const EP& ep, double extra_bytes = 0) {
+        const int Kp = round_up(K, 32), slices = Kp / 16;
+        const auto it = m->hplanes.find((size_t)(Bt - m->arena));
+        const _Float16* Bh = m->harena + it->second.first; const _Float16* Bl = m->harena + it->second.second;
+        const int mt = (M + 31) / 32, nt = (N + 31) / 32;
+        begin(name, "gemm_wt", 2.0 * M * (double)N * K, 4.0 * ((double)M * K + (double)N * K + (double)M * N) + extra_bytes);
+        if (slices <= 6 * WT_MAX_WAVES) {                    // K <= 768: one batch of loads per wave
+            const int kw = (slices + 5) / 6;
+            hipLaunchKernelGGL((gemm_h3_wt_kernel<AL, EP, 6>), dim3(mt * nt), dim3(64 * kw), gemm_wt_lds_bytes(kw), stream, al, Bh, Bl, M, N, Kp, nt, ep);
+        } else { status = UU3D_ERR_UNSUPPORTED; m->err = "gemm_wt: contraction longer than 768"; }
+        end();
+    }
+
     void row_stats(const char* name, const float* x, int D, int M, float2* stats) {
         begin(name, "row_stats", 0.0, 4.0 * (double)M * D + 8.0 * M);
         hipLaunchKernelGGL(row_stats_kernel<4>, dim3((M + 3) / 4), dim3(256), 0, stream, x, D, D, M, 1e-5f, stats);
@@ -937,6 +959,7 @@ int uu3d_forward(uu3d_model* m, const float* kp2d, const uint8_t* mask, int32_t 
     // f16x3 with K % 32 == 0 everywhere: activations that feed a GEMM travel as f16 hi/lo planes (same bytes as the
     // f32 tensors they replace: O and Hb are reused) and the GEMMs are the LDS-DMA kernel gemm_h3g_kernel
     const bool planes = (c.precision == UU3D_PREC_F16X3) && (dt % 32 == 0) && (ht % 32 == 0) && !m->no_planes;
+    constexpr int kFewRows = 512;                                 // up to here a GEMM runs on gemm_h3_wt_kernel (measured: see DESIGN.md)
     _Float16* const Ph = reinterpret_cast<_Float16*>(w.O);       // LayerNorm output (fragment order), then attention output (planes)
     _Float16* const Hh = reinterpret_cast<_Float16*>(w.Hb);      // relu(fc1)
     const _Float16* const hzero = m->harena;                     // 64 zero halfs (uu3d_commit_weights)
@@ -949,6 +972,21 @@ int uu3d_forward(uu3d_model* m, const float* kp2d, const uint8_t* mask, int32_t 
         const int Mr = B * L;
         auto name = [&](const char* what) { snprintf(nm, sizeof nm, "%s%d.%s", tag, i + 1, what); return nm; };
         _Float16* const Pl = Ph + (size_t)Mr * dt; _Float16* const Hl = Hh + (size_t)Mr * ht;
+        // Few rows (strided block 3: 384): the LayerNorm-fed Dense layers as ONE launch each on gemm_h3_wt_kernel (LayerNorm in
+        // the loader, split-K inside the workgroup) instead of row_stats + split-K GEMM + splitk_reduce.  Measured per layer
+        // (h36m_351, batch 128, HIP events): 16.6 vs 14.2 + 6.3 us (QKV), 16.8 vs 12.7 + 6.4 us (fc1).  The other few-row GEMMs
+        // (projection, strided convolution, heads) are SLOWER there -- 32 x 32 tiles re-read both operands too often
+        // (conv: 29 vs 20 us, head1: 19 vs 12 us) -- and stay on the tiled kernels.
+        const bool few = planes && Mr <= kFewRows && Lh.wt_ok(b.wqkv_t, dt) && Lh.wt_ok(b.w1_t, dt);
+        if (few) {
+            WtLoadF32 l1{x, dt, Mr, dt, b.ln1_g, b.ln1_b, 1e-5f, 1};
+            Lh.gemm_wt(name("ln_qkv"), l1, b.wqkv_t, Mr, 3 * dt, dt, EpBias{w.QKV, b.bqkv, 3 * dt});
+            Lh.attn(name("attn"), w.QKV, B, L, kmask, w.O, (size_t)Mr * dt);
+            { GLoadPlain gl{Ph, Pl, dt, Mr}; Lh.gemm_g(name("proj_res"), gl, b.wp_t, Mr, dt, dt, EpBiasResidual{x, b.bp, dt, nullptr, nullptr, 1}, 4.0 * Mr * dt); }
+            WtLoadF32 l2{x, dt, Mr, dt, b.ln2_g, b.ln2_b, 1e-5f, 1};
+            Lh.gemm_wt(name("ln_fc1"), l2, b.w1_t, Mr, ht, dt, EpBiasReluSplit{Hh, Hl, b.b1, ht});
+            return;
+        }
         if (planes && Lh.panel_ok(Mr, 3 * dt, dt, b.wqkv_pf)) {
             Lh.ln_split_frag(name("ln1_split"), x, Mr, b.ln1_g, b.ln1_b, Ph);
             Lh.gemm_panel(name("ln_qkv"), Ph, b.wqkv_pf, b.bqkv, Mr, 3 * dt, PanelEpBias{w.QKV, 3 * dt});
@@ -985,7 +1023,8 @@ int uu3d_forward(uu3d_model* m, const float* kp2d, const uint8_t* mask, int32_t 
         if (planes) { GLoadPlain gl{Hh, Hh + (size_t)M * ht, ht, M}; Lh.gemm_g(nm, gl, b.w2_t, M, dt, ht, ep_fc2, 4.0 * M * dt); }
         else { ALoadPlain al{w.Hb, ht, M, ht}; Lh.gemm(nm, al, b.w2_t, M, dt, ht, ep_fc2, 4.0 * M * dt); }
     }
-    // 4. head1
+    // 4. head1.  (Nothing downstream reads it, but running it on a side stream next to the strided blocks measured SLOWER:
+    // 1.085 vs 1.040 ms per forward replayed from a hipGraph -- the cross-stream edges cost more than the 12 us they hide.)
     if (has_h1) {
         ALoadPlain al{w.X, dt, M, dt}; EpBias ep{full_out, m->h1_b, 3 * J};
         Lh.gemm("head1", al, m->h1_wt, M, 3 * J, dt, ep);
