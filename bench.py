@@ -299,7 +299,7 @@ def main():
         fl = pkg.flops_per_sequence(arch)
         total_ms = sum(a["ms"] for a in agg.values()) / reps
         # GEMM launch classes: the tiled f16x3 kernels ("gemm_h3"), the row-panel f16x3 kernel ("gemm_panel"), exact f32
-        gks = ("gemm_h3", "gemm_panel") if args.precision == "f16x3" else ("gemm_f32",)
+        gks = ("gemm_h3", "gemm_panel", "mlp_fused", "gemm_wt") if args.precision == "f16x3" else ("gemm_f32",)
         peak = PEAK_F16_MFMA_TFLOPS if args.precision == "f16x3" else PEAK_F32_MFMA_TFLOPS
         dom_key = max((k for k in agg if agg[k]["kernel"] in gks), key=lambda k: agg[k]["ms"])
         dom = agg[dom_key]

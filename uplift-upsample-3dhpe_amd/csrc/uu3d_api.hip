@@ -28,6 +28,7 @@
 #include "uu3d_gemm_h3.h"
 #include "uu3d_gemm_panel.h"
 #include "uu3d_gemm_wt.h"
+#include "uu3d_mlp_fused.h"
 #include "uu3d_attn.h"
 #include "uu3d_attn_h3.h"
 #include "uu3d_spatial.h"
@@ -66,6 +67,7 @@ struct BlockDev {
     const float* pe;   // strided blocks: (L_i, d_t)
     // fragment-ordered f16 planes of wqkv / w1 for the row-panel GEMM (uu3d_gemm_panel.h); offsets in harena, 0 = none
     size_t wqkv_pf = 0, w1_pf = 0;
+    size_t w2_mf = 0;                  // fc2 fragments of the fused MLP kernel (uu3d_mlp_fused.h, temporal blocks), offset in harena, 0 = none
 };
 
 struct ProfRec {
@@ -87,6 +89,7 @@ struct uu3d_model {
     bool committed = false;
     float* arena = nullptr;        // packed device weights
     size_t arena_floats = 0;
+    bool no_mlpf = false;          // UU3D_NO_MLPF=1: fc1 and fc2 of the temporal blocks as two GEMM launches (A/B measurements, tests)
     bool no_wt = false;            // UU3D_NO_WT=1: few-row GEMMs stay on the tiled split-K kernels (A/B measurements, tests)
     bool attn_f32 = false;         // UU3D_ATTN_F32=1: sequences of 49-128 tokens stay on the exact-f32 attention kernels (A/B measurements, tests)
     bool attn_wg = false;          // UU3D_ATTN_WG=1: attention with one workgroup per (sequence, head) (attn_f32_kernel) instead of one wave per item (A/B measurements, tests)
@@ -95,7 +98,7 @@ struct uu3d_model {
     _Float16* harena = nullptr;    // f16 hi/lo planes of every GEMM operand (f16x3 mode)
     size_t harena_halfs = 0;
     std::map<size_t, std::pair<size_t, size_t>> hplanes;   // Bt float offset -> (hi offset, lo offset) in harena
-    std::map<size_t, size_t> panel_off;                    // Bt float offset -> fragment-ordered planes in harena (uu3d_gemm_panel.h)
+    std::map<size_t, size_t> panel_off, mlpf_off;          // mlpf_off: Bt float offset of fc2 -> mlpf_pack_w2 fragments in harena                    // Bt float offset -> fragment-ordered planes in harena (uu3d_gemm_panel.h)
     // packed views
     SpatialParams sp{};
     const float* sp_blocks_v1 = nullptr;   // VALU kernel layout (kept for A/B runs: UU3D_SPATIAL=valu)
@@ -298,6 +301,7 @@ int uu3d_create(const uu3d_config* c, int device, uu3d_model** out) {
       m->spatial_f32 = (e != nullptr && std::string(e) == "f32"); m->spatial_h3_always = (e != nullptr && std::string(e) == "h3"); }
     { const char* e = getenv("UU3D_NO_PLANES"); m->no_planes = (e != nullptr && e[0] == '1'); }
     { const char* e = getenv("UU3D_ATTN_WG"); m->attn_wg = (e != nullptr && e[0] == '1'); }
+    { const char* e = getenv("UU3D_NO_MLPF"); m->no_mlpf = (e != nullptr && e[0] == '1'); }
     { const char* e = getenv("UU3D_NO_WT"); m->no_wt = (e != nullptr && e[0] == '1'); }
     { const char* e = getenv("UU3D_ATTN_F32"); m->attn_f32 = (e != nullptr && e[0] == '1'); }
     { const char* e = getenv("UU3D_NO_PANEL"); m->no_panel = (e != nullptr && e[0] == '1'); }
@@ -553,6 +557,17 @@ int uu3d_commit_weights(uu3d_model* m, void* stream_) {
                 m->panel_off[bt_off] = at;
             };
             for (auto& o : toff) { add_panel(o.wqkv, 3 * dt); add_panel(o.w1, ht); }
+            // fused MLP (uu3d_mlp_fused.h): fc2 fragments in the k order fc1's accumulator registers have
+            m->mlpf_off.clear();
+            if (dt == 32 * MLPF_OC && ht == 256 * MLPF_SLICES)
+                for (auto& o : toff) {
+                    const auto it = m->hplanes.find(o.w2);
+                    if (it == m->hplanes.end()) continue;
+                    const size_t at = align_up(hb.size(), 64);
+                    hb.resize(at + mlpf_w2_halfs());
+                    mlpf_pack_w2(hb.data() + it->second.first, hb.data() + it->second.second, Kht, hb.data() + at);
+                    m->mlpf_off[o.w2] = at;
+                }
             for (auto& o : soff) { add_panel(o.wqkv, 3 * dt); add_panel(o.w1, ht); }
         }
         if (m->harena_halfs < hb.size()) {
@@ -578,6 +593,7 @@ int uu3d_commit_weights(uu3d_model* m, void* stream_) {
         b.pe = strided ? A + o.pe : nullptr;
         { const auto it = m->panel_off.find(o.wqkv); b.wqkv_pf = (it != m->panel_off.end()) ? it->second : 0; }
         { const auto it = m->panel_off.find(o.w1); b.w1_pf = (it != m->panel_off.end()) ? it->second : 0; }
+        { const auto it = m->mlpf_off.find(o.w2); b.w2_mf = (!strided && it != m->mlpf_off.end()) ? it->second : 0; }
         return b;
     };
     m->tblocks.clear(); m->sblocks.clear();
@@ -592,7 +608,7 @@ int uu3d_commit_weights(uu3d_model* m, void* stream_) {
 // ---- workspace --------------------------------------------------------------------------
 namespace {
 struct Workspace {
-    float *S, *X, *QKV, *O, *Hb, *XA, *XB, *slab;
+    float *S, *X, *QKV, *O, *Hb, *XA, *XB, *slab, *mslab;
     int* frame_list;
     float2* stats;
     size_t slab_floats;
@@ -616,11 +632,12 @@ Workspace carve(const uu3d_model* m, int B, char* base) {
     w.slab_floats = (size_t)1536 * 4096;            // >= slices * M * N of any split GEMM (slices * tiles <= ~1150)
     const size_t oSl = take(w.slab_floats * 4);
     const size_t oFl = take((rows + 1) * sizeof(int));
+    const size_t oMs = take((size_t)MLPF_SLICES * rows * c.d_temporal * 4);      // fused MLP: fc2 partial sums of the three hidden slices
     w.bytes = off;
     if (base) {
         w.S = (float*)(base + oS); w.X = (float*)(base + oX); w.QKV = (float*)(base + oQ);
         w.O = (float*)(base + oO); w.Hb = (float*)(base + oH); w.XA = (float*)(base + oA);
-        w.XB = (float*)(base + oB); w.stats = (float2*)(base + oT); w.slab = (float*)(base + oSl); w.frame_list = (int*)(base + oFl);
+        w.XB = (float*)(base + oB); w.stats = (float2*)(base + oT); w.slab = (float*)(base + oSl); w.frame_list = (int*)(base + oFl); w.mslab = (float*)(base + oMs);
     }
     return w;
 }
@@ -811,6 +828,27 @@ struct Launcher {
         end();
     }
 
+    // vit.MLP of a temporal block in one launch (uu3d_mlp_fused.h): partial fc2 sums of the 3 hidden slices -> mslab
+    bool mlpf_ok(int M, const BlockDev& b) const {
+        return !m->no_mlpf && b.w2_mf != 0 && panel_ok(M, m->cfg.h_temporal, m->cfg.d_temporal, b.w1_pf);
+    }
+    void mlp_fused(const char* name, const _Float16* Af, const BlockDev& b, int M, float* mslab) {
+        const int mt = (M + 127) / 128, S = MLPF_SLICES;
+        begin(name, "mlp_fused", 4.0 * M * (double)m->cfg.d_temporal * m->cfg.h_temporal, 4.0 * ((double)M * 384 + 2.0 * 384 * 768 + 3.0 * M * 384));
+        static bool attr_done = false;
+        if (!attr_done) { (void)hipFuncSetAttribute((const void*)mlp_fused_h3_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)PANEL_LDS_TOTAL); attr_done = true; }
+        hipLaunchKernelGGL(mlp_fused_h3_kernel, dim3(8 * S, ((mt * S + 7) / 8 + S - 1) / S), dim3(256), PANEL_LDS_TOTAL, stream,
+                           Af, m->harena + b.w1_pf, m->harena + b.w2_mf, b.b1, mslab, M, mt);
+        end();
+    }
+    // the fused MLP's combine (x += b2 + slabs; optionally xa = x + pe) + LayerNorm + split into A fragments
+    void ln_res_split_frag(const char* name, float* x, int M, const float* bias2, const float* mslab, float* xa, const float* pe, int period,
+                           const float* g, const float* b, _Float16* Af) {
+        begin(name, "ln_split_frag", 0.0, 4.0 * (double)M * 384 * (xa ? 8 : 7));
+        hipLaunchKernelGGL((ln_res_split_frag_kernel<24, 8>), dim3((M + 7) / 8), dim3(128), 0, stream, x, 384, M, 1e-5f, bias2, mslab, xa, pe, period, g, b, Af);
+        end();
+    }
+
     // Few rows (strided blocks 2-3, the heads): one workgroup per 32 x 32 tile, split-K over its waves, LayerNorm in the loader
     // (uu3d_gemm_wt.h) -- one launch where the tiled path needs row_stats + split-K GEMM + splitk_reduce.
     bool wt_ok(const float* Bt, int K) const {
@@ -968,7 +1006,10 @@ int uu3d_forward(uu3d_model* m, const float* kp2d, const uint8_t* mask, int32_t 
     // stream x of Mr = B * L rows:  x += proj(MHA(LN1(x)));  Hb = relu(fc1(LN2(x)))  -- Hb as f16 planes when `planes`.
     //   LayerNorm-fed Dense layers: ln_split_frag + the row-panel GEMM (>= 1024 rows), else row_stats + the tiled GEMM
     //   with LayerNorm in its loader.
-    auto block_head = [&](const char* tag, int i, const BlockDev& b, float* x, int L, const uint8_t* kmask) {
+    // `pend` != nullptr: the previous temporal block ended in the fused MLP -- its fc2 result still sits in w.mslab; this
+    // block's first LayerNorm launch adds it to the residual stream (for the first strided block: to w.X, and x = w.XA = X + pe).
+    // `fuse_mlp`: stop after the second LayerNorm (its fragments in Ph feed mlp_fused).
+    auto block_head = [&](const char* tag, int i, const BlockDev& b, float* x, int L, const uint8_t* kmask, const BlockDev* pend, bool fuse_mlp) {
         const int Mr = B * L;
         auto name = [&](const char* what) { snprintf(nm, sizeof nm, "%s%d.%s", tag, i + 1, what); return nm; };
         _Float16* const Pl = Ph + (size_t)Mr * dt; _Float16* const Hl = Hh + (size_t)Mr * ht;
@@ -987,7 +1028,11 @@ int uu3d_forward(uu3d_model* m, const float* kp2d, const uint8_t* mask, int32_t 
             Lh.gemm_wt(name("ln_fc1"), l2, b.w1_t, Mr, ht, dt, EpBiasReluSplit{Hh, Hl, b.b1, ht});
             return;
         }
-        if (planes && Lh.panel_ok(Mr, 3 * dt, dt, b.wqkv_pf)) {
+        if (pend != nullptr) {                                     // (same row count as the block that left it: the panel path holds)
+            if (x == w.X) Lh.ln_res_split_frag(name("ln1_split"), w.X, Mr, pend->b2, w.mslab, nullptr, nullptr, 1, b.ln1_g, b.ln1_b, Ph);
+            else Lh.ln_res_split_frag(name("ln1_split"), w.X, Mr, pend->b2, w.mslab, x, b.pe, L, b.ln1_g, b.ln1_b, Ph);
+            Lh.gemm_panel(name("ln_qkv"), Ph, b.wqkv_pf, b.bqkv, Mr, 3 * dt, PanelEpBias{w.QKV, 3 * dt});
+        } else if (planes && Lh.panel_ok(Mr, 3 * dt, dt, b.wqkv_pf)) {
             Lh.ln_split_frag(name("ln1_split"), x, Mr, b.ln1_g, b.ln1_b, Ph);
             Lh.gemm_panel(name("ln_qkv"), Ph, b.wqkv_pf, b.bqkv, Mr, 3 * dt, PanelEpBias{w.QKV, 3 * dt});
         } else {
@@ -1003,6 +1048,7 @@ int uu3d_forward(uu3d_model* m, const float* kp2d, const uint8_t* mask, int32_t 
         }
         if (planes && Lh.panel_ok(Mr, ht, dt, b.w1_pf)) {
             Lh.ln_split_frag(name("ln2_split"), x, Mr, b.ln2_g, b.ln2_b, Ph);
+            if (fuse_mlp) return;
             Lh.gemm_panel(name("ln_fc1"), Ph, b.w1_pf, b.b1, Mr, ht, PanelEpBiasReluSplit{Hh, Hl, ht});
         } else {
             Lh.row_stats(name("stats2"), x, dt, Mr, w.stats);
@@ -1012,22 +1058,27 @@ int uu3d_forward(uu3d_model* m, const float* kp2d, const uint8_t* mask, int32_t 
         }
     };
 
-    // 3. temporal blocks
+    // 3. temporal blocks.  With >= 1024 token rows the MLP is one launch (uu3d_mlp_fused.h): its three partial fc2 sums are
+    // added to the residual stream by the NEXT block's first LayerNorm launch (`pend`).
+    const BlockDev* pend = nullptr;
     for (int i = 0; i < c.temporal_depth; ++i) {
         const BlockDev& b = m->tblocks[i];
         const bool masked = c.has_strided_input && i < c.first_strided_token_attention_layer;
         const bool last = (i + 1 == c.temporal_depth);
-        block_head("t", i, b, w.X, N, masked ? mask : nullptr);
+        const bool fuse = planes && Lh.mlpf_ok(M, b) && Lh.panel_ok(M, 3 * dt, dt, m->sblocks[0].wqkv_pf) &&
+                          (last || Lh.panel_ok(M, 3 * dt, dt, m->tblocks[i + 1].wqkv_pf));
+        block_head("t", i, b, w.X, N, masked ? mask : nullptr, pend, fuse);
+        pend = nullptr;
+        if (fuse) {
+            snprintf(nm, sizeof nm, "t%d.mlp", i + 1);
+            Lh.mlp_fused(nm, Ph, b, M, w.mslab);
+            pend = &b;
+            continue;
+        }
         EpBiasResidual ep_fc2{w.X, b.b2, dt, last ? w.XA : nullptr, last ? m->sblocks[0].pe : nullptr, N};
         snprintf(nm, sizeof nm, "t%d.fc2_res", i + 1);
         if (planes) { GLoadPlain gl{Hh, Hh + (size_t)M * ht, ht, M}; Lh.gemm_g(nm, gl, b.w2_t, M, dt, ht, ep_fc2, 4.0 * M * dt); }
         else { ALoadPlain al{w.Hb, ht, M, ht}; Lh.gemm(nm, al, b.w2_t, M, dt, ht, ep_fc2, 4.0 * M * dt); }
-    }
-    // 4. head1.  (Nothing downstream reads it, but running it on a side stream next to the strided blocks measured SLOWER:
-    // 1.085 vs 1.040 ms per forward replayed from a hipGraph -- the cross-stream edges cost more than the 12 us they hide.)
-    if (has_h1) {
-        ALoadPlain al{w.X, dt, M, dt}; EpBias ep{full_out, m->h1_b, 3 * J};
-        Lh.gemm("head1", al, m->h1_wt, M, 3 * J, dt, ep);
     }
     // 5. strided blocks
     float* xa = w.XA; float* xb = w.XB;
@@ -1038,7 +1089,14 @@ int uu3d_forward(uu3d_model* m, const float* kp2d, const uint8_t* mask, int32_t 
         const int lo = (c.strides[i] > 1 && c.pad_left[i] == 0) ? 1 : 0;
         const EpConvResidual ep_conv{xb, b.b2, dt, xa, Li, Lo, c.strides[i], lo,
                                      (i + 1 < c.num_strided) ? m->sblocks[i + 1].pe : nullptr};
-        block_head("s", i, b, xa, Li, nullptr);
+        block_head("s", i, b, xa, Li, nullptr, i == 0 ? pend : nullptr, false);
+        if (i == 0 && has_h1) {
+            // 4. head1 (after strided block 1's first LayerNorm launch, which completes w.X when the last MLP was fused).  Nothing
+            // downstream reads it, but a side stream next to the strided blocks measured SLOWER (1.085 vs 1.040 ms per forward
+            // replayed from a hipGraph: the cross-stream edges cost more than the 12 us they hide).
+            ALoadPlain al{w.X, dt, M, dt}; EpBias ep{full_out, m->h1_b, 3 * J};
+            Lh.gemm("head1", al, m->h1_wt, M, 3 * J, dt, ep);
+        }
         snprintf(nm, sizeof nm, "s%d.conv_res", i + 1);
         if (planes) { GLoadConv3 gl{Hh, Hh + (size_t)Mi * ht, hzero, ht, Li, Lo, c.strides[i], c.pad_left[i], Mo};
                       Lh.gemm_g(nm, gl, b.w2_t, Mo, dt, 3 * ht, ep_conv, 4.0 * Mo * dt); }
