@@ -98,10 +98,10 @@ def test_wave_per_head_attention_on_other_lengths(n_frames, strides, batch, monk
     assert dev <= 2e-5
 
 
-@pytest.mark.parametrize("n_frames,strides,batch", [(351, [3, 9, 13], 2), (117, [3, 3, 13], 3), (200, [5, 8, 5], 2), (384, [4, 8, 12], 1)])
+@pytest.mark.parametrize("n_frames,strides,batch", [(351, [3, 9, 13], 2), (117, [3, 3, 13], 3), (200, [5, 8, 5], 2), (416, [4, 8, 13], 1)])
 def test_long_sequences_match_oracle(n_frames, strides, batch, monkeypatch):
     """Sequences beyond the 128 tokens the exact-f32 attention kernels hold: SURVEY 8(d)'s "synthetic dense-351"
-    (351 -> 117 -> 13 -> 1, not a shipped config), other lengths, and the largest supported one (384 tokens = 12 key tiles),
+    (351 -> 117 -> 13 -> 1, not a shipped config), other lengths, and the largest supported one (416 tokens = 13 key tiles),
     on attn_h3_kernel (f16x3 products, online softmax over 32-key tiles, uu3d_attn_h3.h).  Stride masks with masked and
     all-masked rows; the masked first temporal block included."""
     from oracle import uplift_oracle as O
@@ -122,11 +122,11 @@ def test_long_sequences_match_oracle(n_frames, strides, batch, monkeypatch):
 
 
 def test_sequence_length_limits():
-    """385 tokens do not fit the attention kernel's LDS image; precision f32 keeps the 128-token limit of the exact-f32 kernels."""
+    """417 tokens do not fit the attention kernel's LDS image; precision f32 keeps the 128-token limit of the exact-f32 kernels."""
     from uplift_upsample_3dhpe_amd import _capi
     cfg = util.load_config("dense_351")
-    cfg.SEQUENCE_LENGTH, cfg.STRIDES = 385, [4, 8, 12]
-    with pytest.raises(_capi.Uu3dError, match="384"):
+    cfg.SEQUENCE_LENGTH, cfg.STRIDES = 417, [4, 8, 13]
+    with pytest.raises(_capi.Uu3dError, match="416"):
         pkg.build_uplift_upsample_transformer(cfg)
     cfg = util.load_config("dense_351")
     with pytest.raises(_capi.Uu3dError, match="128"):

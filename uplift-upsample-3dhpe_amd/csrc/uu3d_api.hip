@@ -288,7 +288,7 @@ int uu3d_create(const uu3d_config* c, int device, uu3d_model** out) {
         // exact-f32 attention holds a query tile's logits in registers (<= 128 keys); the f16x3 kernel tiles the keys
         if (Lin > (c->precision == UU3D_PREC_F16X3 ? ATTN_H3_MAX_L : 128)) {
             delete m;
-            return fail(nullptr, UU3D_ERR_UNSUPPORTED, c->precision == UU3D_PREC_F16X3 ? "sequence length > 384 tokens" : "sequence length > 128 tokens with precision f32");
+            return fail(nullptr, UU3D_ERR_UNSUPPORTED, c->precision == UU3D_PREC_F16X3 ? "sequence length > 416 tokens" : "sequence length > 128 tokens with precision f32");
         }
         m->L.push_back(Lout);
     }
@@ -874,23 +874,26 @@ struct Launcher {
         end();
     }
 
+    // sequences served by attn_h3_kernel (f16x3 products, online softmax; q / k / v as f16 planes from the QKV epilogue): everything
+    // the exact-f32 kernels cannot hold (> 128 tokens) and, measured faster, 49-128 tokens as well
+    bool attn_is_h3(int L, bool planes_out) const { return planes_out && L <= ATTN_H3_MAX_L && (L > 128 || (L > 48 && !m->attn_f32)); }
+    float attn_qscale() const { return 1.44269504088896341f / sqrtf((float)kDH); }
     // split_lo_off != 0: the context rows go out as f16 planes (hi at out, lo split_lo_off halfs further)
     void attn(const char* name, const float* qkv, int B, int L, const uint8_t* mask, float* out, size_t split_lo_off = 0) {
         const int D = m->cfg.d_temporal, H = m->cfg.num_heads;
         const int NT = (L + 15) / 16;
-        const bool h3a = split_lo_off != 0 && L <= ATTN_H3_MAX_L && (L > 128 || (L > 48 && !m->attn_f32));
+        const bool h3a = attn_is_h3(L, split_lo_off != 0);
         begin(name, h3a ? "attn_h3" : "attn_f32", 4.0 * B * (double)H * L * L * kDH, 4.0 * 4.0 * B * (double)L * D);
         const int items = B * H;
         const dim3 grid(items);
-        // f16x3 products + online softmax over key tiles (uu3d_attn_h3.h): every sequence the f32 kernels cannot hold
-        // (> 128 tokens), and, measured faster, the 49-128 token range as well; needs the f16-plane output
-        if (split_lo_off != 0 && L <= ATTN_H3_MAX_L && (L > 128 || (L > 48 && !m->attn_f32))) {
+        if (h3a) {                                                 // qkv = hi plane [B L][3 D] halfs, lo plane behind it
             const int nt = (L + 31) / 32;
             const size_t lds = attn_h3_lds_bytes(L, kDH);
             _Float16* oh = reinterpret_cast<_Float16*>(out);
+            const _Float16* qh = reinterpret_cast<const _Float16*>(qkv); const _Float16* ql = qh + (size_t)B * L * 3 * D;
 #define UU3D_ATTN_H3(MW, WPE, MASKED, waves) { auto k = attn_h3_kernel<kDH, MW, WPE, MASKED>; \
                 static const bool once = (hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)attn_h3_lds_bytes(ATTN_H3_MAX_L, kDH)) == hipSuccess); (void)once; \
-                hipLaunchKernelGGL(k, grid, dim3(64 * (waves)), lds, stream, qkv, 3 * D, D, L, H, mask, oh, split_lo_off, D); }
+                hipLaunchKernelGGL(k, grid, dim3(64 * (waves)), lds, stream, qh, ql, 3 * D, D, L, H, mask, oh, split_lo_off, D); }
             if (nt <= 3) { if (mask) UU3D_ATTN_H3(3, 3, true, nt) else UU3D_ATTN_H3(3, 3, false, nt) }
             else { if (mask) UU3D_ATTN_H3(8, 2, true, std::min(nt, 8)) else UU3D_ATTN_H3(8, 2, false, std::min(nt, 8)) }
 #undef UU3D_ATTN_H3
@@ -1018,10 +1021,15 @@ int uu3d_forward(uu3d_model* m, const float* kp2d, const uint8_t* mask, int32_t 
         // (h36m_351, batch 128, HIP events): 16.6 vs 14.2 + 6.3 us (QKV), 16.8 vs 12.7 + 6.4 us (fc1).  The other few-row GEMMs
         // (projection, strided convolution, heads) are SLOWER there -- 32 x 32 tiles re-read both operands too often
         // (conv: 29 vs 20 us, head1: 19 vs 12 us) -- and stay on the tiled kernels.
+        // q / k / v for attn_h3_kernel: f16 planes (hi at QKV, lo Mr * 3 d_t halfs further), q pre-multiplied by log2(e) / sqrt(d_h)
+        const bool qsplit = Lh.attn_is_h3(L, planes);
+        _Float16* const Qh = reinterpret_cast<_Float16*>(w.QKV); _Float16* const Ql = Qh + (size_t)Mr * 3 * dt;
+        const EpBiasSplitQ ep_qs{Qh, Ql, b.bqkv, 3 * dt, dt, Lh.attn_qscale()};
         const bool few = planes && Mr <= kFewRows && Lh.wt_ok(b.wqkv_t, dt) && Lh.wt_ok(b.w1_t, dt);
         if (few) {
             WtLoadF32 l1{x, dt, Mr, dt, b.ln1_g, b.ln1_b, 1e-5f, 1};
-            Lh.gemm_wt(name("ln_qkv"), l1, b.wqkv_t, Mr, 3 * dt, dt, EpBias{w.QKV, b.bqkv, 3 * dt});
+            if (qsplit) Lh.gemm_wt(name("ln_qkv"), l1, b.wqkv_t, Mr, 3 * dt, dt, ep_qs);
+            else Lh.gemm_wt(name("ln_qkv"), l1, b.wqkv_t, Mr, 3 * dt, dt, EpBias{w.QKV, b.bqkv, 3 * dt});
             Lh.attn(name("attn"), w.QKV, B, L, kmask, w.O, (size_t)Mr * dt);
             { GLoadPlain gl{Ph, Pl, dt, Mr}; Lh.gemm_g(name("proj_res"), gl, b.wp_t, Mr, dt, dt, EpBiasResidual{x, b.bp, dt, nullptr, nullptr, 1}, 4.0 * Mr * dt); }
             WtLoadF32 l2{x, dt, Mr, dt, b.ln2_g, b.ln2_b, 1e-5f, 1};
@@ -1031,14 +1039,17 @@ int uu3d_forward(uu3d_model* m, const float* kp2d, const uint8_t* mask, int32_t 
         if (pend != nullptr) {                                     // (same row count as the block that left it: the panel path holds)
             if (x == w.X) Lh.ln_res_split_frag(name("ln1_split"), w.X, Mr, pend->b2, w.mslab, nullptr, nullptr, 1, b.ln1_g, b.ln1_b, Ph);
             else Lh.ln_res_split_frag(name("ln1_split"), w.X, Mr, pend->b2, w.mslab, x, b.pe, L, b.ln1_g, b.ln1_b, Ph);
-            Lh.gemm_panel(name("ln_qkv"), Ph, b.wqkv_pf, b.bqkv, Mr, 3 * dt, PanelEpBias{w.QKV, 3 * dt});
+            if (qsplit) Lh.gemm_panel(name("ln_qkv"), Ph, b.wqkv_pf, b.bqkv, Mr, 3 * dt, PanelEpBiasSplitQ{Qh, Ql, 3 * dt, dt, Lh.attn_qscale()});
+            else Lh.gemm_panel(name("ln_qkv"), Ph, b.wqkv_pf, b.bqkv, Mr, 3 * dt, PanelEpBias{w.QKV, 3 * dt});
         } else if (planes && Lh.panel_ok(Mr, 3 * dt, dt, b.wqkv_pf)) {
             Lh.ln_split_frag(name("ln1_split"), x, Mr, b.ln1_g, b.ln1_b, Ph);
-            Lh.gemm_panel(name("ln_qkv"), Ph, b.wqkv_pf, b.bqkv, Mr, 3 * dt, PanelEpBias{w.QKV, 3 * dt});
+            if (qsplit) Lh.gemm_panel(name("ln_qkv"), Ph, b.wqkv_pf, b.bqkv, Mr, 3 * dt, PanelEpBiasSplitQ{Qh, Ql, 3 * dt, dt, Lh.attn_qscale()});
+            else Lh.gemm_panel(name("ln_qkv"), Ph, b.wqkv_pf, b.bqkv, Mr, 3 * dt, PanelEpBias{w.QKV, 3 * dt});
         } else {
             Lh.row_stats(name("stats1"), x, dt, Mr, w.stats);
-            ALoadLayerNorm al{x, w.stats, b.ln1_g, b.ln1_b, dt, Mr, dt}; EpBias ep{w.QKV, b.bqkv, 3 * dt};
-            Lh.gemm(name("ln_qkv"), al, b.wqkv_t, Mr, 3 * dt, dt, ep);
+            ALoadLayerNorm al{x, w.stats, b.ln1_g, b.ln1_b, dt, Mr, dt};
+            if (qsplit) Lh.gemm(name("ln_qkv"), al, b.wqkv_t, Mr, 3 * dt, dt, ep_qs);
+            else { EpBias ep{w.QKV, b.bqkv, 3 * dt}; Lh.gemm(name("ln_qkv"), al, b.wqkv_t, Mr, 3 * dt, dt, ep); }
         }
         Lh.attn(name("attn"), w.QKV, B, L, kmask, w.O, planes ? (size_t)Mr * dt : 0);
         {

@@ -1,28 +1,30 @@
 // uu3d_attn_h3.h -- temporal self-attention with f16x3 products and an online softmax over key tiles: sequences of up
-// to 384 tokens (SURVEY 8(d)'s "synthetic dense-351": 351 -> 117 -> 13 -> 1), and the shipped 71-token ones.
+// to 416 tokens (SURVEY 8(d)'s "synthetic dense-351": 351 -> 117 -> 13 -> 1), and the shipped 71-token ones.
 //
 // Replaces vit.MHA.scaled_dot_product_attention (vision_transformer.py:99-130) like uu3d_attn.h; the exact-f32 kernels
 // there hold all logits of a query tile in registers (<= 128 keys) and run on the f32 MFMA (1/16 of the f16 rate).
 //
 // One workgroup = one (sequence, head); wave w owns the 32-query tiles w, w + NW, ...
-//   * K and V of the head are split ONCE into f16 hi / lo planes (x ~= hi + lo / 2048, uu3d_gemm_h3.h) while they are
-//     staged into LDS, in the layouts the MFMA operand reads want:
-//         K:  [plane][16-deep k-slice (3)][key][16 halfs]   a fragment read is one linear, conflict-free ds_read_b128
-//         Vt: [plane][channel d (48) + a row of ones][key], row stride RS
-//                                                           transposed; RS = 2 * odd dwords: the 32 lanes of a half read
-//                                                           32 different channels at bank offsets 2 * (odd * d mod 32)
+//   * q, k, v arrive as f16 hi / lo PLANES (x ~= hi + lo / 2048, uu3d_gemm_h3.h), written by the QKV projection's epilogue
+//     (q already multiplied by log2(e) / sqrt(d_h)): the kernel does no splitting, and K and V of the head go global -> LDS
+//     by LDS-DMA (global_load_lds_dwordx4, 12 instructions per 32 keys, no registers, no VALU) in the layouts the MFMA
+//     operand reads want:
+//         K: [plane][16-deep k-slice (3)][key][16 halfs]    a fragment read is one linear, conflict-free ds_read_b128
+//         V: [key][hi 48 halfs | lo 48 halfs]               row major, 192-byte rows; the V^T fragments come out of
+//                                                           ds_read_b64_tr_b16 (4 keys x 16 channels per 16 lanes; the 4 rows
+//                                                           of a 32-lane half fall on 4 x 64 bytes = all 64 banks)
 //   * logits TRANSPOSED, S^T = K Q^T with v_mfma_f32_32x32x16_f16 (K fragment = A, Q^T fragment = B, 3 k-slices x 3
 //     passes): in the C/D map a lane holds ONE query (lane & 31) and 16 keys of the tile, so the softmax is in-lane plus
 //     one lane ^ 32 exchange, and the probability registers are, converted to f16 pairs, already the B operand of
-//         O^T = V^T P^T       (A = V^T fragment from Vt; MICROARCH guide: "an accumulator tile as the next MFMA's operand")
-//     whose k order inside a 16-key step is 8 (j >> 2) + 4 h + (j & 3) -- the Vt reads use the same order.
+//         O^T = V^T P^T       (A = V^T fragment; MICROARCH guide: "an accumulator tile as the next MFMA's operand")
+//     whose k order inside a 16-key step is 8 (j >> 2) + 4 h + (j & 3) -- two transposed reads of 4 keys each per fragment.
 //   * The softmax costs as many issue cycles as the MFMAs unless it is kept short (one wave: ~16 values x 20 VALU
 //     instructions per tile at first), so the per-value work is folded away wherever the algebra allows:
-//       - Q is multiplied by log2(e) / sqrt(d_h) before it is split: the accumulator is the exp2 argument;
+//       - q arrives multiplied by log2(e) / sqrt(d_h): the accumulator is the exp2 argument;
 //       - the accumulator STARTS at (key mask term - running maximum + 14): no subtraction per value;  [unmasked launches]
 //       - probabilities are 2^14 times too large (p <= 16384 fits f16; the common factor cancels in O / l): no f16
 //         denormals to flush, so hi comes from the packed conversion and lo = f16((p - hi) * 2048);
-//       - the row sum l is row 48 of O^T: the padding rows of the second O^T tile read a row of ONES from Vt;
+//       - the row sum l is row 48 of O^T: the padding rows of the second O^T tile read a block of ONES instead of V;
 //       - O^T is rescaled only when some maximum of the wave grew (never after the first tiles of most rows).
 //     Masked keys add -1e9 (finite, like the reference: an all-masked row stays uniform -- there the mask term is added in
 //     f32 BEFORE the maximum is subtracted, as the reference does), keys past L add -inf.
@@ -37,18 +39,12 @@
 
 namespace uu3d {
 
-static constexpr int ATTN_H3_MAX_L = 384;              // 12 key tiles: K + Vt planes of one head (148 KiB) fit the 160 KiB LDS; 13 tiles miss it by 16 bytes
+static constexpr int ATTN_H3_MAX_L = 416;              // 13 key tiles: K + V planes of one head (158 KiB) fit the 160 KiB LDS
 __host__ __device__ inline constexpr int attn_h3_lpad(int L) { return (L + 31) / 32 * 32; }
-// Vt row stride in halfs: >= Lpad, and 2 * odd as a dword count (see top): 4 * odd halfs
-__host__ __device__ inline constexpr int attn_h3_vt_rs_halfs(int L) {
-    int odd = (attn_h3_lpad(L) + 3) / 4;
-    if ((odd & 1) == 0) odd += 1;
-    return odd * 4;
-}
 __host__ __device__ inline constexpr size_t attn_h3_lds_bytes(int L, int DH) {
-    return (size_t)2 * (DH / 16) * attn_h3_lpad(L) * 16 * sizeof(_Float16)          // K planes
-         + (size_t)2 * (DH + 1) * attn_h3_vt_rs_halfs(L) * sizeof(_Float16)         // Vt planes + the row of ones
-         + (size_t)attn_h3_lpad(L) * sizeof(float);                                 // additive key mask (x log2 e)
+    return (size_t)2 * DH * attn_h3_lpad(L) * sizeof(_Float16) * 2          // K planes + V rows
+         + 64                                                                   // 16 ones, 16 zeros (halfs)
+         + (size_t)attn_h3_lpad(L) * sizeof(float);                             // additive key mask (x log2 e)
 }
 
 typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
@@ -59,89 +55,73 @@ typedef _Float16 h16x2 __attribute__((ext_vector_type(2)));
 // MASKED = a key mask is given (temporal block 1): the mask term is added before the running maximum is subtracted.
 template <int DH, int MAXW, int WPE, bool MASKED>
 __global__ void __launch_bounds__(64 * MAXW) __attribute__((amdgpu_waves_per_eu(WPE, WPE)))
-attn_h3_kernel(const float* __restrict__ qkv, const int ld, const int D, const int L, const int H,
+attn_h3_kernel(const _Float16* __restrict__ qkv_h, const _Float16* __restrict__ qkv_l, const int ld, const int D, const int L, const int H,
                const uint8_t* __restrict__ key_mask,   // (B, L) 1 = attend; nullptr = no mask
                _Float16* __restrict__ out, const size_t lo_off, const int ldo)
 {
     static_assert(DH == 48, "operand layouts below are written for a head dim of 48 (3 k-slices, 1.5 output row tiles)");
     constexpr int KS = DH / 16;                        // k-slices of Q K^T
-    constexpr int F4 = DH / 4;                         // float4 pieces per row
     constexpr float PSHIFT = 14.0f;                    // probabilities carry a factor 2^14 (see top)
-    h3_flush_f16_denormals();                          // K / V / output planes: hi = 0 below the smallest normal half (uu3d_gemm_h3.h)
+    constexpr int VROW = 2 * DH;                       // halfs per V row in LDS: hi | lo
+    h3_flush_f16_denormals();                          // output planes: hi = 0 below the smallest normal half (uu3d_gemm_h3.h)
     extern __shared__ __attribute__((aligned(16))) unsigned char asm_[];
-    const int Lpad = attn_h3_lpad(L), RS = attn_h3_vt_rs_halfs(L), NT = Lpad >> 5;
+    const int Lpad = attn_h3_lpad(L), NT = Lpad >> 5;
     _Float16* Kp = reinterpret_cast<_Float16*>(asm_);                               // [2][KS][Lpad][16]
-    _Float16* Vt = Kp + (size_t)2 * KS * Lpad * 16;                                 // [2][DH + 1][RS]
-    float* madd = reinterpret_cast<float*>(Vt + (size_t)2 * (DH + 1) * RS);         // [Lpad]
-    const int tid = threadIdx.x, nthr = blockDim.x, lane = tid & 63, w = tid >> 6, NW = nthr >> 6;
-    // consecutive workgroups (the heads of one sequence) on one XCD: they read neighbouring 192-byte column slices of the same rows
+    _Float16* Vr = Kp + (size_t)2 * KS * Lpad * 16;                                 // [Lpad][hi DH | lo DH]
+    _Float16* ones = Vr + (size_t)Lpad * VROW;                                      // 16 x 1.0, then 16 x 0.0
+    float* madd = reinterpret_cast<float*>(ones + 32);                              // [Lpad]
+    const int tid = threadIdx.x, nthr = blockDim.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6), NW = nthr >> 6;
+    // consecutive workgroups (the heads of one sequence) on one XCD: they read neighbouring 96-byte column slices of the same rows
     const int bh = ((int)gridDim.x & 7) == 0 ? ((int)blockIdx.x & 7) * ((int)gridDim.x >> 3) + ((int)blockIdx.x >> 3) : (int)blockIdx.x;
     const int b = bh / H, h = bh - b * H;
-    const float* base = qkv + (size_t)b * L * ld + h * DH;
+    const size_t tok0 = (size_t)b * L;
     constexpr float LOG2E = 1.44269504088896341f;
-
-    // ---- K, V -> f16 planes in LDS.  ALL loads of the thread first (branch-free: clamped row, zeroed afterwards), one
-    // memory round trip; the first query tile's rows go out with them ----
-    constexpr int NPT = MAXW <= 3 ? 6 : 9;             // float4 pieces per thread and matrix: 12 Lpad / (64 waves), Lpad = 32 NT <= 384, waves = min(NT, 8)
     const int q31 = lane & 31, g = lane >> 5;
-    f32x4 qx[KS][2];
-    auto load_q = [&](int qt) {
-        const float* qp = base + (size_t)min(32 * qt + q31, L - 1) * ld + g * 8;
-#pragma unroll
-        for (int s = 0; s < KS; ++s) { qx[s][0] = *reinterpret_cast<const f32x4*>(qp + 16 * s); qx[s][1] = *reinterpret_cast<const f32x4*>(qp + 16 * s + 4); }
-    };
-    {
-        f32x4 kx[NPT], vx[NPT];
-#pragma unroll
-        for (int u = 0; u < NPT; ++u) {
-            const int idx = u * nthr + tid, row = idx / F4, c4 = (idx - row * F4) * 4;
-            const float* p = base + (size_t)min(row, L - 1) * ld + c4;
-            kx[u] = *reinterpret_cast<const f32x4*>(p + D);
-            vx[u] = *reinterpret_cast<const f32x4*>(p + 2 * D);
-        }
-        load_q(w);
-#pragma unroll
-        for (int u = 0; u < NPT; ++u) {
-            const int idx = u * nthr + tid, row = idx / F4, c4 = (idx - row * F4) * 4;
-            if (idx < Lpad * F4) {
-                const float keep = row < L ? 1.0f : 0.0f;
-                h16x4 hi, lo;
-                h3_split(kx[u] * keep, hi, lo);
-                _Float16* kd = Kp + ((size_t)(c4 >> 4) * Lpad + row) * 16 + (c4 & 15);
-                *reinterpret_cast<h16x4*>(kd) = hi;
-                *reinterpret_cast<h16x4*>(kd + (size_t)KS * Lpad * 16) = lo;
-                h3_split(vx[u] * keep, hi, lo);
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    Vt[(size_t)(c4 + e) * RS + row] = hi[e];
-                    Vt[(size_t)((DH + 1) + c4 + e) * RS + row] = lo[e];
-                }
-            }
-        }
-    }
-    for (int k = tid; k < Lpad; k += nthr) {
-        const uint8_t mk = (MASKED && key_mask != nullptr) ? key_mask[(size_t)b * L + min(k, L - 1)] : (uint8_t)1;
-        madd[k] = (k < L) ? (mk ? 0.0f : -1e9f * LOG2E) : -INFINITY;
-        Vt[(size_t)DH * RS + k] = (_Float16)1.0f;                  // row DH of the hi plane: ones (the row sum l comes out as row DH of O^T)
-        Vt[(size_t)((DH + 1) + DH) * RS + k] = (_Float16)0.0f;
-    }
-    __syncthreads();
 
-    const float cscale = LOG2E / sqrtf((float)DH);                 // logits / sqrt(d_h), in log2 units
-    const int dA = q31, dB = min(32 + q31, DH);                    // channel rows of the two O^T tiles; rows >= DH of tile 1 read the ones
+    // ---- K, V of the head: global -> LDS by LDS-DMA, 12 NT instructions shared by the waves; rows past L: a copy of the last
+    // row (finite; those keys get -inf / probability 0) ----
+    for (int e = w; e < 12 * NT; e += NW) {
+        const _Float16* src; _Float16* dst;
+        if (e < 6 * NT) {                                          // K: plane p, slice s, 32 keys kg; lane = (key, k-half)
+            const int p = e / (3 * NT), r = e - p * 3 * NT, sl = r / NT, kg = r - sl * NT;
+            const int key = min(32 * kg + (lane >> 1), L - 1);
+            src = (p ? qkv_l : qkv_h) + (tok0 + key) * ld + D + h * DH + 16 * sl + 8 * (lane & 1);
+            dst = Kp + ((size_t)(p * KS + sl) * Lpad + 32 * kg) * 16;
+        } else {                                                   // V: 64 consecutive 16-byte pieces of the [key][hi | lo] image
+            const int i = e - 6 * NT, P = 64 * i + lane, key = min(P / 12, L - 1), wi = P % 12;
+            src = (wi >= 6 ? qkv_l : qkv_h) + (tok0 + key) * ld + 2 * D + h * DH + 8 * (wi % 6);
+            dst = Vr + (size_t)64 * i * 8;
+        }
+        __builtin_amdgcn_global_load_lds((h3_glb_void*)src, (h3_lds_void*)dst, 16, 0, 0);
+    }
+    // the first query tile's fragments: lane = query, 8 consecutive k per slice, as stored
+    h16x8 qh[KS], ql[KS];
+    auto load_q = [&](int qt) {
+        const size_t o = (tok0 + min(32 * qt + q31, L - 1)) * ld + h * DH + g * 8;
+#pragma unroll
+        for (int s = 0; s < KS; ++s) { qh[s] = *reinterpret_cast<const h16x8*>(qkv_h + o + 16 * s); ql[s] = *reinterpret_cast<const h16x8*>(qkv_l + o + 16 * s); }
+    };
+    load_q(w);
+    for (int k = tid; k < Lpad; k += nthr) {
+        const uint8_t mk = (MASKED && key_mask != nullptr) ? key_mask[tok0 + min(k, L - 1)] : (uint8_t)1;
+        madd[k] = (k < L) ? (mk ? 0.0f : -1e9f * LOG2E) : -INFINITY;
+    }
+    if (tid < 32) ones[tid] = tid < 16 ? (_Float16)1.0f : (_Float16)0.0f;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");               // this wave's DMAs have landed ...
+    __syncthreads();                                               // ... and everybody else's
+
+    // V^T fragment reads (ds_read_b64_tr_b16): the 16 lanes of a group (g = lane >> 5, channel base 16 ((lane >> 4) & 1)) address a
+    // block of 4 keys x 16 channels, lane 4 q + p of the group the 8 bytes of key q, channels 4 p .. 4 p + 3, and lane i
+    // receives channel i of the 4 keys.  Tile A = channels 0-31; tile B = channels 32-47 for the first group, the ones / zeros
+    // block (plane hi / lo) for the second.
+    const int grp = (lane >> 4) & 1, vq = (lane >> 2) & 3, vp = lane & 3;
+    const unsigned vA = (unsigned)(uintptr_t)(h3_lds_void*)(Vr + (size_t)(4 * g + vq) * VROW + 16 * grp + 4 * vp);
+    const unsigned vB_real = (unsigned)(uintptr_t)(h3_lds_void*)(Vr + (size_t)(4 * g + vq) * VROW + 32 + 4 * vp);
+    const unsigned vB_ones = (unsigned)(uintptr_t)(h3_lds_void*)(ones + 4 * vp);
+
 
     for (int qt = w; qt < NT; qt += NW) {                          // MAXW <= 3: exactly one pass
-        // ---- Q^T fragments of this tile: lane = query, 8 consecutive k per slice, pre-scaled, split in registers; the next
-        // tile's rows are requested right away ----
-        h16x8 qh[KS], ql[KS];
-#pragma unroll
-        for (int s = 0; s < KS; ++s) {
-            h16x4 a, bq, c, d;
-            h3_split(qx[s][0] * cscale, a, c); h3_split(qx[s][1] * cscale, bq, d);
-            qh[s] = (h16x8){a[0], a[1], a[2], a[3], bq[0], bq[1], bq[2], bq[3]};
-            ql[s] = (h16x8){c[0], c[1], c[2], c[3], d[0], d[1], d[2], d[3]};
-        }
-        if (MAXW > 3 && qt + NW < NT) load_q(qt + NW);          // (MAXW <= 3 instantiation: one wave per tile, launched with NW = NT)
+        // (the next tile's query fragments are requested at the end of this one: MAXW > 3 only)
         f32x16 oA0, oA1, oB0, oB1;                                 // O^T tiles (channels 0-31 / 32-47 + l), hi-hi and cross-term accumulators
 #pragma unroll
         for (int r = 0; r < 16; ++r) { oA0[r] = 0.f; oA1[r] = 0.f; oB0[r] = 0.f; oB1[r] = 0.f; }
@@ -210,13 +190,24 @@ attn_h3_kernel(const float* __restrict__ qkv, const int ld, const int D, const i
 #pragma unroll
             for (int s = 0; s < 2; ++s) {
                 if (s == 1 && 32 * kt + 16 >= L) break;           // the step holds padding keys only (p = 0)
-                const int key0 = 32 * kt + 16 * s + 4 * g;
-                auto vfrag = [&](int d, int plane) {
-                    const _Float16* vp = Vt + (size_t)(plane * (DH + 1) + d) * RS + key0;
-                    const h16x4 a = *reinterpret_cast<const h16x4*>(vp), c = *reinterpret_cast<const h16x4*>(vp + 8);
-                    return (h16x8){a[0], a[1], a[2], a[3], c[0], c[1], c[2], c[3]};
-                };
-                const h16x8 vAh = vfrag(dA, 0), vAl = vfrag(dA, 1), vBh = vfrag(dB, 0), vBl = vfrag(dB, 1);
+                const unsigned ko = (unsigned)((32 * kt + 16 * s) * VROW * 2);     // byte offset of the step's first key row
+                const unsigned aA = vA + ko, aB = (grp ? vB_ones : vB_real) + (grp ? 0u : ko);
+                typedef _Float16 h16x4v __attribute__((ext_vector_type(4)));
+                h16x4v a0, a1, a2, a3, b0, b1, b2, b3;             // tile A: hi keys 0-3 / 8-11, lo likewise; tile B the same
+                asm volatile("ds_read_b64_tr_b16 %0, %4\n\tds_read_b64_tr_b16 %1, %4 offset:%6\n\t"
+                             "ds_read_b64_tr_b16 %2, %4 offset:%5\n\tds_read_b64_tr_b16 %3, %4 offset:%7"
+                             : "=&v"(a0), "=&v"(a1), "=&v"(a2), "=&v"(a3) : "v"(aA), "i"(DH * 2), "i"(8 * VROW * 2), "i"(8 * VROW * 2 + DH * 2) : "memory");
+                // tile B: the second group's block does not move with the key (stride 0), so the +8-keys read takes its own address
+                const unsigned aB8 = aB + (grp ? 0u : (unsigned)(8 * VROW * 2));
+                const unsigned lo_off = grp ? 32u : (unsigned)(DH * 2);             // ones -> zeros block / hi -> lo half of the row
+                asm volatile("ds_read_b64_tr_b16 %0, %4\n\tds_read_b64_tr_b16 %1, %5\n\t"
+                             "ds_read_b64_tr_b16 %2, %6\n\tds_read_b64_tr_b16 %3, %7"
+                             : "=&v"(b0), "=&v"(b1), "=&v"(b2), "=&v"(b3) : "v"(aB), "v"(aB8), "v"(aB + lo_off), "v"(aB8 + lo_off) : "memory");
+                asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(b0), "+v"(b1), "+v"(b2), "+v"(b3) :: "memory");
+                const h16x8 vAh = (h16x8){a0[0], a0[1], a0[2], a0[3], a1[0], a1[1], a1[2], a1[3]};
+                const h16x8 vAl = (h16x8){a2[0], a2[1], a2[2], a2[3], a3[0], a3[1], a3[2], a3[3]};
+                const h16x8 vBh = (h16x8){b0[0], b0[1], b0[2], b0[3], b1[0], b1[1], b1[2], b1[3]};
+                const h16x8 vBl = (h16x8){b2[0], b2[1], b2[2], b2[3], b3[0], b3[1], b3[2], b3[3]};
                 oA0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(vAh, ph[s], oA0, 0, 0, 0);
                 oA1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(vAh, pl[s], oA1, 0, 0, 0);
                 oA1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(vAl, ph[s], oA1, 0, 0, 0);
@@ -225,11 +216,12 @@ attn_h3_kernel(const float* __restrict__ qkv, const int ld, const int D, const i
                 oB1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(vBl, ph[s], oB1, 0, 0, 0);
             }
         }
+        if (MAXW > 3 && qt + NW < NT) load_q(qt + NW);          // (MAXW <= 3 instantiation: one wave per tile, launched with NW = NT)
         // ---- normalise, split, store: lane (query, g) holds channels 32 t + 8 j + 4 g + (0..3); rows 16 + 4 g of the second
         // tile (register 8) are the ones-row product = the row sum l, with the same 2^14 factor as every other row ----
         const float rl = 1.0f / (oB0[8] + oB1[8] * (1.0f / H3_SCALE));
         const int q = 32 * qt + q31;
-        _Float16* orow = out + (size_t)(b * L + min(q, L - 1)) * ldo + h * DH;
+        _Float16* orow = out + (tok0 + min(q, L - 1)) * ldo + h * DH;
         auto pack4 = [&](const f32x16& a0, const f32x16& a1, int j, unsigned (&hi2)[2], unsigned (&lo2)[2]) {
             _Float16 hh[4], ll[4];
 #pragma unroll

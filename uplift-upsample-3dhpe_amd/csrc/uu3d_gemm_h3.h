@@ -230,6 +230,20 @@ struct EpBiasReluSplit {
     }
 };
 
+// y = acc + bias, the first `qcols` columns (q of a [q | k | v] projection) times qscale = log2(e) / sqrt(d_h), stored as the two
+// planes attn_h3_kernel reads (uu3d_attn_h3.h: no splitting and no scaling left for the attention kernel to do).
+struct EpBiasSplitQ {
+    _Float16* __restrict__ Oh; _Float16* __restrict__ Ol; const float* __restrict__ bias; int ldo, qcols; float qscale;
+    __device__ __forceinline__ float2 colv(int col) const { return make_float2(bias[col], col < qcols ? qscale : 1.0f); }
+    __device__ __forceinline__ float2 pre(int, int) const { return make_float2(0.f, 0.f); }
+    __device__ __forceinline__ void store(int row, int col, float acc, float2 cv, float2) const {
+        const float v = (acc + cv.x) * cv.y;
+        const _Float16 h = h3_hi(v);
+        Oh[(size_t)row * ldo + col] = h;
+        Ol[(size_t)row * ldo + col] = (_Float16)((v - (float)h) * H3_SCALE);
+    }
+};
+
 // ------------------------------------------------------------------------------------------------
 // The pre-split GEMM, staged by LDS-DMA: the four planes of a k-tile go global -> LDS with
 // global_load_lds_dwordx4 (no VGPR staging, no ds_write pass), three LDS buffers, tile kt+2 in flight

@@ -75,6 +75,16 @@ struct PanelEpBias {           // out[row][col] = v
         *reinterpret_cast<float*>(reinterpret_cast<char*>(out) + b) = v;
     }
 };
+struct PanelEpBiasSplitQ {     // [q | k | v] as row-major hi / lo planes for attn_h3_kernel; q (columns < qcols) times qscale = log2(e) / sqrt(d_h)
+    _Float16* __restrict__ Oh; _Float16* __restrict__ Ol; int ldo, qcols; float qscale;
+    __device__ __forceinline__ void store(int row, int col, float x) const {
+        const float v = col < qcols ? x * qscale : x;
+        const _Float16 h = h3_hi(v);
+        const unsigned b = ((unsigned)row * (unsigned)ldo + (unsigned)col) * 2u;
+        *reinterpret_cast<_Float16*>(reinterpret_cast<char*>(Oh) + b) = h;
+        *reinterpret_cast<_Float16*>(reinterpret_cast<char*>(Ol) + b) = (_Float16)((v - (float)h) * H3_SCALE);
+    }
+};
 struct PanelEpBiasReluSplit {  // ReLU(v) as row-major hi / lo planes [M][ldo] (the A operand of the tiled LDS-DMA kernel)
     _Float16* __restrict__ Oh; _Float16* __restrict__ Ol; int ldo;
     __device__ __forceinline__ void store(int row, int col, float x) const {
