@@ -1,0 +1,74 @@
+"""End-to-end evaluation driver (uplift-upsample-3dhpe_amd/eval.py = the reference's eval.py:34-270) on the tiny Human3.6M
+fixture: .npz ingestion -> resident pose table -> window descriptors -> device gather -> flip-batched forward -> all-masked
+windows skipped -> interpolation -> ALL FRAMES / KEYFRAMES reports, against the SAME protocol run the reference's way (every
+window forwarded, two model calls per batch) with the CPU oracle as the model."""
+import os
+
+import numpy as np
+import pytest
+
+import uplift_upsample_3dhpe_amd as pkg
+from tests import util
+
+torch = pytest.importorskip("torch")
+pytestmark = pytest.mark.gpu
+G = os.path.join(util.ROOT, "tests", "golden")
+
+
+def _oracle_reports(cfg, arch, w, msv, action_wise):
+    """eval.py's loop with the oracle: all windows, flip as a second call, then the report bookkeeping."""
+    from oracle import uplift_oracle as O
+    from uplift_upsample_3dhpe_amd import evaluation, h36m
+    from uplift_upsample_3dhpe_amd.data import SequenceGenerator
+    c = cfg.copy(); c.MASK_STRIDE = msv
+    ds, p2 = h36m.load_dataset_and_2d_poses(os.path.join(G, "h36m_tiny_3d.npz"), os.path.join(G, "h36m_tiny_2d.npz"), verbose=False)
+    cams, p3d, p2d, _, subj, act, fps = h36m.filter_and_subsample_dataset(ds, p2, ["S9"], "*", verbose=False)
+    table = h36m.pose_table(p2d, p3d, subj, act, fps)
+    gen = SequenceGenerator(table, seq_len=c.SEQUENCE_LENGTH, subsample=c.DATASET_TEST_3D_SUBSAMPLE_STEP, stride=c.SEQUENCE_STRIDE,
+                            padding_type=c.PADDING_TYPE, flip_augment=False, mask_stride=msv, stride_mask_align_global=True, shuffle=False)
+    desc = gen.descriptors()
+    b = gen.gather(desc, zero_masked=False, with_3d=True)           # raw windows: the oracle's test_step masks them itself
+    x = b["kp2d"].cpu().numpy(); m = b["stride_mask"].cpu().numpy().astype(bool)
+    _, cen = O.eval_step_with_flip(util.hp_from_arch(arch), w, x, m, c.AUGM_FLIP_KEYPOINT_ORDER)
+    gt = b["kp3d"].cpu().numpy()[:, c.SEQUENCE_LENGTH // 2]
+    gt = gt - gt[:, c.ROOT_KEYTPOINT:c.ROOT_KEYTPOINT + 1]
+    return evaluation.evaluate_predictions(cen, gt, b["actions"], b["index"], c, action_wise=action_wise), len(desc)
+
+
+@pytest.mark.parametrize("cfgname,action_wise", [("h36m_81", True), ("h36m_351", False)])
+def test_run_eval_matches_the_reference_protocol(cfgname, action_wise):
+    from uplift_upsample_3dhpe_amd import eval as ev
+    cfg = util.load_config(cfgname)
+    cfg.BATCH_SIZE = 16
+    arch = pkg.arch_from_config(cfg)
+    w = pkg.init_weights(arch, seed=2, perturb=0.1)
+    model = pkg.build_uplift_upsample_transformer(cfg, weights=w)
+    lines = []
+    res = ev.run_eval_multi_mask_stride(cfg, "h36m", os.path.join(G, "h36m_tiny_3d.npz"), os.path.join(G, "h36m_tiny_2d.npz"), "S9",
+                                        model=model, action_wise=action_wise, log=lambda *a: lines.append(" ".join(map(str, a))))
+    assert sorted(res) == sorted(cfg.MASK_STRIDE)
+    assert any("ALL FRAMES" in l for l in lines) and any("KEYFRAMES" in l for l in lines)
+    for msv, r in res.items():
+        ref, n = _oracle_reports(cfg, arch, w, msv, action_wise)
+        assert r["num_windows"] == n and r["num_forwarded"] < n           # non-keyframe windows are never forwarded
+        for part in ("all_frames", "keyframes"):
+            got, want = r[part], ref[part]
+            assert (got is None) == (want is None)
+            if got is None:
+                continue
+            gf, wf = (got[0], want[0]) if action_wise else (got, want)
+            for k in wf:
+                assert abs(gf[k] - wf[k]) <= util.TOL_MPJPE_MM, (msv, part, k, gf[k], wf[k])
+            if action_wise:
+                for k in want[1]:
+                    if np.isfinite(want[1][k]):
+                        assert abs(got[1][k] - want[1][k]) <= util.TOL_MPJPE_MM
+    # every window forwarded (the reference's way) gives the same report: the skipped forwards are never read
+    cfg1 = cfg.copy(); cfg1.MASK_STRIDE = cfg.MASK_STRIDE[0]
+    a = ev.run_eval(cfg1, "h36m", os.path.join(G, "h36m_tiny_3d.npz"), os.path.join(G, "h36m_tiny_2d.npz"), "S9", model=model,
+                    action_wise=False, log=lambda *a: None)
+    bfull = ev.run_eval(cfg1, "h36m", os.path.join(G, "h36m_tiny_3d.npz"), os.path.join(G, "h36m_tiny_2d.npz"), "S9", model=model,
+                        action_wise=False, skip_unused_windows=False, log=lambda *a: None)
+    assert bfull["num_forwarded"] == bfull["num_windows"] > a["num_forwarded"]
+    for k in a["all_frames"]:
+        assert abs(a["all_frames"][k] - bfull["all_frames"][k]) <= 1e-3       # mm: identical windows, batches composed differently
