@@ -729,7 +729,9 @@ struct Launcher {
         const int KT = K / 32;
         const int tiles = ((M + 63) / 64) * ((N + 63) / 64);
         int slices = 1;
-        if (tiles < 384 && KT >= 8) slices = std::max(1, std::min(KT / 4, (768 + tiles / 2) / tiles));
+        // (>= 200 tiles with a short contraction fill the chip unsplit: strided block 2's projection, 276 tiles x 12 k-tiles,
+        // 13.3 us against 12.6 + 6.5 us split three ways + reduce; the heads and the K = 2304 convolutions measured faster split)
+        if (tiles < 384 && KT >= 8 && !(tiles >= 200 && KT <= 16)) slices = std::max(1, std::min(KT / 4, (768 + tiles / 2) / tiles));
         int kps = (KT + slices - 1) / slices;
         slices = (KT + kps - 1) / kps;
         const int ldslab = round_up(N, 4);
@@ -794,7 +796,9 @@ struct Launcher {
         const int Kp = round_up(K, 32), KT = Kp / 32;
         const int tiles = ((M + 63) / 64) * ((N + 63) / 64);
         int slices = 1;
-        if (tiles < 384 && KT >= 8) slices = std::max(1, std::min(KT / 4, (768 + tiles / 2) / tiles));
+        // (>= 200 tiles with a short contraction fill the chip unsplit: strided block 2's projection, 276 tiles x 12 k-tiles,
+        // 13.3 us against 12.6 + 6.5 us split three ways + reduce; the heads and the K = 2304 convolutions measured faster split)
+        if (tiles < 384 && KT >= 8 && !(tiles >= 200 && KT <= 16)) slices = std::max(1, std::min(KT / 4, (768 + tiles / 2) / tiles));
         int kps = (KT + slices - 1) / slices;
         slices = (KT + kps - 1) / kps;
         const int ldslab = round_up(N, 4);
@@ -876,6 +880,8 @@ struct Launcher {
 
     // sequences served by attn_h3_kernel (f16x3 products, online softmax; q / k / v as f16 planes from the QKV epilogue): everything
     // the exact-f32 kernels cannot hold (> 128 tokens) and, measured faster, 49-128 tokens as well
+    // (shorter sequences, h36m_81's 41 tokens: the split epilogue of the QKV projection costs more than the attention gains -- 242.1 k
+    // sequences/s with the exact-f32 kernels there against 240.2 k)
     bool attn_is_h3(int L, bool planes_out) const { return planes_out && L <= ATTN_H3_MAX_L && (L > 128 || (L > 48 && !m->attn_f32)); }
     float attn_qscale() const { return 1.44269504088896341f / sqrtf((float)kDH); }
     // split_lo_off != 0: the context rows go out as f16 planes (hi at out, lo split_lo_off halfs further)
