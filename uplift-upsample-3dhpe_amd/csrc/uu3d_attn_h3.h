@@ -216,7 +216,7 @@ attn_h3_kernel(const _Float16* __restrict__ qkv_h, const _Float16* __restrict__ 
                 oB1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(vBl, ph[s], oB1, 0, 0, 0);
             }
         }
-        if (MAXW > 3 && qt + NW < NT) load_q(qt + NW);          // (MAXW <= 3 instantiation: one wave per tile, launched with NW = NT)
+        if (MAXW == 8 && qt + NW < NT) load_q(qt + NW);         // (the other instantiations are launched with one wave per tile)
         // ---- normalise, split, store: lane (query, g) holds channels 32 t + 8 j + 4 g + (0..3); rows 16 + 4 g of the second
         // tile (register 8) are the ones-row product = the row sum l, with the same 2^14 factor as every other row ----
         const float rl = 1.0f / (oB0[8] + oB1[8] * (1.0f / H3_SCALE));
