@@ -661,7 +661,8 @@ inline bool spatial_h3_pays(int frames) {
     // (the f16x3 kernel's round has since come down to ~86 us: 171 us for the two rounds of h36m_351 at batch 128; at the
     // one shape where the choice flips, h36m_81 at batch 256, the two kernels tie with every frame real, 145 vs 141 us, and
     // the f16x3 one wins whenever frames are masked, 67 vs 113 us at s_in = 10)
-    const int t_h3 = ((waves + 1535) / 1536) * 86, t_f32 = ((waves + 1791) / 1792) * 133;
+    // (round 2, packed-f32 VALU work: ~81 us per round, 164 us for h36m_351 at batch 128)
+    const int t_h3 = ((waves + 1535) / 1536) * 81, t_f32 = ((waves + 1791) / 1792) * 133;
     return t_h3 <= t_f32;
 }
 

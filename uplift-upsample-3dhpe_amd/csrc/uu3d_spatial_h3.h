@@ -20,6 +20,18 @@
 //     - everything a lane writes to LDS (LayerNorm output, attention output, GELU output as f16 planes, K and V
 //       as f32) is a group of 4 consecutive channels: one 8- or 16-byte store.
 //   A workgroup is one wave, so LDS traffic is ordered by the wave itself and there is no barrier at all.
+//
+// * Round 2: the kernel is VALU bound (19 k VALU instructions per wave against 384 MFMAs; SQ counters in
+//   profiles/r02_final_sq_summary.csv), so its elementwise work runs on PACKED f32 instructions (v_pk_fma_f32 /
+//   v_pk_mul_f32 / v_pk_add_f32: two floats per lane and instruction) written by name:
+//     - a lane's 16 channels of a token live as 8 register PAIRS of consecutive channels -- the layout the MFMA result
+//       registers already have -- so LayerNorm, bias / residual adds, the hi / lo split, GELU and the acc0 + acc1 / 2048
+//       combine are pair operations; per-token scalars (mean, rstd, maximum) are splatted into a pair once;
+//     - attention pairs KEYS instead: K and V sit in LDS as [frame][key pair][channel][2], so (logit j, logit j + 1) =
+//       sum_c (q_c, q_c) * (k_jc, k_j+1,c) and the P V sums run over even / odd keys in the two halves;
+//     - none of these instructions carries op_sel / op_sel_hi: the form that loses an operand next to a busy matrix pipe
+//        reads the OTHER half of a register pair, which only those modifiers do.  hipcc itself
+//       still never emits packed f32 (target feature off); tests/test_isa_cpu.py pins both facts.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <hip/hip_fp16.h>
@@ -27,6 +39,10 @@
 #include <math.h>
 #include "uu3d_gemm_h3.h"
 #include "uu3d_spatial.h"
+
+#ifndef UU3D_SP_SKIP
+#define UU3D_SP_SKIP 0      // tools/spatial_stamp_exp: leave a phase out (1 attention, 2 GELU, 3 LayerNorms, 4 parameter copy after block 0, 5 hi/lo splits) to time it by difference
+#endif
 
 namespace uu3d {
 
@@ -41,10 +57,13 @@ struct SpatialFragLayoutH3 {
 };
 
 namespace sh3 {
-constexpr int ROWS_T = 52;       // 51 tokens + one dummy row that out-of-range tokens read and write
+constexpr int TOK = 27;          // token slots per 32-lane tile: 3 frames x 9 joints (tile 0: joints 0..8, tile 1: joints 9..16 + one spare)
+constexpr int ROWS_T = 2 * TOK + 1;   // rows of the LDS operand tiles: 54 token slots + one dummy row for lanes 27..31
+__device__ __forceinline__ int tile_row(const int mt, const int tl) { return tl < TOK ? TOK * mt + tl : ROWS_T - 1; }
 constexpr int XLD = 40;          // halfs per row of the K = 32 operand tile (80 B: conflict-free 16-byte reads)
 constexpr int HLD = 72;          // halfs per row of the K = 64 hidden tile (144 B)
-constexpr int KLD = 36;          // floats per row of the K / V tiles
+constexpr int KLD = 36;          // floats per token row the K / V region is sized by (the hidden planes reuse it)
+constexpr int KPLD = 68;         // floats per key pair of a frame: [32 channels][2 keys] + 4 (272 B: 16-byte aligned, pairs 4 banks apart)
 constexpr int NPARAM = 352;     // LayerNorm parameters and biases of one block (SpatialBlockLayoutV2 up to fq)
 constexpr size_t lds_bytes() { return (size_t)2 * ROWS_T * XLD * 2 + (size_t)2 * ROWS_T * KLD * 4 + NPARAM * 4; }
 static_assert(2 * ROWS_T * HLD * 2 == 2 * ROWS_T * KLD * 4, "the hidden planes reuse the K / V tiles byte for byte");
@@ -76,9 +95,31 @@ __device__ __forceinline__ void wait_w(WFrag<NT, KK>& w) {
         asm volatile("s_waitcnt vmcnt(%8)" : "+v"(w.h[0][0]), "+v"(w.l[0][0]), "+v"(w.h[0][1]), "+v"(w.l[0][1]),
                      "+v"(w.h[NT - 1][KK - 2]), "+v"(w.l[NT - 1][KK - 2]), "+v"(w.h[NT - 1][KK - 1]), "+v"(w.l[NT - 1][KK - 1]) : "i"(NLATER));
 }
+// ---- packed f32 arithmetic by name (see the header): d = a op b on both halves of a register pair, no op_sel ----
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef _Float16 h16x2 __attribute__((ext_vector_type(2)));
+namespace pk {
+__device__ __forceinline__ f32x2 add(const f32x2 a, const f32x2 b) { f32x2 d; asm("v_pk_add_f32 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b)); return d; }
+__device__ __forceinline__ f32x2 sub(const f32x2 a, const f32x2 b) { f32x2 d; asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(d) : "v"(a), "v"(b)); return d; }
+__device__ __forceinline__ f32x2 mul(const f32x2 a, const f32x2 b) { f32x2 d; asm("v_pk_mul_f32 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b)); return d; }
+__device__ __forceinline__ f32x2 fma(const f32x2 a, const f32x2 b, const f32x2 c) { f32x2 d; asm("v_pk_fma_f32 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c)); return d; }
+__device__ __forceinline__ f32x2 fnma(const f32x2 a, const f32x2 b, const f32x2 c) {          // c - a * b (one rounding)
+    f32x2 d; asm("v_pk_fma_f32 %0, %1, %2, %3 neg_lo:[1,0,0] neg_hi:[1,0,0]" : "=v"(d) : "v"(a), "v"(b), "v"(c)); return d;
+}
+__device__ __forceinline__ f32x2 splat(const float v) { return (f32x2){v, v}; }
+// A transcendental result (v_exp / v_rcp / v_rsq / v_sqrt) may not be read by the next non-transcendental VALU instruction
+// (gfx940+: one wait state, software's to insert); hipcc covers its own instructions, not inline asm readers.  fence() sits
+// between such results and the packed ops that read them.
+__device__ __forceinline__ void fence(f32x2& a) { asm volatile("s_nop 0" : "+v"(a)); }
+__device__ __forceinline__ void fence(f32x2& a, f32x2& b) { asm volatile("s_nop 0" : "+v"(a), "+v"(b)); }
+}  // namespace pk
+
+// C^T tiles of W^T X^T for NT output tiles (32 channels each) and both token tiles; K = 16 * KK.
+// out[nt][mt][i] = the pair of registers (2 i, 2 i + 1): token = 32 mt + (lane & 31), channels 32 nt + 8 (i >> 1) +
+// 4 (lane >> 5) + 2 (i & 1) and the next one.
 template <int NT, int KK>
 __device__ __forceinline__ void mm(const WFrag<NT, KK>& w, const _Float16* Bh, const _Float16* Bl, const int ldb,
-                                   const int lane, float (&out)[NT][2][16]) {
+                                   const int lane, f32x2 (&out)[NT][2][8]) {
     f32x16 acc0[NT][2], acc1[NT][2];
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt)
@@ -92,7 +133,7 @@ __device__ __forceinline__ void mm(const WFrag<NT, KK>& w, const _Float16* Bh, c
         h16x8 bh[2], bl[2];
 #pragma unroll
         for (int mt = 0; mt < 2; ++mt) {
-            const int row = min(32 * mt + tl, ROWS_T - 1);
+            const int row = tile_row(mt, tl);
             bh[mt] = *reinterpret_cast<const h16x8*>(Bh + row * ldb + 16 * kk + 8 * half);
             bl[mt] = *reinterpret_cast<const h16x8*>(Bl + row * ldb + 16 * kk + 8 * half);
         }
@@ -105,189 +146,227 @@ __device__ __forceinline__ void mm(const WFrag<NT, KK>& w, const _Float16* Bh, c
                 acc1[nt][mt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w.l[nt][kk], bh[mt], acc1[nt][mt], 0, 0, 0);
             }
     }
+    // The MFMA -> VALU read hazard is software's to cover (8-pass MFMA: 11 wait states, a 16-pass one 19), and hipcc does not
+    // cover it for inline asm readers: without these 20 wait states the packed ops below read the accumulators too early (NaN
+    // in every output).  The operands tie the asm between the MFMAs and every reader.
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+        asm volatile("s_nop 15\n\ts_nop 3" : "+v"(acc0[nt][0]), "+v"(acc1[nt][0]), "+v"(acc0[nt][1]), "+v"(acc1[nt][1]));
+    const f32x2 inv = pk::splat(1.0f / H3_SCALE);
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
         for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) out[nt][mt][r] = acc0[nt][mt][r] + acc1[nt][mt][r] * (1.0f / H3_SCALE);
+            for (int i = 0; i < 8; ++i)
+                out[nt][mt][i] = pk::fma((f32x2){acc1[nt][mt][2 * i], acc1[nt][mt][2 * i + 1]}, inv,
+                                         (f32x2){acc0[nt][mt][2 * i], acc0[nt][mt][2 * i + 1]});
 }
 
-// C^T tiles of W^T X^T for NT output tiles (32 channels each) and both token tiles; K = 16 * KK.
-// out[nt][mt][r]: token = 32 mt + (lane & 31), channel = 32 nt + 8 (r >> 2) + 4 (lane >> 5) + (r & 3).
-template <int NT, int KK>
-__device__ __forceinline__ void mm(const _Float16* __restrict__ wf, const _Float16* Bh, const _Float16* Bl, const int ldb,
-                                   const int lane, float (&out)[NT][2][16]) {
-    f32x16 acc0[NT][2], acc1[NT][2];
+// v[l] + v[l ^ 32] with v = p.x + p.y, in every lane: one v_permlane32_swap (lanes 32..63 of the first operand <-> lanes 0..31 of the second)
+// instead of a ds_bpermute round trip through LDS
+// The pair's own two halves are added by name: left to hipcc, "p.x + p.y, twice" (the swap consumes two copies) becomes ONE
+// v_pk_add_f32 with op_sel:[0,1] op_sel_hi:[1,0] -- the cross-half form this kernel must not contain.
+__device__ __forceinline__ float sum_halves(const f32x2 p) {
+    typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+    float v;
+    asm("v_add_f32 %0, %1, %2\n\ts_nop 1" : "=v"(v) : "v"(p[0]), "v"(p[1]));      // + wait states hipcc would put between a VALU write and the lane swap reading it
+    const u32x2 r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+
+// LayerNormalization over the 32 channels of each of the lane's two tokens (16 here, 16 in lane ^ 32); the arithmetic of
+// ln_row (non-fused Keras path: inv = rstd * gamma, y = x * inv + (beta - mean * inv)) on channel pairs, the two moments summed
+// over even / odd channels first
+__device__ __forceinline__ void ln_tokens(const f32x2 (&x)[2][8], const float* g, const float* b,
+                                          const float eps, const int half, f32x2 (&y)[2][8]) {
+    f32x2 gp[8], bp[8];
 #pragma unroll
-    for (int nt = 0; nt < NT; ++nt)
-#pragma unroll
-        for (int mt = 0; mt < 2; ++mt)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) { acc0[nt][mt][r] = 0.f; acc1[nt][mt][r] = 0.f; }
-    const int tl = lane & 31, half = lane >> 5;
-#pragma unroll
-    for (int kk = 0; kk < KK; ++kk) {
-        h16x8 bh[2], bl[2];
-#pragma unroll
-        for (int mt = 0; mt < 2; ++mt) {
-            const int row = min(32 * mt + tl, ROWS_T - 1);
-            bh[mt] = *reinterpret_cast<const h16x8*>(Bh + row * ldb + 16 * kk + 8 * half);
-            bl[mt] = *reinterpret_cast<const h16x8*>(Bl + row * ldb + 16 * kk + 8 * half);
-        }
-#pragma unroll
-        for (int nt = 0; nt < NT; ++nt) {
-            const h16x8 ah = reinterpret_cast<const h16x8*>(wf)[((nt * KK + kk) * 2 + 0) * 64 + lane];
-            const h16x8 al = reinterpret_cast<const h16x8*>(wf)[((nt * KK + kk) * 2 + 1) * 64 + lane];
-#pragma unroll
-            for (int mt = 0; mt < 2; ++mt) {
-                acc0[nt][mt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh[mt], acc0[nt][mt], 0, 0, 0);
-                acc1[nt][mt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl[mt], acc1[nt][mt], 0, 0, 0);
-                acc1[nt][mt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh[mt], acc1[nt][mt], 0, 0, 0);
-            }
-        }
+    for (int gq = 0; gq < 4; ++gq) {
+        const f32x4 g4 = *reinterpret_cast<const f32x4*>(g + 8 * gq + 4 * half);
+        const f32x4 b4 = *reinterpret_cast<const f32x4*>(b + 8 * gq + 4 * half);
+        gp[2 * gq] = (f32x2){g4[0], g4[1]}; gp[2 * gq + 1] = (f32x2){g4[2], g4[3]};
+        bp[2 * gq] = (f32x2){b4[0], b4[1]}; bp[2 * gq + 1] = (f32x2){b4[2], b4[3]};
     }
-#pragma unroll
-    for (int nt = 0; nt < NT; ++nt)
-#pragma unroll
-        for (int mt = 0; mt < 2; ++mt)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) out[nt][mt][r] = acc0[nt][mt][r] + acc1[nt][mt][r] * (1.0f / H3_SCALE);
-}
-
-// LayerNormalization over the 32 channels of each of the lane's two tokens (16 here, 16 in lane ^ 32); same
-// arithmetic as ln_row (non-fused Keras path: inv = rstd * gamma, y = x * inv + (beta - mean * inv))
-__device__ __forceinline__ void ln_tokens(const float (&x)[2][16], const float* g, const float* b,
-                                          const float eps, const int half, float (&y)[2][16]) {
-#pragma clang fp contract(off)      // see the kernel: both unrolled token copies must round identically
 #pragma unroll
     for (int mt = 0; mt < 2; ++mt) {
-        float s = 0.f;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) s += x[mt][r];
-        s += __shfl_xor(s, 32);
+        const f32x2 s2 = pk::add(pk::add(pk::add(x[mt][0], x[mt][1]), pk::add(x[mt][2], x[mt][3])),
+                                 pk::add(pk::add(x[mt][4], x[mt][5]), pk::add(x[mt][6], x[mt][7])));
+        const float s = sum_halves(s2);
         const float mean = s * (1.0f / 32.0f);
-        float q = 0.f;
+        const f32x2 m2 = pk::splat(mean);
+        f32x2 q2;
+        { const f32x2 d = pk::sub(x[mt][0], m2); q2 = pk::mul(d, d); }
 #pragma unroll
-        for (int r = 0; r < 16; ++r) { const float d = x[mt][r] - mean; q = fmaf(d, d, q); }
-        q += __shfl_xor(q, 32);
-        const float rstd = 1.0f / sqrtf(q * (1.0f / 32.0f) + eps);
+        for (int i = 1; i < 8; ++i) { const f32x2 d = pk::sub(x[mt][i], m2); q2 = pk::fma(d, d, q2); }
+        const float q = sum_halves(q2);
+        const f32x2 r2 = pk::splat(1.0f / sqrtf(q * (1.0f / 32.0f) + eps));
 #pragma unroll
-        for (int gq = 0; gq < 4; ++gq) {
-            const f32x4 g4 = *reinterpret_cast<const f32x4*>(g + 8 * gq + 4 * half);
-            const f32x4 b4 = *reinterpret_cast<const f32x4*>(b + 8 * gq + 4 * half);
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const float inv = rstd * g4[e];
-                y[mt][4 * gq + e] = fmaf(x[mt][4 * gq + e], inv, fmaf(-mean, inv, b4[e]));
-            }
+        for (int i = 0; i < 8; ++i) {
+            const f32x2 inv = pk::mul(r2, gp[i]);
+            y[mt][i] = pk::fma(x[mt][i], inv, pk::fnma(m2, inv, bp[i]));
         }
     }
+}
+
+// two consecutive channel pairs -> 4 hi and 4 lo halfs (h3_split's arithmetic; the lo conversion may keep f16 denormals,
+// which the MFMA reads as zero either way)
+__device__ __forceinline__ void split_pairs(const f32x2 a, const f32x2 b, h16x4& hi, h16x4& lo) {
+    if constexpr (UU3D_SP_SKIP == 5) { hi = (h16x4){(_Float16)a[0], (_Float16)a[1], (_Float16)b[0], (_Float16)b[1]}; lo = hi; return; }
+    const _Float16 h0 = h3_hi(a[0]), h1 = h3_hi(a[1]), h2 = h3_hi(b[0]), h3 = h3_hi(b[1]);
+    const f32x2 sc = pk::splat(H3_SCALE);
+    const f32x2 ra = pk::mul(pk::sub(a, (f32x2){(float)h0, (float)h1}), sc);
+    const f32x2 rb = pk::mul(pk::sub(b, (f32x2){(float)h2, (float)h3}), sc);
+    h16x2 la, lb;
+    asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(la) : "v"(ra[0]), "v"(ra[1]));
+    asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(lb) : "v"(rb[0]), "v"(rb[1]));
+    hi = (h16x4){h0, h1, h2, h3};
+    lo = (h16x4){la[0], la[1], lb[0], lb[1]};
 }
 
 // the lane's 2 x 16 values -> hi / lo planes of a row-major tile (row = token, 4-channel groups of 8 bytes)
 __device__ __forceinline__ void store_planes(_Float16* Th, _Float16* Tl, const int ld, const int coloff, const int lane,
-                                             const float (&v)[2][16]) {
+                                             const f32x2 (&v)[2][8]) {
     const int tl = lane & 31, half = lane >> 5;
 #pragma unroll
     for (int mt = 0; mt < 2; ++mt) {
-        const int row = min(32 * mt + tl, ROWS_T - 1);
+        const int row = tile_row(mt, tl);
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
-            const f32x4 f = {v[mt][4 * g], v[mt][4 * g + 1], v[mt][4 * g + 2], v[mt][4 * g + 3]};
             h16x4 hi, lo;
-            h3_split(f, hi, lo);
+            split_pairs(v[mt][2 * g], v[mt][2 * g + 1], hi, lo);
             *reinterpret_cast<h16x4*>(Th + row * ld + coloff + 8 * g + 4 * half) = hi;
             *reinterpret_cast<h16x4*>(Tl + row * ld + coloff + 8 * g + 4 * half) = lo;
         }
     }
 }
 
-// One (token, head): softmax(q k^T / sqrt(d_h)) v over the J keys of the token's frame; Kp / Vp point at the head's 4
-// channels of the frame's first key row.
-#ifndef UU3D_SPATIAL_ATTN_BYNAME
-#define UU3D_SPATIAL_ATTN_BYNAME 1
-#endif
+// One head of the lane's TWO tokens (same frame, see the kernel): softmax(q k^T / sqrt(d_h)) v over the J keys of the frame.
+// ka / va = LDS byte addresses of the head's 4 channels in key pair 0 of the frame; key pair jp is KPLD floats further and
+// holds, per channel c, (key 2 jp, key 2 jp + 1): two ds_read_b128 = channels (c0, c0 + 1) and (c0 + 2, c0 + 3).  Every K / V
+// register feeds both tokens.  J odd: the last pair's second key is a finite dummy whose probability is forced to zero.
 template <int J>
-__device__ __forceinline__ f32x4 head_attention(const f32x4 q4, const float* Kp, const float* Vp) {
+__device__ __forceinline__ void head_attention(const f32x2 (&qa)[2], const f32x2 (&qb)[2], const unsigned ka, const unsigned va,
+                                               f32x2 (&oa)[2], f32x2 (&ob)[2]) {
+    static_assert(J == 17, "9 key pairs, the last one half empty");
+    constexpr int NP = 9;
     // softmax(x) with x = q.k / 2: exp(x - max) = exp2((q * log2e / 2).k - max'), so the scale and the base change are
     // folded into q once; the 1 / sum normalisation is applied to the 4 outputs instead of the 17 probabilities
-    const f32x4 qs = {q4[0] * 0.72134752044448170368f, q4[1] * 0.72134752044448170368f,
-                      q4[2] * 0.72134752044448170368f, q4[3] * 0.72134752044448170368f};
-    float s[J];
-    float mx = -INFINITY;
-    if constexpr (J == 17 && UU3D_SPATIAL_ATTN_BYNAME) {
-        // The 17 key rows and then the 17 value rows of this head by name, all in flight at once, with counted waits (LDS returns
-        // in order; the counter starts from zero and the "memory" clobbers keep other memory operations out, see uu3d_attn.h).
-        // hipcc had emitted read -> wait -> use for every row: 34 exposed LDS round trips per (token, head), 272 per block.
-        f32x4 kv[17];
-        const unsigned ka = (unsigned)(uintptr_t)(__attribute__((address_space(3))) const void*)Kp;
-        const unsigned va = (unsigned)(uintptr_t)(__attribute__((address_space(3))) const void*)Vp;
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    const f32x2 c = pk::splat(0.72134752044448170368f);
+    f32x2 q0[2], q1[2], q2[2], q3[2];
 #pragma unroll
-        for (int j = 0; j < 17; ++j) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(kv[j]) : "v"(ka), "i"(j * KLD * 4) : "memory");
-#define UU3D_SP_W9(x, o) "+v"(x[o]), "+v"(x[o + 1]), "+v"(x[o + 2]), "+v"(x[o + 3]), "+v"(x[o + 4]), "+v"(x[o + 5]), "+v"(x[o + 6]), "+v"(x[o + 7]), "+v"(x[o + 8])
-        asm volatile("s_waitcnt lgkmcnt(8)" : UU3D_SP_W9(kv, 0) :: "memory");
+    for (int t = 0; t < 2; ++t) {
+        const f32x2 sa = pk::mul(qa[t], c), sb = pk::mul(qb[t], c);
+        q0[t] = pk::splat(sa[0]); q1[t] = pk::splat(sa[1]); q2[t] = pk::splat(sb[0]); q3[t] = pk::splat(sb[1]);
+    }
+    // The 18 key reads and then the 18 value reads of this head by name, all in flight at once, with counted waits (LDS returns
+    // in order; the counter starts from zero and the "memory" clobbers keep other memory operations out, see uu3d_attn.h).
+    // hipcc emits read -> wait -> use for every row otherwise.
+    f32x4 kv[2 * NP];
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #pragma unroll
-        for (int j = 0; j < 9; ++j) {
-            float d = qs[0] * kv[j][0];
-            d = fmaf(qs[1], kv[j][1], d); d = fmaf(qs[2], kv[j][2], d); d = fmaf(qs[3], kv[j][3], d);
-            s[j] = d; mx = fmaxf(mx, d);
+    for (int j = 0; j < 2 * NP; ++j)
+        asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(kv[j]) : "v"(ka), "i"((j >> 1) * KPLD * 4 + (j & 1) * 16) : "memory");
+#define UU3D_SP_W10(x, o) "+v"(x[o]), "+v"(x[o + 1]), "+v"(x[o + 2]), "+v"(x[o + 3]), "+v"(x[o + 4]), "+v"(x[o + 5]), "+v"(x[o + 6]), "+v"(x[o + 7]), "+v"(x[o + 8]), "+v"(x[o + 9])
+#define UU3D_SP_W8(x, o) "+v"(x[o]), "+v"(x[o + 1]), "+v"(x[o + 2]), "+v"(x[o + 3]), "+v"(x[o + 4]), "+v"(x[o + 5]), "+v"(x[o + 6]), "+v"(x[o + 7])
+    f32x2 d[2][NP];
+    auto logits = [&](int jp) __attribute__((always_inline)) {       // the scalar kernel's order: q0 k0, then fma over channels 1..3
+        const f32x2 k0 = {kv[2 * jp][0], kv[2 * jp][1]}, k1 = {kv[2 * jp][2], kv[2 * jp][3]};
+        const f32x2 k2 = {kv[2 * jp + 1][0], kv[2 * jp + 1][1]}, k3 = {kv[2 * jp + 1][2], kv[2 * jp + 1][3]};
+#pragma unroll
+        for (int t = 0; t < 2; ++t) d[t][jp] = pk::fma(q3[t], k3, pk::fma(q2[t], k2, pk::fma(q1[t], k1, pk::mul(q0[t], k0))));
+    };
+    asm volatile("s_waitcnt lgkmcnt(8)" : UU3D_SP_W10(kv, 0) :: "memory");
+#pragma unroll
+    for (int jp = 0; jp < 5; ++jp) logits(jp);
+    asm volatile("s_waitcnt lgkmcnt(0)" : UU3D_SP_W8(kv, 10) :: "memory");
+#pragma unroll
+    for (int jp = 5; jp < NP; ++jp) logits(jp);
+#pragma unroll
+    for (int j = 0; j < 2 * NP; ++j)
+        asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(kv[j]) : "v"(va), "i"((j >> 1) * KPLD * 4 + (j & 1) * 16) : "memory");
+    // the value rows arrive meanwhile
+    f32x2 sum2[2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+        float mx = d[t][NP - 1][0];                    // v_max3 by name: fmaxf() first canonicalises every asm result (17 extra v_max per head)
+#pragma unroll
+        for (int jp = 0; jp < NP - 1; ++jp) asm("v_max3_f32 %0, %0, %1, %2" : "+v"(mx) : "v"(d[t][jp][0]), "v"(d[t][jp][1]));
+        const f32x2 m2 = pk::splat(mx);
+#pragma unroll
+        for (int jp = 0; jp < NP; ++jp) {
+            const f32x2 u = pk::sub(d[t][jp], m2);
+            d[t][jp][0] = __builtin_amdgcn_exp2f(u[0]);
+            d[t][jp][1] = jp < NP - 1 ? __builtin_amdgcn_exp2f(u[1]) : 0.f;
         }
-        asm volatile("s_waitcnt lgkmcnt(0)" : UU3D_SP_W9(kv, 8) :: "memory");
+        asm volatile("s_nop 0" : "+v"(d[t][0]), "+v"(d[t][1]), "+v"(d[t][2]), "+v"(d[t][3]), "+v"(d[t][4]), "+v"(d[t][5]), "+v"(d[t][6]), "+v"(d[t][7]), "+v"(d[t][8]));   // pk::fence
+        sum2[t] = pk::add(pk::add(pk::add(d[t][0], d[t][1]), pk::add(d[t][2], d[t][3])), pk::add(pk::add(pk::add(d[t][4], d[t][5]), pk::add(d[t][6], d[t][7])), d[t][8]));
+    }
+    f32x2 o[2][4];
+    asm volatile("s_waitcnt lgkmcnt(8)" : UU3D_SP_W10(kv, 0) :: "memory");
+    auto pv = [&](int jp) __attribute__((always_inline)) {
+        const f32x2 v0 = {kv[2 * jp][0], kv[2 * jp][1]}, v1 = {kv[2 * jp][2], kv[2 * jp][3]};
+        const f32x2 v2 = {kv[2 * jp + 1][0], kv[2 * jp + 1][1]}, v3 = {kv[2 * jp + 1][2], kv[2 * jp + 1][3]};
 #pragma unroll
-        for (int j = 9; j < 17; ++j) {
-            float d = qs[0] * kv[j][0];
-            d = fmaf(qs[1], kv[j][1], d); d = fmaf(qs[2], kv[j][2], d); d = fmaf(qs[3], kv[j][3], d);
-            s[j] = d; mx = fmaxf(mx, d);
+        for (int t = 0; t < 2; ++t) {
+            if (jp == 0) { o[t][0] = pk::mul(d[t][0], v0); o[t][1] = pk::mul(d[t][0], v1); o[t][2] = pk::mul(d[t][0], v2); o[t][3] = pk::mul(d[t][0], v3); }
+            else { o[t][0] = pk::fma(d[t][jp], v0, o[t][0]); o[t][1] = pk::fma(d[t][jp], v1, o[t][1]); o[t][2] = pk::fma(d[t][jp], v2, o[t][2]); o[t][3] = pk::fma(d[t][jp], v3, o[t][3]); }
         }
+    };
 #pragma unroll
-        for (int j = 0; j < 17; ++j) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(kv[j]) : "v"(va), "i"(j * KLD * 4) : "memory");
-        float sum = 0.f;
+    for (int jp = 0; jp < 5; ++jp) pv(jp);
+    asm volatile("s_waitcnt lgkmcnt(0)" : UU3D_SP_W8(kv, 10) :: "memory");
 #pragma unroll
-        for (int j = 0; j < 17; ++j) { s[j] = __builtin_amdgcn_exp2f(s[j] - mx); sum += s[j]; }     // the value rows arrive meanwhile
-        f32x4 o = {0.f, 0.f, 0.f, 0.f};
-        asm volatile("s_waitcnt lgkmcnt(8)" : UU3D_SP_W9(kv, 0) :: "memory");
+    for (int jp = 5; jp < NP; ++jp) pv(jp);
+#undef UU3D_SP_W10
+#undef UU3D_SP_W8
 #pragma unroll
-        for (int j = 0; j < 9; ++j) { o[0] = fmaf(s[j], kv[j][0], o[0]); o[1] = fmaf(s[j], kv[j][1], o[1]); o[2] = fmaf(s[j], kv[j][2], o[2]); o[3] = fmaf(s[j], kv[j][3], o[3]); }
-        asm volatile("s_waitcnt lgkmcnt(0)" : UU3D_SP_W9(kv, 8) :: "memory");
-#pragma unroll
-        for (int j = 9; j < 17; ++j) { o[0] = fmaf(s[j], kv[j][0], o[0]); o[1] = fmaf(s[j], kv[j][1], o[1]); o[2] = fmaf(s[j], kv[j][2], o[2]); o[3] = fmaf(s[j], kv[j][3], o[3]); }
-#undef UU3D_SP_W9
-        const float rsum = 1.0f / sum;
-        o[0] *= rsum; o[1] *= rsum; o[2] *= rsum; o[3] *= rsum;
-        return o;
-    } else {
-#pragma unroll
-    for (int j = 0; j < J; ++j) {
-        const f32x4 k4 = *reinterpret_cast<const f32x4*>(Kp + j * KLD);
-        float d = qs[0] * k4[0];
-        d = fmaf(qs[1], k4[1], d); d = fmaf(qs[2], k4[2], d); d = fmaf(qs[3], k4[3], d);
-        s[j] = d;
-        mx = fmaxf(mx, d);
+    for (int t = 0; t < 2; ++t) {
+        f32x2 rs = pk::splat(__builtin_amdgcn_rcpf(sum2[t][0] + sum2[t][1]));     // 1 ulp; a correctly rounded quotient costs 10 instructions per head
+        pk::fence(rs);
+        oa[t] = pk::mul((f32x2){o[t][0][0] + o[t][0][1], o[t][1][0] + o[t][1][1]}, rs);
+        ob[t] = pk::mul((f32x2){o[t][2][0] + o[t][2][1], o[t][3][0] + o[t][3][1]}, rs);
     }
-    float sum = 0.f;
-    f32x4 o = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int j = 0; j < J; ++j) {
-        const float e = __builtin_amdgcn_exp2f(s[j] - mx);
-        sum += e;
-        const f32x4 v4 = *reinterpret_cast<const f32x4*>(Vp + j * KLD);
-        o[0] = fmaf(e, v4[0], o[0]); o[1] = fmaf(e, v4[1], o[1]); o[2] = fmaf(e, v4[2], o[2]); o[3] = fmaf(e, v4[3], o[3]);
-    }
-    const float rsum = 1.0f / sum;
-    o[0] *= rsum; o[1] *= rsum; o[2] *= rsum; o[3] *= rsum;
-    return o;
-    }
+}
+
+// GELU 0.5 x (1 + erf(x / sqrt 2)) of a channel pair, erf from Abramowitz-Stegun 7.1.28: erf(z) = 1 - (1 + a1 z + ... + a6 z^6)^-16,
+// |error| <= 3e-7; measured on [-8, 8] in f32: GELU abs error <= 8.8e-7 (7.1.26 as in sv2::gelu_erf: 4.7e-7).  One transcendental
+// (v_rcp) per element instead of two (v_rcp + v_exp, a quarter of the VALU rate each); everything else is packed.  The powers of
+// 1 / sqrt 2 are folded into the coefficients; 0.5 x (1 + sign(x) E) is evaluated as 0.5 (x + |x| E).
+__device__ __forceinline__ f32x2 gelu_pair(const f32x2 x) {
+    const f32x2 ax = {fabsf(x[0]), fabsf(x[1])};
+    f32x2 P = pk::fma(pk::splat(5.3829750000e-06f), ax, pk::splat(4.8890635643e-05f));
+    P = pk::fma(P, ax, pk::splat(3.8003575000e-05f)); P = pk::fma(P, ax, pk::splat(3.2776263241e-03f));
+    P = pk::fma(P, ax, pk::splat(2.1141006150e-02f)); P = pk::fma(P, ax, pk::splat(4.9867346967e-02f));
+    P = pk::fma(P, ax, pk::splat(1.0f));
+    f32x2 r = {__builtin_amdgcn_rcpf(P[0]), __builtin_amdgcn_rcpf(P[1])};
+    pk::fence(r);
+    r = pk::mul(r, r); r = pk::mul(r, r); r = pk::mul(r, r); r = pk::mul(r, r);
+    const f32x2 E = pk::sub(pk::splat(1.0f), r);                                          // erf(|x| / sqrt 2)
+    return pk::mul(pk::fma(ax, E, x), pk::splat(0.5f));
 }
 }  // namespace sh3
 
+#ifdef UU3D_SPATIAL_STAMP
+__device__ unsigned long long spatial_clk[12];   // tools/spatial_stamp_exp: s_memtime ticks per phase, summed over waves and blocks; [11] = waves
+#define SP_STAMP(i) { const long long t_ = clock64(); sp_t[i] += (unsigned)(t_ - sp_last); sp_last = t_; }
+#else
+#define SP_STAMP(i)
+#endif
 // out_lo == nullptr: out is the f32 (frames, J, 32) tensor; otherwise out / out_lo are its two f16 planes
 #ifndef UU3D_SPATIAL_H3_WAVES
 #define UU3D_SPATIAL_H3_WAVES 2     // 3 (168 VGPRs) spills into the block loop: 0.30 ms instead of 0.20
 #endif
+// The library is compiled with the packed-fp32-ops target feature OFF, which also makes the assembler
+// refuse the instructions in inline asm; this one kernel switches it back on for itself.  That lets hipcc emit packed f32 here
+// on its own again, op_sel forms included -- tests/test_isa_cpu.py checks that no packed instruction of this kernel has one.
+#if defined(__HIP_DEVICE_COMPILE__)
+#define UU3D_PK_TARGET __attribute__((target("packed-fp32-ops")))
+#else
+#define UU3D_PK_TARGET
+#endif
 template <int J, int FR>
-__global__ void __launch_bounds__(64, UU3D_SPATIAL_H3_WAVES)
+__global__ void __launch_bounds__(64, UU3D_SPATIAL_H3_WAVES) UU3D_PK_TARGET
 spatial_stack_h3_kernel(const float* __restrict__ kp2d, const SpatialParams p, const _Float16* __restrict__ wfrag,
                         float* __restrict__ out, _Float16* __restrict__ out_hi, _Float16* __restrict__ out_lo)
 {
@@ -297,16 +376,16 @@ spatial_stack_h3_kernel(const float* __restrict__ kp2d, const SpatialParams p, c
 #pragma clang fp contract(off)
     using namespace sh3;
     h3_flush_f16_denormals();
-    constexpr int DS = 32, HS = 64, ROWS = FR * J;
-    static_assert(ROWS <= ROWS_T - 1 && DS == 32 && HS == 64, "one wave = 3 frames of 17 joints, d = 32");
+    constexpr int DS = 32, HS = 64;
+    static_assert(FR * ((J + 1) / 2) == TOK && DS == 32 && HS == 64, "one wave = 3 frames of 17 joints, d = 32");
     using LY = SpatialBlockLayoutV2<DS, HS>;          // LayerNorm parameters and biases (f32) come from the V2 block
     using FL = SpatialFragLayoutH3;
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
-    _Float16* Xh = reinterpret_cast<_Float16*>(lds_raw);               // [52][40] operand tile, hi
+    _Float16* Xh = reinterpret_cast<_Float16*>(lds_raw);               // [55][40] operand tile, hi
     _Float16* Xl = Xh + ROWS_T * XLD;                                   // lo
-    float* TK = reinterpret_cast<float*>(Xl + ROWS_T * XLD);           // [52][36] K
-    float* TV = TK + ROWS_T * KLD;                                      // [52][36] V
-    _Float16* Hh = reinterpret_cast<_Float16*>(TK);                    // [52][72] GELU(fc1), hi (K / V are dead by then)
+    float* TK = reinterpret_cast<float*>(Xl + ROWS_T * XLD);           // K: [3 frames][9 key pairs][68] floats inside a [55][36] region
+    float* TV = TK + ROWS_T * KLD;                                      // V likewise
+    _Float16* Hh = reinterpret_cast<_Float16*>(TK);                    // [55][72] GELU(fc1), hi (K / V are dead by then)
     _Float16* Hl = Hh + ROWS_T * HLD;
     float* P = TV + ROWS_T * KLD;                                       // [352] this block's LayerNorm parameters and biases
 
@@ -316,149 +395,201 @@ spatial_stack_h3_kernel(const float* __restrict__ kp2d, const SpatialParams p, c
         nframes = p.frame_list[p.total_frames];
         if ((int)blockIdx.x * FR >= nframes) return;
     }
-    int frame[2], joint[2], fbase[2];
-    bool valid[2];
+    // Token -> lane: lane tl of token tile mt holds joint (tl % JH) + JH * mt of frame tl / JH of this wave (JH = 9 joints per
+    // frame and tile; lanes 27..31 and the tenth joint of tile 1 are padding).  A lane's two tokens then belong to the SAME
+    // frame: the attention below loads every K / V register once for both.
+    constexpr int JH = (J + 1) / 2;
+    static_assert(FR * JH == TOK, "the frames of a wave side by side in one token tile");
+    int frame[2], joint[2];
+    bool valid[2], real[2];
+    const int fl = min(tl / JH, FR - 1);                // frame of this lane inside the wave
 #pragma unroll
     for (int mt = 0; mt < 2; ++mt) {
-        const int tok = 32 * mt + tl;
-        const int fl = min(tok / J, FR - 1);
-        joint[mt] = min(tok - fl * J, J - 1);
-        fbase[mt] = fl * J;
+        const int jn = (tl - fl * JH) + JH * mt;
+        real[mt] = (tl < TOK) && (jn < J);
+        joint[mt] = min(jn, J - 1);
         int f = blockIdx.x * FR + fl;
-        valid[mt] = (tok < ROWS) && (f < nframes);
+        valid[mt] = real[mt] && (f < nframes);
         if (p.frame_list != nullptr) f = p.frame_list[min(f, nframes - 1)];
         frame[mt] = min(f, p.total_frames - 1);
     }
 
-    // keypoint embedding + spatial PE (u_u_t.py:321-323), this lane's 16 channels of each token
-    float x[2][16];
+    // K / V slots of this lane's two tokens in the key-pair layout (floats from TK / TV): [frame][key pair][channel][2]; padding
+    // tokens go to the spare half of the last pair of their frame (never read with a non-zero probability)
+    constexpr int NP = (J + 1) / 2;
+    static_assert((J & 1) == 1 && FR * NP * KPLD <= ROWS_T * KLD, "odd J: one spare key slot per frame; fits the K / V region");
+    int kslot[2];
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt) {
+        const int jp = real[mt] ? (joint[mt] >> 1) : NP - 1, par = real[mt] ? (joint[mt] & 1) : 1;
+        kslot[mt] = (fl * NP + jp) * KPLD + par;
+    }
+    const unsigned kfr = (unsigned)(fl * NP * KPLD * 4);   // LDS byte offset of the lane's frame inside TK / TV
+    const unsigned tk_a = (unsigned)(uintptr_t)(__attribute__((address_space(3))) const void*)TK;
+    const unsigned tv_a = (unsigned)(uintptr_t)(__attribute__((address_space(3))) const void*)TV;
+
+    // keypoint embedding + spatial PE (u_u_t.py:321-323), this lane's 16 channels of each token as 8 pairs.  Packed by name
+    // like everything else: left as scalar code, hipcc's SLP pass pairs it up itself -- with op_sel broadcasts of (kx, ky).
+    f32x2 x[2][8];
 #pragma unroll
     for (int mt = 0; mt < 2; ++mt) {
         float kx = 0.f, ky = 0.f;
         if (valid[mt]) { const float2 k2 = *reinterpret_cast<const float2*>(kp2d + ((size_t)frame[mt] * J + joint[mt]) * 2); kx = k2.x; ky = k2.y; }
+        const f32x2 kx2 = pk::splat(kx), ky2 = pk::splat(ky);
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int c = 8 * (r >> 2) + 4 * half + (r & 3);
-            x[mt][r] = (fmaf(ky, p.embed_w[DS + c], kx * p.embed_w[c]) + p.embed_b[c]) + p.pe[joint[mt] * DS + c];
+        for (int i = 0; i < 8; ++i) {
+            const int c = 8 * (i >> 1) + 4 * half + 2 * (i & 1);
+            const f32x2 w0 = *reinterpret_cast<const f32x2*>(p.embed_w + c), w1 = *reinterpret_cast<const f32x2*>(p.embed_w + DS + c);
+            const f32x2 eb = *reinterpret_cast<const f32x2*>(p.embed_b + c), pe = *reinterpret_cast<const f32x2*>(p.pe + joint[mt] * DS + c);
+            x[mt][i] = pk::add(pk::add(pk::fma(ky2, w1, pk::mul(kx2, w0)), eb), pe);
         }
     }
+    // bias pairs of this lane's channels: param[8 g + 4 half + 2 e .. + 2]
+    auto bias_pairs = [&](const float* b, f32x2 (&bp)[8]) __attribute__((always_inline)) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const f32x4 b4 = *reinterpret_cast<const f32x4*>(b + 8 * g + 4 * half);
+            bp[2 * g] = (f32x2){b4[0], b4[1]}; bp[2 * g + 1] = (f32x2){b4[2], b4[3]};
+        }
+    };
 
+#ifdef UU3D_SPATIAL_STAMP
+    unsigned sp_t[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    long long sp_last = clock64();
+    const long long sp_first = sp_last;
+#endif
     for (int blk = 0; blk < p.depth; ++blk) {
         const _Float16* __restrict__ F = wfrag + (size_t)blk * FL::size;
         {   // one coalesced copy of the block's 352 parameters into LDS: the 16-byte group reads below then cost an LDS
             // round trip instead of a dependent global load each (133 of them per block before)
             const float* __restrict__ Wg = p.blocks + (size_t)blk * LY::size;
+            if (UU3D_SP_SKIP != 4 || blk == 0)
 #pragma unroll
             for (int i = 0; i < (NPARAM + 63) / 64; ++i) { const int k = 64 * i + lane; if (k < NPARAM) P[k] = Wg[k]; }
         }
         const float* W = P;
-        float y[2][16];
+        f32x2 y[2][8];
 
         // ---- attention half ----
         WFrag<1, 2> wq, wk, wv, wp;
         load_w<1, 2>(F + FL::fq, lane, wq); load_w<1, 2>(F + FL::fk, lane, wk); load_w<1, 2>(F + FL::fv, lane, wv);
+        if constexpr (UU3D_SP_SKIP == 3) { for (int mt = 0; mt < 2; ++mt) for (int i = 0; i < 8; ++i) y[mt][i] = x[mt][i]; } else
         ln_tokens(x, W + LY::ln1_g, W + LY::ln1_b, 1e-5f, half, y);
         store_planes(Xh, Xl, XLD, 0, lane, y);
-        float q[1][2][16];
+        SP_STAMP(0)
+        f32x2 q[1][2][8];
         {
-            float kv[1][2][16];
+            f32x2 kv[1][2][8], bp[8];
             wait_w<8>(wq);
             mm<1, 2>(wq, Xh, Xl, XLD, lane, q);
+            bias_pairs(W + LY::bq, bp);
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                for (int i = 0; i < 8; ++i) q[0][mt][i] = pk::add(q[0][mt][i], bp[i]);
             wait_w<4>(wk);
             mm<1, 2>(wk, Xh, Xl, XLD, lane, kv);
+            // the spare key slot of every frame: finite (zero) whatever the hidden planes of the previous block left there
+            if (lane < 2 * DS) { const int c = lane & 31; float* T = lane < DS ? TK : TV;
 #pragma unroll
-            for (int mt = 0; mt < 2; ++mt) {
-                const int row = min(32 * mt + tl, ROWS_T - 1);
+                for (int f = 0; f < FR; ++f) T[(f * NP + NP - 1) * KPLD + 2 * c + 1] = 0.f; }
+            bias_pairs(W + LY::bk, bp);
 #pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    const int c = 8 * g + 4 * half;
-                    const f32x4 b4 = *reinterpret_cast<const f32x4*>(W + LY::bk + c);
-                    *reinterpret_cast<f32x4*>(&TK[row * KLD + c]) =
-                        (f32x4){kv[0][mt][4 * g] + b4[0], kv[0][mt][4 * g + 1] + b4[1], kv[0][mt][4 * g + 2] + b4[2], kv[0][mt][4 * g + 3] + b4[3]};
+            for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    const f32x2 v = pk::add(kv[0][mt][i], bp[i]);
+                    const int c = 8 * (i >> 1) + 4 * half + 2 * (i & 1);
+                    TK[kslot[mt] + 2 * c] = v[0]; TK[kslot[mt] + 2 * c + 2] = v[1];
                 }
-            }
             load_w<1, 2>(F + FL::fp, lane, wp);            // in flight over the attention arithmetic
             wait_w<4>(wv);
             mm<1, 2>(wv, Xh, Xl, XLD, lane, kv);
+            bias_pairs(W + LY::bv, bp);
 #pragma unroll
-            for (int mt = 0; mt < 2; ++mt) {
-                const int row = min(32 * mt + tl, ROWS_T - 1);
+            for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    const int c = 8 * g + 4 * half;
-                    const f32x4 b4 = *reinterpret_cast<const f32x4*>(W + LY::bv + c);
-                    *reinterpret_cast<f32x4*>(&TV[row * KLD + c]) =
-                        (f32x4){kv[0][mt][4 * g] + b4[0], kv[0][mt][4 * g + 1] + b4[1], kv[0][mt][4 * g + 2] + b4[2], kv[0][mt][4 * g + 3] + b4[3]};
+                for (int i = 0; i < 8; ++i) {
+                    const f32x2 v = pk::add(kv[0][mt][i], bp[i]);
+                    const int c = 8 * (i >> 1) + 4 * half + 2 * (i & 1);
+                    TV[kslot[mt] + 2 * c] = v[0]; TV[kslot[mt] + 2 * c + 2] = v[1];
                 }
-            }
         }
-        // scaled dot-product attention over the J joints of the token's frame; group g = head 2g + half
-        float o[2][16];
-#pragma unroll
-        for (int mt = 0; mt < 2; ++mt)
+        SP_STAMP(1)
+        // scaled dot-product attention over the J joints of the lane's frame, both tokens at once; group g = head 2g + half
+        f32x2 o[2][8];
+        {
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
-                const int c = 8 * g + 4 * half;
-                const f32x4 b4 = *reinterpret_cast<const f32x4*>(W + LY::bq + c);
-                const f32x4 q4 = {q[0][mt][4 * g] + b4[0], q[0][mt][4 * g + 1] + b4[1], q[0][mt][4 * g + 2] + b4[2], q[0][mt][4 * g + 3] + b4[3]};
-                const f32x4 o4 = head_attention<J>(q4, TK + fbase[mt] * KLD + c, TV + fbase[mt] * KLD + c);
-                o[mt][4 * g] = o4[0]; o[mt][4 * g + 1] = o4[1]; o[mt][4 * g + 2] = o4[2]; o[mt][4 * g + 3] = o4[3];
+                const unsigned off = kfr + (unsigned)((8 * g + 4 * half) * 2 * 4);
+                const f32x2 qa[2] = {q[0][0][2 * g], q[0][1][2 * g]};
+                const f32x2 qb[2] = {q[0][0][2 * g + 1], q[0][1][2 * g + 1]};
+                f32x2 oa[2], ob[2];
+                if constexpr (UU3D_SP_SKIP == 1) { oa[0] = qa[0]; oa[1] = qa[1]; ob[0] = qb[0]; ob[1] = qb[1]; (void)off; (void)tk_a; (void)tv_a; }
+                else head_attention<J>(qa, qb, tk_a + off, tv_a + off, oa, ob);
+                o[0][2 * g] = oa[0]; o[0][2 * g + 1] = ob[0]; o[1][2 * g] = oa[1]; o[1][2 * g + 1] = ob[1];
             }
+        }
+        SP_STAMP(2)
         store_planes(Xh, Xl, XLD, 0, lane, o);
         {
-            float pr[1][2][16];
+            f32x2 pr[1][2][8], bp[8];
             wait_w<0>(wp);
             mm<1, 2>(wp, Xh, Xl, XLD, lane, pr);
+            bias_pairs(W + LY::bp, bp);
 #pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const f32x4 b4 = *reinterpret_cast<const f32x4*>(W + LY::bp + 8 * g + 4 * half);
+            for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
-                for (int mt = 0; mt < 2; ++mt)
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) x[mt][4 * g + e] += pr[0][mt][4 * g + e] + b4[e];
-            }
+                for (int i = 0; i < 8; ++i) x[mt][i] = pk::add(x[mt][i], pk::add(pr[0][mt][i], bp[i]));
         }
 
+        SP_STAMP(3)
         // ---- MLP half ----
         WFrag<2, 2> w1;
         load_w<2, 2>(F + FL::f1, lane, w1);
+        if constexpr (UU3D_SP_SKIP == 3) { for (int mt = 0; mt < 2; ++mt) for (int i = 0; i < 8; ++i) y[mt][i] = x[mt][i]; } else
         ln_tokens(x, W + LY::ln2_g, W + LY::ln2_b, 1e-5f, half, y);
         store_planes(Xh, Xl, XLD, 0, lane, y);
+        SP_STAMP(4)
         WFrag<1, 4> w2;
         {
-            float hd[2][2][16];
+            f32x2 hd[2][2][8], bp[8];
             wait_w<0>(w1);
             mm<2, 2>(w1, Xh, Xl, XLD, lane, hd);
             load_w<1, 4>(F + FL::f2, lane, w2);             // in flight over the GELU
+            SP_STAMP(5)
 #pragma unroll
             for (int nt = 0; nt < 2; ++nt) {
-#pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    const f32x4 b4 = *reinterpret_cast<const f32x4*>(W + LY::b1 + 32 * nt + 8 * g + 4 * half);
-#pragma unroll
-                    for (int mt = 0; mt < 2; ++mt)
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) hd[nt][mt][4 * g + e] = sv2::gelu_erf(hd[nt][mt][4 * g + e] + b4[e]);
-                }
-                store_planes(Hh, Hl, HLD, 32 * nt, lane, hd[nt]);
-            }
-        }
-        {
-            float z[1][2][16];
-            wait_w<0>(w2);
-            mm<1, 4>(w2, Hh, Hl, HLD, lane, z);
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const f32x4 b4 = *reinterpret_cast<const f32x4*>(W + LY::b2 + 8 * g + 4 * half);
+                bias_pairs(W + LY::b1 + 32 * nt, bp);
 #pragma unroll
                 for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) x[mt][4 * g + e] += z[0][mt][4 * g + e] + b4[e];
+                    for (int i = 0; i < 8; ++i) hd[nt][mt][i] = UU3D_SP_SKIP == 2 ? pk::add(hd[nt][mt][i], bp[i]) : gelu_pair(pk::add(hd[nt][mt][i], bp[i]));
+                store_planes(Hh, Hl, HLD, 32 * nt, lane, hd[nt]);
             }
         }
+        SP_STAMP(6)
+        {
+            f32x2 z[1][2][8], bp[8];
+            wait_w<0>(w2);
+            mm<1, 4>(w2, Hh, Hl, HLD, lane, z);
+            bias_pairs(W + LY::b2, bp);
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                for (int i = 0; i < 8; ++i) x[mt][i] = pk::add(x[mt][i], pk::add(z[0][mt][i], bp[i]));
+        }
+        SP_STAMP(7)
     }
+#ifdef UU3D_SPATIAL_STAMP
+    if (lane == 0) {
+        for (int i = 0; i < 8; ++i) atomicAdd(&spatial_clk[i], (unsigned long long)sp_t[i]);
+        atomicAdd(&spatial_clk[10], (unsigned long long)(clock64() - sp_first));
+        atomicAdd(&spatial_clk[11], 1ull);
+    }
+#endif
 
-    float y[2][16];
+    f32x2 y[2][8];
     sh3::ln_tokens(x, p.norm_g, p.norm_b, 1e-6f, half, y);
 #pragma unroll
     for (int mt = 0; mt < 2; ++mt) {
@@ -467,14 +598,13 @@ spatial_stack_h3_kernel(const float* __restrict__ kp2d, const SpatialParams p, c
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
             const int c = 8 * g + 4 * half;
-            const f32x4 f = {y[mt][4 * g], y[mt][4 * g + 1], y[mt][4 * g + 2], y[mt][4 * g + 3]};
             if (out_lo != nullptr) {
                 h16x4 hi, lo;
-                h3_split(f, hi, lo);
+                split_pairs(y[mt][2 * g], y[mt][2 * g + 1], hi, lo);
                 *reinterpret_cast<h16x4*>(out_hi + at + c) = hi;
                 *reinterpret_cast<h16x4*>(out_lo + at + c) = lo;
             } else {
-                *reinterpret_cast<f32x4*>(out + at + c) = f;
+                *reinterpret_cast<f32x4*>(out + at + c) = (f32x4){y[mt][2 * g][0], y[mt][2 * g][1], y[mt][2 * g + 1][0], y[mt][2 * g + 1][1]};
             }
         }
     }
