@@ -27,7 +27,7 @@ template __global__ void uu3d::attn_head_wave_kernel<5, 48, true>(const float*, 
 template __global__ void uu3d::attn_f32_kernel<3, 48, true>(const float*, int, int, int, int, const uint8_t*, float*, int, size_t);
 template __global__ void uu3d::gemm_tn_h3_kernel<TnLoadLayerNorm, EpSlab>(const TnLoadLayerNorm, const float*, int, int, int, int, int, int, int, const EpSlab);
 template __global__ void uu3d::gemm_tn_kernel<TnLoadLayerNorm, EpSlab>(const TnLoadLayerNorm, const float*, int, int, int, int, int, int, int, const EpSlab);
-template __global__ void uu3d::spatial_stack_h3_kernel<17, 3>(const float*, const SpatialParams, const _Float16*, float*, _Float16*, _Float16*);
+template __global__ void uu3d::spatial_stack_h3_kernel<17, 3, 1>(const float*, const SpatialParams, const _Float16*, float*, _Float16*, _Float16*);
 template __global__ void uu3d::gemm_h3_panel_kernel<24, PanelEpBias>(const _Float16*, const _Float16*, const float*, int, int, int, int, const PanelEpBias);
 template __global__ void uu3d::gemm_h3_panel_kernel<24, PanelEpBiasReluSplit>(const _Float16*, const _Float16*, const float*, int, int, int, int, const PanelEpBiasReluSplit);
 template __global__ void uu3d::ln_split_frag_kernel<24, 8>(const float*, int, int, float, const float*, const float*, _Float16*);
@@ -99,7 +99,7 @@ def test_no_packed_fp32_valu_ops(asm):
     for name, body in ks.items():
         pk = re.findall(r"v_pk_(?:mul|fma|add)_f32[^\n]*", body)
         if "spatial_stack_h3_kernel" in name:
-            assert len(pk) > 1000
+            assert len(pk) > 500
             assert not any("op_sel" in l for l in pk)
         else:
             assert not pk, name
@@ -179,11 +179,12 @@ def test_spatial_stack_weight_fragments_are_prefetched(asm):
     assert re.search(r"(global_load_dwordx4 v\[\d+:\d+\], v\[\d+:\d+\], off\n(?:\t[sv]_\w+.*\n){0,6}?\t?){12}", sp) or sp.count("global_load_dwordx4") >= 32
     for n in (8, 4, 0):
         assert f"s_waitcnt vmcnt({n})" in sp
-    # the per-head attention reads its 9 key pairs (then its 9 value pairs), two 16-byte reads each, in one by-name batch
+    # the per-head attention reads its key pairs (then its value pairs), two 16-byte reads each, in by-name batches of 10 and 8
     code = [l.strip() for l in sp.split("\n") if l.strip() and not l.strip().startswith(";")]
     run = best = 0
     for l in code:
         run = run + 1 if l.startswith("ds_read_b128") else 0
         best = max(best, run)
-    assert best >= 18, best                                  # 9 key pairs x 2 reads
-    assert "s_waitcnt lgkmcnt(8)" in sp
+    assert best >= 10, best                                  # first batch: 5 key pairs x 2 reads
+    m = re.search(r"spatial_stack_h3_kernel\w*\n(?:.*\n)*?\s*\.vgpr_count:\s+(\d+)", asm)
+    assert m and int(m.group(1)) <= 168, m and m.group(1)    # three waves per SIMD

@@ -47,6 +47,10 @@ constexpr int kJ = 17, kDS = 32, kHS = 64, kHeads = 8, kDH = 48;
 using SLY = SpatialBlockLayout<kDS, kHS>;
 using SLY2 = SpatialBlockLayoutV2<kDS, kHS>;
 constexpr int kFR = 3;   // frames per wave in the MFMA spatial kernel (3 * 17 = 51 rows)
+#ifndef UU3D_SPATIAL_MT
+#define UU3D_SPATIAL_MT 1
+#endif
+constexpr int kSpatialMT = UU3D_SPATIAL_MT;   // token tiles per wave of the f16x3 spatial kernel: 1 = two waves per 3 frames (see uu3d_spatial_h3.h)
 
 std::string g_create_error;
 
@@ -651,18 +655,14 @@ size_t uu3d_workspace_bytes(const uu3d_model* m, int32_t batch) {
 // ---- launch helpers ---------------------------------------------------------------------
 namespace {
 
-// Both spatial kernels are one wave per 3 frames and latency bound: a launch takes (rounds of resident waves) x (one
-// wave's run time).  Measured on MI355X: the f16x3 kernel runs ~100 us per wave and 6 waves fit a CU (24.7 KB LDS
-// each: 1536 per round), the exact-f32 kernel ~133 us with 7 per CU (1792 per round).  E.g. 1515 waves (h36m_351,
-// 64 sequences): 0.10 vs 0.13 ms; 1750 waves (h36m_81, 128 sequences): 0.20 vs 0.14 ms.  The frame count of the
-// launch decides (an upper bound of the waves: masked frames drop out on the device).
+// Both spatial kernels work on 3 frames per workgroup and are latency bound: a launch takes (rounds of resident workgroups)
+// x (one workgroup's run time).  Measured on MI355X, h36m_351 at batch 128 (3030 workgroups): the f16x3 kernel (two waves per
+// workgroup, 26 KB LDS: 6 workgroups per CU = 1536 per round) 135 us for its two rounds; the exact-f32 kernel (one wave, 7 per
+// CU = 1792 per round) ~133 us per round.  The frame count of the launch decides (an upper bound: masked frames drop out on
+// the device).
 inline bool spatial_h3_pays(int frames) {
-    const int waves = (frames + kFR - 1) / kFR;
-    // (the f16x3 kernel's round has since come down to ~86 us: 171 us for the two rounds of h36m_351 at batch 128; at the
-    // one shape where the choice flips, h36m_81 at batch 256, the two kernels tie with every frame real, 145 vs 141 us, and
-    // the f16x3 one wins whenever frames are masked, 67 vs 113 us at s_in = 10)
-    // (round 2, packed-f32 VALU work: ~81 us per round, 164 us for h36m_351 at batch 128)
-    const int t_h3 = ((waves + 1535) / 1536) * 81, t_f32 = ((waves + 1791) / 1792) * 133;
+    const int wgs = (frames + kFR - 1) / kFR;
+    const int t_h3 = ((wgs + 1535) / 1536) * 68, t_f32 = ((wgs + 1791) / 1792) * 133;
     return t_h3 <= t_f32;
 }
 
@@ -986,9 +986,9 @@ int uu3d_forward(uu3d_model* m, const float* kp2d, const uint8_t* mask, int32_t 
             Lh.end();
         } else if (c.precision == UU3D_PREC_F16X3 && !m->spatial_f32 && (m->spatial_h3_always || spatial_h3_pays(M))) {
             sp.blocks = m->sp_blocks_v2;             // LayerNorm parameters and biases
-            auto kern = spatial_stack_h3_kernel<kJ, kFR>;
+            auto kern = spatial_stack_h3_kernel<kJ, kFR, kSpatialMT>;
             Lh.begin("spatial_stack", "spatial_h3", fl, 4.0 * M * J * (2.0 + ds));
-            hipLaunchKernelGGL(kern, dim3((M + kFR - 1) / kFR), dim3(64), sh3::lds_bytes(), Lh.stream, kp2d, sp,
+            hipLaunchKernelGGL(kern, dim3((M + kFR - 1) / kFR), dim3(64 * (2 / kSpatialMT)), sh3::lds_bytes(), Lh.stream, kp2d, sp,
                                m->harena + m->sp_frag_off, w.S, (_Float16*)nullptr, (_Float16*)nullptr);
             Lh.end();
         } else {

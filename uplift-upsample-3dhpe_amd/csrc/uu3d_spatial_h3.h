@@ -37,6 +37,7 @@
 #include <hip/hip_fp16.h>
 #include <stdint.h>
 #include <math.h>
+#include <type_traits>
 #include "uu3d_gemm_h3.h"
 #include "uu3d_spatial.h"
 
@@ -114,33 +115,33 @@ __device__ __forceinline__ void fence(f32x2& a) { asm volatile("s_nop 0" : "+v"(
 __device__ __forceinline__ void fence(f32x2& a, f32x2& b) { asm volatile("s_nop 0" : "+v"(a), "+v"(b)); }
 }  // namespace pk
 
-// C^T tiles of W^T X^T for NT output tiles (32 channels each) and both token tiles; K = 16 * KK.
-// out[nt][mt][i] = the pair of registers (2 i, 2 i + 1): token = 32 mt + (lane & 31), channels 32 nt + 8 (i >> 1) +
-// 4 (lane >> 5) + 2 (i & 1) and the next one.
-template <int NT, int KK>
+// C^T tiles of W^T X^T for NT output tiles (32 channels each) and the wave's MT token tiles (tiles mt0 .. mt0 + MT - 1);
+// K = 16 * KK.  out[nt][mt][i] = the pair of registers (2 i, 2 i + 1): token slot (lane & 31) of tile mt0 + mt, channels
+// 32 nt + 8 (i >> 1) + 4 (lane >> 5) + 2 (i & 1) and the next one.
+template <int MT, int NT, int KK>
 __device__ __forceinline__ void mm(const WFrag<NT, KK>& w, const _Float16* Bh, const _Float16* Bl, const int ldb,
-                                   const int lane, f32x2 (&out)[NT][2][8]) {
-    f32x16 acc0[NT][2], acc1[NT][2];
+                                   const int lane, const int mt0, f32x2 (&out)[NT][MT][8]) {
+    f32x16 acc0[NT][MT], acc1[NT][MT];
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
-        for (int mt = 0; mt < 2; ++mt)
+        for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
             for (int r = 0; r < 16; ++r) { acc0[nt][mt][r] = 0.f; acc1[nt][mt][r] = 0.f; }
     const int tl = lane & 31, half = lane >> 5;
 #pragma unroll
     for (int kk = 0; kk < KK; ++kk) {
-        h16x8 bh[2], bl[2];
+        h16x8 bh[MT], bl[MT];
 #pragma unroll
-        for (int mt = 0; mt < 2; ++mt) {
-            const int row = tile_row(mt, tl);
+        for (int mt = 0; mt < MT; ++mt) {
+            const int row = tile_row(mt0 + mt, tl);
             bh[mt] = *reinterpret_cast<const h16x8*>(Bh + row * ldb + 16 * kk + 8 * half);
             bl[mt] = *reinterpret_cast<const h16x8*>(Bl + row * ldb + 16 * kk + 8 * half);
         }
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
-            for (int mt = 0; mt < 2; ++mt) {
+            for (int mt = 0; mt < MT; ++mt) {
                 acc0[nt][mt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w.h[nt][kk], bh[mt], acc0[nt][mt], 0, 0, 0);
                 acc1[nt][mt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w.h[nt][kk], bl[mt], acc1[nt][mt], 0, 0, 0);
                 acc1[nt][mt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w.l[nt][kk], bh[mt], acc1[nt][mt], 0, 0, 0);
@@ -148,15 +149,19 @@ __device__ __forceinline__ void mm(const WFrag<NT, KK>& w, const _Float16* Bh, c
     }
     // The MFMA -> VALU read hazard is software's to cover (8-pass MFMA: 11 wait states, a 16-pass one 19), and hipcc does not
     // cover it for inline asm readers: without these 20 wait states the packed ops below read the accumulators too early (NaN
-    // in every output).  The operands tie the asm between the MFMAs and every reader.
+    // in every output).  The operands tie the asm between the MFMAs and every reader: volatile asm statements keep their order,
+    // so the empty ones (and with them the readers of their operands) stay behind the wait.
+    asm volatile("s_nop 15\n\ts_nop 3" : "+v"(acc0[NT - 1][MT - 1]), "+v"(acc1[NT - 1][MT - 1]));
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt)
-        asm volatile("s_nop 15\n\ts_nop 3" : "+v"(acc0[nt][0]), "+v"(acc1[nt][0]), "+v"(acc0[nt][1]), "+v"(acc1[nt][1]));
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+            if (nt != NT - 1 || mt != MT - 1) asm volatile("" : "+v"(acc0[nt][mt]), "+v"(acc1[nt][mt]));
     const f32x2 inv = pk::splat(1.0f / H3_SCALE);
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
-        for (int mt = 0; mt < 2; ++mt)
+        for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
             for (int i = 0; i < 8; ++i)
                 out[nt][mt][i] = pk::fma((f32x2){acc1[nt][mt][2 * i], acc1[nt][mt][2 * i + 1]}, inv,
@@ -178,8 +183,9 @@ __device__ __forceinline__ float sum_halves(const f32x2 p) {
 // LayerNormalization over the 32 channels of each of the lane's two tokens (16 here, 16 in lane ^ 32); the arithmetic of
 // ln_row (non-fused Keras path: inv = rstd * gamma, y = x * inv + (beta - mean * inv)) on channel pairs, the two moments summed
 // over even / odd channels first
-__device__ __forceinline__ void ln_tokens(const f32x2 (&x)[2][8], const float* g, const float* b,
-                                          const float eps, const int half, f32x2 (&y)[2][8]) {
+template <int MT>
+__device__ __forceinline__ void ln_tokens(const f32x2 (&x)[MT][8], const float* g, const float* b,
+                                          const float eps, const int half, f32x2 (&y)[MT][8]) {
     f32x2 gp[8], bp[8];
 #pragma unroll
     for (int gq = 0; gq < 4; ++gq) {
@@ -189,7 +195,7 @@ __device__ __forceinline__ void ln_tokens(const f32x2 (&x)[2][8], const float* g
         bp[2 * gq] = (f32x2){b4[0], b4[1]}; bp[2 * gq + 1] = (f32x2){b4[2], b4[3]};
     }
 #pragma unroll
-    for (int mt = 0; mt < 2; ++mt) {
+    for (int mt = 0; mt < MT; ++mt) {
         const f32x2 s2 = pk::add(pk::add(pk::add(x[mt][0], x[mt][1]), pk::add(x[mt][2], x[mt][3])),
                                  pk::add(pk::add(x[mt][4], x[mt][5]), pk::add(x[mt][6], x[mt][7])));
         const float s = sum_halves(s2);
@@ -225,12 +231,13 @@ __device__ __forceinline__ void split_pairs(const f32x2 a, const f32x2 b, h16x4&
 }
 
 // the lane's 2 x 16 values -> hi / lo planes of a row-major tile (row = token, 4-channel groups of 8 bytes)
-__device__ __forceinline__ void store_planes(_Float16* Th, _Float16* Tl, const int ld, const int coloff, const int lane,
-                                             const f32x2 (&v)[2][8]) {
+template <int MT>
+__device__ __forceinline__ void store_planes(_Float16* Th, _Float16* Tl, const int ld, const int coloff, const int lane, const int mt0,
+                                             const f32x2 (&v)[MT][8]) {
     const int tl = lane & 31, half = lane >> 5;
 #pragma unroll
-    for (int mt = 0; mt < 2; ++mt) {
-        const int row = tile_row(mt, tl);
+    for (int mt = 0; mt < MT; ++mt) {
+        const int row = tile_row(mt0 + mt, tl);
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
             h16x4 hi, lo;
@@ -241,54 +248,61 @@ __device__ __forceinline__ void store_planes(_Float16* Th, _Float16* Tl, const i
     }
 }
 
-// One head of the lane's TWO tokens (same frame, see the kernel): softmax(q k^T / sqrt(d_h)) v over the J keys of the frame.
+// One head of the lane's NTOK tokens (two: same frame, see the kernel): softmax(q k^T / sqrt(d_h)) v over the J keys of the frame.
 // ka / va = LDS byte addresses of the head's 4 channels in key pair 0 of the frame; key pair jp is KPLD floats further and
 // holds, per channel c, (key 2 jp, key 2 jp + 1): two ds_read_b128 = channels (c0, c0 + 1) and (c0 + 2, c0 + 3).  Every K / V
 // register feeds both tokens.  J odd: the last pair's second key is a finite dummy whose probability is forced to zero.
-template <int J>
-__device__ __forceinline__ void head_attention(const f32x2 (&qa)[2], const f32x2 (&qb)[2], const unsigned ka, const unsigned va,
-                                               f32x2 (&oa)[2], f32x2 (&ob)[2]) {
+template <int J, int NTOK>
+__device__ __forceinline__ void head_attention(const f32x2 (&qa)[NTOK], const f32x2 (&qb)[NTOK], const unsigned ka, const unsigned va,
+                                               f32x2 (&oa)[NTOK], f32x2 (&ob)[NTOK]) {
     static_assert(J == 17, "9 key pairs, the last one half empty");
     constexpr int NP = 9;
     // softmax(x) with x = q.k / 2: exp(x - max) = exp2((q * log2e / 2).k - max'), so the scale and the base change are
     // folded into q once; the 1 / sum normalisation is applied to the 4 outputs instead of the 17 probabilities
     const f32x2 c = pk::splat(0.72134752044448170368f);
-    f32x2 q0[2], q1[2], q2[2], q3[2];
+    f32x2 q0[NTOK], q1[NTOK], q2[NTOK], q3[NTOK];
 #pragma unroll
-    for (int t = 0; t < 2; ++t) {
+    for (int t = 0; t < NTOK; ++t) {
         const f32x2 sa = pk::mul(qa[t], c), sb = pk::mul(qb[t], c);
         q0[t] = pk::splat(sa[0]); q1[t] = pk::splat(sa[1]); q2[t] = pk::splat(sb[0]); q3[t] = pk::splat(sb[1]);
     }
-    // The 18 key reads and then the 18 value reads of this head by name, all in flight at once, with counted waits (LDS returns
-    // in order; the counter starts from zero and the "memory" clobbers keep other memory operations out, see uu3d_attn.h).
-    // hipcc emits read -> wait -> use for every row otherwise.
-    f32x4 kv[2 * NP];
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    // Key and value pairs by name in two batches each (pairs 0..4: 10 reads, pairs 5..8: 8 reads) through the same 10
+    // registers, each batch in flight at once and waited for as a whole (the "memory" clobbers keep other LDS operations out of
+    // the counter, see uu3d_attn.h); hipcc emits read -> wait -> use for every row otherwise.  The second batch goes out when
+    // the first is used up: its latency is what the other waves of the SIMD are for (all 18 in flight cost 32 more registers --
+    // with one token tile per wave, the difference between three waves per SIMD and spilling).
+    f32x4 kv[10];
+#define UU3D_SP_W10(x) "+v"(x[0]), "+v"(x[1]), "+v"(x[2]), "+v"(x[3]), "+v"(x[4]), "+v"(x[5]), "+v"(x[6]), "+v"(x[7]), "+v"(x[8]), "+v"(x[9])
+#define UU3D_SP_W8(x) "+v"(x[0]), "+v"(x[1]), "+v"(x[2]), "+v"(x[3]), "+v"(x[4]), "+v"(x[5]), "+v"(x[6]), "+v"(x[7])
+    auto read_pairs = [&](auto first_tag, const unsigned base) __attribute__((always_inline)) {
+        constexpr int P0 = decltype(first_tag)::value, N = P0 == 0 ? 10 : 8;
 #pragma unroll
-    for (int j = 0; j < 2 * NP; ++j)
-        asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(kv[j]) : "v"(ka), "i"((j >> 1) * KPLD * 4 + (j & 1) * 16) : "memory");
-#define UU3D_SP_W10(x, o) "+v"(x[o]), "+v"(x[o + 1]), "+v"(x[o + 2]), "+v"(x[o + 3]), "+v"(x[o + 4]), "+v"(x[o + 5]), "+v"(x[o + 6]), "+v"(x[o + 7]), "+v"(x[o + 8]), "+v"(x[o + 9])
-#define UU3D_SP_W8(x, o) "+v"(x[o]), "+v"(x[o + 1]), "+v"(x[o + 2]), "+v"(x[o + 3]), "+v"(x[o + 4]), "+v"(x[o + 5]), "+v"(x[o + 6]), "+v"(x[o + 7])
-    f32x2 d[2][NP];
-    auto logits = [&](int jp) __attribute__((always_inline)) {       // the scalar kernel's order: q0 k0, then fma over channels 1..3
-        const f32x2 k0 = {kv[2 * jp][0], kv[2 * jp][1]}, k1 = {kv[2 * jp][2], kv[2 * jp][3]};
-        const f32x2 k2 = {kv[2 * jp + 1][0], kv[2 * jp + 1][1]}, k3 = {kv[2 * jp + 1][2], kv[2 * jp + 1][3]};
-#pragma unroll
-        for (int t = 0; t < 2; ++t) d[t][jp] = pk::fma(q3[t], k3, pk::fma(q2[t], k2, pk::fma(q1[t], k1, pk::mul(q0[t], k0))));
+        for (int j = 0; j < N; ++j)
+            asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(kv[j]) : "v"(base), "i"((P0 + (j >> 1)) * KPLD * 4 + (j & 1) * 16) : "memory");
+        if constexpr (P0 == 0) asm volatile("s_waitcnt lgkmcnt(0)" : UU3D_SP_W10(kv) :: "memory");
+        else asm volatile("s_waitcnt lgkmcnt(0)" : UU3D_SP_W8(kv) :: "memory");
     };
-    asm volatile("s_waitcnt lgkmcnt(8)" : UU3D_SP_W10(kv, 0) :: "memory");
+    f32x2 d[NTOK][NP];
+    auto logits = [&](int jp, int r) __attribute__((always_inline)) {       // the scalar kernel's order: q0 k0, then fma over channels 1..3
+        const f32x2 k0 = {kv[2 * r][0], kv[2 * r][1]}, k1 = {kv[2 * r][2], kv[2 * r][3]};
+        const f32x2 k2 = {kv[2 * r + 1][0], kv[2 * r + 1][1]}, k3 = {kv[2 * r + 1][2], kv[2 * r + 1][3]};
 #pragma unroll
-    for (int jp = 0; jp < 5; ++jp) logits(jp);
-    asm volatile("s_waitcnt lgkmcnt(0)" : UU3D_SP_W8(kv, 10) :: "memory");
+        for (int t = 0; t < NTOK; ++t) d[t][jp] = pk::fma(q3[t], k3, pk::fma(q2[t], k2, pk::fma(q1[t], k1, pk::mul(q0[t], k0))));
+    };
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    read_pairs(std::integral_constant<int, 0>{}, ka);
 #pragma unroll
-    for (int jp = 5; jp < NP; ++jp) logits(jp);
+    for (int jp = 0; jp < 5; ++jp) logits(jp, jp);
+    read_pairs(std::integral_constant<int, 5>{}, ka);
 #pragma unroll
-    for (int j = 0; j < 2 * NP; ++j)
+    for (int jp = 5; jp < NP; ++jp) logits(jp, jp - 5);
+    // first value batch: issued here, waited for after the softmax arithmetic
+#pragma unroll
+    for (int j = 0; j < 10; ++j)
         asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(kv[j]) : "v"(va), "i"((j >> 1) * KPLD * 4 + (j & 1) * 16) : "memory");
-    // the value rows arrive meanwhile
-    f32x2 sum2[2];
+    f32x2 sum2[NTOK];
 #pragma unroll
-    for (int t = 0; t < 2; ++t) {
+    for (int t = 0; t < NTOK; ++t) {
         float mx = d[t][NP - 1][0];                    // v_max3 by name: fmaxf() first canonicalises every asm result (17 extra v_max per head)
 #pragma unroll
         for (int jp = 0; jp < NP - 1; ++jp) asm("v_max3_f32 %0, %0, %1, %2" : "+v"(mx) : "v"(d[t][jp][0]), "v"(d[t][jp][1]));
@@ -302,26 +316,26 @@ __device__ __forceinline__ void head_attention(const f32x2 (&qa)[2], const f32x2
         asm volatile("s_nop 0" : "+v"(d[t][0]), "+v"(d[t][1]), "+v"(d[t][2]), "+v"(d[t][3]), "+v"(d[t][4]), "+v"(d[t][5]), "+v"(d[t][6]), "+v"(d[t][7]), "+v"(d[t][8]));   // pk::fence
         sum2[t] = pk::add(pk::add(pk::add(d[t][0], d[t][1]), pk::add(d[t][2], d[t][3])), pk::add(pk::add(pk::add(d[t][4], d[t][5]), pk::add(d[t][6], d[t][7])), d[t][8]));
     }
-    f32x2 o[2][4];
-    asm volatile("s_waitcnt lgkmcnt(8)" : UU3D_SP_W10(kv, 0) :: "memory");
-    auto pv = [&](int jp) __attribute__((always_inline)) {
-        const f32x2 v0 = {kv[2 * jp][0], kv[2 * jp][1]}, v1 = {kv[2 * jp][2], kv[2 * jp][3]};
-        const f32x2 v2 = {kv[2 * jp + 1][0], kv[2 * jp + 1][1]}, v3 = {kv[2 * jp + 1][2], kv[2 * jp + 1][3]};
+    f32x2 o[NTOK][4];
+    auto pv = [&](int jp, int r) __attribute__((always_inline)) {
+        const f32x2 v0 = {kv[2 * r][0], kv[2 * r][1]}, v1 = {kv[2 * r][2], kv[2 * r][3]};
+        const f32x2 v2 = {kv[2 * r + 1][0], kv[2 * r + 1][1]}, v3 = {kv[2 * r + 1][2], kv[2 * r + 1][3]};
 #pragma unroll
-        for (int t = 0; t < 2; ++t) {
+        for (int t = 0; t < NTOK; ++t) {
             if (jp == 0) { o[t][0] = pk::mul(d[t][0], v0); o[t][1] = pk::mul(d[t][0], v1); o[t][2] = pk::mul(d[t][0], v2); o[t][3] = pk::mul(d[t][0], v3); }
             else { o[t][0] = pk::fma(d[t][jp], v0, o[t][0]); o[t][1] = pk::fma(d[t][jp], v1, o[t][1]); o[t][2] = pk::fma(d[t][jp], v2, o[t][2]); o[t][3] = pk::fma(d[t][jp], v3, o[t][3]); }
         }
     };
+    asm volatile("s_waitcnt lgkmcnt(0)" : UU3D_SP_W10(kv) :: "memory");
 #pragma unroll
-    for (int jp = 0; jp < 5; ++jp) pv(jp);
-    asm volatile("s_waitcnt lgkmcnt(0)" : UU3D_SP_W8(kv, 10) :: "memory");
+    for (int jp = 0; jp < 5; ++jp) pv(jp, jp);
+    read_pairs(std::integral_constant<int, 5>{}, va);
 #pragma unroll
-    for (int jp = 5; jp < NP; ++jp) pv(jp);
+    for (int jp = 5; jp < NP; ++jp) pv(jp, jp - 5);
 #undef UU3D_SP_W10
 #undef UU3D_SP_W8
 #pragma unroll
-    for (int t = 0; t < 2; ++t) {
+    for (int t = 0; t < NTOK; ++t) {
         f32x2 rs = pk::splat(__builtin_amdgcn_rcpf(sum2[t][0] + sum2[t][1]));     // 1 ulp; a correctly rounded quotient costs 10 instructions per head
         pk::fence(rs);
         oa[t] = pk::mul((f32x2){o[t][0][0] + o[t][0][1], o[t][1][0] + o[t][1][1]}, rs);
@@ -365,19 +379,24 @@ __device__ unsigned long long spatial_clk[12];   // tools/spatial_stamp_exp: s_m
 #else
 #define UU3D_PK_TARGET
 #endif
-template <int J, int FR>
-__global__ void __launch_bounds__(64, UU3D_SPATIAL_H3_WAVES) UU3D_PK_TARGET
+// MT = token tiles per wave.  MT = 2: one wave per workgroup runs both tiles of its 3 frames (two tokens per lane).  MT = 1: a
+// workgroup of TWO waves shares the frames and the LDS tiles, wave w owns tile w (one token per lane): half the registers per
+// wave (three waves per SIMD instead of 1.5), half the dependent instruction chain, and s_barriers where the waves exchange
+// K / V through LDS.
+template <int J, int FR, int MT>
+__global__ void __launch_bounds__(64 * (2 / MT), MT == 2 ? UU3D_SPATIAL_H3_WAVES : 3) UU3D_PK_TARGET
 spatial_stack_h3_kernel(const float* __restrict__ kp2d, const SpatialParams p, const _Float16* __restrict__ wfrag,
                         float* __restrict__ out, _Float16* __restrict__ out_hi, _Float16* __restrict__ out_lo)
 {
-    // A lane runs the same arithmetic twice, once per token (mt = 0, 1), fully unrolled; the two copies must round
+    // The two token tiles run the same arithmetic, fully unrolled (MT = 2) or in two waves; the copies must round
     // identically or a frame's result depends on its slot in the wave (bitwise permutation test).  Contraction is off
-    // and every intended FMA is an fmaf(); the f16 conversions go through h3_hi (one instruction form, see there).
+    // and every intended FMA is an fmaf() / a packed fma by name; the f16 conversions go through h3_hi (one instruction form).
 #pragma clang fp contract(off)
     using namespace sh3;
+    static_assert(MT == 1 || MT == 2, "one or two token tiles per wave");
     h3_flush_f16_denormals();
     constexpr int DS = 32, HS = 64;
-    static_assert(FR * ((J + 1) / 2) == TOK && DS == 32 && HS == 64, "one wave = 3 frames of 17 joints, d = 32");
+    static_assert(FR * ((J + 1) / 2) == TOK && DS == 32 && HS == 64, "one workgroup = 3 frames of 17 joints, d = 32");
     using LY = SpatialBlockLayoutV2<DS, HS>;          // LayerNorm parameters and biases (f32) come from the V2 block
     using FL = SpatialFragLayoutH3;
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
@@ -389,23 +408,32 @@ spatial_stack_h3_kernel(const float* __restrict__ kp2d, const SpatialParams p, c
     _Float16* Hl = Hh + ROWS_T * HLD;
     float* P = TV + ROWS_T * KLD;                                       // [352] this block's LayerNorm parameters and biases
 
-    const int lane = threadIdx.x, tl = lane & 31, half = lane >> 5;
+    const int lane = threadIdx.x & 63, tl = lane & 31, half = lane >> 5;
+    const int mt0 = MT == 2 ? 0 : __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);    // first (only) token tile of this wave
+    // every wave of the workgroup is done with the LDS tiles the next phase overwrites (MT = 1; own LDS operations retired first)
+    auto wg_sync = [&]() __attribute__((always_inline)) {
+        if constexpr (MT == 1) {
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+        }
+    };
     int nframes = p.total_frames;
     if (p.frame_list != nullptr) {
         nframes = p.frame_list[p.total_frames];
         if ((int)blockIdx.x * FR >= nframes) return;
     }
-    // Token -> lane: lane tl of token tile mt holds joint (tl % JH) + JH * mt of frame tl / JH of this wave (JH = 9 joints per
-    // frame and tile; lanes 27..31 and the tenth joint of tile 1 are padding).  A lane's two tokens then belong to the SAME
-    // frame: the attention below loads every K / V register once for both.
+    // Token -> lane: lane tl of token tile t holds joint (tl % JH) + JH * t of frame tl / JH of this workgroup (JH = 9 joints
+    // per frame and tile; lanes 27..31 and the tenth joint of tile 1 are padding).  With MT = 2 a lane's two tokens then belong
+    // to the SAME frame: the attention below loads every K / V register once for both.
     constexpr int JH = (J + 1) / 2;
-    static_assert(FR * JH == TOK, "the frames of a wave side by side in one token tile");
-    int frame[2], joint[2];
-    bool valid[2], real[2];
-    const int fl = min(tl / JH, FR - 1);                // frame of this lane inside the wave
+    static_assert(FR * JH == TOK, "the frames of a workgroup side by side in one token tile");
+    int frame[MT], joint[MT];
+    bool valid[MT], real[MT];
+    const int fl = min(tl / JH, FR - 1);                // frame of this lane inside the workgroup
 #pragma unroll
-    for (int mt = 0; mt < 2; ++mt) {
-        const int jn = (tl - fl * JH) + JH * mt;
+    for (int mt = 0; mt < MT; ++mt) {
+        const int jn = (tl - fl * JH) + JH * (mt0 + mt);
         real[mt] = (tl < TOK) && (jn < J);
         joint[mt] = min(jn, J - 1);
         int f = blockIdx.x * FR + fl;
@@ -418,9 +446,9 @@ spatial_stack_h3_kernel(const float* __restrict__ kp2d, const SpatialParams p, c
     // tokens go to the spare half of the last pair of their frame (never read with a non-zero probability)
     constexpr int NP = (J + 1) / 2;
     static_assert((J & 1) == 1 && FR * NP * KPLD <= ROWS_T * KLD, "odd J: one spare key slot per frame; fits the K / V region");
-    int kslot[2];
+    int kslot[MT];
 #pragma unroll
-    for (int mt = 0; mt < 2; ++mt) {
+    for (int mt = 0; mt < MT; ++mt) {
         const int jp = real[mt] ? (joint[mt] >> 1) : NP - 1, par = real[mt] ? (joint[mt] & 1) : 1;
         kslot[mt] = (fl * NP + jp) * KPLD + par;
     }
@@ -430,9 +458,9 @@ spatial_stack_h3_kernel(const float* __restrict__ kp2d, const SpatialParams p, c
 
     // keypoint embedding + spatial PE (u_u_t.py:321-323), this lane's 16 channels of each token as 8 pairs.  Packed by name
     // like everything else: left as scalar code, hipcc's SLP pass pairs it up itself -- with op_sel broadcasts of (kx, ky).
-    f32x2 x[2][8];
+    f32x2 x[MT][8];
 #pragma unroll
-    for (int mt = 0; mt < 2; ++mt) {
+    for (int mt = 0; mt < MT; ++mt) {
         float kx = 0.f, ky = 0.f;
         if (valid[mt]) { const float2 k2 = *reinterpret_cast<const float2*>(kp2d + ((size_t)frame[mt] * J + joint[mt]) * 2); kx = k2.x; ky = k2.y; }
         const f32x2 kx2 = pk::splat(kx), ky2 = pk::splat(ky);
@@ -460,7 +488,8 @@ spatial_stack_h3_kernel(const float* __restrict__ kp2d, const SpatialParams p, c
 #endif
     for (int blk = 0; blk < p.depth; ++blk) {
         const _Float16* __restrict__ F = wfrag + (size_t)blk * FL::size;
-        {   // one coalesced copy of the block's 352 parameters into LDS: the 16-byte group reads below then cost an LDS
+        wg_sync();                                         // the other wave may still read the previous block's parameters and hidden planes
+        {   // one coalesced copy (per wave: each reads back what it wrote itself) of the block's 352 parameters into LDS: the 16-byte group reads below then cost an LDS
             // round trip instead of a dependent global load each (133 of them per block before)
             const float* __restrict__ Wg = p.blocks + (size_t)blk * LY::size;
             if (UU3D_SP_SKIP != 4 || blk == 0)
@@ -468,34 +497,34 @@ spatial_stack_h3_kernel(const float* __restrict__ kp2d, const SpatialParams p, c
             for (int i = 0; i < (NPARAM + 63) / 64; ++i) { const int k = 64 * i + lane; if (k < NPARAM) P[k] = Wg[k]; }
         }
         const float* W = P;
-        f32x2 y[2][8];
+        f32x2 y[MT][8];
 
         // ---- attention half ----
         WFrag<1, 2> wq, wk, wv, wp;
         load_w<1, 2>(F + FL::fq, lane, wq); load_w<1, 2>(F + FL::fk, lane, wk); load_w<1, 2>(F + FL::fv, lane, wv);
-        if constexpr (UU3D_SP_SKIP == 3) { for (int mt = 0; mt < 2; ++mt) for (int i = 0; i < 8; ++i) y[mt][i] = x[mt][i]; } else
+        if constexpr (UU3D_SP_SKIP == 3) { for (int mt = 0; mt < MT; ++mt) for (int i = 0; i < 8; ++i) y[mt][i] = x[mt][i]; } else
         ln_tokens(x, W + LY::ln1_g, W + LY::ln1_b, 1e-5f, half, y);
-        store_planes(Xh, Xl, XLD, 0, lane, y);
+        store_planes<MT>(Xh, Xl, XLD, 0, lane, mt0, y);
         SP_STAMP(0)
-        f32x2 q[1][2][8];
+        f32x2 q[1][MT][8];
         {
-            f32x2 kv[1][2][8], bp[8];
+            f32x2 kv[1][MT][8], bp[8];
             wait_w<8>(wq);
-            mm<1, 2>(wq, Xh, Xl, XLD, lane, q);
+            mm<MT, 1, 2>(wq, Xh, Xl, XLD, lane, mt0, q);
             bias_pairs(W + LY::bq, bp);
 #pragma unroll
-            for (int mt = 0; mt < 2; ++mt)
+            for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
                 for (int i = 0; i < 8; ++i) q[0][mt][i] = pk::add(q[0][mt][i], bp[i]);
             wait_w<4>(wk);
-            mm<1, 2>(wk, Xh, Xl, XLD, lane, kv);
+            mm<MT, 1, 2>(wk, Xh, Xl, XLD, lane, mt0, kv);
             // the spare key slot of every frame: finite (zero) whatever the hidden planes of the previous block left there
             if (lane < 2 * DS) { const int c = lane & 31; float* T = lane < DS ? TK : TV;
 #pragma unroll
                 for (int f = 0; f < FR; ++f) T[(f * NP + NP - 1) * KPLD + 2 * c + 1] = 0.f; }
             bias_pairs(W + LY::bk, bp);
 #pragma unroll
-            for (int mt = 0; mt < 2; ++mt)
+            for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
                 for (int i = 0; i < 8; ++i) {
                     const f32x2 v = pk::add(kv[0][mt][i], bp[i]);
@@ -504,10 +533,10 @@ spatial_stack_h3_kernel(const float* __restrict__ kp2d, const SpatialParams p, c
                 }
             load_w<1, 2>(F + FL::fp, lane, wp);            // in flight over the attention arithmetic
             wait_w<4>(wv);
-            mm<1, 2>(wv, Xh, Xl, XLD, lane, kv);
+            mm<MT, 1, 2>(wv, Xh, Xl, XLD, lane, mt0, kv);
             bias_pairs(W + LY::bv, bp);
 #pragma unroll
-            for (int mt = 0; mt < 2; ++mt)
+            for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
                 for (int i = 0; i < 8; ++i) {
                     const f32x2 v = pk::add(kv[0][mt][i], bp[i]);
@@ -516,29 +545,32 @@ spatial_stack_h3_kernel(const float* __restrict__ kp2d, const SpatialParams p, c
                 }
         }
         SP_STAMP(1)
-        // scaled dot-product attention over the J joints of the lane's frame, both tokens at once; group g = head 2g + half
-        f32x2 o[2][8];
+        wg_sync();                                         // K / V of every token of the frames are in LDS
+        // scaled dot-product attention over the J joints of the lane's frame, the lane's tokens at once; group g = head 2g + half
+        f32x2 o[MT][8];
         {
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 const unsigned off = kfr + (unsigned)((8 * g + 4 * half) * 2 * 4);
-                const f32x2 qa[2] = {q[0][0][2 * g], q[0][1][2 * g]};
-                const f32x2 qb[2] = {q[0][0][2 * g + 1], q[0][1][2 * g + 1]};
-                f32x2 oa[2], ob[2];
-                if constexpr (UU3D_SP_SKIP == 1) { oa[0] = qa[0]; oa[1] = qa[1]; ob[0] = qb[0]; ob[1] = qb[1]; (void)off; (void)tk_a; (void)tv_a; }
-                else head_attention<J>(qa, qb, tk_a + off, tv_a + off, oa, ob);
-                o[0][2 * g] = oa[0]; o[0][2 * g + 1] = ob[0]; o[1][2 * g] = oa[1]; o[1][2 * g + 1] = ob[1];
+                f32x2 qa[MT], qb[MT], oa[MT], ob[MT];
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt) { qa[mt] = q[0][mt][2 * g]; qb[mt] = q[0][mt][2 * g + 1]; }
+                if constexpr (UU3D_SP_SKIP == 1) { for (int mt = 0; mt < MT; ++mt) { oa[mt] = qa[mt]; ob[mt] = qb[mt]; } (void)off; (void)tk_a; (void)tv_a; }
+                else head_attention<J, MT>(qa, qb, tk_a + off, tv_a + off, oa, ob);
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt) { o[mt][2 * g] = oa[mt]; o[mt][2 * g + 1] = ob[mt]; }
             }
         }
+        wg_sync();                                         // nobody reads K / V any more: the hidden planes may overwrite them
         SP_STAMP(2)
-        store_planes(Xh, Xl, XLD, 0, lane, o);
+        store_planes<MT>(Xh, Xl, XLD, 0, lane, mt0, o);
         {
-            f32x2 pr[1][2][8], bp[8];
+            f32x2 pr[1][MT][8], bp[8];
             wait_w<0>(wp);
-            mm<1, 2>(wp, Xh, Xl, XLD, lane, pr);
+            mm<MT, 1, 2>(wp, Xh, Xl, XLD, lane, mt0, pr);
             bias_pairs(W + LY::bp, bp);
 #pragma unroll
-            for (int mt = 0; mt < 2; ++mt)
+            for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
                 for (int i = 0; i < 8; ++i) x[mt][i] = pk::add(x[mt][i], pk::add(pr[0][mt][i], bp[i]));
         }
@@ -547,35 +579,35 @@ spatial_stack_h3_kernel(const float* __restrict__ kp2d, const SpatialParams p, c
         // ---- MLP half ----
         WFrag<2, 2> w1;
         load_w<2, 2>(F + FL::f1, lane, w1);
-        if constexpr (UU3D_SP_SKIP == 3) { for (int mt = 0; mt < 2; ++mt) for (int i = 0; i < 8; ++i) y[mt][i] = x[mt][i]; } else
+        if constexpr (UU3D_SP_SKIP == 3) { for (int mt = 0; mt < MT; ++mt) for (int i = 0; i < 8; ++i) y[mt][i] = x[mt][i]; } else
         ln_tokens(x, W + LY::ln2_g, W + LY::ln2_b, 1e-5f, half, y);
-        store_planes(Xh, Xl, XLD, 0, lane, y);
+        store_planes<MT>(Xh, Xl, XLD, 0, lane, mt0, y);
         SP_STAMP(4)
         WFrag<1, 4> w2;
         {
-            f32x2 hd[2][2][8], bp[8];
+            f32x2 hd[2][MT][8], bp[8];
             wait_w<0>(w1);
-            mm<2, 2>(w1, Xh, Xl, XLD, lane, hd);
+            mm<MT, 2, 2>(w1, Xh, Xl, XLD, lane, mt0, hd);
             load_w<1, 4>(F + FL::f2, lane, w2);             // in flight over the GELU
             SP_STAMP(5)
 #pragma unroll
             for (int nt = 0; nt < 2; ++nt) {
                 bias_pairs(W + LY::b1 + 32 * nt, bp);
 #pragma unroll
-                for (int mt = 0; mt < 2; ++mt)
+                for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
                     for (int i = 0; i < 8; ++i) hd[nt][mt][i] = UU3D_SP_SKIP == 2 ? pk::add(hd[nt][mt][i], bp[i]) : gelu_pair(pk::add(hd[nt][mt][i], bp[i]));
-                store_planes(Hh, Hl, HLD, 32 * nt, lane, hd[nt]);
+                store_planes<MT>(Hh, Hl, HLD, 32 * nt, lane, mt0, hd[nt]);
             }
         }
         SP_STAMP(6)
         {
-            f32x2 z[1][2][8], bp[8];
+            f32x2 z[1][MT][8], bp[8];
             wait_w<0>(w2);
-            mm<1, 4>(w2, Hh, Hl, HLD, lane, z);
+            mm<MT, 1, 4>(w2, Hh, Hl, HLD, lane, mt0, z);
             bias_pairs(W + LY::b2, bp);
 #pragma unroll
-            for (int mt = 0; mt < 2; ++mt)
+            for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
                 for (int i = 0; i < 8; ++i) x[mt][i] = pk::add(x[mt][i], pk::add(z[0][mt][i], bp[i]));
         }
@@ -589,10 +621,10 @@ spatial_stack_h3_kernel(const float* __restrict__ kp2d, const SpatialParams p, c
     }
 #endif
 
-    f32x2 y[2][8];
+    f32x2 y[MT][8];
     sh3::ln_tokens(x, p.norm_g, p.norm_b, 1e-6f, half, y);
 #pragma unroll
-    for (int mt = 0; mt < 2; ++mt) {
+    for (int mt = 0; mt < MT; ++mt) {
         if (!valid[mt]) continue;
         const size_t at = ((size_t)frame[mt] * J + joint[mt]) * DS;
 #pragma unroll
