@@ -119,10 +119,17 @@ def train_bench(args, world, rank, local_rank, use_dist):
         dist.destroy_process_group()
 
 
-PMC_SUMMARY = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r02_final_pmc_summary.csv")
 
 
-def pmc_traffic(kernel_class, dom_key):
+def pmc_summary_for(config, batch):
+    """The committed --pmc summary that was collected on THIS workload (config, per-GPU batch), or None: counters of another
+    shape say nothing about this one."""
+    name = {("h36m_351", 128): "r02_final_pmc_summary.csv", ("dense_351", 32): "r02_final_dense351_pmc_summary.csv",
+            ("h36m_81", 256): "r02_final_h36m81_pmc_summary.csv"}.get((config, batch))
+    return None if name is None else os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", name)
+
+
+def pmc_traffic(kernel_class, dom_key, summary=None):
     """HBM bytes per launch of the dominant kernel from the committed rocprofv3 --pmc summary (FETCH_SIZE x2 on gfx950 +
     WRITE_SIZE, separate --pmc passes, tools/profile_r02.sh -> tools/rocpd_summary.py; one launch = the whole batch, like
     `achieved`).  None when the summary does not hold that kernel."""
@@ -133,10 +140,10 @@ def pmc_traffic(kernel_class, dom_key):
             "gemm_h3": {"proj_res": ("gemm_h3g_kernel", "GLoadPlain", "EpBiasResidual"), "fc2_res": ("gemm_h3g_kernel", "GLoadPlain", "EpBiasResidual"),
                         "conv_res": ("gemm_h3g_kernel", "GLoadConv3"), "s2t": ("gemm_h3_kernel", "EpSpatialToTemporal")}.get(op),
             "gemm_f32": ("gemm_f32_kernel",)}.get(kernel_class)
-    if want is None or not os.path.exists(PMC_SUMMARY):
+    if want is None or summary is None or not os.path.exists(summary):
         return None
     best = None
-    for r in csv.DictReader(open(PMC_SUMMARY)):
+    for r in csv.DictReader(open(summary)):
         k = r["kernel"]
         if all(w in k for w in want) and r["HBM_read_bytes_avg_x2_gfx950_corrected"] and r["HBM_write_bytes_avg"]:
             t = float(r["HBM_read_bytes_avg_x2_gfx950_corrected"]) + float(r["HBM_write_bytes_avg"])
@@ -327,7 +334,7 @@ def main():
                        "concurrent_half_batches": bool(args.halves and not args.no_halves and B >= 64)},
             "roofline": {"bound": "mfma", "kernel": f"{gk} [{dom_key}]",
                          "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s",
-                         "frac": round(ach / peak, 4), "traffic": pmc_traffic(gk, dom_key),
+                         "frac": round(ach / peak, 4), "traffic": pmc_traffic(gk, dom_key, pmc_summary_for(args.config, B)),
                          "note": ("algorithmic 2*M*N*K FLOPs (mlp_fused: both Dense layers of the MLP, 4*M*d*h); the f16x3 kernels issue 3 f16 "
                                   "MFMA passes per product, so the matrix pipe does 3x this work (frac of pipe = 3 * frac)") if args.precision == "f16x3" else
                                  "exact f32-input MFMA",
