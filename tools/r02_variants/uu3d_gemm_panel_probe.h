@@ -1,0 +1,314 @@
+// uu3d_gemm_panel.h -- f16x3 "row panel" GEMM: A fragments resident in registers, the weight operand streamed.
+//
+// The tiled kernels of uu3d_gemm_h3.h restart a 12-iteration k-loop in every 64 x 128 tile, re-stage the same A rows
+// in each of the N / 128 workgroups along N, and move four f16 planes through LDS per k-tile.  Here the roles are
+// fixed differently:
+//
+//   * BOTH operands are stored in MFMA FRAGMENT ORDER, one 1 KiB fragment = [lane][8 halfs]:
+//         A (activations):  [32-row panel][16-deep k-slice][plane hi|lo]            written by the producing kernel
+//         B (weights):      [32-column chunk][k-step of 12 slices][k-slice][plane]  written once at commit time
+//     so a wave loads its panel with 2 K/16 fully coalesced 16-byte loads straight into the registers the MFMAs read
+//     (no LDS transposition, no arithmetic), and a k-step of B is one linear 24 KiB piece that goes global -> LDS by
+//     global_load_lds_dwordx4 with no swizzle; a B fragment is one conflict-free ds_read_b128 at lane * 16;
+//   * a wave owns a PANEL of 32 token rows over the full contraction length and keeps its 2 K/16 A fragments
+//     resident for the whole kernel (K = 384: 192 registers);
+//   * a workgroup = 4 waves = 128 rows shares the weight stream through a 3-slot LDS ring (3 x 48 KiB), one barrier per
+//     k-step of 24 slices (72 MFMAs per wave), two k-steps in flight (6 slots of 12 slices: 3 % slower);
+//   * per k-slice a wave issues 2 ds_read_b128 and 3 MFMAs (ah*bh -> acc0; ah*bl, al*bh -> acc1); the fragment reads
+//     run two slices ahead (asm with counted lgkmcnt waits: hipcc sinks plain loads to their use);
+//   * the epilogue of chunk c-1 is interleaved with the MFMAs of chunk c (two accumulator sets): issued as a block
+//     between chunks it cost 1340 cycles per chunk with the matrix pipe idle;
+//   * ~330 registers per wave, so ONE wave per SIMD / one workgroup per CU: everything is software pipelined instead
+//     of relying on co-resident waves.
+//
+// Grid: (M / 128) row tiles x S column ranges of N / (32 S) chunks each, launched as (8 S, ceil(ceil(items / 8) / S)).  Measured (tools/gemm_panel_exp): see DESIGN.md.
+// Forms that measured slower and live in tools/ now: LayerNorm statistics + split in the kernel's own prologue
+// (tools/gemm_panel_lnfold_exp.h), LayerNorm folded into the operand with producer-side fragment stores ("LNF") and the
+// accumulating variant for the residual Dense layers (tools/r01_variants/uu3d_gemm_panel.h).
+#pragma once
+#include "../../uplift-upsample-3dhpe_amd/csrc/uu3d_gemm_h3.h"
+#include <type_traits>
+
+namespace uu3d {
+
+#ifndef UU3D_PANEL_SS
+#define UU3D_PANEL_SS 24
+#endif
+static constexpr int PANEL_SS = UU3D_PANEL_SS;           // k-slices per k-step (12 or 24)
+static constexpr int PANEL_STEP_BYTES = PANEL_SS * 2 * 1024;   // one k-step of B: slices x 2 planes x 1 KiB
+static constexpr int PANEL_SLOTS = 144 / (2 * PANEL_SS); // ring depth (144 KiB): all but one slot in flight while one is consumed
+static constexpr int PANEL_PIECES = PANEL_SS / 2;        // 1 KiB pieces of a k-step each of the 4 waves moves
+static constexpr size_t PANEL_RING_BYTES = (size_t)PANEL_SLOTS * PANEL_STEP_BYTES;   // 144 KiB
+static constexpr int PANEL_COLV_FLOATS = 1024;           // per-column epilogue vector of this workgroup's columns (<= 32 chunks)
+static constexpr size_t PANEL_LDS_TOTAL = PANEL_RING_BYTES + PANEL_COLV_FLOATS * sizeof(float);
+
+// halfs in the fragment-ordered operands (A is allocated in whole 32-row panels)
+__host__ __device__ inline constexpr size_t panel_b_halfs(int N, int K) { return (size_t)(N / 32) * (K / 16) * 2 * 512; }
+__host__ __device__ inline constexpr size_t panel_a_halfs(int M, int K) { return (size_t)((M + 31) / 32) * (K / 16) * 2 * 512; }
+// element (row, k) of the hi plane in the A operand; the lo plane element is 512 halfs further
+__host__ __device__ inline size_t panel_a_index(int row, int k, int K) {
+    return ((((size_t)(row >> 5) * (K / 16) + (k >> 4)) * 2) * 64 + ((k >> 3) & 1) * 32 + (row & 31)) * 8 + (k & 7);
+}
+
+// Host side: fragment-ordered B planes from the transposed, padded Bt[N][Kp] (k contiguous) of the tiled kernels.
+// hi / lo as produced by the commit-time split (lo pre-scaled by 2048).  K % 192 == 0, N % 32 == 0.
+inline void panel_pack_operand(const _Float16* Bh, const _Float16* Bl, int N, int K, int Kp, _Float16* out) {
+    const int steps = K / 192;
+    for (int c = 0; c < N / 32; ++c)
+        for (int st = 0; st < steps; ++st)
+            for (int kk = 0; kk < 12; ++kk)
+                for (int p = 0; p < 2; ++p)
+                    for (int l = 0; l < 64; ++l)
+                        for (int j = 0; j < 8; ++j) {
+                            const int n = 32 * c + (l & 31), k = st * 192 + kk * 16 + (l >> 5) * 8 + j;
+                            out[((((size_t)(c * steps + st) * 12 + kk) * 2 + p) * 64 + l) * 8 + j] = (p ? Bl : Bh)[(size_t)n * Kp + k];
+                        }
+}
+
+// ---- epilogues: v = acc + colv[col] ----
+// Addresses are a scalar base + a 32-bit BYTE offset per lane (global_store ... saddr): a 64-bit address pair per unrolled
+// output register cost the fc1 kernel its register budget (512 + scratch).  The launcher keeps M * ldo * 4 below 2^32.
+struct PanelEpBias {           // out[row][col] = v
+    float* __restrict__ out; int ldo;
+    __device__ __forceinline__ void store(int row, int col, float v) const {
+        const unsigned b = ((unsigned)row * (unsigned)ldo + (unsigned)col) * 4u;
+        *reinterpret_cast<float*>(reinterpret_cast<char*>(out) + b) = v;
+    }
+};
+struct PanelEpBiasSplitQ {     // [q | k | v] as row-major hi / lo planes for attn_h3_kernel; q (columns < qcols) times qscale = log2(e) / sqrt(d_h)
+    _Float16* __restrict__ Oh; _Float16* __restrict__ Ol; int ldo, qcols; float qscale;
+    __device__ __forceinline__ void store(int row, int col, float x) const {
+        const float v = col < qcols ? x * qscale : x;
+        const _Float16 h = h3_hi(v);
+        const unsigned b = ((unsigned)row * (unsigned)ldo + (unsigned)col) * 2u;
+        *reinterpret_cast<_Float16*>(reinterpret_cast<char*>(Oh) + b) = h;
+        *reinterpret_cast<_Float16*>(reinterpret_cast<char*>(Ol) + b) = (_Float16)((v - (float)h) * H3_SCALE);
+    }
+};
+struct PanelEpBiasReluSplit {  // ReLU(v) as row-major hi / lo planes [M][ldo] (the A operand of the tiled LDS-DMA kernel)
+    _Float16* __restrict__ Oh; _Float16* __restrict__ Ol; int ldo;
+    __device__ __forceinline__ void store(int row, int col, float x) const {
+        const float v = fmaxf(x, 0.f);
+        const _Float16 h = h3_hi(v);
+        const unsigned b = ((unsigned)row * (unsigned)ldo + (unsigned)col) * 2u;
+        *reinterpret_cast<_Float16*>(reinterpret_cast<char*>(Oh) + b) = h;
+        *reinterpret_cast<_Float16*>(reinterpret_cast<char*>(Ol) + b) = (_Float16)((v - (float)h) * H3_SCALE);
+    }
+};
+#ifdef UU3D_PANEL_STAMP
+__device__ unsigned long long panel_clk[8];   // tools/gemm_panel_exp: s_memtime ticks in prologue / loop / tail, summed over workgroups
+#define PANEL_STAMP(...) __VA_ARGS__
+#else
+#define PANEL_STAMP(...)
+#endif
+
+// Counted LDS waits of the main loop.  Issue order of a k-step (all asm, in program order): B(0) B(1), then per k-slice g:
+// B(g+2) | wait B(g) | 3 MFMAs, where B(g) = the two fragment reads of slice g.  LDS returns in order, so a wait for an
+// operation = lgkmcnt(number of operations issued after it).
+constexpr int panel_wait_count(const int g) { return g + 2 < PANEL_SS ? 4 : (g + 1 < PANEL_SS ? 2 : 0); }
+
+// C[M][N] = A[M][K] B + colv,  K = 16 KS (KS % 24 == 0), A / B fragment ordered (see top).
+template <int KS, class EP>
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1)))
+gemm_h3_panel_kernel(const _Float16* __restrict__ Af, const _Float16* __restrict__ Bf, const float* __restrict__ colv,
+                     const int M, const int m_tiles, const int splits, const int chunks_per_wg, const EP ep)
+{
+    constexpr int SPC = KS / PANEL_SS;                           // k-steps per chunk
+    h3_flush_f16_denormals();                              // the epilogue may split its result
+    extern __shared__ __attribute__((aligned(16))) unsigned char psm[];
+
+    // Work item u = row tile * S + column range.  The dispatcher deals workgroups to the 8 XCDs round robin; XCD x takes
+    // the contiguous items [x per, (x + 1) per): the column ranges of a row tile share an L2 (A panels), and no XCD gets
+    // more than ceil(items / 8) workgroups (dealing whole row tiles gave 33 on two XCDs at 82 tiles x 3: a second round).
+    const int id = blockIdx.y * gridDim.x + blockIdx.x;
+    const int total = m_tiles * splits, per = (total + 7) >> 3;
+    const int u = (id & 7) * per + (id >> 3);
+    if ((id >> 3) >= per || u >= total) return;
+    const int bm = u / splits, ns = u - bm * splits;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // scalar: the LDS-DMA destinations (M0) then come from SALU arithmetic
+    const int row0 = bm * 128 + wave * 32;                 // this wave's panel
+    const int chunk0 = ns * chunks_per_wg;
+    const int T = SPC * chunks_per_wg;                     // k-steps this workgroup consumes
+
+    // ---- weight stream: k-step t -> ring slot t % PANEL_SLOTS; each wave moves 6 of its 24 pieces of 1 KiB ----
+    // the global address of a piece = scalar base (SGPR arithmetic) + lane * 16 as a 32-bit offset: no 64-bit VGPR address pairs
+    const unsigned char* bsrc = reinterpret_cast<const unsigned char*>(Bf) + (size_t)chunk0 * SPC * PANEL_STEP_BYTES + (wave * PANEL_PIECES) * 1024;
+    const unsigned lane16 = (unsigned)lane * 16u;
+    auto dma1 = [&](int t, int slot, int p) __attribute__((always_inline)) {       // piece p of this wave's share of k-step t
+        const unsigned char* s = bsrc + (size_t)min(t, T - 1) * PANEL_STEP_BYTES + (p >> 2) * 4096;
+        unsigned char* d = psm + slot * PANEL_STEP_BYTES + (wave * PANEL_PIECES) * 1024 + (p >> 2) * 4096;
+        // the instruction's immediate offset advances the global and the LDS address alike: one M0 value / base per 4 pieces
+        // instead of a v_readfirstlane + s_mov m0 + 64-bit add for every piece (31.4 -> 30.1 us for the QKV projection)
+        switch (p & 3) {
+            case 0: __builtin_amdgcn_global_load_lds((h3_glb_void*)(s + lane16), (h3_lds_void*)d, 16, 0, 0); break;
+            case 1: __builtin_amdgcn_global_load_lds((h3_glb_void*)(s + lane16), (h3_lds_void*)d, 16, 1024, 0); break;
+            case 2: __builtin_amdgcn_global_load_lds((h3_glb_void*)(s + lane16), (h3_lds_void*)d, 16, 2048, 0); break;
+            default: __builtin_amdgcn_global_load_lds((h3_glb_void*)(s + lane16), (h3_lds_void*)d, 16, 3072, 0); break;
+        }
+    };
+    auto dma = [&](int t, int slot) __attribute__((always_inline)) {
+#pragma unroll
+        for (int p = 0; p < PANEL_PIECES; ++p) dma1(t, slot, p);
+    };
+    PANEL_STAMP(const long long c_start = clock64();)
+
+    // ---- A panel: 2 KS fragments straight into registers (panels past M: clamped to the last one, never stored) ----
+    h16x8 ah[KS], al[KS];
+    {
+        const int panel = min(row0, M - 1) >> 5;
+        const h16x8* ap = reinterpret_cast<const h16x8*>(Af) + (size_t)panel * KS * 2 * 64 + lane;
+#pragma unroll
+        for (int q = 0; q < KS; ++q) { ah[q] = ap[(q * 2 + 0) * 64]; al[q] = ap[(q * 2 + 1) * 64]; }
+    }
+    // the ring's first five k-steps go out AFTER the panel loads: vector memory retires in order, so the panel (needed
+    // first) must not queue behind 120 KiB of weights
+#pragma unroll
+    for (int t = 0; t < PANEL_SLOTS - 1; ++t) dma(t, t);
+    float* colv_s = reinterpret_cast<float*>(psm + PANEL_RING_BYTES);
+    for (int i = tid; i < chunks_per_wg * 32; i += 256) colv_s[i] = colv[chunk0 * 32 + i];
+    // ---- main loop ----
+    // Every wait is "vmcnt(6 x k-steps left in flight)": k-step t was issued before t+1 .. t+4, whose pieces are the
+    // newest loads at that point, and vector memory operations retire in order -- wherever the compiler puts the
+    // epilogue's stores (or the panel loads above), the wait can only become stricter, never weaker.
+    int slot_r = 0, slot_w = PANEL_SLOTS - 1;              // slot consumed / refilled in the current step
+    const int crow = (lane >> 5) * 4, ccol = lane & 31;
+    const int valid = min(32, M - row0);                   // wave-uniform: rows of this panel that exist (<= 0: none)
+    PANEL_STAMP(asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); const long long c_pro = clock64();)
+
+#ifdef UU3D_PANEL_PROBE_DOUBLE
+    f32x16 probe0, probe1;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { probe0[r] = 0.f; probe1[r] = 0.f; }
+#endif
+    auto emit = [&](int c, int r, const f32x16& p0, const f32x16& p1, float cv) __attribute__((always_inline)) {
+        ep.store(row0 + 8 * (r >> 2) + crow + (r & 3), (chunk0 + c) * 32 + ccol, p0[r] + p1[r] * (1.0f / H3_SCALE) + cv);
+    };
+    // WHOLE = every row of the panel exists: the 16 stores of chunk c-1 are spread over the first 16 k-slices of chunk c
+    // (an MFMA holds the vector issue port for 8 of its 32 cycles).  Otherwise they are predicated and issued as a block.
+    auto chunk = [&](auto whole_tag, int c, f32x16& acc0, f32x16& acc1, const f32x16& p0, const f32x16& p1) __attribute__((always_inline)) {
+        constexpr bool WHOLE = decltype(whole_tag)::value;
+        const bool prev = c > 0;
+        const float pcv = colv_s[max(c - 1, 0) * 32 + ccol];                       // the previous chunk's bias
+#pragma unroll
+        for (int st = 0; st < SPC; ++st) {
+            asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" :: "i"(PANEL_PIECES * (PANEL_SLOTS - 2)) : "memory");   // k-step t landed (this wave's pieces); own reads of t-1 returned
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_barrier();                                  // ... everybody's; the slot refilled below was last read in t-1
+            __builtin_amdgcn_sched_barrier(0);
+            if (!WHOLE && st == 0 && prev) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    if (8 * (r >> 2) + crow + (r & 3) < valid) emit(c - 1, r, p0, p1, pcv);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            if (st == 0) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) { acc0[r] = 0.f; acc1[r] = 0.f; }
+            }
+            const unsigned sb = (unsigned)(uintptr_t)(h3_lds_void*)(psm + slot_r * PANEL_STEP_BYTES + lane * 16);
+            h16x8 bh[3], bl[3];
+#define UU3D_PANEL_READ(i, kk) \
+            asm volatile("ds_read_b128 %0, %2 offset:%3\n\tds_read_b128 %1, %2 offset:%4" \
+                         : "=&v"(bh[i]), "=&v"(bl[i]) : "v"(sb), "i"((kk) * 2048), "i"((kk) * 2048 + 1024))
+            UU3D_PANEL_READ(0, 0);
+            UU3D_PANEL_READ(1, 1);
+#pragma unroll
+            for (int kk = 0; kk < PANEL_SS; ++kk) {
+                if (kk + 2 < PANEL_SS) UU3D_PANEL_READ((kk + 2) % 3, kk + 2);
+                asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(bh[kk % 3]), "+v"(bl[kk % 3]) : "i"(panel_wait_count(kk)));
+                acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[st * PANEL_SS + kk], bh[kk % 3], acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[st * PANEL_SS + kk], bl[kk % 3], acc1, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[st * PANEL_SS + kk], bh[kk % 3], acc1, 0, 0, 0);
+#ifdef UU3D_PANEL_PROBE_DOUBLE      // tools/gemm_panel2_exp: twice the MFMAs per fragment read (is the loop bound by LDS reads or by the matrix pipe?)
+                probe0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[st * PANEL_SS + kk], bh[kk % 3], probe0, 0, 0, 0);
+                probe1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[st * PANEL_SS + kk], bl[kk % 3], probe1, 0, 0, 0);
+                probe1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[st * PANEL_SS + kk], bh[kk % 3], probe1, 0, 0, 0);
+#endif
+                if (WHOLE && st * PANEL_SS + kk < 16 && prev) emit(c - 1, st * PANEL_SS + kk, p0, p1, pcv);
+                if (kk & 1) dma1(c * SPC + st + PANEL_SLOTS - 1, slot_w, kk >> 1);   // the refill of the slot read in step t-1, spread over the step (-2 %)
+            }
+#undef UU3D_PANEL_READ
+            slot_r = slot_r + 1 == PANEL_SLOTS ? 0 : slot_r + 1;
+            slot_w = slot_w + 1 == PANEL_SLOTS ? 0 : slot_w + 1;
+        }
+    };
+    f32x16 a0, a1, b0, b1;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { b0[r] = 0.f; b1[r] = 0.f; }
+    auto run = [&](auto whole_tag) __attribute__((always_inline)) {
+        for (int c = 0; c < chunks_per_wg; c += 2) {
+            chunk(whole_tag, c, a0, a1, b0, b1);
+            if (c + 1 < chunks_per_wg) chunk(whole_tag, c + 1, b0, b1, a0, a1);
+        }
+    };
+    if (valid == 32) run(std::true_type{}); else run(std::false_type{});
+    PANEL_STAMP(const long long c_loop = clock64();)
+    {   // last chunk
+        const int c = chunks_per_wg - 1;
+        const float cv = colv_s[c * 32 + ccol];
+        if (c & 1) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                if (8 * (r >> 2) + crow + (r & 3) < valid) emit(c, r, b0, b1, cv);
+        } else {
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                if (8 * (r >> 2) + crow + (r & 3) < valid) emit(c, r, a0, a1, cv);
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // the clamped tail DMAs must not outlive the LDS allocation
+#ifdef UU3D_PANEL_PROBE_DOUBLE
+    if (probe0[0] + probe1[0] == 12345.678f) ep.store(row0, chunk0 * 32, probe0[1]);      // keep the probe alive
+#endif
+    PANEL_STAMP(if (tid == 0) { atomicAdd(&panel_clk[0], (unsigned long long)(c_pro - c_start)); atomicAdd(&panel_clk[1], (unsigned long long)(c_loop - c_pro));
+        atomicAdd(&panel_clk[4], (unsigned long long)(clock64() - c_loop)); atomicAdd(&panel_clk[5], 1ull); })
+}
+
+// ------------------------------------------------------------------------------------------------
+// LayerNorm (two-pass, eps inside the root) of M rows of D = 16 KS floats, written as the fragment-ordered hi / lo
+// planes of a panel GEMM's A operand.  ROWS rows per workgroup, 16 threads per row, 4-float pieces interleaved across
+// them, so that a wave's stores for one piece index are runs of 64 contiguous bytes of the operand.  At M = 9088:
+// 6.6 us with 8 or 4 rows per workgroup, 7.0 with 16, 7.9 with 32 -- the floor of 28 MB through the Infinity Cache in
+// one short launch.
+template <int KS, int ROWS = 16>
+__global__ void __launch_bounds__(16 * ROWS)
+ln_split_frag_kernel(const float* __restrict__ x, const int ld, const int M, const float eps,
+                     const float* __restrict__ gamma, const float* __restrict__ beta, _Float16* __restrict__ Af)
+{
+    constexpr int D = 16 * KS, NV = D / 64;                // float4 pieces per thread
+    h3_flush_f16_denormals();
+    const int tid = threadIdx.x, j = tid & 15, lr = tid >> 4;
+    const int row = blockIdx.x * ROWS + lr;
+    const float* p = x + (size_t)min(row, M - 1) * ld;
+    f32x4 v[NV];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) { v[i] = *reinterpret_cast<const f32x4*>(p + 4 * (j + 16 * i)); s += (v[i][0] + v[i][1]) + (v[i][2] + v[i][3]); }
+    s += __shfl_xor(s, 1); s += __shfl_xor(s, 2); s += __shfl_xor(s, 4); s += __shfl_xor(s, 8);
+    const float mean = s * (1.0f / D);
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const float a = v[i][0] - mean, b = v[i][1] - mean, c = v[i][2] - mean, d = v[i][3] - mean;
+        q += (a * a + b * b) + (c * c + d * d);
+    }
+    q += __shfl_xor(q, 1); q += __shfl_xor(q, 2); q += __shfl_xor(q, 4); q += __shfl_xor(q, 8);
+    const float rstd = 1.0f / sqrtf(q * (1.0f / D) + eps);
+    _Float16* base = Af + (size_t)(row >> 5) * KS * 2 * 512 + (row & 31) * 8;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int c = 4 * (j + 16 * i);                    // first of 4 consecutive k
+        const f32x4 g = *reinterpret_cast<const f32x4*>(gamma + c);
+        const f32x4 bt = *reinterpret_cast<const f32x4*>(beta + c);
+        f32x4 y;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { const float inv = rstd * g[e]; y[e] = v[i][e] * inv + (bt[e] - mean * inv); }
+        h16x4 hi, lo;
+        h3_split(y, hi, lo);
+        _Float16* d = base + (size_t)(c >> 4) * 2 * 512 + ((c >> 3) & 1) * 256 + (c & 4);
+        *reinterpret_cast<h16x4*>(d) = hi;
+        *reinterpret_cast<h16x4*>(d + 512) = lo;
+    }
+}
+
+}  // namespace uu3d
