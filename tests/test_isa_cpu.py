@@ -20,11 +20,14 @@ SRC = r'''
 #include "uu3d_gemm_h3.h"
 #include "uu3d_gemm_panel.h"
 #include "uu3d_attn.h"
+#include "uu3d_attn_h3.h"
 #include "uu3d_bwd.h"
 #include "uu3d_spatial_h3.h"
 using namespace uu3d;
 template __global__ void uu3d::attn_head_wave_kernel<5, 48, true>(const float*, int, int, int, int, const uint8_t*, float*, int, size_t, int);
 template __global__ void uu3d::attn_f32_kernel<3, 48, true>(const float*, int, int, int, int, const uint8_t*, float*, int, size_t);
+template __global__ void uu3d::attn_h3_kernel<48, 3, 3, false>(const _Float16*, const _Float16*, int, int, int, int, const uint8_t*, _Float16*, size_t, int);
+template __global__ void uu3d::attn_h3_kernel<48, 12, 3, true>(const _Float16*, const _Float16*, int, int, int, int, const uint8_t*, _Float16*, size_t, int);
 template __global__ void uu3d::gemm_tn_h3_kernel<TnLoadLayerNorm, EpSlab>(const TnLoadLayerNorm, const float*, int, int, int, int, int, int, int, const EpSlab);
 template __global__ void uu3d::gemm_tn_kernel<TnLoadLayerNorm, EpSlab>(const TnLoadLayerNorm, const float*, int, int, int, int, int, int, int, const EpSlab);
 template __global__ void uu3d::spatial_stack_h3_kernel<17, 3, 1>(const float*, const SpatialParams, const _Float16*, float*, _Float16*, _Float16*);
@@ -94,13 +97,14 @@ def test_row_panel_gemm_code_shape(asm):
 def test_no_packed_fp32_valu_ops(asm):
     """a packed-f32 op whose op_sel reads the OTHER half of a register pair can lose that operand next to
     a busy matrix pipe.  hipcc never emits packed f32 (target feature off); the only ones in the library are written by name in
-    the spatial stack (uu3d_spatial_h3.h, namespace pk), and none of them carries op_sel / op_sel_hi."""
+    the spatial stack (uu3d_pk.h, namespace pk), and none of them carries op_sel / op_sel_hi."""
     ks = _kernels(asm)
     for name, body in ks.items():
         pk = re.findall(r"v_pk_(?:mul|fma|add)_f32[^\n]*", body)
         if "spatial_stack_h3_kernel" in name:
-            assert len(pk) > 500
-            assert not any("op_sel" in l for l in pk)
+            assert len(pk) > 500, (name, len(pk))
+            assert not any("op_sel" in l for l in pk), name
+            assert "scratch_" not in body, name
         else:
             assert not pk, name
     assert "v_mfma_f32_32x32x16_f16" in asm

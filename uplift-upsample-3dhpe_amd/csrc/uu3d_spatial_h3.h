@@ -40,6 +40,7 @@
 #include <type_traits>
 #include "uu3d_gemm_h3.h"
 #include "uu3d_spatial.h"
+#include "uu3d_pk.h"
 
 #ifndef UU3D_SP_SKIP
 #define UU3D_SP_SKIP 0      // tools/spatial_stamp_exp: leave a phase out (1 attention, 2 GELU, 3 LayerNorms, 4 parameter copy after block 0, 5 hi/lo splits) to time it by difference
@@ -96,24 +97,7 @@ __device__ __forceinline__ void wait_w(WFrag<NT, KK>& w) {
         asm volatile("s_waitcnt vmcnt(%8)" : "+v"(w.h[0][0]), "+v"(w.l[0][0]), "+v"(w.h[0][1]), "+v"(w.l[0][1]),
                      "+v"(w.h[NT - 1][KK - 2]), "+v"(w.l[NT - 1][KK - 2]), "+v"(w.h[NT - 1][KK - 1]), "+v"(w.l[NT - 1][KK - 1]) : "i"(NLATER));
 }
-// ---- packed f32 arithmetic by name (see the header): d = a op b on both halves of a register pair, no op_sel ----
-typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef _Float16 h16x2 __attribute__((ext_vector_type(2)));
-namespace pk {
-__device__ __forceinline__ f32x2 add(const f32x2 a, const f32x2 b) { f32x2 d; asm("v_pk_add_f32 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b)); return d; }
-__device__ __forceinline__ f32x2 sub(const f32x2 a, const f32x2 b) { f32x2 d; asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(d) : "v"(a), "v"(b)); return d; }
-__device__ __forceinline__ f32x2 mul(const f32x2 a, const f32x2 b) { f32x2 d; asm("v_pk_mul_f32 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b)); return d; }
-__device__ __forceinline__ f32x2 fma(const f32x2 a, const f32x2 b, const f32x2 c) { f32x2 d; asm("v_pk_fma_f32 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c)); return d; }
-__device__ __forceinline__ f32x2 fnma(const f32x2 a, const f32x2 b, const f32x2 c) {          // c - a * b (one rounding)
-    f32x2 d; asm("v_pk_fma_f32 %0, %1, %2, %3 neg_lo:[1,0,0] neg_hi:[1,0,0]" : "=v"(d) : "v"(a), "v"(b), "v"(c)); return d;
-}
-__device__ __forceinline__ f32x2 splat(const float v) { return (f32x2){v, v}; }
-// A transcendental result (v_exp / v_rcp / v_rsq / v_sqrt) may not be read by the next non-transcendental VALU instruction
-// (gfx940+: one wait state, software's to insert); hipcc covers its own instructions, not inline asm readers.  fence() sits
-// between such results and the packed ops that read them.
-__device__ __forceinline__ void fence(f32x2& a) { asm volatile("s_nop 0" : "+v"(a)); }
-__device__ __forceinline__ void fence(f32x2& a, f32x2& b) { asm volatile("s_nop 0" : "+v"(a), "+v"(b)); }
-}  // namespace pk
 
 // C^T tiles of W^T X^T for NT output tiles (32 channels each) and the wave's MT token tiles (tiles mt0 .. mt0 + MT - 1);
 // K = 16 * KK.  out[nt][mt][i] = the pair of registers (2 i, 2 i + 1): token slot (lane & 31) of tile mt0 + mt, channels
@@ -151,12 +135,12 @@ __device__ __forceinline__ void mm(const WFrag<NT, KK>& w, const _Float16* Bh, c
     // cover it for inline asm readers: without these 20 wait states the packed ops below read the accumulators too early (NaN
     // in every output).  The operands tie the asm between the MFMAs and every reader: volatile asm statements keep their order,
     // so the empty ones (and with them the readers of their operands) stay behind the wait.
-    asm volatile("s_nop 15\n\ts_nop 3" : "+v"(acc0[NT - 1][MT - 1]), "+v"(acc1[NT - 1][MT - 1]));
+    pk::mfma_fence(acc0[NT - 1][MT - 1], acc1[NT - 1][MT - 1]);
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt)
-            if (nt != NT - 1 || mt != MT - 1) asm volatile("" : "+v"(acc0[nt][mt]), "+v"(acc1[nt][mt]));
+            if (nt != NT - 1 || mt != MT - 1) pk::behind_fence(acc0[nt][mt], acc1[nt][mt]);
     const f32x2 inv = pk::splat(1.0f / H3_SCALE);
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt)
@@ -371,14 +355,7 @@ __device__ unsigned long long spatial_clk[12];   // tools/spatial_stamp_exp: s_m
 #ifndef UU3D_SPATIAL_H3_WAVES
 #define UU3D_SPATIAL_H3_WAVES 2     // 3 (168 VGPRs) spills into the block loop: 0.30 ms instead of 0.20
 #endif
-// The library is compiled with the packed-fp32-ops target feature OFF, which also makes the assembler
-// refuse the instructions in inline asm; this one kernel switches it back on for itself.  That lets hipcc emit packed f32 here
-// on its own again, op_sel forms included -- tests/test_isa_cpu.py checks that no packed instruction of this kernel has one.
-#if defined(__HIP_DEVICE_COMPILE__)
-#define UU3D_PK_TARGET __attribute__((target("packed-fp32-ops")))
-#else
-#define UU3D_PK_TARGET
-#endif
+// (UU3D_PK_TARGET: uu3d_pk.h -- this kernel switches the packed-fp32-ops target feature back on for itself)
 // MT = token tiles per wave.  MT = 2: one wave per workgroup runs both tiles of its 3 frames (two tokens per lane).  MT = 1: a
 // workgroup of TWO waves shares the frames and the LDS tiles, wave w owns tile w (one token per lane): half the registers per
 // wave (three waves per SIMD instead of 1.5), half the dependent instruction chain, and s_barriers where the waves exchange
