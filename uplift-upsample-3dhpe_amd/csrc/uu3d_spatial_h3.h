@@ -2,8 +2,8 @@
 //
 // Same function as spatial_stack_mfma_kernel (uu3d_spatial.h; reference u_u_t.py:313-330 and
 // vision_transformer.py:71-195 at d = 32): keypoint embedding + PE, 4 pre-LN blocks of 8-head attention over the
-// 17 joints of a frame and a GELU MLP 32 -> 64 -> 32, spatial_norm, one launch, one wave = 3 frames = 51 tokens.
-// Two changes of structure:
+// 17 joints of a frame and a GELU MLP 32 -> 64 -> 32, spatial_norm, one launch, one workgroup = 3 frames = 51 tokens.
+// Four changes of structure:
 //
 // * Products are f16x3 (uu3d_gemm_h3.h): x ~= hi + lo / 2048, three v_mfma_f32_32x32x16_f16 per 16-deep k-step.
 //   A K = 32 product of a 32 x 32 tile costs 6 MFMAs x 32 cycles instead of 16 x 64 cycles of 32x32x2_f32.
@@ -13,13 +13,17 @@
 //   row of token m (16 bytes of a row-major LDS tile).  In the C/D map of the 32x32 MFMA a lane then holds, for
 //   ITS token m = lane & 31 (+ 32 per m-tile), the 16 channels n = 8g + 4 (lane >> 5) + e (g, e = 0..3): groups of
 //   four consecutive channels.  With d_h = 4 a group is exactly one head, so
-//     - the residual stream lives in that layout for the whole kernel (2 tokens x 16 channels per lane; the two
+//     - the residual stream lives in that layout for the whole kernel (16 channels of a token per lane; the two
 //       lanes l and l + 32 share a token), GEMM results add to it in registers -- no C tile round trip through LDS;
-//     - q stays in registers, lane (l, half) runs heads {half, 2 + half, 4 + half, 6 + half} of its two tokens;
+//     - q stays in registers, lane (l, half) runs heads {half, 2 + half, 4 + half, 6 + half} of its token(s);
 //     - LayerNorm needs one cross-lane add (lane ^ 32) per moment;
 //     - everything a lane writes to LDS (LayerNorm output, attention output, GELU output as f16 planes, K and V
 //       as f32) is a group of 4 consecutive channels: one 8- or 16-byte store.
-//   A workgroup is one wave, so LDS traffic is ordered by the wave itself and there is no barrier at all.
+//
+// * Round 2, occupancy: the kernel waits for LATENCY (one wave alone on a SIMD needs 62 us for 3 frames, two sharing it 81 us
+//   each), so a workgroup is TWO waves that share the 3 frames and the LDS tiles, wave w owning token tile w (template
+//   parameter MT = 1; MT = 2 is the one-wave form with two tokens per lane): half the registers (152: three waves per SIMD
+//   instead of 1.5), half the dependent chain per wave, three s_barriers per block where K / V cross the waves.  164 -> 135 us.
 //
 // * Round 2: the kernel is VALU bound (19 k VALU instructions per wave against 384 MFMAs; SQ counters in
 //   profiles/r02_final_sq_summary.csv), so its elementwise work runs on PACKED f32 instructions (v_pk_fma_f32 /
