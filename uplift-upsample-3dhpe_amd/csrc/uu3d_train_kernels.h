@@ -17,6 +17,12 @@ namespace uu3d {
 //   kind 5: conv-transpose    WT[c * ld + j * N + n]       = Wc[j][c][n]  (K = 3*C rows (j, c), ld = 3*N)
 struct PackDesc { long long src, dst; int kind, K, N, ld, n0, C; };
 
+// Blocks per descriptor (host and device agree through repack_blocks): kind 1 is a TRANSPOSE and goes through LDS in 32 x 32
+// tiles, reads and writes both in 128-byte runs (as a flat copy its 10 M stores were 4 bytes each, ld apart: 138 us per
+// optimizer step against 30 for the tiled form); the other kinds are copies with a different row stride, 1024 elements per block.
+__host__ __device__ inline int repack_blocks(const int kind, const int K, const int N) {
+    return kind == 1 ? ((K + 31) / 32) * ((N + 31) / 32) : (int)(((long long)K * N + 1023) / 1024);
+}
 static __global__ void __launch_bounds__(256)
 repack_kernel(const float* __restrict__ master, float* __restrict__ arena, const PackDesc* __restrict__ desc,
               const int* __restrict__ blk_first, const int ndesc)
@@ -24,8 +30,26 @@ repack_kernel(const float* __restrict__ master, float* __restrict__ arena, const
     int lo = 0, hi = ndesc - 1;                       // last descriptor whose first block <= blockIdx.x
     while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (blk_first[mid] <= (int)blockIdx.x) lo = mid; else hi = mid - 1; }
     const PackDesc d = desc[lo];
+    const int bt = (int)blockIdx.x - blk_first[lo];
+    if (d.kind == 1) {                                 // block-uniform
+        __shared__ float tile[32][33];
+        const int ntn = (d.N + 31) / 32, tk = bt / ntn, tn = bt - tk * ntn;
+        const int c = threadIdx.x & 31, r = threadIdx.x >> 5;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int k = tk * 32 + r + 8 * i, n = tn * 32 + c;
+            tile[r + 8 * i][c] = (k < d.K && n < d.N) ? master[d.src + (long long)k * d.N + n] : 0.f;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int n = tn * 32 + r + 8 * i, k = tk * 32 + c;
+            if (k < d.K && n < d.N) arena[d.dst + (long long)(d.n0 + n) * d.ld + k] = tile[c][r + 8 * i];
+        }
+        return;
+    }
     const long long total = (long long)d.K * d.N;
-    const long long base = (long long)(blockIdx.x - blk_first[lo]) * 1024;
+    const long long base = (long long)bt * 1024;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const long long e = base + i * 256 + threadIdx.x;
@@ -33,8 +57,7 @@ repack_kernel(const float* __restrict__ master, float* __restrict__ arena, const
         const int k = (int)(e / d.N), n = (int)(e - (long long)k * d.N);
         const float v = master[d.src + e];
         long long o;
-        if (d.kind == 1) o = (long long)(d.n0 + n) * d.ld + k;
-        else if (d.kind == 4) o = (long long)k * d.ld + d.n0 + n;
+        if (d.kind == 4) o = (long long)k * d.ld + d.n0 + n;
         else { const int j = k / d.C, c = k - j * d.C; o = (long long)c * d.ld + (long long)j * d.N + n; }
         arena[d.dst + o] = v;
     }
