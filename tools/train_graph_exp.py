@@ -13,6 +13,9 @@ cfg = util.load_config("h36m_351_pt"); B = 64; cfg.BATCH_SIZE = B
 arch = pkg.arch_from_config(cfg)
 model = pkg.build_uplift_upsample_transformer(cfg, weights=pkg.init_weights(arch, seed=0), device="cuda:0")
 tr = Trainer(model, cfg, seed=100)
+from uplift_upsample_3dhpe_amd import _capi
+_capi.check(tr._lib, tr._lib.uu3d_train_set_grad_callback(model._h, _capi.GRAD_READY_FN(0), None), model._h)      # no bucket callback: it would only run at capture time
+tr._buckets.wait = lambda: None
 rng = np.random.default_rng(3000)
 N, J = arch.num_frames, arch.num_keypoints
 x = torch.from_numpy(rng.uniform(-1, 1, size=(B, N, J, 2)).astype(np.float32)).cuda()

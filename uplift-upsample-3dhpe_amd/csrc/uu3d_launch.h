@@ -13,7 +13,8 @@ namespace uu3d {
 constexpr size_t kOpScratchFloats = (size_t)1536 * 4096;
 
 inline int ru(int v, int m) { return (v + m - 1) / m * m; }
-inline int hip_status() { return hipGetLastError() == hipSuccess ? UU3D_OK : UU3D_ERR_HIP; }
+inline hipError_t& last_launch_error() { static thread_local hipError_t e = hipSuccess; return e; }      // what hip_status() last consumed (for the error text)
+inline int hip_status() { const hipError_t e = hipGetLastError(); if (e != hipSuccess) last_launch_error() = e; return e == hipSuccess ? UU3D_OK : UU3D_ERR_HIP; }
 
 // C = A-op x Bt^T with the forward GEMM kernel (64x64 tiles, deterministic split-K when few tiles).
 // Bh / Bl != nullptr: the operand's f16 hi / lo planes (same [Np][Kp] layout) -> f16x3 kernel (uu3d_gemm_h3.h).
