@@ -747,7 +747,10 @@ struct Launcher {
             else gemm_h3g_tile<1, 1>(gl, Bh, Bl, M, N, K, 1, KT, ep);
         } else {
             EpSlab es{slab, ldslab, (size_t)M * ldslab};
-            gemm_h3g_tile<1, 1>(gl, Bh, Bl, M, N, K, slices, kps, es);
+            // split K with many tiles (strided block 1's convolution: 276 tiles x 3 slices of K = 768): 64 x 128 tiles move a
+            // quarter less through L2 -> LDS than 64 x 64 (41.6 -> 36.5 us); with few tiles the 64 x 64 grid fills more CUs
+            if (N % 128 == 0 && tiles >= 200) gemm_h3g_tile<1, 2>(gl, Bh, Bl, M, N, K, slices, kps, es);
+            else gemm_h3g_tile<1, 1>(gl, Bh, Bl, M, N, K, slices, kps, es);
             hipLaunchKernelGGL(splitk_reduce_kernel<EP>, dim3((M * N + 255) / 256), dim3(256), 0, stream,
                                slab, slices, (size_t)M * ldslab, M, N, ldslab, ep);
         }
