@@ -1,0 +1,57 @@
+"""Soak tests of the hand-scheduled pieces: the same work many times over, every result bitwise equal to the first.
+
+* forward: the spatial stack's packed-f32 arithmetic by name relies on hand-placed hazard fences (MFMA and transcendental
+  results read by inline asm) -- a missing one reads a stale register only when the timing lines up;
+* training step: three parameter-gradient streams with event marks -- a missing cross-stream
+  dependency shows up as a rare mismatch in the gradient buffer.
+The long versions are tools/soak_determinism.py (10 000 forwards: 0 mismatches) and tools/soak_train_determinism.py."""
+import numpy as np
+import pytest
+
+import uplift_upsample_3dhpe_amd as pkg
+from tests import util
+
+torch = pytest.importorskip("torch")
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("cfgname,batch", [("h36m_351", 128), ("h36m_81", 37)])
+def test_forward_is_bitwise_repeatable_over_many_launches(cfgname, batch):
+    cfg = util.load_config(cfgname)
+    arch = pkg.arch_from_config(cfg)
+    model = pkg.build_uplift_upsample_transformer(cfg, weights=pkg.init_weights(arch, seed=0, perturb=0.1), device="cuda:0")
+    x, m = util.synthetic_batch(cfg, batch=batch, seed=11)
+    xt = torch.from_numpy(x * m[:, :, None, None].astype(np.float32)).cuda()
+    mt = torch.from_numpy(m).cuda()
+    full0, cen0 = (t.clone() for t in model([xt, mt], training=False))
+    assert torch.isfinite(full0).all()
+    for i in range(400):
+        full, cen = model([xt, mt], training=False)
+        assert torch.equal(full, full0) and torch.equal(cen, cen0), f"launch {i} differs from the first"
+
+
+def test_training_pass_is_bitwise_repeatable_over_many_steps():
+    from uplift_upsample_3dhpe_amd import _capi, harness
+    from uplift_upsample_3dhpe_amd.trainer import Trainer
+    B = 24
+    cfg = util.load_config("h36m_351_pt")
+    cfg.BATCH_SIZE = B
+    arch = pkg.arch_from_config(cfg)
+    model = pkg.build_uplift_upsample_transformer(cfg, weights=pkg.init_weights(arch, seed=0, perturb=0.1), device="cuda:0")
+    tr = Trainer(model, cfg, seed=100)
+    # repeated backward passes without the optimizer in between: no bucket bookkeeping
+    _capi.check(tr._lib, tr._lib.uu3d_train_set_grad_callback(model._h, _capi.GRAD_READY_FN(0), None), model._h)
+    tr._buckets.wait = lambda: None
+    rng = np.random.default_rng(3000)
+    N, J = arch.num_frames, arch.num_keypoints
+    x = torch.from_numpy(rng.uniform(-1, 1, size=(B, N, J, 2)).astype(np.float32)).cuda()
+    gt = torch.from_numpy(rng.normal(0, 0.3, size=(B, N, J, 3)).astype(np.float32)).cuda()
+    m = torch.from_numpy(harness.stride_masks_train(N, cfg.SEQUENCE_STRIDE, cfg.MASK_STRIDE, B, rng, cfg.STRIDE_MASK_RAND_SHIFT)).cuda()
+    u = torch.rand(tr.drop_path_size(B), device="cuda")
+    loss0, _, _ = tr.forward_backward(x, gt, m, drop_path_uniform=u)
+    torch.cuda.synchronize()
+    g0, l0 = tr.grads.clone(), loss0.clone()
+    for i in range(60):
+        loss, _, _ = tr.forward_backward(x, gt, m, drop_path_uniform=u)
+        torch.cuda.synchronize()
+        assert torch.equal(tr.grads, g0) and torch.equal(loss, l0), f"pass {i} differs from the first"
