@@ -30,7 +30,8 @@ template __global__ void uu3d::attn_h3_kernel<48, 3, 3, false>(const _Float16*, 
 template __global__ void uu3d::attn_h3_kernel<48, 12, 3, true>(const _Float16*, const _Float16*, int, int, int, int, const uint8_t*, _Float16*, size_t, int);
 template __global__ void uu3d::gemm_tn_h3_kernel<TnLoadLayerNorm, EpSlab>(const TnLoadLayerNorm, const float*, int, int, int, int, int, int, int, const EpSlab);
 template __global__ void uu3d::gemm_tn_kernel<TnLoadLayerNorm, EpSlab>(const TnLoadLayerNorm, const float*, int, int, int, int, int, int, int, const EpSlab);
-template __global__ void uu3d::spatial_stack_h3_kernel<17, 3, 1>(const float*, const SpatialParams, const _Float16*, float*, _Float16*, _Float16*);
+template __global__ void uu3d::spatial_stack_h3_kernel<17, 3, 1, false>(const float*, const SpatialParams, const _Float16*, float*, _Float16*, _Float16*, const SpatialTrainIO);
+template __global__ void uu3d::spatial_stack_h3_kernel<17, 3, 1, true>(const float*, const SpatialParams, const _Float16*, float*, _Float16*, _Float16*, const SpatialTrainIO);
 template __global__ void uu3d::gemm_h3_panel_kernel<24, PanelEpBias>(const _Float16*, const _Float16*, const float*, int, int, int, int, const PanelEpBias);
 template __global__ void uu3d::gemm_h3_panel_kernel<24, PanelEpBiasReluSplit>(const _Float16*, const _Float16*, const float*, int, int, int, int, const PanelEpBiasReluSplit);
 template __global__ void uu3d::ln_split_frag_kernel<24, 8>(const float*, int, int, float, const float*, const float*, _Float16*);

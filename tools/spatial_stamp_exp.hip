@@ -33,7 +33,7 @@ int main(int argc, char** argv) {
 #endif
     auto kern = spatial_stack_h3_kernel<17, 3, MTV>;
     CK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    auto launch = [&] { hipLaunchKernelGGL(kern, dim3((M + 2) / 3), dim3(64 * (2 / MTV)), lds, 0, kp, p, dfrag, out, (_Float16*)nullptr, (_Float16*)nullptr); };
+    auto launch = [&] { hipLaunchKernelGGL(kern, dim3((M + 2) / 3), dim3(64 * (2 / MTV)), lds, 0, kp, p, dfrag, out, (_Float16*)nullptr, (_Float16*)nullptr, SpatialTrainIO{}); };
     for (int i = 0; i < 3; ++i) launch();
     CK(hipDeviceSynchronize());
     unsigned long long zz[12] = {0}, h[12];

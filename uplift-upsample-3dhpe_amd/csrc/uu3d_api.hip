@@ -992,7 +992,7 @@ int uu3d_forward(uu3d_model* m, const float* kp2d, const uint8_t* mask, int32_t 
             auto kern = spatial_stack_h3_kernel<kJ, kFR, kSpatialMT>;
             Lh.begin("spatial_stack", "spatial_h3", fl, 4.0 * M * J * (2.0 + ds));
             hipLaunchKernelGGL(kern, dim3((M + kFR - 1) / kFR), dim3(64 * (2 / kSpatialMT)), sh3::lds_bytes(), Lh.stream, kp2d, sp,
-                               m->harena + m->sp_frag_off, w.S, (_Float16*)nullptr, (_Float16*)nullptr);
+                               m->harena + m->sp_frag_off, w.S, (_Float16*)nullptr, (_Float16*)nullptr, SpatialTrainIO{});
             Lh.end();
         } else {
             sp.blocks = m->sp_blocks_v2;

@@ -173,7 +173,7 @@ __device__ __forceinline__ float sum_halves(const f32x2 p) {
 // over even / odd channels first
 template <int MT>
 __device__ __forceinline__ void ln_tokens(const f32x2 (&x)[MT][8], const float* g, const float* b,
-                                          const float eps, const int half, f32x2 (&y)[MT][8]) {
+                                          const float eps, const int half, f32x2 (&y)[MT][8], float2* stats = nullptr) {
     f32x2 gp[8], bp[8];
 #pragma unroll
     for (int gq = 0; gq < 4; ++gq) {
@@ -194,7 +194,9 @@ __device__ __forceinline__ void ln_tokens(const f32x2 (&x)[MT][8], const float* 
 #pragma unroll
         for (int i = 1; i < 8; ++i) { const f32x2 d = pk::sub(x[mt][i], m2); q2 = pk::fma(d, d, q2); }
         const float q = sum_halves(q2);
-        const f32x2 r2 = pk::splat(1.0f / sqrtf(q * (1.0f / 32.0f) + eps));
+        const float rstd = 1.0f / sqrtf(q * (1.0f / 32.0f) + eps);
+        if (stats != nullptr) stats[mt] = make_float2(mean, rstd);     // (training: the backward pass reads the row statistics)
+        const f32x2 r2 = pk::splat(rstd);
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
             const f32x2 inv = pk::mul(r2, gp[i]);
@@ -360,14 +362,24 @@ __device__ unsigned long long spatial_clk[12];   // tools/spatial_stamp_exp: s_m
 #define UU3D_SPATIAL_H3_WAVES 2     // 3 (168 VGPRs) spills into the block loop: 0.30 ms instead of 0.20
 #endif
 // (UU3D_PK_TARGET: uu3d_pk.h -- this kernel switches the packed-fp32-ops target feature back on for itself)
+// Training-mode forward (TRAIN = true; uu3d_train_step.inc): the same kernel also writes what the backward pass reads -- per block
+// its input, both LayerNorms' row statistics (mean, 1 / sqrt(var + eps)), q | k | v with bias, the attention output, the stream
+// after the attention residual and the pre-GELU hidden activations; at the end the stack's output before spatial_norm and that
+// LayerNorm's statistics -- and applies the DropPath gates of vision_transformer.py:16-43 (per frame, scaled by 1 / keep) to the
+// two residual branches.  One launch instead of the 31 of the unfused chain (generic GEMMs with K = 32 / 64 at 77 k rows).
+struct SpatialTrainIO {
+    float* X[9]; float2* St1[8]; float* QKV[8]; float* O[8]; float* Xmid[8]; float2* St2[8]; float* Hpre[8]; float2* StF;
+    const float* gate1[8]; const float* gate2[8]; float inv_keep[8];      // gate == nullptr: no DropPath in that block
+};
+
 // MT = token tiles per wave.  MT = 2: one wave per workgroup runs both tiles of its 3 frames (two tokens per lane).  MT = 1: a
 // workgroup of TWO waves shares the frames and the LDS tiles, wave w owns tile w (one token per lane): half the registers per
 // wave (three waves per SIMD instead of 1.5), half the dependent instruction chain, and s_barriers where the waves exchange
 // K / V through LDS.
-template <int J, int FR, int MT>
+template <int J, int FR, int MT, bool TRAIN = false>
 __global__ void __launch_bounds__(64 * (2 / MT), MT == 2 ? UU3D_SPATIAL_H3_WAVES : 3) UU3D_PK_TARGET
 spatial_stack_h3_kernel(const float* __restrict__ kp2d, const SpatialParams p, const _Float16* __restrict__ wfrag,
-                        float* __restrict__ out, _Float16* __restrict__ out_hi, _Float16* __restrict__ out_lo)
+                        float* __restrict__ out, _Float16* __restrict__ out_hi, _Float16* __restrict__ out_lo, const SpatialTrainIO tio = SpatialTrainIO{})
 {
     // The two token tiles run the same arithmetic, fully unrolled (MT = 2) or in two waves; the copies must round
     // identically or a frame's result depends on its slot in the wave (bitwise permutation test).  Contraction is off
@@ -462,6 +474,29 @@ spatial_stack_h3_kernel(const float* __restrict__ kp2d, const SpatialParams p, c
         }
     };
 
+    // TRAIN: this lane's 16 channels of its token(s) to row (frame * J + joint) of a (rows, ldt) tensor, 4 channels per store
+    size_t trow[MT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) trow[mt] = (size_t)frame[mt] * J + joint[mt];
+    auto save16 = [&](float* T, const int ldt, const int coloff, const f32x2 (&v)[MT][8]) __attribute__((always_inline)) {
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+            if (!valid[mt]) continue;
+            float* d = T + trow[mt] * ldt + coloff + 4 * half;
+#pragma unroll
+            for (int g = 0; g < 4; ++g)
+                *reinterpret_cast<f32x4*>(d + 8 * g) = (f32x4){v[mt][2 * g][0], v[mt][2 * g][1], v[mt][2 * g + 1][0], v[mt][2 * g + 1][1]};
+        }
+    };
+    auto save_stats = [&](float2* T, const float2 (&st)[MT]) __attribute__((always_inline)) {
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) if (valid[mt] && half == 0) T[trow[mt]] = st[mt];
+    };
+    // DropPath scale of a residual branch: gate[frame] / keep (1 without the layer)
+    auto gate_pairs = [&](const float* gate, const float inv_keep, f32x2 (&sc)[MT]) __attribute__((always_inline)) {
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) sc[mt] = pk::splat(gate != nullptr ? gate[frame[mt]] * inv_keep : 1.0f);
+    };
 #ifdef UU3D_SPATIAL_STAMP
     unsigned sp_t[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     long long sp_last = clock64();
@@ -483,8 +518,11 @@ spatial_stack_h3_kernel(const float* __restrict__ kp2d, const SpatialParams p, c
         // ---- attention half ----
         WFrag<1, 2> wq, wk, wv, wp;
         load_w<1, 2>(F + FL::fq, lane, wq); load_w<1, 2>(F + FL::fk, lane, wk); load_w<1, 2>(F + FL::fv, lane, wv);
+        float2 lnst[MT];
+        if constexpr (TRAIN) save16(tio.X[blk], DS, 0, x);
         if constexpr (UU3D_SP_SKIP == 3) { for (int mt = 0; mt < MT; ++mt) for (int i = 0; i < 8; ++i) y[mt][i] = x[mt][i]; } else
-        ln_tokens(x, W + LY::ln1_g, W + LY::ln1_b, 1e-5f, half, y);
+        ln_tokens(x, W + LY::ln1_g, W + LY::ln1_b, 1e-5f, half, y, TRAIN ? lnst : nullptr);
+        if constexpr (TRAIN) save_stats(tio.St1[blk], lnst);
         store_planes<MT>(Xh, Xl, XLD, 0, lane, mt0, y);
         SP_STAMP(0)
         f32x2 q[1][MT][8];
@@ -497,6 +535,7 @@ spatial_stack_h3_kernel(const float* __restrict__ kp2d, const SpatialParams p, c
             for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
                 for (int i = 0; i < 8; ++i) q[0][mt][i] = pk::add(q[0][mt][i], bp[i]);
+            if constexpr (TRAIN) save16(tio.QKV[blk], 3 * DS, 0, q[0]);
             wait_w<4>(wk);
             mm<MT, 1, 2>(wk, Xh, Xl, XLD, lane, mt0, kv);
             // the spare key slot of every frame: finite (zero) whatever the hidden planes of the previous block left there
@@ -511,7 +550,9 @@ spatial_stack_h3_kernel(const float* __restrict__ kp2d, const SpatialParams p, c
                     const f32x2 v = pk::add(kv[0][mt][i], bp[i]);
                     const int c = 8 * (i >> 1) + 4 * half + 2 * (i & 1);
                     TK[kslot[mt] + 2 * c] = v[0]; TK[kslot[mt] + 2 * c + 2] = v[1];
+                    if constexpr (TRAIN) kv[0][mt][i] = v;
                 }
+            if constexpr (TRAIN) save16(tio.QKV[blk], 3 * DS, DS, kv[0]);
             load_w<1, 2>(F + FL::fp, lane, wp);            // in flight over the attention arithmetic
             wait_w<4>(wv);
             mm<MT, 1, 2>(wv, Xh, Xl, XLD, lane, mt0, kv);
@@ -523,7 +564,9 @@ spatial_stack_h3_kernel(const float* __restrict__ kp2d, const SpatialParams p, c
                     const f32x2 v = pk::add(kv[0][mt][i], bp[i]);
                     const int c = 8 * (i >> 1) + 4 * half + 2 * (i & 1);
                     TV[kslot[mt] + 2 * c] = v[0]; TV[kslot[mt] + 2 * c + 2] = v[1];
+                    if constexpr (TRAIN) kv[0][mt][i] = v;
                 }
+            if constexpr (TRAIN) save16(tio.QKV[blk], 3 * DS, 2 * DS, kv[0]);
         }
         SP_STAMP(1)
         wg_sync();                                         // K / V of every token of the frames are in LDS
@@ -544,24 +587,31 @@ spatial_stack_h3_kernel(const float* __restrict__ kp2d, const SpatialParams p, c
         }
         wg_sync();                                         // nobody reads K / V any more: the hidden planes may overwrite them
         SP_STAMP(2)
+        if constexpr (TRAIN) save16(tio.O[blk], DS, 0, o);
         store_planes<MT>(Xh, Xl, XLD, 0, lane, mt0, o);
         {
-            f32x2 pr[1][MT][8], bp[8];
+            f32x2 pr[1][MT][8], bp[8], sc[MT];
             wait_w<0>(wp);
             mm<MT, 1, 2>(wp, Xh, Xl, XLD, lane, mt0, pr);
             bias_pairs(W + LY::bp, bp);
+            if constexpr (TRAIN) gate_pairs(tio.gate1[blk], tio.inv_keep[blk], sc);
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-                for (int i = 0; i < 8; ++i) x[mt][i] = pk::add(x[mt][i], pk::add(pr[0][mt][i], bp[i]));
+                for (int i = 0; i < 8; ++i) {
+                    if constexpr (TRAIN) x[mt][i] = pk::fma(pk::add(pr[0][mt][i], bp[i]), sc[mt], x[mt][i]);
+                    else x[mt][i] = pk::add(x[mt][i], pk::add(pr[0][mt][i], bp[i]));
+                }
         }
+        if constexpr (TRAIN) save16(tio.Xmid[blk], DS, 0, x);
 
         SP_STAMP(3)
         // ---- MLP half ----
         WFrag<2, 2> w1;
         load_w<2, 2>(F + FL::f1, lane, w1);
         if constexpr (UU3D_SP_SKIP == 3) { for (int mt = 0; mt < MT; ++mt) for (int i = 0; i < 8; ++i) y[mt][i] = x[mt][i]; } else
-        ln_tokens(x, W + LY::ln2_g, W + LY::ln2_b, 1e-5f, half, y);
+        ln_tokens(x, W + LY::ln2_g, W + LY::ln2_b, 1e-5f, half, y, TRAIN ? lnst : nullptr);
+        if constexpr (TRAIN) save_stats(tio.St2[blk], lnst);
         store_planes<MT>(Xh, Xl, XLD, 0, lane, mt0, y);
         SP_STAMP(4)
         WFrag<1, 4> w2;
@@ -577,20 +627,31 @@ spatial_stack_h3_kernel(const float* __restrict__ kp2d, const SpatialParams p, c
 #pragma unroll
                 for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-                    for (int i = 0; i < 8; ++i) hd[nt][mt][i] = UU3D_SP_SKIP == 2 ? pk::add(hd[nt][mt][i], bp[i]) : gelu_pair(pk::add(hd[nt][mt][i], bp[i]));
+                    for (int i = 0; i < 8; ++i) hd[nt][mt][i] = pk::add(hd[nt][mt][i], bp[i]);
+                if constexpr (TRAIN) save16(tio.Hpre[blk], HS, 32 * nt, hd[nt]);      // pre-GELU: the backward pass differentiates the exact GELU
+                if constexpr (UU3D_SP_SKIP != 2) {
+#pragma unroll
+                    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                        for (int i = 0; i < 8; ++i) hd[nt][mt][i] = gelu_pair(hd[nt][mt][i]);
+                }
                 store_planes<MT>(Hh, Hl, HLD, 32 * nt, lane, mt0, hd[nt]);
             }
         }
         SP_STAMP(6)
         {
-            f32x2 z[1][MT][8], bp[8];
+            f32x2 z[1][MT][8], bp[8], sc[MT];
             wait_w<0>(w2);
             mm<MT, 1, 4>(w2, Hh, Hl, HLD, lane, mt0, z);
             bias_pairs(W + LY::b2, bp);
+            if constexpr (TRAIN) gate_pairs(tio.gate2[blk], tio.inv_keep[blk], sc);
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-                for (int i = 0; i < 8; ++i) x[mt][i] = pk::add(x[mt][i], pk::add(z[0][mt][i], bp[i]));
+                for (int i = 0; i < 8; ++i) {
+                    if constexpr (TRAIN) x[mt][i] = pk::fma(pk::add(z[0][mt][i], bp[i]), sc[mt], x[mt][i]);
+                    else x[mt][i] = pk::add(x[mt][i], pk::add(z[0][mt][i], bp[i]));
+                }
         }
         SP_STAMP(7)
     }
@@ -603,7 +664,10 @@ spatial_stack_h3_kernel(const float* __restrict__ kp2d, const SpatialParams p, c
 #endif
 
     f32x2 y[MT][8];
-    sh3::ln_tokens(x, p.norm_g, p.norm_b, 1e-6f, half, y);
+    float2 lnstf[MT];
+    if constexpr (TRAIN) save16(tio.X[p.depth], DS, 0, x);
+    sh3::ln_tokens(x, p.norm_g, p.norm_b, 1e-6f, half, y, TRAIN ? lnstf : nullptr);
+    if constexpr (TRAIN) save_stats(tio.StF, lnstf);
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) {
         if (!valid[mt]) continue;

@@ -5,6 +5,7 @@
 #include <stdint.h>
 #include <math.h>
 #include "uu3d_gemm.h"
+#include "uu3d_gemm_h3.h"
 
 namespace uu3d {
 
@@ -60,6 +61,46 @@ repack_kernel(const float* __restrict__ master, float* __restrict__ arena, const
         if (d.kind == 4) o = (long long)k * d.ld + d.n0 + n;
         else { const int j = k / d.C, c = k - j * d.C; o = (long long)c * d.ld + (long long)j * d.N + n; }
         arena[d.dst + o] = v;
+    }
+}
+
+// Operands of the fused f16x3 spatial stack (uu3d_spatial_h3.h) for the training-mode forward, regenerated from the master
+// buffer after each optimizer step: per block the A-operand fragments of W^T ([n-tile][kk][plane hi / lo][lane][8], element
+// = split(W[16 kk + 8 (lane >> 5) + e][32 nt + (lane & 31)]), SpatialFragLayoutH3) and the 352 LayerNorm parameters / biases
+// in SpatialBlockLayoutV2 order.  Offsets are into the master buffer; < 0: tensor absent (qkv_bias false) -> zeros.
+struct SpatialPackSrc { long long ln1_g, ln1_b, wq, bq, wk, bk, wv, bv, wp, bp, ln2_g, ln2_b, w1, b1, w2, b2; };
+static __global__ void __launch_bounds__(256)
+spatial_train_pack_kernel(const float* __restrict__ master, const SpatialPackSrc* __restrict__ src, _Float16* __restrict__ frag,
+                          float* __restrict__ blocks, const int frag_stride, const int blk_stride)
+{
+    h3_flush_f16_denormals();
+    const SpatialPackSrc d = src[blockIdx.x];
+    _Float16* F = frag + (size_t)blockIdx.x * frag_stride;
+    float* Bk = blocks + (size_t)blockIdx.x * blk_stride;
+    // fragments: matrices (offset in halfs, source, K, N) in SpatialFragLayoutH3 order
+    const long long ms[6] = {d.wq, d.wk, d.wv, d.wp, d.w1, d.w2};
+    const int mk[6] = {32, 32, 32, 32, 32, 64}, mn[6] = {32, 32, 32, 32, 64, 32};
+    int off = 0;
+    for (int mi = 0; mi < 6; ++mi) {
+        const int K = mk[mi], N = mn[mi], total = K * N;
+        for (int e0 = threadIdx.x; e0 < total; e0 += 256) {
+            // element index inside the matrix's fragments: ((nt * KK + kk) * 64 + lane) * 8 + e  (per plane)
+            const int e = e0 & 7, lane = (e0 >> 3) & 63, t = e0 >> 9, KK = K / 16, kk = t % KK, nt = t / KK;
+            const float x = master[ms[mi] + (long long)(16 * kk + 8 * (lane >> 5) + e) * N + 32 * nt + (lane & 31)];
+            const _Float16 h = h3_hi(x);
+            const size_t at = (size_t)off + (((size_t)(nt * KK + kk) * 2) * 64 + lane) * 8 + e;
+            F[at] = h;
+            F[at + 64 * 8] = (_Float16)((x - (float)h) * H3_SCALE);
+        }
+        off += 2 * total;
+    }
+    // parameters: ln1_g, ln1_b, ln2_g, ln2_b, bq, bk, bv, bp (32 each), b1 (64), b2 (32)
+    const long long ps[10] = {d.ln1_g, d.ln1_b, d.ln2_g, d.ln2_b, d.bq, d.bk, d.bv, d.bp, d.b1, d.b2};
+    const int pn[10] = {32, 32, 32, 32, 32, 32, 32, 32, 64, 32};
+    int po = 0;
+    for (int pi = 0; pi < 10; ++pi) {
+        if ((int)threadIdx.x < pn[pi]) Bk[po + threadIdx.x] = ps[pi] >= 0 ? master[ps[pi] + threadIdx.x] : 0.f;
+        po += pn[pi];
     }
 }
 
