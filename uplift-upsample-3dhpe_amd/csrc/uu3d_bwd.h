@@ -688,6 +688,93 @@ attn_generic_bwd_kernel(const float* __restrict__ qkv, const float* __restrict__
 }
 
 // ------------------------------------------------------------------------------------
+// The spatial stack's attention backward: L = 17 joints, head dim 4, no key mask -- attn_generic_bwd_kernel<4> with every
+// loop unrolled over a compile-time L, the probability / dS rows of a query in REGISTERS, K / V / Q / dO rows read as 16-byte
+// LDS broadcasts in batches, and P^T / dS^T written to LDS once for the per-key pass.  Same arithmetic order as the generic
+// kernel (bitwise equal results); 45.8 -> see DESIGN.md section 10.  `pack` (sequence, head) pairs per workgroup of 128 threads.
+template <int L>
+__host__ __device__ inline constexpr size_t attn_small_bwd_lds_bytes() { return (size_t)(4 * L * 4 + 2 * L * ((L + 3) / 4 * 4)) * sizeof(float); }
+template <int L>
+__global__ void __launch_bounds__(128)
+attn_small_bwd_kernel(const float* __restrict__ qkv, const float* __restrict__ dO, const int ld, const int D, const int H,
+                      float* __restrict__ dqkv, const int ldo, const int pack, const int total)
+{
+    constexpr int DH = 4, LP = (L + 3) / 4 * 4;          // padded row of the transposed P / dS tiles
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    const int slot = threadIdx.x / L, i = threadIdx.x - slot * L;
+    const int bh = blockIdx.x * pack + slot;
+    const bool live = slot < pack && bh < total;
+    float* Qs = sm + (size_t)min(slot, pack - 1) * (4 * L * 4 + 2 * L * LP);
+    float* Ks = Qs + L * 4; float* Vs = Ks + L * 4; float* Gs = Vs + L * 4;
+    float* Pt = Gs + L * 4;                   // [key][query]
+    float* St = Pt + L * LP;                  // dS^T
+    const int b = live ? bh / H : 0, h = live ? bh - b * H : 0;
+    const float* base = qkv + ((size_t)b * L + i) * ld + h * DH;
+    f32x4 q = {0.f, 0.f, 0.f, 0.f}, g = q;
+    if (live) {
+        q = *reinterpret_cast<const f32x4*>(base);
+        g = *reinterpret_cast<const f32x4*>(dO + ((size_t)b * L + i) * ldo + h * DH);
+        *reinterpret_cast<f32x4*>(&Qs[i * 4]) = q;
+        *reinterpret_cast<f32x4*>(&Ks[i * 4]) = *reinterpret_cast<const f32x4*>(base + D);
+        *reinterpret_cast<f32x4*>(&Vs[i * 4]) = *reinterpret_cast<const f32x4*>(base + 2 * D);
+        *reinterpret_cast<f32x4*>(&Gs[i * 4]) = g;
+    }
+    __syncthreads();
+    const float rsq = 1.0f / sqrtf((float)DH);
+    if (live) {
+        float p[L], ds[L];
+        float mx = -INFINITY;
+#pragma unroll
+        for (int j = 0; j < L; ++j) {
+            const f32x4 k = *reinterpret_cast<const f32x4*>(&Ks[j * 4]);
+            float sc = 0.f;
+#pragma unroll
+            for (int c = 0; c < DH; ++c) sc = fmaf(q[c], k[c], sc);
+            sc = sc * rsq;
+            p[j] = sc; mx = fmaxf(mx, sc);
+        }
+        float sum = 0.f;
+#pragma unroll
+        for (int j = 0; j < L; ++j) { p[j] = __builtin_amdgcn_exp2f((p[j] - mx) * 1.44269504088896341f); sum += p[j]; }
+        const float rsum = 1.0f / sum;
+        float delta = 0.f;
+#pragma unroll
+        for (int j = 0; j < L; ++j) {
+            const f32x4 v = *reinterpret_cast<const f32x4*>(&Vs[j * 4]);
+            p[j] = p[j] * rsum;
+            float dp = 0.f;
+#pragma unroll
+            for (int c = 0; c < DH; ++c) dp = fmaf(g[c], v[c], dp);
+            ds[j] = dp;
+            delta = fmaf(p[j], dp, delta);
+        }
+        f32x4 dq = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int j = 0; j < L; ++j) {
+            const f32x4 k = *reinterpret_cast<const f32x4*>(&Ks[j * 4]);
+            ds[j] = p[j] * (ds[j] - delta);
+#pragma unroll
+            for (int c = 0; c < DH; ++c) dq[c] = fmaf(ds[j], k[c], dq[c]);
+            Pt[j * LP + i] = p[j]; St[j * LP + i] = ds[j];
+        }
+        *reinterpret_cast<f32x4*>(dqkv + ((size_t)b * L + i) * ld + h * DH) = (f32x4){dq[0] * rsq, dq[1] * rsq, dq[2] * rsq, dq[3] * rsq};
+    }
+    __syncthreads();
+    if (live) {                                  // thread = key row i
+        f32x4 dk = {0.f, 0.f, 0.f, 0.f}, dv = dk;
+#pragma unroll
+        for (int r = 0; r < L; ++r) {
+            const float dsr = St[i * LP + r], pr = Pt[i * LP + r];
+            const f32x4 qq = *reinterpret_cast<const f32x4*>(&Qs[r * 4]), gg = *reinterpret_cast<const f32x4*>(&Gs[r * 4]);
+#pragma unroll
+            for (int c = 0; c < DH; ++c) { dk[c] = fmaf(dsr, qq[c], dk[c]); dv[c] = fmaf(pr, gg[c], dv[c]); }
+        }
+        *reinterpret_cast<f32x4*>(dqkv + ((size_t)b * L + i) * ld + D + h * DH) = (f32x4){dk[0] * rsq, dk[1] * rsq, dk[2] * rsq, dk[3] * rsq};
+        *reinterpret_cast<f32x4*>(dqkv + ((size_t)b * L + i) * ld + 2 * D + h * DH) = dv;
+    }
+}
+
+// ------------------------------------------------------------------------------------
 // Softmax-attention backward on the matrix pipe (v_mfma_f32_16x16x4_f32, exact f32), one workgroup per (sequence,
 // head), one wave per tile of 16 tokens -- the structure of attn_f32_kernel (uu3d_attn.h).  Two passes, both keep
 // their L x L tiles in REGISTERS:

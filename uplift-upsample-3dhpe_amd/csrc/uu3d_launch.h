@@ -170,7 +170,9 @@ inline int launch_attn_generic(bool backward, const float* qkv, const float* dO,
         const int pack = std::max(1, 128 / L);                         // (sequence, head) pairs per workgroup
         const dim3 grid((total + pack - 1) / pack);
         const size_t lds = attn_generic_lds_bytes<4>(L, backward) * pack;
-        if (backward) hipLaunchKernelGGL(attn_generic_bwd_kernel<4>, grid, block, lds, stream, qkv, dO, ld, D, L, H, mask, out, ldo, pack, total);
+        if (backward && L == 17 && mask == nullptr && !getenv("UU3D_ATTN_BWD_GENERIC"))     // the spatial stack's shape: unrolled, rows in registers
+            hipLaunchKernelGGL(attn_small_bwd_kernel<17>, grid, block, attn_small_bwd_lds_bytes<17>() * pack, stream, qkv, dO, ld, D, H, out, ldo, pack, total);
+        else if (backward) hipLaunchKernelGGL(attn_generic_bwd_kernel<4>, grid, block, lds, stream, qkv, dO, ld, D, L, H, mask, out, ldo, pack, total);
         else hipLaunchKernelGGL(attn_generic_fwd_kernel<4>, grid, block, lds, stream, qkv, ld, D, L, H, mask, out, ldo, pack, total);
     } else {
         const dim3 grid(total);
