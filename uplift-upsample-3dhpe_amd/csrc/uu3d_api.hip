@@ -967,6 +967,9 @@ int uu3d_forward(uu3d_model* m, const float* kp2d, const uint8_t* mask, int32_t 
     char nm[48];
 
     // 1. spatial stack
+    // the f16x3 spatial kernel writes its output as the two f16 planes spatial_to_temporal_fc reads (LDS-DMA GEMM, no split in
+    // the GEMM's loader): 32.6 -> 29.6 us for the GEMM, the spatial kernel unchanged (round 1's kernel paid 1-2 us for the split stores)
+    const bool s2t_planes = !m->no_planes && c.precision == UU3D_PREC_F16X3 && !m->spatial_valu && !m->spatial_f32 && (m->spatial_h3_always || spatial_h3_pays(B * c.num_frames)) && ((c.num_keypoints * c.d_spatial) % 32 == 0);
     {
         SpatialParams sp = m->sp;
         sp.total_frames = M;
@@ -992,7 +995,8 @@ int uu3d_forward(uu3d_model* m, const float* kp2d, const uint8_t* mask, int32_t 
             auto kern = spatial_stack_h3_kernel<kJ, kFR, kSpatialMT>;
             Lh.begin("spatial_stack", "spatial_h3", fl, 4.0 * M * J * (2.0 + ds));
             hipLaunchKernelGGL(kern, dim3((M + kFR - 1) / kFR), dim3(64 * (2 / kSpatialMT)), sh3::lds_bytes(), Lh.stream, kp2d, sp,
-                               m->harena + m->sp_frag_off, w.S, (_Float16*)nullptr, (_Float16*)nullptr, SpatialTrainIO{});
+                               m->harena + m->sp_frag_off, w.S, s2t_planes ? reinterpret_cast<_Float16*>(w.S) : (_Float16*)nullptr,
+                               s2t_planes ? reinterpret_cast<_Float16*>(w.S) + (size_t)M * J * ds : (_Float16*)nullptr, SpatialTrainIO{});
             Lh.end();
         } else {
             sp.blocks = m->sp_blocks_v2;
@@ -1004,9 +1008,13 @@ int uu3d_forward(uu3d_model* m, const float* kp2d, const uint8_t* mask, int32_t 
     }
     // 2. spatial_to_temporal_fc + token blend + temporal PE
     {
-        ALoadPlain al{w.S, J * ds, M, J * ds};
         EpSpatialToTemporal ep{w.X, m->s2t_b, dt, mask, m->token, m->pe_t, N};
-        Lh.gemm("s2t", al, m->s2t_wt, M, dt, J * ds, ep);
+        if (s2t_planes) {
+            Lh.gemm_g("s2t", GLoadPlain{reinterpret_cast<const _Float16*>(w.S), reinterpret_cast<const _Float16*>(w.S) + (size_t)M * J * ds, J * ds, M}, m->s2t_wt, M, dt, J * ds, ep);
+        } else {
+            ALoadPlain al{w.S, J * ds, M, J * ds};
+            Lh.gemm("s2t", al, m->s2t_wt, M, dt, J * ds, ep);
+        }
     }
     // f16x3 with K % 32 == 0 everywhere: activations that feed a GEMM travel as f16 hi/lo planes (same bytes as the
     // f32 tensors they replace: O and Hb are reused) and the GEMMs are the LDS-DMA kernel gemm_h3g_kernel
