@@ -1,16 +1,18 @@
 // uu3d_api.hip -- C ABI (include/uu3d.h) over the gfx950 kernels: model object, weight
 // inventory / repacking, workspace carving and the forward launch schedule.
 //
-// Forward schedule (reference: UpliftUpsampleTransformer.call, u_u_t.py:388-421):
-//   spatial_stack                       kp2d -> S (B*N, J*d_s)                [u_u_t.py:313-330]
+// Forward schedule (reference: UpliftUpsampleTransformer.call, u_u_t.py:388-421); f16x3 product path at >= 1024 token rows
+// (fewer rows / precision f32: the tiled kernels with row_stats in front, same order):
+//   compact_frames (mask given) ; spatial_stack  kp2d -> S as f16 planes (B*N, J*d_s)      [u_u_t.py:313-330]
 //   gemm  S x W_s2t  (+token blend +PE) -> X (B*N, d_t)                       [:332,344-352]
 //   temporal block i (x temporal_depth)                                       [vit.py:176-195]
-//     row_stats(X); gemm LN1(X) x Wqkv -> QKV; attn -> O; gemm O x Wp (+res) -> X
-//     row_stats(X); gemm LN2(X) x W1 (+relu) -> Hb; gemm Hb x W2 (+res) -> X
-//       (last block also writes XA = X + strided_pe_1)
+//     LN1 -> A fragments (ln_split_frag; blocks > 0: ln_res_split_frag, which first adds the previous MLP's three partial slabs
+//     + bias into X); row-panel GEMM LN1(X) x Wqkv -> q | k | v planes; attn_h3 -> O planes; gemm O x Wp (+res) -> X;
+//     LN2 -> A fragments; mlp_fused (fc1, ReLU, fc2 per hidden slice) -> slabs
+//       (the combine after the last block also writes XA = X + strided_pe_1)
 //   gemm X x W_head1 -> full_out                                              [:400-404]
 //   strided block i (x len(STRIDES)) on XA (B*L_i, d_t)                       [:122-160]
-//     row_stats; gemm LN1 x Wqkv; attn; gemm proj (+res); row_stats; gemm LN2 x W1 (+relu);
+//     LN1 / QKV / attention / projection as above (few rows: gemm_h3_wt_kernel, exact-f32 attention); LN2 x W1 (+relu) -> planes;
 //     gemm conv3(Hb) x Wc (+identity gather +bias +strided_pe_{i+1}) -> XB ; swap
 //   gemm XA x W_head2 -> central_out                                          [:414-416]
 #include <hip/hip_runtime.h>
