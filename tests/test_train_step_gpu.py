@@ -267,3 +267,37 @@ def test_train_step_at_the_benchmarked_batch():
     assert (ga + tr.grads - gfull).abs().max() <= 2e-5 * gfull.abs().max()
     tr.apply_gradients()
     assert torch.isfinite(tr.params).all()
+
+
+def test_fused_and_unfused_spatial_training_forward_agree(monkeypatch):
+    """The training-mode forward of the spatial stack: ONE launch of spatial_stack_h3_kernel<.., TRAIN> (saved activations, row
+    statistics, DropPath gates written by the kernel) against the chain of generic kernels it replaces
+    (UU3D_TRAIN_SPATIAL_UNFUSED=1, read by uu3d_train_init), and the spatial attention backward on attn_small_bwd_kernel<17>
+    against the generic kernel (UU3D_ATTN_BWD_GENERIC=1): outputs, loss and every gradient tensor, with DropPath."""
+    from uplift_upsample_3dhpe_amd.trainer import Trainer
+    B = 5
+    results = []
+    for env in ({}, {"UU3D_TRAIN_SPATIAL_UNFUSED": "1", "UU3D_ATTN_BWD_GENERIC": "1"}):
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        cfg, arch, w, model, x, m, gt = _setup("h36m_351", B, seed=21, batch_norm=4)
+        tr = Trainer(model, cfg)
+        u = torch.from_numpy(np.random.default_rng(13).random(tr.drop_path_size(B)).astype(np.float32)).cuda()
+        loss, full, central = tr.forward_backward(torch.from_numpy(x).cuda(), torch.from_numpy(gt).cuda(), torch.from_numpy(m).cuda(), drop_path_uniform=u)
+        torch.cuda.synchronize()
+        results.append((loss.cpu().numpy().copy(), full.cpu().numpy().copy(), central.cpu().numpy().copy(), {k_: v_.copy() for k_, v_ in tr.grads_dict().items()}))
+        for k in env:
+            monkeypatch.delenv(k)
+    (l0, f0, c0, g0), (l1, f1, c1, g1) = results
+    assert np.abs(f0 - f1).max() <= 2e-5 and np.abs(c0 - c1).max() <= 2e-5
+    assert l0[0] == pytest.approx(l1[0], rel=1e-5)
+    assert np.abs(f0 - f1).max() > 0.0, "the switch did not change the path"
+    worst = ("", 0.0)
+    gmax = max(np.abs(v).max() for v in g1.values())
+    for name in g0:
+        scale = max(np.abs(g1[name]).max(), 1e-4 * gmax)     # floor: the key-bias gradients are identically zero (see above)
+        e = np.abs(g0[name] - g1[name]).max() / scale
+        if e > worst[1]:
+            worst = (name, e)
+    print(f"fused vs unfused spatial training path: worst gradient deviation {worst[1]:.2e} of scale ({worst[0]})")
+    assert worst[1] <= 1e-4, worst
