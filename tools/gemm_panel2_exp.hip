@@ -54,7 +54,7 @@ int main(int argc, char** argv) {
     auto k2 = gemm_h3_panel2_kernel<PanelEpBias>;
     CK(hipFuncSetAttribute((const void*)k1, hipFuncAttributeMaxDynamicSharedMemorySize, (int)PANEL_LDS_TOTAL));
     CK(hipFuncSetAttribute((const void*)k2, hipFuncAttributeMaxDynamicSharedMemorySize, (int)PANEL2_LDS_TOTAL));
-    for (int S : {2, 3, 4, 6}) {
+    for (int S : {2, 3, 4, 6, 8, 9, 12}) {
         if (nch % S) continue;
         const int cpw = nch / S;
         const dim3 grid(8 * S, ((mt * S + 7) / 8 + S - 1) / S);
