@@ -269,15 +269,17 @@ def test_train_step_at_the_benchmarked_batch():
     assert torch.isfinite(tr.params).all()
 
 
-def test_fused_and_unfused_spatial_training_forward_agree(monkeypatch):
+@pytest.mark.parametrize("B,alt", [(5, {"UU3D_TRAIN_SPATIAL_UNFUSED": "1", "UU3D_ATTN_BWD_GENERIC": "1"}), (16, {"UU3D_TRAIN_NO_PANEL": "1"})])
+def test_fused_and_unfused_spatial_training_forward_agree(monkeypatch, B, alt):
     """The training-mode forward of the spatial stack: ONE launch of spatial_stack_h3_kernel<.., TRAIN> (saved activations, row
     statistics, DropPath gates written by the kernel) against the chain of generic kernels it replaces
     (UU3D_TRAIN_SPATIAL_UNFUSED=1, read by uu3d_train_init), and the spatial attention backward on attn_small_bwd_kernel<17>
     against the generic kernel (UU3D_ATTN_BWD_GENERIC=1): outputs, loss and every gradient tensor, with DropPath."""
     from uplift_upsample_3dhpe_amd.trainer import Trainer
-    B = 5
+    # second case: 16 x 71 = 1136 token rows >= 1024: the LayerNorm-fed Dense layers of the temporal blocks and of strided block 1 run
+    # on ln_split_frag_stats + the row-panel GEMM (UU3D_TRAIN_NO_PANEL=1: row_stats + the tiled GEMM with the LayerNorm loader)
     results = []
-    for env in ({}, {"UU3D_TRAIN_SPATIAL_UNFUSED": "1", "UU3D_ATTN_BWD_GENERIC": "1"}):
+    for env in ({}, alt):
         for k, v in env.items():
             monkeypatch.setenv(k, v)
         cfg, arch, w, model, x, m, gt = _setup("h36m_351", B, seed=21, batch_norm=4)

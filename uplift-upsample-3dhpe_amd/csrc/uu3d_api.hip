@@ -787,6 +787,22 @@ struct Launcher {
         hipLaunchKernelGGL(kern, dim3(8 * S, ((mt * S + 7) / 8 + S - 1) / S), dim3(256), PANEL_LDS_TOTAL, stream, Af, m->harena + pf, colv, M, mt, S, (N / 32) / S, ep);
         end();
     }
+    // the same with the operand given by address (training: the packs regenerated from the master buffer) -- K = 384, N % 32 == 0
+    template <class EP>
+    void gemm_panel_at(const char* name, const _Float16* Af, const _Float16* Bf, const float* colv, int M, int N, const EP& ep) {
+        const int K = 384, S = panel_splits(M, N), mt = (M + 127) / 128;
+        begin(name, "gemm_panel", 2.0 * M * (double)N * K, 4.0 * ((double)M * K + (double)N * K + (double)M * N));
+        auto kern = gemm_h3_panel_kernel<24, EP>;
+        static bool attr_done = false;
+        if (!attr_done) { (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)PANEL_LDS_TOTAL); attr_done = true; }
+        hipLaunchKernelGGL(kern, dim3(8 * S, ((mt * S + 7) / 8 + S - 1) / S), dim3(256), PANEL_LDS_TOTAL, stream, Af, Bf, colv, M, mt, S, (N / 32) / S, ep);
+        end();
+    }
+    void ln_split_frag_stats(const char* name, const float* x, int M, const float* g, const float* b, _Float16* Af, float2* stats) {
+        begin(name, "ln_split_frag", 0.0, 8.0 * (double)M * 384);
+        hipLaunchKernelGGL((ln_split_frag_stats_kernel<24, 8>), dim3((M + 7) / 8), dim3(128), 0, stream, x, 384, M, 1e-5f, g, b, Af, stats);
+        end();
+    }
     // LayerNorm (eps 1e-5) of M rows of 384 floats, written as the fragment-ordered planes of the panel GEMM's A operand
     void ln_split_frag(const char* name, const float* x, int M, const float* g, const float* b, _Float16* Af) {
         begin(name, "ln_split_frag", 0.0, 8.0 * (double)M * 384);

@@ -75,6 +75,13 @@ struct PanelEpBias {           // out[row][col] = v
         *reinterpret_cast<float*>(reinterpret_cast<char*>(out) + b) = v;
     }
 };
+struct PanelEpBiasRelu {       // out[row][col] = max(v, 0)   (training-mode forward: the hidden activations stay f32 for the backward pass)
+    float* __restrict__ out; int ldo;
+    __device__ __forceinline__ void store(int row, int col, float v) const {
+        const unsigned b = ((unsigned)row * (unsigned)ldo + (unsigned)col) * 4u;
+        *reinterpret_cast<float*>(reinterpret_cast<char*>(out) + b) = fmaxf(v, 0.f);
+    }
+};
 struct PanelEpBiasSplitQ {     // [q | k | v] as row-major hi / lo planes for attn_h3_kernel; q (columns < qcols) times qscale = log2(e) / sqrt(d_h)
     _Float16* __restrict__ Oh; _Float16* __restrict__ Ol; int ldo, qcols; float qscale;
     __device__ __forceinline__ void store(int row, int col, float x) const {
@@ -257,10 +264,10 @@ gemm_h3_panel_kernel(const _Float16* __restrict__ Af, const _Float16* __restrict
 // them, so that a wave's stores for one piece index are runs of 64 contiguous bytes of the operand.  At M = 9088:
 // 6.6 us with 8 or 4 rows per workgroup, 7.0 with 16, 7.9 with 32 -- the floor of 28 MB through the Infinity Cache in
 // one short launch.
-template <int KS, int ROWS = 16>
-__global__ void __launch_bounds__(16 * ROWS)
-ln_split_frag_kernel(const float* __restrict__ x, const int ld, const int M, const float eps,
-                     const float* __restrict__ gamma, const float* __restrict__ beta, _Float16* __restrict__ Af)
+template <int KS, int ROWS>
+__device__ __forceinline__ void ln_split_frag_body(const float* __restrict__ x, const int ld, const int M, const float eps,
+                                                   const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                   _Float16* __restrict__ Af, float2* __restrict__ stats)
 {
     constexpr int D = 16 * KS, NV = D / 64;                // float4 pieces per thread
     h3_flush_f16_denormals();
@@ -281,6 +288,7 @@ ln_split_frag_kernel(const float* __restrict__ x, const int ld, const int M, con
     }
     q += __shfl_xor(q, 1); q += __shfl_xor(q, 2); q += __shfl_xor(q, 4); q += __shfl_xor(q, 8);
     const float rstd = 1.0f / sqrtf(q * (1.0f / D) + eps);
+    if (stats != nullptr && j == 0 && row < M) stats[row] = make_float2(mean, rstd);      // (training: the backward pass reads them)
     _Float16* base = Af + (size_t)(row >> 5) * KS * 2 * 512 + (row & 31) * 8;
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
@@ -296,6 +304,22 @@ ln_split_frag_kernel(const float* __restrict__ x, const int ld, const int M, con
         *reinterpret_cast<h16x4*>(d) = hi;
         *reinterpret_cast<h16x4*>(d + 512) = lo;
     }
+}
+
+template <int KS, int ROWS = 16>
+__global__ void __launch_bounds__(16 * ROWS)
+ln_split_frag_kernel(const float* __restrict__ x, const int ld, const int M, const float eps,
+                     const float* __restrict__ gamma, const float* __restrict__ beta, _Float16* __restrict__ Af)
+{
+    ln_split_frag_body<KS, ROWS>(x, ld, M, eps, gamma, beta, Af, nullptr);
+}
+// the same, also writing the rows' (mean, 1 / sqrt(var + eps)) -- the training-mode forward keeps them for the backward pass
+template <int KS, int ROWS = 16>
+__global__ void __launch_bounds__(16 * ROWS)
+ln_split_frag_stats_kernel(const float* __restrict__ x, const int ld, const int M, const float eps,
+                           const float* __restrict__ gamma, const float* __restrict__ beta, _Float16* __restrict__ Af, float2* __restrict__ stats)
+{
+    ln_split_frag_body<KS, ROWS>(x, ld, M, eps, gamma, beta, Af, stats);
 }
 
 }  // namespace uu3d

@@ -104,6 +104,36 @@ spatial_train_pack_kernel(const float* __restrict__ master, const SpatialPackSrc
     }
 }
 
+// Row-panel GEMM operands (uu3d_gemm_panel.h: fragment-ordered f16 planes, [32-column chunk][k-step of 12 slices][k-slice][plane]
+// [lane][8]) of the LayerNorm-fed Dense layers (fused q | k | v, fc1) for the training-mode forward, regenerated from the master
+// buffer after each optimizer step.  K = 384.  src[part] = Keras (384, N / parts) kernels side by side along N.
+struct PanelPackSrc { long long src[3]; long long dst; int N, parts; };
+static __global__ void __launch_bounds__(256)
+panel_train_pack_kernel(const float* __restrict__ master, const PanelPackSrc* __restrict__ desc, const int* __restrict__ blk_first, const int ndesc,
+                        _Float16* __restrict__ out)
+{
+    h3_flush_f16_denormals();
+    int lo = 0, hi = ndesc - 1;
+    while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (blk_first[mid] <= (int)blockIdx.x) lo = mid; else hi = mid - 1; }
+    const PanelPackSrc d = desc[lo];
+    const int e0 = ((int)blockIdx.x - blk_first[lo]) * 256 + threadIdx.x;        // one (chunk, k-step, slice, lane) = 8 consecutive k of one column
+    const int lane = e0 & 63, kk = (e0 >> 6) % 12, st = (e0 / (64 * 12)) & 1, c = e0 / (64 * 12 * 2);
+    if (c >= d.N / 32) return;
+    const int n = 32 * c + (lane & 31), k0 = st * 192 + kk * 16 + (lane >> 5) * 8;
+    const int Np = d.N / d.parts, part = n / Np, nn = n - part * Np;
+    const float* w = master + d.src[part] + (size_t)k0 * Np + nn;
+    h16x8 hv, lv;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const float x = w[(size_t)j * Np];
+        const _Float16 h = h3_hi(x);
+        hv[j] = h; lv[j] = (_Float16)((x - (float)h) * H3_SCALE);
+    }
+    _Float16* o = out + d.dst + ((((size_t)(c * 2 + st) * 12 + kk) * 2) * 64 + lane) * 8;
+    *reinterpret_cast<h16x8*>(o) = hv;
+    *reinterpret_cast<h16x8*>(o + 512) = lv;
+}
+
 // ---- DropPath (vision_transformer.py:16-43): gate = floor(u + keep) per leading-dim sample -------
 static __global__ void __launch_bounds__(256)
 droppath_gate_kernel(const float* __restrict__ u, const int n, const float keep, float* __restrict__ gate)
