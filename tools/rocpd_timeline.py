@@ -39,3 +39,9 @@ for g, a, b in gaps:
     if g >= 5000: big[(a, b)][0] += g; big[(a, b)][1] += 1
 for (a, b), (g, k) in sorted(big.items(), key=lambda kv: -kv[1][0])[:14]:
     print(f"  {g / 1e3 / k:7.1f} us x {k:4d}  after {a}  ->  {b}")
+# what the busiest stream spends its time on
+top = collections.defaultdict(lambda: [0, 0])
+for s, e, q, n in mr: top[n[:110]][0] += e - s; top[n[:110]][1] += 1
+print(f"stream {main}: kernels by time")
+for n, (b, k) in sorted(top.items(), key=lambda kv: -kv[1][0])[:40]:
+    print(f"  {b / 1e6:8.3f} ms  {k:5d} x {b / 1e3 / k:7.1f} us  {n}")

@@ -376,13 +376,14 @@ inline void launch_reduce_partials(const float* partial, int n, size_t pstride, 
 //   dgamma = sum_r dy * xhat ; dbeta = sum_r dy
 // One wave per row, RPW rows per wave, 4 waves per workgroup; each workgroup writes its partial
 // dgamma / dbeta to partial[wg][2][D]; reduce_partials_kernel adds them in a fixed order (deterministic).
-// dx is written, or added to dx_out when accumulate != 0 (residual-stream gradient).
+// dx is written, or res + dx when accumulate != 0 (residual-stream gradient; res may be dx_out itself: each element is read
+// by the lane that writes it).
 // ------------------------------------------------------------------------------------
 template <int MAXV>
 __global__ void __launch_bounds__(256)
 ln_bwd_kernel(const float* __restrict__ x, const float* __restrict__ dy, const float2* __restrict__ stats,
               const float* __restrict__ gamma, const int ld, const int D, const int M, const int rows_per_wave,
-              float* __restrict__ dx_out, const int accumulate, float* __restrict__ partial)
+              float* dx_out, const float* res, const int accumulate, float* __restrict__ partial)
 {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     f32x4 dg[MAXV], db[MAXV], gm[MAXV];
@@ -425,9 +426,8 @@ ln_bwd_kernel(const float* __restrict__ x, const float* __restrict__ dy, const f
                 f32x4 o;
 #pragma unroll
                 for (int e = 0; e < 4; ++e) o[e] = st.y * (g[i][e] - m1 - xh[i][e] * m2);
-                float* po = dx_out + (size_t)row * ld + c;
-                if (accumulate) { const f32x4 old = *reinterpret_cast<const f32x4*>(po); o += old; }
-                *reinterpret_cast<f32x4*>(po) = o;
+                if (accumulate) { const f32x4 old = *reinterpret_cast<const f32x4*>(res + (size_t)row * ld + c); o += old; }
+                *reinterpret_cast<f32x4*>(dx_out + (size_t)row * ld + c) = o;
             }
         }
     }
@@ -454,7 +454,7 @@ template <int LPR>
 __global__ void __launch_bounds__(256)
 ln_bwd_narrow_kernel(const float* __restrict__ x, const float* __restrict__ dy, const float2* __restrict__ stats,
                      const float* __restrict__ gamma, const int ld, const int M, const int rows_per_group,
-                     float* __restrict__ dx_out, const int accumulate, float* __restrict__ partial)
+                     float* dx_out, const float* res, const int accumulate, float* __restrict__ partial)
 {
     constexpr int RG = 256 / LPR, D = 4 * LPR;
     const int l = threadIdx.x % LPR, rg = threadIdx.x / LPR;
@@ -486,9 +486,8 @@ ln_bwd_narrow_kernel(const float* __restrict__ x, const float* __restrict__ dy, 
             f32x4 o;
 #pragma unroll
             for (int e = 0; e < 4; ++e) o[e] = st.y * (g[e] - m1 - xh[e] * m2);
-            float* po = dx_out + (size_t)row * ld + 4 * l;
-            if (accumulate) { const f32x4 old = *reinterpret_cast<const f32x4*>(po); o += old; }
-            *reinterpret_cast<f32x4*>(po) = o;
+            if (accumulate) { const f32x4 old = *reinterpret_cast<const f32x4*>(res + (size_t)row * ld + 4 * l); o += old; }
+            *reinterpret_cast<f32x4*>(dx_out + (size_t)row * ld + 4 * l) = o;
         }
     }
     __shared__ __attribute__((aligned(16))) float red[RG][2][D];

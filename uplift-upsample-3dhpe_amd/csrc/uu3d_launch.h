@@ -128,9 +128,12 @@ inline int launch_colsum(const float* x, int ldx, int R, int C, int period, cons
     return hip_status();
 }
 
-// dgamma/dbeta: written (acc_params == 0) or accumulated.
-inline int launch_ln_bwd(const float* x, const float* dy, const float2* stats, const float* gamma, int ld, int D, int M, float* dx,
-                         int accumulate, float* dgamma, float* dbeta, int acc_params, float* scratch, size_t scratch_floats, hipStream_t stream) {
+// LayerNorm backward in two launches: the row kernel (dx, per-workgroup partial dgamma / dbeta in scratch; returns the number of
+// partial slices) and the combine of the partials, which may run on another stream behind the first.
+// accumulate: dx = res + d x (res == nullptr: dx itself, in place).
+inline int launch_ln_bwd_rows(const float* x, const float* dy, const float2* stats, const float* gamma, int ld, int D, int M, float* dx,
+                              int accumulate, const float* res, float* scratch, size_t scratch_floats, hipStream_t stream) {
+    if (!res) res = dx;
     // wide rows (D = 384): >= 500 workgroups at M = 4544 (8 rows per wave left 114 of 256 CUs idle), <= 2048 partial rows;
     // the spatial stack's D = 32 rows are cheap and many (77 k): fewer, longer workgroups keep the combine short
     if ((D == 32 || D == 64) && ld % 4 == 0) {          // narrow rows: D / 4 lanes per row, 256 * 4 / D rows per workgroup at once
@@ -138,27 +141,32 @@ inline int launch_ln_bwd(const float* x, const float* dy, const float2* stats, c
         int rpg = std::max(4, (M + RG * 512 - 1) / (RG * 512));
         int wgs = (M + RG * rpg - 1) / (RG * rpg);
         while ((size_t)wgs * 2 * D > scratch_floats) { rpg *= 2; wgs = (M + RG * rpg - 1) / (RG * rpg); }
-        if (D == 32) hipLaunchKernelGGL(ln_bwd_narrow_kernel<8>, dim3(wgs), dim3(256), 0, stream, x, dy, stats, gamma, ld, M, rpg, dx, accumulate, scratch);
-        else hipLaunchKernelGGL(ln_bwd_narrow_kernel<16>, dim3(wgs), dim3(256), 0, stream, x, dy, stats, gamma, ld, M, rpg, dx, accumulate, scratch);
-        if (dbeta == dgamma + D) launch_reduce_partials(scratch, 2 * D, (size_t)2 * D, wgs, dgamma, acc_params, stream);
-        else {
-            launch_reduce_partials(scratch, D, (size_t)2 * D, wgs, dgamma, acc_params, stream);
-            launch_reduce_partials(scratch + D, D, (size_t)2 * D, wgs, dbeta, acc_params, stream);
-        }
-        return hip_status();
+        if (D == 32) hipLaunchKernelGGL(ln_bwd_narrow_kernel<8>, dim3(wgs), dim3(256), 0, stream, x, dy, stats, gamma, ld, M, rpg, dx, res, accumulate, scratch);
+        else hipLaunchKernelGGL(ln_bwd_narrow_kernel<16>, dim3(wgs), dim3(256), 0, stream, x, dy, stats, gamma, ld, M, rpg, dx, res, accumulate, scratch);
+        return wgs;
     }
     int rpw = (D > 64) ? std::max(2, (M + 4 * 2048 - 1) / (4 * 2048)) : std::max(8, (M + 4 * 512 - 1) / (4 * 512));
     int wgs = (M + 4 * rpw - 1) / (4 * rpw);
     while ((size_t)wgs * 2 * D > scratch_floats) { rpw *= 2; wgs = (M + 4 * rpw - 1) / (4 * rpw); }
-    if (D <= 512) hipLaunchKernelGGL(ln_bwd_kernel<2>, dim3(wgs), dim3(256), 0, stream, x, dy, stats, gamma, ld, D, M, rpw, dx, accumulate, scratch);
-    else hipLaunchKernelGGL(ln_bwd_kernel<4>, dim3(wgs), dim3(256), 0, stream, x, dy, stats, gamma, ld, D, M, rpw, dx, accumulate, scratch);
-    // partial layout [wg][2][D] -> finish over "n = 2*D" with wgs slices; dgamma and dbeta must be adjacent? no: two calls
+    if (D <= 512) hipLaunchKernelGGL(ln_bwd_kernel<2>, dim3(wgs), dim3(256), 0, stream, x, dy, stats, gamma, ld, D, M, rpw, dx, res, accumulate, scratch);
+    else hipLaunchKernelGGL(ln_bwd_kernel<4>, dim3(wgs), dim3(256), 0, stream, x, dy, stats, gamma, ld, D, M, rpw, dx, res, accumulate, scratch);
+    return wgs;
+}
+
+// partial layout [slice][2][D]; dgamma/dbeta: written (acc_params == 0) or accumulated
+inline void launch_ln_bwd_combine(const float* scratch, int D, int slices, float* dgamma, float* dbeta, int acc_params, hipStream_t stream) {
     if (dbeta == dgamma + D) {      // gamma and beta are neighbours in the flat gradient buffer: one combine over [dgamma | dbeta]
-        launch_reduce_partials(scratch, 2 * D, (size_t)2 * D, wgs, dgamma, acc_params, stream);
+        launch_reduce_partials(scratch, 2 * D, (size_t)2 * D, slices, dgamma, acc_params, stream);
     } else {
-        launch_reduce_partials(scratch, D, (size_t)2 * D, wgs, dgamma, acc_params, stream);
-        launch_reduce_partials(scratch + D, D, (size_t)2 * D, wgs, dbeta, acc_params, stream);
+        launch_reduce_partials(scratch, D, (size_t)2 * D, slices, dgamma, acc_params, stream);
+        launch_reduce_partials(scratch + D, D, (size_t)2 * D, slices, dbeta, acc_params, stream);
     }
+}
+
+inline int launch_ln_bwd(const float* x, const float* dy, const float2* stats, const float* gamma, int ld, int D, int M, float* dx,
+                         int accumulate, float* dgamma, float* dbeta, int acc_params, float* scratch, size_t scratch_floats, hipStream_t stream) {
+    const int slices = launch_ln_bwd_rows(x, dy, stats, gamma, ld, D, M, dx, accumulate, nullptr, scratch, scratch_floats, stream);
+    launch_ln_bwd_combine(scratch, D, slices, dgamma, dbeta, acc_params, stream);
     return hip_status();
 }
 
