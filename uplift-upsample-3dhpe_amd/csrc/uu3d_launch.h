@@ -24,7 +24,7 @@ int launch_gemm(const AL& al, const float* Bt, int M, int N, int K, const EP& ep
     const int Kp = ru(K, 32), KT = Kp / 32;
     const int tiles = ((M + 63) / 64) * ((N + 63) / 64);
     int slices = 1;
-    if (tiles < 384 && KT >= 8) slices = std::max(1, std::min(KT / 4, (768 + tiles / 2) / tiles));
+    if (tiles < 384 && KT >= 8) slices = std::max(1, std::min(KT / 4, (768 + tiles / 2) / tiles));     // (training step: 384 / 1536 target workgroups measure +0.5 %, no split +6 %)
     int kps = (KT + slices - 1) / slices;
     slices = (KT + kps - 1) / kps;
     const int ldslab = ru(N, 4);
@@ -55,7 +55,7 @@ int launch_gemm(const AL& al, const float* Bt, int M, int N, int K, const EP& ep
     return hip_status();
 }
 
-inline int tnh_target_wgs() { static const int v = getenv("UU3D_TNH_WGS") ? atoi(getenv("UU3D_TNH_WGS")) : 384; return v; }
+inline int tnh_target_wgs() { static const int v = getenv("UU3D_TNH_WGS") ? atoi(getenv("UU3D_TNH_WGS")) : 192; return v; }     // these GEMMs share the chip with the activation-gradient chain: fewer, longer workgroups and half the combine traffic (384: 3.74 ms per step, 192: 3.60, 128: 3.61, 96: 3.65)
 // C[P][Q] = A^T B over R rows, split over R into slabs, combined in order.
 template <class AL, class EP>
 int launch_gemm_tn(const AL& al, const float* B, int ldb, int R, int P, int Q, const EP& ep, float* slab, size_t slab_floats, hipStream_t stream,
@@ -87,9 +87,9 @@ int launch_gemm_tn(const AL& al, const float* B, int ldb, int R, int P, int Q, c
     const int pt = (P + 63) / 64, qt = (Q + 63) / 64, tiles = pt * qt;
     const int KT = (R + 31) / 32;
     // <= 48 slabs when the combine is one thread per element; tall-skinny results (<= 4 tiles, e.g. the spatial stack's
-    // 32 x 32 weight gradients over 77k rows) take up to 512 slabs and the 16-lane combine instead
+    // 32 x 32 weight gradients over 77k rows) take up to 256 slabs and the 16-lane combine instead (512 slabs: +1.4 % per training step)
     const bool skinny = tiles <= 4 && KT >= 256;
-    int slices = skinny ? std::max(1, std::min(KT / 4, 512 / tiles))
+    int slices = skinny ? std::max(1, std::min(KT / 4, 256 / tiles))
                         : std::max(1, std::min(std::min(std::max(KT / 4, 1), 48), (1024 + tiles / 2) / tiles));
     const int ldslab = ru(Q, 4);
     while (slices > 1 && (size_t)slices * P * ldslab > slab_floats) --slices;
