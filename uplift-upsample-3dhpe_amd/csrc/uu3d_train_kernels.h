@@ -142,6 +142,23 @@ droppath_gate_kernel(const float* __restrict__ u, const int n, const float keep,
     if (i < n) gate[i] = (u != nullptr) ? floorf(u[i] + keep) : 1.0f;
 }
 
+// every layer's gates of both stacks in one launch: layer i of the spatial stack has ns gates (u and gate at i * ns), the
+// temporal stack's follow (u at Ls * ns + i * nt, gates in their own array); keep[i] >= 1 or u == nullptr: gate = 1
+struct GateKeeps { float s[16], t[16]; };
+static __global__ void __launch_bounds__(256)
+droppath_gates_kernel(const float* __restrict__ u, const int Ls, const int ns, const int Lt, const int nt, const GateKeeps keeps,
+                      float* __restrict__ gate_s, float* __restrict__ gate_t)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    const int total_s = Ls * ns;
+    if (i >= total_s + Lt * nt) return;
+    const bool sp = i < total_s;
+    const int j = sp ? i : i - total_s;
+    const float keep = sp ? keeps.s[j / ns] : keeps.t[j / nt];
+    const float g = (u != nullptr && keep < 1.f) ? floorf(u[i] + keep) : 1.0f;
+    (sp ? gate_s : gate_t)[j] = g;
+}
+
 // ---- elementwise helpers ------------------------------------------------------------------------
 // x0 = kp @ We + be + pe[joint]   (u_u_t.py:321-323), rows = frames * J
 static __global__ void __launch_bounds__(256)
