@@ -299,6 +299,32 @@ colsum_kernel(const float* __restrict__ X, const int ldx, const int R, const int
         __syncthreads();
     }
 }
+// Periodic column sums (positional-encoding gradients: out[ph][c] = sum over the nb = R / P samples b of X[b * P + ph][c]) with
+// C % 4 == 0 and no mask: one thread per 4 outputs and slice of samples, 16-byte loads a sample apart, no LDS, no barrier.
+// colsum_kernel walks the P phases one after the other with two barriers each (23 - 40 us for the 71 x 384 temporal encoding).
+// grid (ceil(P * C / 4 / 256), slices); partial[slice][P * C].
+static __global__ void __launch_bounds__(256)
+colsum_period4_kernel(const float* __restrict__ X, const int ldx, const int nb, const int P, const int C, float* __restrict__ partial,
+                      const int slices)
+{
+    const int c4 = C >> 2, o = blockIdx.x * 256 + threadIdx.x;
+    if (o >= P * c4) return;
+    const int ph = o / c4, c = (o - ph * c4) * 4;
+    const int per = (nb + slices - 1) / slices;
+    const int b_lo = blockIdx.y * per, b_hi = min(nb, b_lo + per);
+    const float* x = X + (size_t)ph * ldx + c;
+    const size_t bs = (size_t)P * ldx;
+    f32x4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = s0, s2 = s0, s3 = s0;
+    int b = b_lo;
+    for (; b + 3 < b_hi; b += 4) {
+        s0 += *reinterpret_cast<const f32x4*>(x + (size_t)b * bs);
+        s1 += *reinterpret_cast<const f32x4*>(x + (size_t)(b + 1) * bs);
+        s2 += *reinterpret_cast<const f32x4*>(x + (size_t)(b + 2) * bs);
+        s3 += *reinterpret_cast<const f32x4*>(x + (size_t)(b + 3) * bs);
+    }
+    for (; b < b_hi; ++b) s0 += *reinterpret_cast<const f32x4*>(x + (size_t)b * bs);
+    *reinterpret_cast<f32x4*>(partial + (size_t)blockIdx.y * P * C + (size_t)ph * C + c) = (s0 + s1) + (s2 + s3);
+}
 // Fast path of colsum_kernel for the common case (no period, no mask, C % 4 == 0): 16-byte loads, 4 independent
 // partial sums per thread.  A workgroup covers cgs = min(64, C / 4) column groups and gives the other 256 / cgs thread
 // rows to more matrix rows, so narrow matrices (the spatial stack's 32 .. 96 columns over 77 k rows) use every lane;
@@ -379,11 +405,15 @@ inline void launch_reduce_partials(const float* partial, int n, size_t pstride, 
 // dx is written, or res + dx when accumulate != 0 (residual-stream gradient; res may be dx_out itself: each element is read
 // by the lane that writes it).
 // ------------------------------------------------------------------------------------
+// gated.out (optional) additionally receives the DropPath-gated copy of the result the next Dense-layer backward reads:
+// (dx / keep) * gate[row / rps], the arithmetic of scale_rows_kernel.
+struct LnBwdGated { const float* gate; float keep; int rps; float* out; };
+
 template <int MAXV>
 __global__ void __launch_bounds__(256)
 ln_bwd_kernel(const float* __restrict__ x, const float* __restrict__ dy, const float2* __restrict__ stats,
               const float* __restrict__ gamma, const int ld, const int D, const int M, const int rows_per_wave,
-              float* dx_out, const float* res, const int accumulate, float* __restrict__ partial)
+              float* dx_out, const float* res, const int accumulate, float* __restrict__ partial, const LnBwdGated gated)
 {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     f32x4 dg[MAXV], db[MAXV], gm[MAXV];
@@ -428,6 +458,12 @@ ln_bwd_kernel(const float* __restrict__ x, const float* __restrict__ dy, const f
                 for (int e = 0; e < 4; ++e) o[e] = st.y * (g[i][e] - m1 - xh[i][e] * m2);
                 if (accumulate) { const f32x4 old = *reinterpret_cast<const f32x4*>(res + (size_t)row * ld + c); o += old; }
                 *reinterpret_cast<f32x4*>(dx_out + (size_t)row * ld + c) = o;
+                if (gated.out != nullptr) {
+                    const float gt = gated.gate[row / gated.rps];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) o[e] = (o[e] / gated.keep) * gt;
+                    *reinterpret_cast<f32x4*>(gated.out + (size_t)row * ld + c) = o;
+                }
             }
         }
     }
@@ -454,7 +490,7 @@ template <int LPR>
 __global__ void __launch_bounds__(256)
 ln_bwd_narrow_kernel(const float* __restrict__ x, const float* __restrict__ dy, const float2* __restrict__ stats,
                      const float* __restrict__ gamma, const int ld, const int M, const int rows_per_group,
-                     float* dx_out, const float* res, const int accumulate, float* __restrict__ partial)
+                     float* dx_out, const float* res, const int accumulate, float* __restrict__ partial, const LnBwdGated gated)
 {
     constexpr int RG = 256 / LPR, D = 4 * LPR;
     const int l = threadIdx.x % LPR, rg = threadIdx.x / LPR;
@@ -488,6 +524,12 @@ ln_bwd_narrow_kernel(const float* __restrict__ x, const float* __restrict__ dy, 
             for (int e = 0; e < 4; ++e) o[e] = st.y * (g[e] - m1 - xh[e] * m2);
             if (accumulate) { const f32x4 old = *reinterpret_cast<const f32x4*>(res + (size_t)row * ld + 4 * l); o += old; }
             *reinterpret_cast<f32x4*>(dx_out + (size_t)row * ld + 4 * l) = o;
+            if (gated.out != nullptr) {
+                const float gt = gated.gate[row / gated.rps];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) o[e] = (o[e] / gated.keep) * gt;
+                *reinterpret_cast<f32x4*>(gated.out + (size_t)row * ld + 4 * l) = o;
+            }
         }
     }
     __shared__ __attribute__((aligned(16))) float red[RG][2][D];

@@ -116,6 +116,13 @@ inline int launch_colsum(const float* x, int ldx, int R, int C, int period, cons
     int slices = std::max(1, std::min(256, R / std::max(128, P)));      // >= 128 rows (and one period) per workgroup
     while (slices > 1 && (size_t)slices * P * C > scratch_floats) --slices;
     if ((size_t)slices * P * C > scratch_floats) return UU3D_ERR_WORKSPACE;
+    if (period > 0 && mask == nullptr && (C % 4) == 0 && (ldx % 4) == 0 && R % period == 0) {
+        const int nb = R / period, xb = (period * (C / 4) + 255) / 256;
+        slices = std::max(1, std::min(std::max(1, 512 / xb), nb / 4));         // ~512 workgroups, >= 4 samples per thread
+        while (slices > 1 && (size_t)slices * P * C > scratch_floats) --slices;
+        if ((size_t)slices * P * C > scratch_floats) return UU3D_ERR_WORKSPACE;
+        hipLaunchKernelGGL(colsum_period4_kernel, dim3(xb, slices), dim3(256), 0, stream, x, ldx, nb, period, C, scratch, slices);
+    } else
     if (period <= 0 && mask == nullptr && (C % 4) == 0 && (ldx % 4) == 0) {
         const int cgs = std::max(1, std::min(64, (C + 3) / 4));
         const int xb = (C + 4 * cgs - 1) / (4 * cgs);
@@ -132,7 +139,8 @@ inline int launch_colsum(const float* x, int ldx, int R, int C, int period, cons
 // partial slices) and the combine of the partials, which may run on another stream behind the first.
 // accumulate: dx = res + d x (res == nullptr: dx itself, in place).
 inline int launch_ln_bwd_rows(const float* x, const float* dy, const float2* stats, const float* gamma, int ld, int D, int M, float* dx,
-                              int accumulate, const float* res, float* scratch, size_t scratch_floats, hipStream_t stream) {
+                              int accumulate, const float* res, float* scratch, size_t scratch_floats, hipStream_t stream,
+                              const LnBwdGated gated = LnBwdGated{nullptr, 1.f, 1, nullptr}) {
     if (!res) res = dx;
     // wide rows (D = 384): >= 500 workgroups at M = 4544 (8 rows per wave left 114 of 256 CUs idle), <= 2048 partial rows;
     // the spatial stack's D = 32 rows are cheap and many (77 k): fewer, longer workgroups keep the combine short
@@ -141,15 +149,15 @@ inline int launch_ln_bwd_rows(const float* x, const float* dy, const float2* sta
         int rpg = std::max(4, (M + RG * 512 - 1) / (RG * 512));
         int wgs = (M + RG * rpg - 1) / (RG * rpg);
         while ((size_t)wgs * 2 * D > scratch_floats) { rpg *= 2; wgs = (M + RG * rpg - 1) / (RG * rpg); }
-        if (D == 32) hipLaunchKernelGGL(ln_bwd_narrow_kernel<8>, dim3(wgs), dim3(256), 0, stream, x, dy, stats, gamma, ld, M, rpg, dx, res, accumulate, scratch);
-        else hipLaunchKernelGGL(ln_bwd_narrow_kernel<16>, dim3(wgs), dim3(256), 0, stream, x, dy, stats, gamma, ld, M, rpg, dx, res, accumulate, scratch);
+        if (D == 32) hipLaunchKernelGGL(ln_bwd_narrow_kernel<8>, dim3(wgs), dim3(256), 0, stream, x, dy, stats, gamma, ld, M, rpg, dx, res, accumulate, scratch, gated);
+        else hipLaunchKernelGGL(ln_bwd_narrow_kernel<16>, dim3(wgs), dim3(256), 0, stream, x, dy, stats, gamma, ld, M, rpg, dx, res, accumulate, scratch, gated);
         return wgs;
     }
     int rpw = (D > 64) ? std::max(2, (M + 4 * 2048 - 1) / (4 * 2048)) : std::max(8, (M + 4 * 512 - 1) / (4 * 512));
     int wgs = (M + 4 * rpw - 1) / (4 * rpw);
     while ((size_t)wgs * 2 * D > scratch_floats) { rpw *= 2; wgs = (M + 4 * rpw - 1) / (4 * rpw); }
-    if (D <= 512) hipLaunchKernelGGL(ln_bwd_kernel<2>, dim3(wgs), dim3(256), 0, stream, x, dy, stats, gamma, ld, D, M, rpw, dx, res, accumulate, scratch);
-    else hipLaunchKernelGGL(ln_bwd_kernel<4>, dim3(wgs), dim3(256), 0, stream, x, dy, stats, gamma, ld, D, M, rpw, dx, res, accumulate, scratch);
+    if (D <= 512) hipLaunchKernelGGL(ln_bwd_kernel<2>, dim3(wgs), dim3(256), 0, stream, x, dy, stats, gamma, ld, D, M, rpw, dx, res, accumulate, scratch, gated);
+    else hipLaunchKernelGGL(ln_bwd_kernel<4>, dim3(wgs), dim3(256), 0, stream, x, dy, stats, gamma, ld, D, M, rpw, dx, res, accumulate, scratch, gated);
     return wgs;
 }
 
