@@ -89,6 +89,18 @@ def test_colsum_plain_period_mask(lib):
     _close(outm.cpu().numpy(), 1.0 + x[~m].astype(np.float64).sum(0), 2e-6)
 
 
+@pytest.mark.parametrize("nb,P,Cc", [(4544, 17, 32), (64, 24, 384), (3, 1, 384), (5, 7, 30)])
+def test_colsum_periodic_shapes(lib, nb, P, Cc):
+    """Positional-encoding gradients on colsum_period4_kernel (C % 4 == 0: the spatial stack's 17 x 32 over 4544 frames, a strided
+    block's 24 x 384, a one-token sequence) and on the generic kernel (C % 4 != 0)."""
+    rng = np.random.default_rng(12)
+    x = rng.normal(size=(nb * P, Cc)).astype(np.float32)
+    sc, n = _scratch(lib)
+    out = torch.full((P, Cc), 7.0, device="cuda")
+    assert lib.uu3d_op_colsum(_p(_d(x)), Cc, nb * P, Cc, P, None, 0, _p(out), 0, _p(sc), n, None) == 0
+    _close(out.cpu().numpy(), x.astype(np.float64).reshape(nb, P, Cc).sum(0), 2e-6)
+
+
 @pytest.mark.parametrize("M,D", [(9088, 384), (5000, 32), (3, 384)])
 def test_layernorm_backward(lib, M, D):
     rng = np.random.default_rng(3)
