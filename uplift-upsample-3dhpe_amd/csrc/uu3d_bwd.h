@@ -83,6 +83,17 @@ struct EpStore {
     __device__ __forceinline__ void store(int row, int col, float v, float2, float2) const { out[(size_t)row * ldo + col] = v; }
 };
 
+// C[P][3 seg] stored as three separate [P][seg] tensors (q | k | v weight gradients of one GEMM over the concatenated d q|k|v)
+struct EpStore3 {
+    float* __restrict__ out0; float* __restrict__ out1; float* __restrict__ out2; int seg;
+    __device__ __forceinline__ float2 colv(int) const { return make_float2(0.f, 0.f); }
+    __device__ __forceinline__ float2 pre(int, int) const { return make_float2(0.f, 0.f); }
+    __device__ __forceinline__ void store(int row, int col, float v, float2, float2) const {
+        const int s = col / seg, c = col - s * seg;
+        (s == 0 ? out0 : (s == 1 ? out1 : out2))[(size_t)row * seg + c] = v;
+    }
+};
+
 // C[P][Q] (+= over blockIdx.y slices into slabs) ; 64x64 tile, 4 waves 2x2, BK = 32 rows of R.
 // LDS: TA[2][32][68], TB[2][32][68] (r-major).  MFMA 32x32x2: A operand element (i = p, k = r),
 // lane (p = lane & 31, h) reads TA[8kk + 4h + s][p] for step s -- ds_read_b32 down a column.
@@ -358,12 +369,17 @@ colsum4_kernel(const float* __restrict__ X, const int ldx, const int R, const in
         *reinterpret_cast<f32x4*>(partial + (size_t)blockIdx.y * C + c) = t;
     }
 }
+// where element c of a combined result goes: one tensor, or up to three of `seg` elements each (the q | k | v bias gradients)
+struct ReduceOut {
+    float* p0; float* p1; float* p2; int seg;
+    __host__ __device__ __forceinline__ float* at(int c) const { const int s = c / seg; return (s == 0 ? p0 : (s == 1 ? p1 : p2)) + (c - s * seg); }
+};
 // out[i] (+)= sum_k partial[k * pstride + i], i < n.  Thread (column c of 16, lane q of 16): lane q adds the
 // slices k = q, q+QL, ... in order; the QL lane sums are then added in lane order -> deterministic.
 template <int QL>
 __global__ void __launch_bounds__(16 * QL)
 reduce_partials_kernel(const float* __restrict__ partial, const int n, const size_t pstride, const int slices,
-                       float* __restrict__ out, const int accumulate)
+                       const ReduceOut out, const int accumulate)
 {
     __shared__ float red[QL][17];
     const int cl = threadIdx.x & 15, q = threadIdx.x >> 4;
@@ -387,13 +403,18 @@ reduce_partials_kernel(const float* __restrict__ partial, const int n, const siz
         float t = red[0][cl];
 #pragma unroll
         for (int k = 1; k < QL; ++k) t += red[k][cl];
-        out[c] = accumulate ? out[c] + t : t;
+        float* o = out.at(c);
+        *o = accumulate ? *o + t : t;
     }
 }
 // out[0..n) (+)= sum over `slices` partial rows: 64 lanes per column when there are many slices, 16 otherwise.
-inline void launch_reduce_partials(const float* partial, int n, size_t pstride, int slices, float* out, int accumulate, hipStream_t stream) {
+inline void launch_reduce_partials(const float* partial, int n, size_t pstride, int slices, float* out, int accumulate, hipStream_t stream);
+inline void launch_reduce_partials(const float* partial, int n, size_t pstride, int slices, const ReduceOut out, int accumulate, hipStream_t stream) {
     if (slices >= 128) hipLaunchKernelGGL(reduce_partials_kernel<64>, dim3((n + 15) / 16), dim3(1024), 0, stream, partial, n, pstride, slices, out, accumulate);
     else hipLaunchKernelGGL(reduce_partials_kernel<16>, dim3((n + 15) / 16), dim3(256), 0, stream, partial, n, pstride, slices, out, accumulate);
+}
+inline void launch_reduce_partials(const float* partial, int n, size_t pstride, int slices, float* out, int accumulate, hipStream_t stream) {
+    launch_reduce_partials(partial, n, pstride, slices, ReduceOut{out, nullptr, nullptr, n > 0 ? n : 1}, accumulate, stream);
 }
 
 // ------------------------------------------------------------------------------------

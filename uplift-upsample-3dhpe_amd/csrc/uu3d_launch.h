@@ -110,7 +110,7 @@ int launch_gemm_tn(const AL& al, const float* B, int ldb, int R, int P, int Q, c
     return hip_status();
 }
 
-inline int launch_colsum(const float* x, int ldx, int R, int C, int period, const uint8_t* mask, int want, float* out,
+inline int launch_colsum(const float* x, int ldx, int R, int C, int period, const uint8_t* mask, int want, const ReduceOut out,
                          int accumulate, float* scratch, size_t scratch_floats, hipStream_t stream) {
     const int P = period > 0 ? period : 1;
     int slices = std::max(1, std::min(256, R / std::max(128, P)));      // >= 128 rows (and one period) per workgroup
@@ -133,6 +133,11 @@ inline int launch_colsum(const float* x, int ldx, int R, int C, int period, cons
     hipLaunchKernelGGL(colsum_kernel, dim3((C + 63) / 64, slices), dim3(256), 0, stream, x, ldx, R, C, period, mask, want, scratch, slices);
     launch_reduce_partials(scratch, P * C, (size_t)P * C, slices, out, accumulate, stream);
     return hip_status();
+}
+inline int launch_colsum(const float* x, int ldx, int R, int C, int period, const uint8_t* mask, int want, float* out,
+                         int accumulate, float* scratch, size_t scratch_floats, hipStream_t stream) {
+    const int n = (period > 0 ? period : 1) * C;
+    return launch_colsum(x, ldx, R, C, period, mask, want, ReduceOut{out, nullptr, nullptr, n > 0 ? n : 1}, accumulate, scratch, scratch_floats, stream);
 }
 
 // LayerNorm backward in two launches: the row kernel (dx, per-workgroup partial dgamma / dbeta in scratch; returns the number of
