@@ -227,8 +227,19 @@ splitk_reduce_kernel(const float* __restrict__ slab, const int slices, const siz
     if (idx >= M * N) return;
     const int row = idx / N, col = idx - row * N;
     const float* p = slab + (size_t)row * ld + col;
+    // eight slices in flight, added in slice order (as a plain loop the thread waited for one load after the other: 10 us for a
+    // 22-slice combine of 384 x 384 = 1.2 TB/s)
     float v = p[0];
-    for (int s = 1; s < slices; ++s) v += p[s * slice_stride];
+    int s = 1;
+    for (; s + 7 < slices; s += 8) {
+        float a[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) a[u] = p[(size_t)(s + u) * slice_stride];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v += a[u];
+    }
+    for (; s + 1 < slices; s += 2) { const float a0 = p[(size_t)s * slice_stride], a1 = p[(size_t)(s + 1) * slice_stride]; v += a0; v += a1; }
+    if (s < slices) v += p[(size_t)s * slice_stride];
     ep.store(row, col, v, ep.colv(col), ep.pre(row, col));
 }
 
@@ -247,7 +258,15 @@ splitk_reduce16_kernel(const float* __restrict__ slab, const int slices, const s
     const int row = ok ? idx / N : 0, col = ok ? idx - row * N : 0;
     const float* p = slab + (size_t)row * ld + col;
     float v = 0.f;
-    if (ok) for (int s = q; s < slices; s += 16) v += p[s * slice_stride];
+    if (ok) {                                               // four of this lane's slices in flight, added in slice order
+        int s = q;
+        for (; s + 48 < slices; s += 64) {
+            const float a0 = p[(size_t)s * slice_stride], a1 = p[(size_t)(s + 16) * slice_stride];
+            const float a2 = p[(size_t)(s + 32) * slice_stride], a3 = p[(size_t)(s + 48) * slice_stride];
+            v += a0; v += a1; v += a2; v += a3;
+        }
+        for (; s < slices; s += 16) v += p[(size_t)s * slice_stride];
+    }
     red[q][el] = v;
     __syncthreads();
     if (q == 0 && ok) {
