@@ -707,12 +707,18 @@ struct Launcher {
     template <int TM, int TN, class AL, class EP>
     void gemm_h3_tile(const AL& al, const _Float16* Bh, const _Float16* Bl, int M, int N, int Kp, int slices, int kt_per_split, const EP& ep) {
         auto kern = gemm_h3_kernel<TM, TN, AL, EP>;
+        auto kern_deep = gemm_h3_kernel<TM, TN, AL, EP, 1>;     // few workgroups per CU: loads three k-tiles ahead (uu3d_gemm_h3.h)
         constexpr size_t lds = gemm_h3_lds_bytes(64 * TM, 64 * TN);
         static bool attr_done = false;
-        if (!attr_done) { (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr_done = true; }
+        if (!attr_done) {
+            (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            (void)hipFuncSetAttribute((const void*)kern_deep, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            attr_done = true;
+        }
         const int mt = (M + 64 * TM - 1) / (64 * TM), nt = (N + 64 * TN - 1) / (64 * TN);
         const int grid = round_up(mt, 8) * nt;
-        hipLaunchKernelGGL(kern, dim3(grid, slices), dim3(256), lds, stream, al, Bh, Bl, M, N, Kp, mt, nt, kt_per_split, ep);
+        if (gemm_h3_deep(grid * slices)) hipLaunchKernelGGL(kern_deep, dim3(grid, slices), dim3(256), lds, stream, al, Bh, Bl, M, N, Kp, mt, nt, kt_per_split, ep);
+        else hipLaunchKernelGGL(kern, dim3(grid, slices), dim3(256), lds, stream, al, Bh, Bl, M, N, Kp, mt, nt, kt_per_split, ep);
     }
 
     template <int TM, int TN, class GL, class EP>

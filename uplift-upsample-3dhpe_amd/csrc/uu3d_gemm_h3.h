@@ -16,6 +16,8 @@
 // 40 (80 B): the 16 lanes of every ds_read_b128 group fall on 16 distinct 16-byte slots.
 // Workgroup = 256 threads = 4 waves as 2 x 2, wave tile (32 TM) x (32 TN).
 #pragma once
+#include <cstdlib>
+#include <type_traits>
 #include <hip/hip_runtime.h>
 #include <hip/hip_fp16.h>
 #include <stdint.h>
@@ -62,7 +64,12 @@ __device__ __forceinline__ void h3_split(const f32x4 x, h16x4& hi, h16x4& lo) {
     }
 }
 
-template <int TM, int TN, class AL, class EP>
+inline bool gemm_h3_deep(int workgroups) {
+    static const int limit = getenv("UU3D_GEMM_DEEP_WGS") ? atoi(getenv("UU3D_GEMM_DEEP_WGS")) : 640;      // 0: never
+    return workgroups <= limit;
+}
+
+template <int TM, int TN, class AL, class EP, int DEEP = 0>
 __global__ void __launch_bounds__(256)
 gemm_h3_kernel(const AL al, const _Float16* __restrict__ Bh, const _Float16* __restrict__ Bl, const int M, const int N,
                const int Kp, const int m_tiles, const int n_tiles, const int kt_per_split, const EP ep)
@@ -96,8 +103,14 @@ gemm_h3_kernel(const AL al, const _Float16* __restrict__ Bh, const _Float16* __r
         bhp[i] = Bh + o; blp[i] = Bl + o;
     }
 
-    typename AL::Raw ra[AI];
-    h16x8 rbh[BI], rbl[BI];
+    // Global loads run NS - 1 k-tiles ahead of their use, in NS register sets.  DEEP (NS = 4) is for launches of at most ~2
+    // workgroups per CU: a k-tile is 12 MFMAs = 0.2 us of work per wave and such a workgroup's whole life is its k-loop, which one
+    // tile ahead ran at the latency of a global load per k-tile (~1 us; 27.7 -> 24.5 us for the 432-workgroup input-gradient GEMMs
+    // of the training step).  With more workgroups per CU the other workgroups hide that latency and the 48 extra registers
+    // only cost occupancy (1208 workgroups: 12.8 -> 14.1 us), hence the launcher's choice (gemm_h3_deep).
+    constexpr int NS = (DEEP && sizeof(typename AL::Raw) <= 20) ? 4 : 2;
+    typename AL::Raw ra[NS][AI];
+    h16x8 rbh[NS][BI], rbl[NS][BI];
     f32x16 acc0[TM][TN], acc1[TM][TN];
 #pragma unroll
     for (int i = 0; i < TM; ++i)
@@ -109,22 +122,24 @@ gemm_h3_kernel(const AL al, const _Float16* __restrict__ Bh, const _Float16* __r
     const int kt_lo = blockIdx.y * kt_per_split;
     const int KT = min(Kp / GEMM_BK, kt_lo + kt_per_split);
 
-    auto issue = [&](int kt) {
+    auto issue = [&](auto set, int kt) {                // kt is clamped by the caller: a tile past the end re-reads the last one
+        constexpr int Q = decltype(set)::value;
         const int k0 = kt * GEMM_BK;
 #pragma unroll
-        for (int i = 0; i < AI; ++i) ra[i] = al.issue(actx[i], k0 + acol);
+        for (int i = 0; i < AI; ++i) ra[Q][i] = al.issue(actx[i], k0 + acol);
 #pragma unroll
         for (int i = 0; i < BI; ++i) {
-            rbh[i] = *reinterpret_cast<const h16x8*>(bhp[i] + k0);
-            rbl[i] = *reinterpret_cast<const h16x8*>(blp[i] + k0);
+            rbh[Q][i] = *reinterpret_cast<const h16x8*>(bhp[i] + k0);
+            rbl[Q][i] = *reinterpret_cast<const h16x8*>(blp[i] + k0);
         }
     };
-    auto stage = [&](int kt, int buf) {
+    auto stage = [&](auto set, int kt, int buf) {
+        constexpr int Q = decltype(set)::value;
         _Float16* S = hsm + buf * STAGE;
         const int k0 = kt * GEMM_BK;
 #pragma unroll
         for (int i = 0; i < AI; ++i) {
-            const f32x4 x = al.finish(actx[i], k0 + acol, ra[i]);
+            const f32x4 x = al.finish(actx[i], k0 + acol, ra[Q][i]);
             h16x4 hi, lo;
             h3_split(x, hi, lo);
             *reinterpret_cast<h16x4*>(&S[(arow + 32 * i) * LD + acol]) = hi;
@@ -132,20 +147,26 @@ gemm_h3_kernel(const AL al, const _Float16* __restrict__ Bh, const _Float16* __r
         }
 #pragma unroll
         for (int i = 0; i < BI; ++i) {
-            *reinterpret_cast<h16x8*>(&S[2 * BM * LD + (brow + 64 * i) * LD + bcol]) = rbh[i];
-            *reinterpret_cast<h16x8*>(&S[2 * BM * LD + BN * LD + (brow + 64 * i) * LD + bcol]) = rbl[i];
+            *reinterpret_cast<h16x8*>(&S[2 * BM * LD + (brow + 64 * i) * LD + bcol]) = rbh[Q][i];
+            *reinterpret_cast<h16x8*>(&S[2 * BM * LD + BN * LD + (brow + 64 * i) * LD + bcol]) = rbl[Q][i];
         }
     };
+    auto set_c = [](auto q) { return std::integral_constant<int, decltype(q)::value % NS>{}; };
 
-    issue(kt_lo);
-    stage(kt_lo, kt_lo & 1);
+    // tiles kt_lo .. kt_lo + NS - 2 go out first (tile t lives in set t % NS), the first one is staged
+    issue(std::integral_constant<int, 0>{}, kt_lo);
+    if constexpr (NS > 2) {
+        issue(std::integral_constant<int, 1>{}, min(kt_lo + 1, KT - 1));
+        issue(std::integral_constant<int, 2>{}, min(kt_lo + 2, KT - 1));
+    }
+    stage(std::integral_constant<int, 0>{}, kt_lo, kt_lo & 1);
     __syncthreads();
 
     const int fr = lane & 31, fk = (lane >> 5) * 8;
-    for (int kt = kt_lo; kt < KT; ++kt) {
+    // one k-tile: tile kt (set Q) is in LDS buffer kt & 1; the set of tile kt - 1 is free and receives tile kt + NS - 1
+    auto body = [&](auto q, int kt) {
         const int cur = kt & 1;
-        const int ktn = min(kt + 1, KT - 1);
-        issue(ktn);
+        issue(set_c(std::integral_constant<int, decltype(q)::value + NS - 1>{}), min(kt + NS - 1, KT - 1));
         const _Float16* S = hsm + cur * STAGE;
         const _Float16* Ahp = S + (wm * (BM / 2) + fr) * LD + fk;
         const _Float16* Alp = Ahp + BM * LD;
@@ -173,8 +194,16 @@ gemm_h3_kernel(const AL al, const _Float16* __restrict__ Bh, const _Float16* __r
                     acc1[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(alo[i], bh[j], acc1[i][j], 0, 0, 0);
                 }
         }
-        stage(ktn, cur ^ 1);
+        stage(set_c(std::integral_constant<int, decltype(q)::value + 1>{}), min(kt + 1, KT - 1), cur ^ 1);
         __syncthreads();
+    };
+    for (int kt = kt_lo; kt < KT; kt += NS) {
+        body(std::integral_constant<int, 0>{}, kt);
+        if (kt + 1 < KT) body(std::integral_constant<int, 1>{}, kt + 1);
+        if constexpr (NS > 2) {
+            if (kt + 2 < KT) body(std::integral_constant<int, 2>{}, kt + 2);
+            if (kt + 3 < KT) body(std::integral_constant<int, 3>{}, kt + 3);
+        }
     }
 
     const int crow0 = bm0 + wm * (BM / 2) + 4 * (lane >> 5);

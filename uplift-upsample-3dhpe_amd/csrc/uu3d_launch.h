@@ -34,10 +34,12 @@ int launch_gemm(const AL& al, const float* Bt, int M, int N, int K, const EP& ep
     if (Bh != nullptr && Bl != nullptr) {
         constexpr size_t ldsh = gemm_h3_lds_bytes(64, 64);
         if (slices == 1) {
-            hipLaunchKernelGGL((gemm_h3_kernel<1, 1, AL, EP>), dim3(grid, 1), dim3(256), ldsh, stream, al, Bh, Bl, M, N, Kp, mt, nt, KT, ep);
+            if (gemm_h3_deep(grid)) hipLaunchKernelGGL((gemm_h3_kernel<1, 1, AL, EP, 1>), dim3(grid, 1), dim3(256), ldsh, stream, al, Bh, Bl, M, N, Kp, mt, nt, KT, ep);
+            else hipLaunchKernelGGL((gemm_h3_kernel<1, 1, AL, EP>), dim3(grid, 1), dim3(256), ldsh, stream, al, Bh, Bl, M, N, Kp, mt, nt, KT, ep);
         } else {
             EpSlab es{slab, ldslab, (size_t)M * ldslab};
-            hipLaunchKernelGGL((gemm_h3_kernel<1, 1, AL, EpSlab>), dim3(grid, slices), dim3(256), ldsh, stream, al, Bh, Bl, M, N, Kp, mt, nt, kps, es);
+            if (gemm_h3_deep(grid * slices)) hipLaunchKernelGGL((gemm_h3_kernel<1, 1, AL, EpSlab, 1>), dim3(grid, slices), dim3(256), ldsh, stream, al, Bh, Bl, M, N, Kp, mt, nt, kps, es);
+            else hipLaunchKernelGGL((gemm_h3_kernel<1, 1, AL, EpSlab>), dim3(grid, slices), dim3(256), ldsh, stream, al, Bh, Bl, M, N, Kp, mt, nt, kps, es);
             hipLaunchKernelGGL(splitk_reduce_kernel<EP>, dim3((M * N + 255) / 256), dim3(256), 0, stream, slab, slices,
                                (size_t)M * ldslab, M, N, ldslab, ep);
         }
