@@ -38,7 +38,7 @@ def cpu_baseline(cfg, arch, weights, x, m, budget_s=60.0):
     ncpu = os.cpu_count() or 1
     ns = min(16, x.shape[0])
     sweep, best, best_t = {}, None, None
-    for t in [c for c in (4, 8, 16, 32, 64, 128, 256) if c <= ncpu]:
+    for t in ([c for c in (4, 8, 16, 32, 64, 128, 256) if c <= ncpu] or [ncpu]):      # a host with < 4 threads: just all of them
         torch.set_num_threads(t)
         O.forward(hp, weights, x[:ns], m[:ns], torch.float32)                  # thread-pool start / page in
         t0 = time.time(); O.forward(hp, weights, x[:ns], m[:ns], torch.float32); dt = time.time() - t0
@@ -49,11 +49,18 @@ def cpu_baseline(cfg, arch, weights, x, m, budget_s=60.0):
             break
     torch.set_num_threads(best)
     warm, times = 0, []
-    while warm < 3 and time.time() - t_start < budget_s * 0.4:
+    while warm < 3 and time.time() - t_start < budget_s * 0.4 and best_t * x.shape[0] / ns < budget_s * 0.2:
         O.forward(hp, weights, x, m, torch.float32); warm += 1
+    # the sample shrinks (whole sequences) when one forward of the bench batch would not fit the budget twice: bounded CPU time
+    nb = x.shape[0]
+    est = best_t * nb / ns
+    if 2 * est > budget_s:
+        nb = max(ns, int(nb * budget_s / (2 * est)))
+    xs, ms_ = x[:nb], m[:nb]
     while len(times) < 10 and (len(times) < 2 or time.time() - t_start < budget_s):
-        t0 = time.time(); O.forward(hp, weights, x, m, torch.float32); times.append(time.time() - t0)
+        t0 = time.time(); O.forward(hp, weights, xs, ms_, torch.float32); times.append(time.time() - t0)
     med = statistics.median(times)
+    x = xs
     return {"value": round(x.shape[0] / med, 2), "unit": "pose-sequences/s", "cores": int(best), "kind": "port",
             "host_cores": int(ncpu), "thread_sweep_s_per_16_sequences": {str(k): round(v, 3) for k, v in sweep.items()},
             "sample": f"median of {len(times)} forwards of the bench batch ({x.shape[0]} sequences) after {warm} warm-ups, "

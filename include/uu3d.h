@@ -142,6 +142,14 @@ int uu3d_forward(uu3d_model* model, const float* kp2d_dev, const uint8_t* stride
 int uu3d_mpjpe(const float* pred_dev, const float* gt_dev, int32_t batch, int32_t num_keypoints,
                int32_t root_index, double* out_dev, void* stream);
 
+/* Diagnostics of the XCD-cooperative tail kernel (csrc/uu3d_tail.h; replaces the launch chain of the reference's last
+ * StridedTransformerBlock + strided_temporal_fc, common/net/uplift_upsample_transformer.py:93-160,414-416) after the last
+ * uu3d_forward on this workspace: synchronises the device, then returns the kernel's error word (bit 0: a bounded spin gave
+ * up, bit 1: a workgroup observed data stamped by a foreign XCC id -- both must be 0), which XCC id (+1) worked on each
+ * sequence group (0: the kernel did not run / the group was empty) and how many workgroups reported each XCC id. */
+int uu3d_tail_status(const uu3d_model* model, const void* workspace, int32_t batch, uint32_t* out_err,
+                     uint32_t out_owner[8], uint32_t out_census[8]);
+
 /*
  * "Next" row 3 of the scope table: the window / stride-mask generator as a gather over a RESIDENT pose table.
  * Replaces the per-sample slicing, padding, stride mask and flip of H36mSequenceGenerator
@@ -225,6 +233,20 @@ int uu3d_mpjpe_loss(const float* pred_full_dev, const float* pred_central_dev, c
 int uu3d_adamw_update(float* var_dev, float* m_dev, float* v_dev, float* vhat_dev, const float* grad_dev, int64_t n,
                       float lr, float wd, float beta1, float beta2, float epsilon, int64_t step,
                       void* stream);
+/* The same update, skipped ON THE DEVICE (weights and moments untouched) when *skip_flag_dev != 0 -- no host synchronisation.
+ * skip_flag_dev = uu3d_train_nonfinite_flag(model): uu3d_train_forward_backward clears it and its loss-scaled backward pass
+ * (f16x3 gradient GEMMs, train.py:477,498 replaced) raises it when a finished gradient range holds a non-finite value; NULL =
+ * uu3d_adamw_update.  A skipped step keeps TF's semantics of "no update" only approximately: the host-side iteration counter
+ * (bias correction, schedules) still advances. */
+int uu3d_adamw_update_guarded(float* var_dev, float* m_dev, float* v_dev, float* vhat_dev, const float* grad_dev, int64_t n,
+                              float lr, float wd, float beta1, float beta2, float epsilon, int64_t step,
+                              const uint32_t* skip_flag_dev, void* stream);
+/* Device address of the model's non-finite-gradient word (valid after uu3d_train_init, until the next uu3d_train_init /
+ * uu3d_destroy); NULL without training state. */
+uint32_t* uu3d_train_nonfinite_flag(const uu3d_model* model);
+/* Host-side read of that word (synchronises the device): *out = 1 when the last backward pass flagged non-finite gradients. */
+int uu3d_train_nonfinite(uu3d_model* model, int32_t* out);
+
 
 /* T4 -- replaces the EMA update of train_step (train.py:502-504): ema -= (1 - decay) * (ema - w). */
 int uu3d_ema_update(float* ema_dev, const float* w_dev, int64_t n, float decay, void* stream);

@@ -199,7 +199,7 @@ def test_optional_kernel_paths_agree(env, monkeypatch):
     """The opt-out switches kept for A/B measurements at the full h36m_351 batch, where every one of them
     changes the kernels that run: same results as the product path to rounding.  (The round-1 experiments that measured
     neutral or slower -- LNFUSE, PANEL_ACC, LNFOLD, LN_PLANES, ATTN_PIPE, S2T_PLANES, G_TILE22 -- left the library for
-    tools/r01_variants/.)"""
+    the git history (round 1).)"""
     cfg = util.load_config("h36m_351")
     arch = pkg.arch_from_config(cfg)
     w = pkg.init_weights(arch, seed=5, perturb=0.1)

@@ -1,0 +1,85 @@
+"""GPU: the XCD-cooperative tail kernel (csrc/uu3d_tail.h: the last StridedTransformerBlock + strided_temporal_fc of
+common/net/uplift_upsample_transformer.py:93-160,414-416 as one launch) against the CPU oracle, against the launch chain it
+replaces (UU3D_NO_TAIL=1), and its own protocol diagnostics: no bounded spin may give up and no workgroup may ever observe
+data stamped by a foreign XCC id."""
+import numpy as np
+import pytest
+
+import uplift_upsample_3dhpe_amd as pkg
+from tests import util
+
+torch = pytest.importorskip("torch")
+pytestmark = pytest.mark.gpu
+
+
+def _model(cfg, w):
+    return pkg.build_uplift_upsample_transformer(cfg, weights=w, precision="f16x3")
+
+
+def _forward(model, x, m):
+    xm = x * m[:, :, None, None].astype(np.float32)
+    full, central = model([torch.from_numpy(xm).cuda(), torch.from_numpy(m).cuda()], training=False)
+    torch.cuda.synchronize()
+    return full.cpu().numpy(), central.cpu().numpy(), xm
+
+
+# ragged groups (batch not a multiple of 8), a single sequence, fewer sequences than groups, the bench batches
+@pytest.mark.parametrize("cfgname,batch", [("h36m_351", 1), ("h36m_351", 3), ("h36m_351", 8), ("h36m_351", 21), ("h36m_351", 128),
+                                           ("h36m_81", 5), ("h36m_81", 19), ("h36m_81", 256)])
+def test_tail_matches_oracle_and_chain(cfgname, batch, monkeypatch):
+    from oracle import uplift_oracle as O
+    cfg = util.load_config(cfgname)
+    arch = pkg.arch_from_config(cfg)
+    w = pkg.init_weights(arch, seed=5, perturb=0.1)
+    x, m = util.synthetic_batch(cfg, batch=batch, seed=batch)
+    model = _model(cfg, w)
+    full, central, xm = _forward(model, x, m)
+    st = model.tail_status(batch)
+    print(cfgname, batch, st)
+    assert st["err"] == 0, f"tail kernel protocol error word {st['err']:#x} (1: spin timeout, 2: foreign XCC id)"
+    groups = min(8, batch)                       # ceil(B / ceil(B / 8)) non-empty groups, at most 8
+    per = -(-batch // 8)
+    groups = -(-batch // per)
+    assert all(o != 0 for o in st["owner"][:groups]), "a non-empty sequence group was never claimed: the tail kernel did not run"
+    assert all(o == 0 for o in st["owner"][groups:])
+    assert sum(st["census"]) > 0
+    # every owner word names an XCD that really had workgroups
+    for o in st["owner"][:groups]:
+        assert st["census"][o - 1] > 0
+    monkeypatch.setenv("UU3D_NO_TAIL", "1")
+    chain = _model(cfg, w)
+    monkeypatch.delenv("UU3D_NO_TAIL")
+    full_c, central_c, _ = _forward(chain, x, m)
+    assert all(o == 0 for o in chain.tail_status(batch)["owner"]), "UU3D_NO_TAIL=1 still ran the tail kernel"
+    n_oracle = min(batch, 12)                    # the oracle on the first sequences (sequences are independent)
+    f32, c32 = O.forward(util.hp_from_arch(arch), w, xm[:n_oracle], m[:n_oracle], torch.float32)
+    err = np.abs(central[:n_oracle] - c32).max()
+    err_c = np.abs(central_c[:n_oracle] - c32).max()
+    dev = np.abs(central - central_c).max()
+    print(f"{cfgname} batch {batch}: tail vs oracle {err:.3e}, chain vs oracle {err_c:.3e}, tail vs chain {dev:.3e}")
+    assert np.isfinite(central).all()
+    assert err <= util.TOL_MAX_ABS and err_c <= util.TOL_MAX_ABS
+    assert dev <= 5e-5
+    assert np.array_equal(full, full_c)          # head1 / the temporal stack are untouched by the switch
+    # run-to-run bitwise: ticket order and XCD placement must not matter (every sum has a fixed order)
+    for _ in range(5):
+        _, central2, _ = _forward(model, x, m)
+        assert np.array_equal(central, central2)
+        assert model.tail_status(batch)["err"] == 0
+
+
+def test_tail_under_concurrent_streams():
+    """Two forwards on two streams at once (concurrent_halves): both tail kernels are in flight together, each workgroup
+    still only joins groups of its own XCD; results equal the single-chain run bit for bit."""
+    cfg = util.load_config("h36m_351")
+    arch = pkg.arch_from_config(cfg)
+    w = pkg.init_weights(arch, seed=7, perturb=0.1)
+    x, m = util.synthetic_batch(cfg, batch=128, seed=11)
+    one = pkg.build_uplift_upsample_transformer(cfg, weights=w, precision="f16x3")
+    two = pkg.build_uplift_upsample_transformer(cfg, weights=w, precision="f16x3", concurrent_halves=True)
+    _, c1, _ = _forward(one, x, m)
+    for _ in range(10):
+        _, c2, _ = _forward(two, x, m)
+        assert two.tail_status(64, 0)["err"] == 0 and two.tail_status(64, 1)["err"] == 0
+        # the halves see groups of 8 sequences instead of 16: same arithmetic per sequence, same bits
+        assert np.abs(c1 - c2).max() <= 2e-5

@@ -303,3 +303,51 @@ def test_fused_and_unfused_spatial_training_forward_agree(monkeypatch, B, alt):
             worst = (name, e)
     print(f"fused vs unfused spatial training path: worst gradient deviation {worst[1]:.2e} of scale ({worst[0]})")
     assert worst[1] <= 1e-4, worst
+
+
+def test_ema_export_survives_the_validation_forward():
+    """train.py:398-401 validates on ema_model.  Trainer.export_to_model(use_ema=True) must leave the EMA weights in the model for the
+    inference call that follows (a dirty flag made model(...) re-export the live weights over them), and the next
+    train step must make the model follow the live weights again."""
+    from uplift_upsample_3dhpe_amd.trainer import Trainer
+    cfg, arch, w, model, x, m, gt = _setup("h36m_81", 2, seed=9, batch_norm=2)
+    assert cfg.EMA_ENABLED                                               # h36m_81 ships with EMA on
+    cfg.EMA_DECAY = 0.5                                                  # far from 1: EMA and live weights clearly differ after two steps
+    tr = Trainer(model, cfg)
+    T_ = lambda a: torch.from_numpy(a).cuda()
+    for _ in range(2):
+        tr.train_step(T_(x), T_(gt), T_(m), drop_path_uniform=None)
+    ema, live = tr.ema.cpu().numpy(), tr.params.cpu().numpy()
+    assert not np.array_equal(ema, live)
+    tr.export_to_model(use_ema=True)
+    xm = T_(x * m[:, :, None, None])
+    full, central = model([xm, T_(m)], training=False)                   # must NOT resync from the trainer
+    got = np.concatenate([a.ravel() for a in model.get_weights()])
+    assert np.array_equal(got, ema) and not np.array_equal(got, live)
+    names = model.weight_names
+    o, wd = 0, {}
+    for n, s in model._spec:
+        k = int(np.prod(s)); wd[n] = ema[o:o + k].reshape(s); o += k
+    fresh = pkg.build_uplift_upsample_transformer(cfg, weights=wd)
+    f2, c2 = fresh([xm, T_(m)], training=False)
+    assert torch.equal(full, f2) and torch.equal(central, c2)
+    # the next step: live weights again, without an explicit export
+    tr.train_step(T_(x), T_(gt), T_(m), drop_path_uniform=None)
+    got = np.concatenate([a.ravel() for a in model.get_weights()])
+    assert np.array_equal(got, tr.params.cpu().numpy())
+    assert len(names) == len(model._spec)
+
+
+def test_two_backward_passes_without_an_optimizer_step():
+    """forward_backward twice (gradient inspection / accumulation), then apply_gradients: the bucket bookkeeping of the first pass
+    must not leak into the second ("gradient ranges do not tile the buffer")."""
+    from uplift_upsample_3dhpe_amd.trainer import Trainer
+    cfg, arch, w, model, x, m, gt = _setup("h36m_81", 2, seed=3, batch_norm=2)
+    tr = Trainer(model, cfg)
+    T_ = lambda a: torch.from_numpy(a).cuda()
+    tr.forward_backward(T_(x), T_(gt), T_(m), drop_path_uniform=None)
+    g1 = tr.grads.clone()
+    tr.forward_backward(T_(x), T_(gt), T_(m), drop_path_uniform=None)
+    assert torch.equal(g1, tr.grads)
+    tr.apply_gradients()
+    assert tr.global_step == 1

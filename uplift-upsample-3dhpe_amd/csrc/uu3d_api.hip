@@ -32,6 +32,7 @@
 #include "uu3d_gemm_panel.h"
 #include "uu3d_gemm_wt.h"
 #include "uu3d_mlp_fused.h"
+#include "uu3d_tail.h"
 #include "uu3d_attn.h"
 #include "uu3d_attn_h3.h"
 #include "uu3d_spatial.h"
@@ -75,6 +76,7 @@ struct BlockDev {
     // fragment-ordered f16 planes of wqkv / w1 for the row-panel GEMM (uu3d_gemm_panel.h); offsets in harena, 0 = none
     size_t wqkv_pf = 0, w1_pf = 0;
     size_t w2_mf = 0;                  // fc2 fragments of the fused MLP kernel (uu3d_mlp_fused.h, temporal blocks), offset in harena, 0 = none
+    size_t wp_pf = 0, wc_pf = 0;       // strided blocks: fragment-ordered projection / strided-convolution operands (uu3d_tail.h), 0 = none
 };
 
 struct ProfRec {
@@ -101,6 +103,9 @@ struct uu3d_model {
     bool attn_f32 = false;         // UU3D_ATTN_F32=1: sequences of 49-128 tokens stay on the exact-f32 attention kernels (A/B measurements, tests)
     bool attn_wg = false;          // UU3D_ATTN_WG=1: attention with one workgroup per (sequence, head) (attn_f32_kernel) instead of one wave per item (A/B measurements, tests)
     bool no_panel = false;         // UU3D_NO_PANEL=1: LayerNorm-fed GEMMs stay on the tiled kernels (A/B measurements, tests)
+    bool no_tail = false;          // UU3D_NO_TAIL=1: the last strided block + head2 stay a chain of launches instead of strided_tail_kernel (A/B measurements, tests)
+    size_t h2_pf = 0;              // fragment-ordered head2 operand (uu3d_tail.h), offset in harena, 0 = none
+    int num_cus = 256;
     bool no_planes = false;        // UU3D_NO_PLANES=1: keep the on-the-fly split GEMMs in f16x3 mode (A/B measurements, tests)
     _Float16* harena = nullptr;    // f16 hi/lo planes of every GEMM operand (f16x3 mode)
     size_t harena_halfs = 0;
@@ -312,6 +317,8 @@ int uu3d_create(const uu3d_config* c, int device, uu3d_model** out) {
     { const char* e = getenv("UU3D_NO_WT"); m->no_wt = (e != nullptr && e[0] == '1'); }
     { const char* e = getenv("UU3D_ATTN_F32"); m->attn_f32 = (e != nullptr && e[0] == '1'); }
     { const char* e = getenv("UU3D_NO_PANEL"); m->no_panel = (e != nullptr && e[0] == '1'); }
+    { const char* e = getenv("UU3D_NO_TAIL"); m->no_tail = (e != nullptr && e[0] == '1'); }
+    { hipDeviceProp_t pr; if (hipGetDeviceProperties(&pr, device) == hipSuccess && pr.multiProcessorCount > 0) m->num_cus = pr.multiProcessorCount; }
     *out = m;
     return UU3D_OK;
 }
@@ -576,6 +583,11 @@ int uu3d_commit_weights(uu3d_model* m, void* stream_) {
                     m->mlpf_off[o.w2] = at;
                 }
             for (auto& o : soff) { add_panel(o.wqkv, 3 * dt); add_panel(o.w1, ht); }
+            // the cooperative tail kernel (uu3d_tail.h) reads every operand of the last strided block and of head2 in fragment order
+            if (!soff.empty() && ht == 2 * dt) {
+                add_panel(soff.back().wp, dt); add_panel(soff.back().w2, dt, 3 * ht, round_up(3 * ht, 32));
+                add_panel(o_h2, round_up(3 * J, 32));
+            }
         }
         if (m->harena_halfs < hb.size()) {
             if (m->harena) HIPCHK(m, hipFree(m->harena));
@@ -601,6 +613,8 @@ int uu3d_commit_weights(uu3d_model* m, void* stream_) {
         { const auto it = m->panel_off.find(o.wqkv); b.wqkv_pf = (it != m->panel_off.end()) ? it->second : 0; }
         { const auto it = m->panel_off.find(o.w1); b.w1_pf = (it != m->panel_off.end()) ? it->second : 0; }
         { const auto it = m->mlpf_off.find(o.w2); b.w2_mf = (!strided && it != m->mlpf_off.end()) ? it->second : 0; }
+        { const auto it = m->panel_off.find(o.wp); b.wp_pf = (it != m->panel_off.end()) ? it->second : 0; }
+        { const auto it = m->panel_off.find(o.w2); b.wc_pf = (strided && it != m->panel_off.end()) ? it->second : 0; }
         return b;
     };
     m->tblocks.clear(); m->sblocks.clear();
@@ -608,6 +622,7 @@ int uu3d_commit_weights(uu3d_model* m, void* stream_) {
     for (auto& o : soff) m->sblocks.push_back(view(o, true));
     m->h1_wt = has_h1 ? A + o_h1 : nullptr; m->h1_b = has_h1 ? A + o_h1b : nullptr;
     m->h2_wt = A + o_h2; m->h2_b = A + o_h2b;
+    { const auto it = m->panel_off.find(o_h2); m->h2_pf = (it != m->panel_off.end()) ? it->second : 0; }
     m->committed = true;
     return UU3D_OK;
 }
@@ -617,6 +632,7 @@ namespace {
 struct Workspace {
     float *S, *X, *QKV, *O, *Hb, *XA, *XB, *slab, *mslab;
     int* frame_list;
+    TailCtl* tail_ctl;
     float2* stats;
     size_t slab_floats;
     size_t bytes;
@@ -640,11 +656,12 @@ Workspace carve(const uu3d_model* m, int B, char* base) {
     const size_t oSl = take(w.slab_floats * 4);
     const size_t oFl = take((rows + 1) * sizeof(int));
     const size_t oMs = take((size_t)MLPF_SLICES * rows * c.d_temporal * 4);      // fused MLP: fc2 partial sums of the three hidden slices
+    const size_t oTc = take(sizeof(TailCtl));                                   // strided_tail_kernel: tickets / done counters / XCC stamps
     w.bytes = off;
     if (base) {
         w.S = (float*)(base + oS); w.X = (float*)(base + oX); w.QKV = (float*)(base + oQ);
         w.O = (float*)(base + oO); w.Hb = (float*)(base + oH); w.XA = (float*)(base + oA);
-        w.XB = (float*)(base + oB); w.stats = (float2*)(base + oT); w.slab = (float*)(base + oSl); w.frame_list = (int*)(base + oFl); w.mslab = (float*)(base + oMs);
+        w.XB = (float*)(base + oB); w.stats = (float2*)(base + oT); w.slab = (float*)(base + oSl); w.frame_list = (int*)(base + oFl); w.mslab = (float*)(base + oMs); w.tail_ctl = (TailCtl*)(base + oTc);
     }
     return w;
 }
@@ -1137,9 +1154,34 @@ int uu3d_forward(uu3d_model* m, const float* kp2d, const uint8_t* mask, int32_t 
     }
     // 5. strided blocks
     float* xa = w.XA; float* xb = w.XB;
+    bool tail_done = false;
     for (int i = 0; i < c.num_strided; ++i) {
         const BlockDev& b = m->sblocks[i];
         const int Li = m->L[i], Lo = m->L[i + 1], Mi = B * Li, Mo = B * Lo;
+        // the last strided block + head2 as ONE launch of XCD-cooperative workgroups (uu3d_tail.h) when the block is small: few
+        // rows make every launch of the chain a bare memory round trip (h36m_351 at batch 128: 9 launches, 76 us)
+        if (i >= 1 && i + 1 == c.num_strided && planes && !m->no_tail && dt == 384 && ht == 768 && Li <= 32 && Mi <= 1024 &&
+            b.wqkv_pf != 0 && b.w1_pf != 0 && b.wp_pf != 0 && b.wc_pf != 0 && m->h2_pf != 0) {
+            TailParams tp{};
+            tp.B = B; tp.G = (B + TAIL_GROUPS - 1) / TAIL_GROUPS;
+            tp.L_in = Li; tp.L_out = Lo; tp.stride = c.strides[i]; tp.pad_left = c.pad_left[i];
+            tp.res_lo = (c.strides[i] > 1 && c.pad_left[i] == 0) ? 1 : 0;
+            tp.n_out = 3 * J;
+            tp.x = xa; tp.qkv = w.QKV; tp.o = w.O; tp.hb = w.Hb; tp.part = w.slab; tp.out = central_out;
+            tp.ln1_g = b.ln1_g; tp.ln1_b = b.ln1_b; tp.bqkv = b.bqkv; tp.bp = b.bp; tp.ln2_g = b.ln2_g; tp.ln2_b = b.ln2_b;
+            tp.b1 = b.b1; tp.b2 = b.b2; tp.bh = m->h2_b;
+            tp.wqkv_f = m->harena + b.wqkv_pf; tp.wp_f = m->harena + b.wp_pf; tp.w1_f = m->harena + b.w1_pf;
+            tp.wc_f = m->harena + b.wc_pf; tp.wh_f = m->harena + m->h2_pf;
+            tp.ctl = w.tail_ctl;
+            const double fl = 2.0 * Mi * (double)dt * (3 * dt + dt + ht) + 4.0 * B * (double)c.num_heads * Li * Li * kDH + 2.0 * Mo * (double)dt * 3 * ht + 2.0 * Mo * (double)dt * 3 * J;
+            snprintf(nm, sizeof nm, "s%d.tail_head2", i + 1);
+            Lh.begin(nm, "strided_tail", fl, 4.0 * ((double)dt * (3 * dt + dt + ht + 3 * ht + 3 * J) + (double)Mi * dt));
+            (void)hipMemsetAsync(w.tail_ctl, 0, sizeof(TailCtl), Lh.stream);
+            hipLaunchKernelGGL(strided_tail_kernel_t<false>, dim3(m->num_cus), dim3(256), 0, Lh.stream, tp);
+            Lh.end();
+            tail_done = true;
+            break;
+        }
         // MaxPool1D(pool 1, stride s) on the trimmed sequence; stride 1 keeps x untrimmed (u_u_t.py:138-154)
         const int lo = (c.strides[i] > 1 && c.pad_left[i] == 0) ? 1 : 0;
         const EpConvResidual ep_conv{xb, b.b2, dt, xa, Li, Lo, c.strides[i], lo,
@@ -1161,7 +1203,7 @@ int uu3d_forward(uu3d_model* m, const float* kp2d, const uint8_t* mask, int32_t 
         if (i == 0) xb = w.XA;   // XA (B*N rows) is free again; XB only needs B*L_1 rows
     }
     // 6. head2
-    {
+    if (!tail_done) {
         ALoadPlain al{xa, dt, B, dt}; EpBias ep{central_out, m->h2_b, 3 * J};
         Lh.gemm("head2", al, m->h2_wt, B, 3 * J, dt, ep);
     }
@@ -1173,6 +1215,16 @@ int uu3d_mpjpe(const float* pred, const float* gt, int32_t B, int32_t J, int32_t
     if (!pred || !gt || !out || B < 1 || J < 1 || root < 0 || root >= J) return UU3D_ERR_INVALID_ARGUMENT;
     hipLaunchKernelGGL(mpjpe_kernel, dim3((B * J + 255) / 256), dim3(256), 0, (hipStream_t)stream, pred, gt, B, J, root, out);
     return hipGetLastError() == hipSuccess ? UU3D_OK : UU3D_ERR_HIP;
+}
+
+int uu3d_tail_status(const uu3d_model* m, const void* workspace, int32_t batch, uint32_t* err, uint32_t owner[8], uint32_t census[8]) {
+    if (!m || !workspace || batch < 1) return UU3D_ERR_INVALID_ARGUMENT;
+    const Workspace w = carve(m, batch, (char*)const_cast<void*>(workspace));
+    TailCtl h;
+    if (hipDeviceSynchronize() != hipSuccess || hipMemcpy(&h, w.tail_ctl, sizeof h, hipMemcpyDeviceToHost) != hipSuccess) return UU3D_ERR_HIP;
+    if (err) *err = h.err;
+    for (int i = 0; i < 8; ++i) { if (owner) owner[i] = h.owner[i]; if (census) census[i] = h.census[i]; }
+    return UU3D_OK;
 }
 
 int uu3d_gather_windows(const float* poses, const int64_t* video_start, const int32_t* video_len, const uu3d_window* windows,
@@ -1245,6 +1297,11 @@ int uu3d_mpjpe_loss(const float* pred_full, const float* pred_central, const flo
 
 int uu3d_adamw_update(float* var, float* m, float* v, float* vhat, const float* grad, int64_t n, float lr, float wd, float beta1,
                       float beta2, float epsilon, int64_t step, void* stream) {
+    return uu3d_adamw_update_guarded(var, m, v, vhat, grad, n, lr, wd, beta1, beta2, epsilon, step, nullptr, stream);
+}
+
+int uu3d_adamw_update_guarded(float* var, float* m, float* v, float* vhat, const float* grad, int64_t n, float lr, float wd, float beta1,
+                              float beta2, float epsilon, int64_t step, const uint32_t* skip, void* stream) {
     if (!var || !m || !v || !grad || n < 1 || step < 1) return UU3D_ERR_INVALID_ARGUMENT;
     if ((((uintptr_t)var | (uintptr_t)m | (uintptr_t)v | (uintptr_t)vhat | (uintptr_t)grad) & 15) != 0) return UU3D_ERR_INVALID_ARGUMENT;
     // float32 like the TF kernel: alpha = lr * sqrt(1 - beta2^t) / (1 - beta1^t)
@@ -1254,9 +1311,9 @@ int uu3d_adamw_update(float* var, float* m, float* v, float* vhat, const float* 
     const long long n4 = n >> 2;
     const int grid = (int)std::min<long long>(std::max<long long>((n4 + 255) / 256, 1), 256 * 32);
     if (vhat) hipLaunchKernelGGL(adamw_kernel<true>, dim3(grid), dim3(256), 0, (hipStream_t)stream, var, m, v, vhat, grad, (long long)n, wd, alpha,
-                                 1.0f - beta1, 1.0f - beta2, epsilon);
+                                 1.0f - beta1, 1.0f - beta2, epsilon, skip);
     else hipLaunchKernelGGL(adamw_kernel<false>, dim3(grid), dim3(256), 0, (hipStream_t)stream, var, m, v, vhat, grad, (long long)n, wd, alpha,
-                            1.0f - beta1, 1.0f - beta2, epsilon);
+                            1.0f - beta1, 1.0f - beta2, epsilon, skip);
     return hipGetLastError() == hipSuccess ? UU3D_OK : UU3D_ERR_HIP;
 }
 

@@ -89,8 +89,10 @@ __device__ __forceinline__ void adamw_one(float& var, float& m, float& v, float&
 template <bool AMS>
 static __global__ void __launch_bounds__(256)
 adamw_kernel(float* __restrict__ var, float* __restrict__ m, float* __restrict__ v, float* __restrict__ vhat, const float* __restrict__ grad,
-             const long long n, const float wd, const float alpha, const float omb1, const float omb2, const float eps)
+             const long long n, const float wd, const float alpha, const float omb1, const float omb2, const float eps,
+             const unsigned* __restrict__ skip)
 {
+    if (skip != nullptr && *skip != 0u) return;            // the backward pass flagged non-finite gradients: leave weights and moments alone
     const long long n4 = n >> 2;
     const long long stride = (long long)gridDim.x * 256;
     for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n4; i += stride) {

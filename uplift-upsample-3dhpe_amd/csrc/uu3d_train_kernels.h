@@ -337,12 +337,18 @@ struct TnLoadGelu {
     __device__ __forceinline__ f32x4 load(int r, int p) const { return finish(fetch(r, p), col(p)); }
 };
 
-// x[i] *= s over a range of the flat gradient buffer (s = 1 / loss scale, a power of two: exact)
+// x[i] *= s over a range of the flat gradient buffer (s = 1 / loss scale, a power of two: exact).  A non-finite value -- a
+// loss-scaled activation gradient beyond the f16 range makes the hi plane of the f16x3 split infinite -- raises *flag, which
+// the guarded AdamW update (uu3d_adamw_update_guarded) reads on the device: the step is then skipped, no host sync.
 static __global__ void __launch_bounds__(256)
-scale_flat_kernel(float* __restrict__ x, const long long n, const float s)
+scale_flat_kernel(float* __restrict__ x, const long long n, const float s, unsigned* __restrict__ flag)
 {
     const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
-    if (i < n) x[i] *= s;
+    if (i < n) {
+        const float v = x[i] * s;
+        x[i] = v;
+        if (flag != nullptr && !(fabsf(v) <= 3.4e38f)) atomicOr(flag, 1u);
+    }
 }
 
 }  // namespace uu3d

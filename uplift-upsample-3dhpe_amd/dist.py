@@ -77,6 +77,20 @@ class BucketedAllReduce(object):
         self.group = group
         self.works = []
         self.ranges = []
+        self.error = None
+
+    def begin(self):
+        """Start of a backward pass: wait for collectives a previous pass left outstanding (gradient inspection, a step that
+        failed halfway) and forget their ranges, so that this pass's ranges tile the buffer on their own."""
+        works, self.works, self.ranges, self.error = self.works, [], [], None
+        for w in works:
+            w.wait()
+
+    def raise_pending(self):
+        """Re-raise what ``ready`` caught inside the C callback (ctypes would only print it and go on)."""
+        if self.error is not None:
+            e, self.error = self.error, None
+            raise e
 
     def _active(self):
         import torch.distributed as dist
@@ -85,23 +99,29 @@ class BucketedAllReduce(object):
     def ready(self, first, count, stream=None):
         import torch
         import torch.distributed as dist
-        self.ranges.append((int(first), int(count)))
-        if not self._active():
-            return
-        view = self.flat[first:first + count]
-        if stream is not None and self.flat.is_cuda:
-            # the range was written on a raw HIP stream of the library: issue the collective from it, so that the
-            # process group's communication stream waits for exactly that work
-            with torch.cuda.stream(torch.cuda.ExternalStream(int(stream), device=self.flat.device)):
-                self.works.append(dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
-        else:
-            self.works.append(dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+        try:
+            if self._active():
+                view = self.flat[first:first + count]
+                if stream is not None and self.flat.is_cuda:
+                    # the range was written on a raw HIP stream of the library: issue the collective from it, so that the
+                    # process group's communication stream waits for exactly that work
+                    with torch.cuda.stream(torch.cuda.ExternalStream(int(stream), device=self.flat.device)):
+                        self.works.append(dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+                else:
+                    self.works.append(dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+            self.ranges.append((int(first), int(count)))       # only a range whose collective was issued counts as covered
+        except BaseException as e:                              # raised again by raise_pending() / wait()
+            if self.error is None:
+                self.error = e
 
     def wait(self):
         """Current stream (GPU) / host (CPU tensors) waits for every started bucket; checks the ranges tiled the buffer."""
-        for w in self.works:
+        works, ranges = self.works, self.ranges
+        self.works, self.ranges = [], []                        # cleared whatever happens below
+        self.raise_pending()
+        for w in works:
             w.wait()
-        covered = sorted(self.ranges)
+        covered = sorted(ranges)
         pos = 0
         for f, c in covered:
             if f != pos:
@@ -109,4 +129,3 @@ class BucketedAllReduce(object):
             pos = f + c
         if covered and pos != self.flat.numel():
             raise RuntimeError(f"gradient ranges end at {pos}, the buffer has {self.flat.numel()} elements")
-        self.works, self.ranges = [], []

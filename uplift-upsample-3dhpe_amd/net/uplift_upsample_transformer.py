@@ -31,12 +31,16 @@ class WeightView(object):
         self._model, self.name, self.shape = model, name, tuple(shape)
 
     def numpy(self):
-        return self._model.get_weights_dict()[self.name]
+        return self._model._get_one(self.name, self.shape)
 
     def assign(self, value):
-        d = self._model.get_weights_dict()
-        d[self.name] = np.asarray(value, np.float32).reshape(self.shape)
-        self._model.set_weights_dict(d)
+        """tf.Variable.assign: ONE uu3d_set_weight; the operand packs (and an attached Trainer's master buffer) are refreshed once,
+        by the next call that reads the weights -- a loop over model.weights (train.py:503) stays linear."""
+        self._model._assign_one(self.name, self.shape, value)
+
+    def assign_sub(self, delta):
+        """tf.Variable.assign_sub, the call the reference's EMA update makes (train.py:503: ema_w.assign_sub((1 - d) * (ema_w - w)))."""
+        self._model._assign_one(self.name, self.shape, self.numpy() - np.asarray(delta, np.float32).reshape(self.shape))
 
     def __repr__(self):
         return f"<WeightView {self.name} {self.shape}>"
@@ -96,6 +100,7 @@ class UpliftUpsampleTransformer(object):
         self._ws = {}
         self._trainer = None              # a trainer.Trainer owns the live weights once attached
         self._weights_dirty = False       # live (trainer) weights newer than the host / inference copies
+        self._holds_ema = False           # Trainer.export_to_model(use_ema=True): the model holds the EMA weights until the next step
         self._train_params = None         # master buffer of a training-mode forward without a Trainer
         self._train_ws = None
         self._seed = seed
@@ -133,6 +138,33 @@ class UpliftUpsampleTransformer(object):
         """save_weights / get_weights / inference calls see the trained weights (train.py:393,706,719 use the live model)."""
         if self._trainer is not None and self._weights_dirty:
             self._trainer.export_to_model()
+        self._flush_assigns()
+
+    # ---- single-variable access (WeightView) ----------------------------------------------------
+    def _get_one(self, name, shape):
+        if self._trainer is not None and self._weights_dirty:
+            self._trainer.export_to_model()
+        a = np.empty(shape, np.float32)
+        _capi.check(self._lib, self._lib.uu3d_get_weight(self._h, name.encode(), a.ctypes.data_as(C.c_void_p), a.size), self._h)
+        return a
+
+    def _assign_one(self, name, shape, value):
+        if self._trainer is not None and self._weights_dirty:
+            self._trainer.export_to_model()                    # the other variables keep their trained values
+        a = np.ascontiguousarray(np.asarray(value, dtype=np.float32).reshape(shape))
+        _capi.check(self._lib, self._lib.uu3d_set_weight(self._h, name.encode(), a.ctypes.data_as(C.c_void_p), a.size), self._h)
+        self._pending_assigns = True
+
+    def _flush_assigns(self):
+        """Deferred half of WeightView.assign: one commit (+ one reload of an attached Trainer's master buffer) for any number of
+        assigned variables."""
+        if getattr(self, "_pending_assigns", False):
+            self._pending_assigns = False
+            self._commit()
+            self._holds_ema = False
+            if self._trainer is not None:
+                self._trainer.reload_from_model()
+            self._train_params = None
 
     @property
     def weights(self):
@@ -151,6 +183,8 @@ class UpliftUpsampleTransformer(object):
             _capi.check(self._lib, st, self._h)
         self._commit()
         self._weights_dirty = False
+        self._pending_assigns = False
+        self._holds_ema = False
         if self._trainer is not None:       # the trainer's master buffer follows (Adam moments are kept, like tf.Variable.assign)
             self._trainer.reload_from_model()
         self._train_params = None
@@ -277,6 +311,7 @@ class UpliftUpsampleTransformer(object):
             if self._returns_full else None
         central = torch.empty((B, a.num_keypoints, 3), dtype=torch.float32, device=self.device)
         if training:
+            self._flush_assigns()
             self._training_forward(x, stride_mask, full, central)
             return full, central
         self._sync_from_trainer()
@@ -299,6 +334,18 @@ class UpliftUpsampleTransformer(object):
                       full[h:] if full is not None else None, central[h:], 1, side)
         main.wait_stream(side)
         return full, central
+
+    def tail_status(self, batch, slot=0):
+        """Diagnostics of the XCD-cooperative tail kernel after the last forward of ``batch`` sequences (uu3d_tail_status):
+        dict(err, owner[8], census[8]); err must be 0 (bit 0: spin timeout, bit 1: foreign XCC id observed)."""
+        ws = self._ws.get(slot)
+        if ws is None:
+            raise RuntimeError("no forward has run on this workspace slot")
+        err = C.c_uint32()
+        owner, census = (C.c_uint32 * 8)(), (C.c_uint32 * 8)()
+        _capi.check(self._lib, self._lib.uu3d_tail_status(self._h, C.c_void_p(ws.data_ptr()), int(batch), C.byref(err),
+                                                          C.byref(owner), C.byref(census)), self._h)
+        return dict(err=int(err.value), owner=[int(v) for v in owner], census=[int(v) for v in census])
 
     # ---- profiling -------------------------------------------------------------------------
     def set_profiling(self, enabled):

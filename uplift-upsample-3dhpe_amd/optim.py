@@ -79,18 +79,20 @@ class AdamW(object):
     def _value(self, x):
         return float(x(self.iterations)) if callable(x) else float(x)
 
-    def apply_gradients(self, grads):
+    def apply_gradients(self, grads, skip_flag_ptr=None):
+        """skip_flag_ptr: device address of a word that, when non-zero, makes the update a no-op on the device
+        (uu3d_train_nonfinite_flag: the backward pass found non-finite gradients)."""
         torch = self._torch
         g = grads.view(-1)
         if g.shape != self.params.shape or g.dtype != torch.float32 or g.device != self.params.device:
             raise ValueError("grads must match params (flat float32, same device)")
         lr, wd = self._value(self.learning_rate), self._value(self.weight_decay)
         stream = torch.cuda.current_stream(self.params.device).cuda_stream
-        st = self._lib.uu3d_adamw_update(C.c_void_p(self.params.data_ptr()), C.c_void_p(self.m.data_ptr()),
-                                         C.c_void_p(self.v.data_ptr()),
-                                         C.c_void_p(self.vhat.data_ptr()) if self.amsgrad else None, C.c_void_p(g.contiguous().data_ptr()),
-                                         self.params.numel(), lr, wd, self.beta_1, self.beta_2, self.epsilon,
-                                         self.iterations + 1, C.c_void_p(stream))
+        st = self._lib.uu3d_adamw_update_guarded(C.c_void_p(self.params.data_ptr()), C.c_void_p(self.m.data_ptr()),
+                                                 C.c_void_p(self.v.data_ptr()),
+                                                 C.c_void_p(self.vhat.data_ptr()) if self.amsgrad else None, C.c_void_p(g.contiguous().data_ptr()),
+                                                 self.params.numel(), lr, wd, self.beta_1, self.beta_2, self.epsilon,
+                                                 self.iterations + 1, C.c_void_p(skip_flag_ptr) if skip_flag_ptr else None, C.c_void_p(stream))
         _capi.check(self._lib, st, None)
         self.iterations += 1
 

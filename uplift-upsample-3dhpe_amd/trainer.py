@@ -100,6 +100,7 @@ class Trainer(object):
         central = torch.empty((B, a.num_keypoints, 3), dtype=torch.float32, device=dev)
         ws = self._workspace(B)
         rates = (C.c_float * 3)(*[float(r) for r in self.drop_path_rates])
+        self._buckets.begin()                                               # a previous pass without apply_gradients leaves nothing behind
         st = self._lib.uu3d_train_forward_backward(
             self.model._h, C.c_void_p(self.params.data_ptr()), C.c_void_p(x.data_ptr()), m_ptr, C.c_void_p(gt.data_ptr()), B,
             int(cfg.BATCH_SIZE), float(cfg.LOSS_WEIGHT_CENTER), float(cfg.LOSS_WEIGHT_SEQUENCE), int(cfg.ROOT_KEYTPOINT),
@@ -107,18 +108,28 @@ class Trainer(object):
             C.c_void_p(full.data_ptr()), C.c_void_p(central.data_ptr()), C.c_void_p(self.grads.data_ptr()),
             C.c_void_p(ws.data_ptr()), self._ws_bytes, self._stream())
         _capi.check(self._lib, st, self.model._h)
+        self._buckets.raise_pending()                                       # an exception inside the gradient-ready callback (ctypes only prints it)
         return self.loss, full, central
 
     def apply_gradients(self):
         """optimizer.apply_gradients (+ EMA), then refresh the operand packs.  With more than one rank the gradient buckets
         were started by forward_backward while the backward pass ran; here the stream only waits for them."""
         self._buckets.wait()                                                 # loss normaliser is the GLOBAL batch size: sums, no rescale
-        self.optimizer.apply_gradients(self.grads)
+        # a backward pass that produced non-finite gradients (loss-scaled f16x3 overflow) leaves weights and moments alone:
+        # the flag is read on the device, the host never waits (nonfinite() reads it back for logging)
+        self.optimizer.apply_gradients(self.grads, skip_flag_ptr=self._lib.uu3d_train_nonfinite_flag(self.model._h))
         if self.ema is not None:
             optim.ema_update(self.ema, self.params, optim.ema_decay_value(self.config.EMA_DECAY, self.global_step))
         _capi.check(self._lib, self._lib.uu3d_train_repack(self.model._h, C.c_void_p(self.params.data_ptr()), self._stream()), self.model._h)
         self.global_step += 1
         self.model._weights_dirty = True                                      # the model's host / inference weights are now stale
+        self.model._holds_ema = False
+
+    def nonfinite(self):
+        """True when the last backward pass flagged non-finite gradients (its optimizer step was skipped).  Synchronises."""
+        out = C.c_int32()
+        _capi.check(self._lib, self._lib.uu3d_train_nonfinite(self.model._h, C.byref(out)), self.model._h)
+        return out.value != 0
 
     def train_step(self, keypoints2d, keypoints3d, stride_masks, drop_path_uniform="draw"):
         loss, _, _ = self.forward_backward(keypoints2d, keypoints3d, stride_masks, drop_path_uniform)
@@ -134,7 +145,11 @@ class Trainer(object):
         """Copy the trained (or EMA) weights back into the inference model (val_model, train.py:400-401)."""
         src = self.ema if (use_ema and self.ema is not None) else self.params
         _capi.check(self._lib, self._lib.uu3d_train_export(self.model._h, C.c_void_p(src.data_ptr()), self._stream()), self.model._h)
-        self.model._weights_dirty = bool(use_ema and self.ema is not None)    # EMA weights in the model: the live ones differ again
+        # The model now holds exactly what was asked for.  After an EMA export it must KEEP the EMA weights for the validation
+        # forward (val_model = ema_model, train.py:398-401) -- the next apply_gradients / load_state_dict marks it stale again;
+        # a "dirty" flag here made model(...) re-export the live weights over them (ADVICE round 2).
+        self.model._weights_dirty = False
+        self.model._holds_ema = bool(use_ema and self.ema is not None)
 
     # ---- checkpoint / resume (the role of tf.train.Checkpoint(model, optimizer, ema_model) in train.py:420-436) ----
     def state_dict(self):
@@ -169,6 +184,7 @@ class Trainer(object):
             self.ema.copy_(torch.from_numpy(np.asarray(sd["ema"], np.float32)))
         _capi.check(self._lib, self._lib.uu3d_train_repack(self.model._h, C.c_void_p(self.params.data_ptr()), self._stream()), self.model._h)
         self.model._weights_dirty = True
+        self.model._holds_ema = False
 
     def save_checkpoint(self, path):
         np.savez(path, **self.state_dict())
