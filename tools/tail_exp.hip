@@ -38,16 +38,18 @@ int main(int argc, char** argv) {
     p.wqkv_f = hrand((size_t)36 * 24 * 1024, .05f); p.wp_f = hrand((size_t)12 * 24 * 1024, .05f); p.w1_f = hrand((size_t)24 * 24 * 1024, .05f);
     p.wc_f = hrand((size_t)12 * 144 * 1024, .03f); p.wh_f = hrand((size_t)2 * 24 * 1024, .05f);
     p.ctl = dalloc<TailCtl>(1);
-    p.dbg = dalloc<unsigned long long>((size_t)cus * 32);
+    p.dbg = dalloc<unsigned long long>((size_t)cus * 64);
     float* xsave = dalloc<float>((size_t)M * 384); CK(hipMemcpy(xsave, p.x, (size_t)M * 384 * 4, hipMemcpyDeviceToDevice));
     char* flush = dalloc<char>((size_t)512 << 20);
     hipStream_t st; CK(hipStreamCreate(&st));
+    CK(hipFuncSetAttribute((const void*)strided_tail_kernel_t<true>, hipFuncAttributeMaxDynamicSharedMemorySize, tail::LDS_BYTES));
+    CK(hipFuncSetAttribute((const void*)strided_tail_kernel_t<false>, hipFuncAttributeMaxDynamicSharedMemorySize, tail::LDS_BYTES));
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
 
     auto launch = [&](bool stamp) {
         CK(hipMemsetAsync(p.ctl, 0, sizeof(TailCtl), st));
-        if (stamp) hipLaunchKernelGGL(strided_tail_kernel_t<true>, dim3(cus), dim3(256), 0, st, p);
-        else hipLaunchKernelGGL(strided_tail_kernel_t<false>, dim3(cus), dim3(256), 0, st, p);
+        if (stamp) hipLaunchKernelGGL(strided_tail_kernel_t<true>, dim3(cus), dim3(256), tail::LDS_BYTES, st, p);
+        else hipLaunchKernelGGL(strided_tail_kernel_t<false>, dim3(cus), dim3(256), tail::LDS_BYTES, st, p);
     };
     for (int i = 0; i < 5; ++i) launch(false);
     CK(hipStreamSynchronize(st));
@@ -69,25 +71,23 @@ int main(int argc, char** argv) {
     TailCtl h; CK(hipMemcpy(&h, p.ctl, sizeof h, hipMemcpyDeviceToHost));
     printf("err %u owner", h.err); for (int i = 0; i < 8; ++i) printf(" %u", h.owner[i]);
     printf(" census"); for (int i = 0; i < 8; ++i) printf(" %u", h.census[i]); printf("\n");
-    // stamps
-    CK(hipMemsetAsync(p.dbg, 0, (size_t)cus * 32 * 8, st));
+    // stamps: slot ids = 0 start, 1 group claimed, 2 tickets; 8 + 8 phase + {0 weights issued, 1 previous phase complete, 2 operand
+    // rows loaded + normalised (proj: K | V staged), 3 fragments in LDS, 4 MFMAs done, 5 stores issued, 7 published}
+    CK(hipMemsetAsync(p.dbg, 0, (size_t)cus * 64 * 8, st));
     launch(true); CK(hipStreamSynchronize(st));
-    std::vector<unsigned long long> d((size_t)cus * 32);
+    std::vector<unsigned long long> d((size_t)cus * 64);
     CK(hipMemcpy(d.data(), p.dbg, d.size() * 8, hipMemcpyDeviceToHost));
     unsigned long long t0 = ~0ull;
-    for (int w = 0; w < cus; ++w) if (d[(size_t)w * 32]) t0 = std::min(t0, d[(size_t)w * 32]);
-    printf("stamps (us after the first workgroup started; min / median / max over workgroups that reached the stamp)\n");
-    for (int k = 0; k < 32; ++k) {
+    for (int w = 0; w < cus; ++w) if (d[(size_t)w * 64]) t0 = std::min(t0, d[(size_t)w * 64]);
+    printf("stamps (us after the first workgroup started; n, min / median / max over workgroups that reached the stamp)\n");
+    const char* phn[6] = {"qkv", "attn", "proj", "fc1", "conv", "head"};
+    for (int k = 0; k < 56; ++k) {
         std::vector<double> v;
-        for (int w = 0; w < cus; ++w) if (d[(size_t)w * 32 + k]) v.push_back((double)(d[(size_t)w * 32 + k] - t0) * 0.01);
-        if (v.empty()) break;
+        for (int w = 0; w < cus; ++w) if (d[(size_t)w * 64 + k]) v.push_back((double)(d[(size_t)w * 64 + k] - t0) * 0.01);
+        if (v.empty()) continue;
         std::sort(v.begin(), v.end());
-        printf("  stamp %2d: n %3zu  %7.2f %7.2f %7.2f\n", k, v.size(), v.front(), v[v.size() / 2], v.back());
-    }
-    // one workgroup that had a task in every phase
-    for (int w = 0; w < cus; ++w) {
-        int n = 0; while (n < 32 && d[(size_t)w * 32 + n]) ++n;
-        if (n >= 14) { printf("workgroup %d:", w); for (int k = 0; k < n; ++k) printf(" %.2f", (double)(d[(size_t)w * 32 + k] - t0) * 0.01); printf("\n"); break; }
+        if (k < 8) printf("  %-8s %d: n %3zu  %7.2f %7.2f %7.2f\n", "start", k, v.size(), v.front(), v[v.size() / 2], v.back());
+        else printf("  %-8s %d: n %3zu  %7.2f %7.2f %7.2f\n", phn[(k - 8) / 8], (k - 8) % 8, v.size(), v.front(), v[v.size() / 2], v.back());
     }
     return 0;
 }

@@ -1160,7 +1160,7 @@ int uu3d_forward(uu3d_model* m, const float* kp2d, const uint8_t* mask, int32_t 
         const int Li = m->L[i], Lo = m->L[i + 1], Mi = B * Li, Mo = B * Lo;
         // the last strided block + head2 as ONE launch of XCD-cooperative workgroups (uu3d_tail.h) when the block is small: few
         // rows make every launch of the chain a bare memory round trip (h36m_351 at batch 128: 9 launches, 76 us)
-        if (i >= 1 && i + 1 == c.num_strided && planes && !m->no_tail && dt == 384 && ht == 768 && Li <= 32 && Mi <= 1024 &&
+        if (i >= 1 && i + 1 == c.num_strided && planes && !m->no_tail && dt == 384 && ht == 768 && Li <= tail::MAX_L && Mi <= 1024 &&
             b.wqkv_pf != 0 && b.w1_pf != 0 && b.wp_pf != 0 && b.wc_pf != 0 && m->h2_pf != 0) {
             TailParams tp{};
             tp.B = B; tp.G = (B + TAIL_GROUPS - 1) / TAIL_GROUPS;
@@ -1177,7 +1177,8 @@ int uu3d_forward(uu3d_model* m, const float* kp2d, const uint8_t* mask, int32_t 
             snprintf(nm, sizeof nm, "s%d.tail_head2", i + 1);
             Lh.begin(nm, "strided_tail", fl, 4.0 * ((double)dt * (3 * dt + dt + ht + 3 * ht + 3 * J) + (double)Mi * dt));
             (void)hipMemsetAsync(w.tail_ctl, 0, sizeof(TailCtl), Lh.stream);
-            hipLaunchKernelGGL(strided_tail_kernel_t<false>, dim3(m->num_cus), dim3(256), 0, Lh.stream, tp);
+            { static const bool once = (hipFuncSetAttribute((const void*)strided_tail_kernel_t<false>, hipFuncAttributeMaxDynamicSharedMemorySize, tail::LDS_BYTES) == hipSuccess); (void)once; }
+            hipLaunchKernelGGL(strided_tail_kernel_t<false>, dim3(m->num_cus), dim3(256), tail::LDS_BYTES, Lh.stream, tp);
             Lh.end();
             tail_done = true;
             break;

@@ -25,6 +25,7 @@
 // 32 bytes of a row per lane), the contraction split over 1, 2 or 4 waves of the workgroup and combined in wave order
 // through LDS (deterministic); attention (<= 32 tokens) in exact f32 on the vector ALU (online softmax).
 #pragma once
+#include <type_traits>
 #include "uu3d_gemm_h3.h"
 
 namespace uu3d {
@@ -37,7 +38,10 @@ struct TailCtl {                           // zeroed before every launch (hipMem
     unsigned owner[TAIL_GROUPS];           // 0 = unowned, else 1 + the XCC id of the XCD that works on the group
     unsigned err, pad0[23];
     struct Line { unsigned v[32]; };
-    Line ticket[TAIL_GROUPS];              // [group].v[phase]: next task
+    struct TLine { unsigned v[8][8]; };    // [owner XCC][phase]
+    TLine ticket[TAIL_GROUPS];             // [group].v[xcc][phase]: next task, counted separately per CLAIMING XCD: a workgroup draws its
+                                           // first tickets together with its claim; if the claim fails (a foreign XCD owns the group) the
+                                           // tickets it drew are from a counter nobody else uses
     Line done[TAIL_GROUPS];                // [group].v[phase]: finished tasks
     unsigned stamp[TAIL_GROUPS][TAIL_PHASES][TAIL_STAMPS];   // 1 + XCC id of the workgroup that ran task t (t < 64)
     unsigned census[TAIL_GROUPS];          // workgroups seen per XCC id (diagnostics: uu3d_tail_status)
@@ -51,14 +55,14 @@ struct TailParams {
     int n_out;                             // 3 J
     float* x;                              // [B L_in][384]  block input (+ PE), updated in place by the projection
     float* qkv;                            // [B L_in][1152]
-    float* o;                              // [B L_in][384]
+    float* o;                              // attention output as A FRAGMENTS: [group][32-row tile of the group's rows][24 k-slices][hi | lo][64 lanes][8 halfs]
     float* hb;                             // [B L_in][768]
     float* part;                           // [2][B L_out][384] partial sums of the convolution (two halves of K = 2304)
     float* out;                            // [B L_out][n_out]
     const float *ln1_g, *ln1_b, *bqkv, *bp, *ln2_g, *ln2_b, *b1, *b2, *bh;
     const _Float16 *wqkv_f, *wp_f, *w1_f, *wc_f, *wh_f;      // fragment-ordered planes (panel_pack_operand)
     TailCtl* ctl;
-    unsigned long long* dbg;               // STAMP builds (tools/tail_exp.hip): [workgroup][32] s_memrealtime ticks (10 ns); else unused
+    unsigned long long* dbg;               // STAMP builds (tools/tail_exp.hip): [workgroup][64] s_memrealtime ticks (10 ns); else unused
 };
 
 namespace tail {
@@ -78,26 +82,15 @@ struct Sc1Buf {
 };
 __device__ __forceinline__ unsigned ld_u32_agent(const unsigned* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 
-struct Shared {                            // static part of the LDS
-    float red[4][16][64];                  // partial tiles of the waves of a unit
-    float stat[2][4][32];                  // LayerNorm partial sums [pass][wave][row]
-    float gam[384], bet[384];              // LayerNorm parameters of the current phase
-    int bcast;
-    int first[TAIL_PHASES];                // this workgroup's first ticket of every phase (taken together, up front)
-};
-
-// ---- claim a group for this XCD: the preferred one (group == XCC id) first -------------------------------------------------
-__device__ __forceinline__ int claim_group(TailCtl* ctl, const unsigned xcc, unsigned& visited, const int ngroups) {
-    // one vector load of all owner words; compare-and-swap only where it can succeed
-    for (int i = 0; i < TAIL_GROUPS; ++i) {
-        const int g = (int)((xcc + i) & 7u);
-        if (g >= ngroups || (visited >> g) & 1u) continue;
-        unsigned cur = ld_u32_agent(&ctl->owner[g]);
-        if (cur == 0u) cur = atomicCAS(&ctl->owner[g], 0u, xcc + 1u) == 0u ? xcc + 1u : ld_u32_agent(&ctl->owner[g]);
-        if (cur == xcc + 1u) { visited |= 1u << g; return g; }
-    }
-    return -1;
-}
+// LDS (all dynamic, 16-byte aligned pieces): [0, BIG): the K | V rows of the attention, then the A fragments (aliased: a barrier
+// between the last K / V read and the first fragment write); red: partial tiles of a unit whose K is split over waves
+constexpr int AFRAG_BYTES = 24 * 2 * 1024;               // A fragments of one 32-row tile, K = 384: [k-slice][plane][lane][8 halfs]
+constexpr int KV_HS = 52, KV_LD = 2 * 8 * KV_HS + 8;     // staged key | value rows (f32): [k | v][head][48 + 4 pad] (+ 8): conflict-free 16-byte reads of 8 heads
+constexpr int KV_ROWS = 40;
+constexpr int BIG_BYTES = KV_ROWS * KV_LD * 4;           // 124 160
+constexpr int RED_BYTES = 4 * 16 * 64 * 4;
+constexpr int LDS_BYTES = BIG_BYTES + RED_BYTES + 256 + 2 * 384 * 4;   // + broadcast words + LayerNorm gamma | beta
+constexpr int MAX_L = 4;                                 // tokens per sequence the staged attention holds (KV_ROWS >= 32 + 2 MAX_L)
 
 // ---- the product of one unit: rows (lane & 31) of a 32-row tile x 32 columns, k-slices [0, SPW) of this wave -------------------
 template <int SPW>
@@ -132,55 +125,83 @@ __device__ __forceinline__ void load_b(const _Float16* __restrict__ Bf, const in
 
 }  // namespace tail
 
-// One workgroup = 4 waves = one wave per SIMD (~300 registers); grid = number of CUs.
+// One workgroup = 4 waves = one wave per SIMD (a wave keeps the 48 weight fragments of its 32-column chunk in registers);
+// grid = number of CUs.
 template <bool STAMP>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1)))
 strided_tail_kernel_t(const TailParams p)
 {
     using namespace tail;
     h3_flush_f16_denormals();
-    __shared__ Shared sh;
+    extern __shared__ __attribute__((aligned(16))) unsigned char tsm[];
+    float* const kvs = reinterpret_cast<float*>(tsm);                               // [KV_ROWS][KV_LD]
+    h16x8* const afr = reinterpret_cast<h16x8*>(tsm);                               // [24][2][64]
+    float (*red)[16][64] = reinterpret_cast<float (*)[16][64]>(tsm + BIG_BYTES);
+    int* const ish = reinterpret_cast<int*>(tsm + BIG_BYTES + RED_BYTES);           // [0]: broadcast, [8 ..]: first tickets
+    float* const gbs = reinterpret_cast<float*>(tsm + BIG_BYTES + RED_BYTES + 256); // gamma[384] | beta[384] of the current LayerNorm
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int r = lane & 31, g2 = lane >> 5;
     TailCtl* const ctl = p.ctl;
     const unsigned xcc = xcc_id();
-    if (tid == 0) atomicAdd(&ctl->census[xcc & 7u], 1u);
     const int ngroups = (p.B + p.G - 1) / p.G;
     unsigned visited = 0;
-    int stamp_i = 0;
-    auto stamp = [&]() { if (STAMP) { if (tid == 0 && stamp_i < 32) p.dbg[(size_t)blockIdx.x * 32 + stamp_i] = __builtin_amdgcn_s_memrealtime(); ++stamp_i; } };
-    stamp();                                                           // 0: start
+    // STAMP builds: slot id of this workgroup's row <- s_memrealtime (first write wins: the first task of a phase)
+    auto stamp = [&](int id) { if (STAMP) { if (tid == 0 && id < 64 && p.dbg[(size_t)blockIdx.x * 64 + id] == 0) p.dbg[(size_t)blockIdx.x * 64 + id] = __builtin_amdgcn_s_memrealtime(); } };
+    stamp(0);                                                          // 0: start
 
+    bool first_claim = true;
     for (;;) {
-        if (tid == 0) sh.bcast = claim_group(ctl, xcc, visited, ngroups);
+        // Claim + the first ticket of EVERY phase in ONE round trip: lane 0 .. 5 draw tickets of the candidate group (from this
+        // XCD's own counters), lane 8 runs the compare-and-swap on its owner word.  First the preferred group (== XCC id), then --
+        // after this XCD's group is done, or if a foreign XCD holds the preferred one -- whatever is unowned.
+        if (wave == 0) {
+            int cand = -1;
+            if (first_claim) { cand = (int)(xcc & 7u); if (cand >= ngroups) cand = -1; }
+            if (cand < 0) {
+                for (int i = 0; i < TAIL_GROUPS && cand < 0; ++i) {
+                    const int g = (int)((xcc + i) & 7u);
+                    if (g >= ngroups || (visited >> g) & 1u) continue;
+                    const unsigned cur = ld_u32_agent(&ctl->owner[g]);
+                    if (cur == 0u || cur == xcc + 1u) cand = g;
+                }
+            }
+            int got = -1;
+            if (cand >= 0) {
+                unsigned tk = 0, own = 0;
+                if (lane < TAIL_PHASES) tk = atomicAdd(&ctl->ticket[cand].v[xcc & 7u][lane], 1u);
+                if (lane == 8) own = atomicCAS(&ctl->owner[cand], 0u, xcc + 1u);
+                own = __shfl(own, 8);
+                if (own == 0u || own == xcc + 1u) { got = cand; if (lane < TAIL_PHASES) ish[8 + lane] = (int)tk; }
+                else visited |= 1u << cand;                            // foreign: never look at it again (wave 0's copy of `visited`)
+            }
+            if (lane == 0) ish[0] = got, ish[1] = cand;
+        }
+        first_claim = false;
         __syncthreads();
-        const int grp = sh.bcast;
+        const int grp = ish[0], cand_seen = ish[1];
         __syncthreads();
-        if (grp < 0) break;
+        if (grp < 0) { if (cand_seen < 0) break; visited |= 1u << cand_seen; continue; }
         visited |= 1u << grp;
-        stamp();                                                       // 1: group claimed
-        // the first ticket of EVERY phase in one vector atomic: no ticket round trip on the path between two phases
-        if (tid < TAIL_PHASES) sh.first[tid] = (int)atomicAdd(&ctl->ticket[grp].v[tid], 1u);
-        __syncthreads();
-        stamp();                                                       // 2: tickets
+        stamp(2);                                                      // 2: group claimed, tickets drawn
 
         const int seq0 = grp * p.G, nb = min(p.G, p.B - seq0);
         const int R = nb * p.L_in, Ro = nb * p.L_out;                 // rows of this group: block input / block output
         const int row_in0 = seq0 * p.L_in, row_out0 = seq0 * p.L_out;
         const int RT = (R + 31) >> 5, RTo = (Ro + 31) >> 5;
+        const int RTG = (p.G * p.L_in + 31) >> 5;                      // row tiles a full group has (fragment images per group)
         int ntask[TAIL_PHASES];
-        ntask[TP_QKV] = (RT * 36 + 1) >> 1;                           // 2 units (row tile, 32-column chunk) per workgroup, K over wave pairs
-        ntask[TP_ATTN] = (R * 8 + 255) >> 8;                          // one thread per (row, head)
-        ntask[TP_PROJ] = RT * 12;                                     // one unit per workgroup, K over its 4 waves
-        ntask[TP_FC1] = (RT * 24 + 1) >> 1;                           // 2 units per workgroup, K over wave pairs
+        ntask[TP_QKV] = RT * 9;                                       // (row tile, 4 chunks of 32 columns): one chunk per wave
+        ntask[TP_ATTN] = (R + 15) >> 4;                               // 16 rows x 8 heads x 2 halves of the head dimension = 256 threads
+        ntask[TP_PROJ] = RT * 12;                                     // (row tile, chunk), K over the 4 waves
+        ntask[TP_FC1] = RT * 6;
         ntask[TP_CONV] = RTo * 12 * 2;                                // (row tile, chunk, half of K = 2304), K half over 4 waves
         ntask[TP_HEAD] = RTo * ((p.n_out + 31) >> 5);
 
-        auto first_task = [&](int ph) -> int { return sh.first[ph]; };
+        auto first_task = [&](int ph) -> int { return ish[8 + ph]; };
         auto next_task = [&](int ph) -> int {
-            if (tid == 0) sh.bcast = (int)atomicAdd(&ctl->ticket[grp].v[ph], 1u);
+            if (tid == 0) ish[0] = (int)atomicAdd(&ctl->ticket[grp].v[xcc & 7u][ph], 1u);
             __syncthreads();
-            const int t = sh.bcast;
+            const int t = ish[0];
             __syncthreads();
             return t;
         };
@@ -206,191 +227,252 @@ strided_tail_kernel_t(const TailParams p)
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // every storing wave: its stores are in the XCD's L2
             __syncthreads();
             if (tid == 0) atomicAdd(&ctl->done[grp].v[ph], 1u);
-            stamp();
+            stamp(8 + 8 * ph + 7);
         };
-        // LayerNorm statistics of the rows of a unit whose K = 384 is spread over KSPL waves (wave index inside the unit: kp):
-        // two-pass, partial sums through LDS.  s1 = this wave's partial sum; sq(mean) = its partial sum of squared deviations.
-        // every wave of the workgroup calls this (barriers).
-        auto ln_stats = [&](float s1, auto&& sq, const int KSPL, float& mean, float& rstd) {
-            s1 += __shfl_xor(s1, 32);
-            if (g2 == 0) sh.stat[0][wave][r] = s1;
-            __syncthreads();
-            float tot = 0.f;
-            const int w0 = wave - (wave % KSPL);
-            for (int i = 0; i < KSPL; ++i) tot += sh.stat[0][w0 + i][r];
-            mean = tot * (1.0f / D);
-            float v = sq(mean);
-            v += __shfl_xor(v, 32);
-            if (g2 == 0) sh.stat[1][wave][r] = v;
-            __syncthreads();
-            float vt = 0.f;
-            for (int i = 0; i < KSPL; ++i) vt += sh.stat[1][w0 + i][r];
-            rstd = 1.0f / sqrtf(vt * (1.0f / D) + 1e-5f);
-        };
-        // combine the KSPL partial tiles of a unit in wave order; true for the wave that then owns the result
-        auto combine = [&](f32x16& acc, const int KSPL) -> bool {
-            if (KSPL == 1) return true;
-            const int kp = wave % KSPL, w0 = wave - kp;
-            if (kp != 0) {
+        // combine the 4 partial tiles of a unit in wave order; true for the wave that then owns the result
+        auto combine4 = [&](f32x16& acc) -> bool {
+            if (wave != 0) {
 #pragma unroll
-                for (int i = 0; i < 16; ++i) sh.red[wave][i][lane] = acc[i];
+                for (int i = 0; i < 16; ++i) red[wave][i][lane] = acc[i];
             }
             __syncthreads();
-            if (kp == 0) {
-                for (int u = 1; u < KSPL; ++u)
+            if (wave == 0) {
+                for (int u = 1; u < 4; ++u)
 #pragma unroll
-                    for (int i = 0; i < 16; ++i) acc[i] += sh.red[w0 + u][i][lane];
+                    for (int i = 0; i < 16; ++i) acc[i] += red[u][i][lane];
             }
             __syncthreads();                                          // red is reused by the next task
-            return kp == 0;
+            return wave == 0;
+        };
+        // 48 consecutive channels [kb, kb + 48) of tile row tr, split and stored as A fragments (thread = (tr, kb / 48))
+        auto write_afrag = [&](const int tr, const int kb, const f32x4 (&v)[12]) {
+#pragma unroll
+            for (int m = 0; m < 6; ++m) {
+                h16x8 hi, lo;
+                split8(v[2 * m], v[2 * m + 1], hi, lo);
+                const int k = kb + 8 * m;
+                h16x8* d = afr + ((k >> 4) * 2) * 64 + tr + 32 * ((k >> 3) & 1);
+                d[0] = hi; d[64] = lo;
+            }
+        };
+        // this wave's 32 x 32 tile: A fragments from LDS, the chunk's weight fragments from registers
+        auto mfma_lds = [&](const h16x8 (&bh)[24], const h16x8 (&bl)[24], f32x16& acc) {
+            f32x16 a0, a1;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) { a0[i] = 0.f; a1[i] = 0.f; }
+#pragma unroll
+            for (int q = 0; q < 24; ++q) {
+                const h16x8 ah = afr[(q * 2) * 64 + lane], al = afr[(q * 2 + 1) * 64 + lane];
+                a0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh[q], a0, 0, 0, 0);
+                a1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl[q], a1, 0, 0, 0);
+                a1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh[q], a1, 0, 0, 0);
+            }
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[i] = a0[i] + a1[i] * (1.0f / H3_SCALE);
         };
 
-        // LayerNorm-fed Dense layer: out[row][col] = epi(LN(x)[row] . W[:, col] + bias[col]); 2 units (row tile, 32-column chunk) per
-        // workgroup, K = 384 over a wave pair (12 k-slices each)
+        // LayerNorm-fed Dense layer, out = LN(x) W + bias.  A task = one 32-row tile x 4 chunks of 32 columns (one per wave): the
+        // workgroup normalises and splits the tile ONCE (thread = (row, 48 channels)), the fragments go through LDS.
+        // planes == false: out[row][col] = v (f32, leading dimension ldo); true: relu(v) as f16 hi / lo planes [rows][ldo]
         auto ln_dense = [&](const int ph, const int prev, const int nchunks, const _Float16* __restrict__ Wf, const float* __restrict__ gamma,
-                            const float* __restrict__ beta, const float* __restrict__ bias, float* __restrict__ outp, const int ldo, const bool relu) {
-            if (tid < 96) { *reinterpret_cast<f32x4*>(sh.gam + 4 * tid) = *reinterpret_cast<const f32x4*>(gamma + 4 * tid);
-                            *reinterpret_cast<f32x4*>(sh.bet + 4 * tid) = *reinterpret_cast<const f32x4*>(beta + 4 * tid); }
+                            const float* __restrict__ beta, const float* __restrict__ bias, float* __restrict__ outp, const int ldo, const bool planes) {
             const Sc1Buf bx(p.x);
+            const int tpr = nchunks >> 2;                              // tasks per row tile
+            if (tid < 96) { *reinterpret_cast<f32x4*>(gbs + 4 * tid) = *reinterpret_cast<const f32x4*>(gamma + 4 * tid);
+                            *reinterpret_cast<f32x4*>(gbs + D + 4 * tid) = *reinterpret_cast<const f32x4*>(beta + 4 * tid); }
+            bool gb_ready = false;                                     // (the first phase has no other barrier in front of the first read)
             int t = first_task(ph);
             bool waited = prev < 0;
             while (t < ntask[ph]) {
-                const int u = t * 2 + (wave >> 1), rt = u / nchunks, c = u - rt * nchunks, s0 = (wave & 1) * 12;
-                const bool act = rt < RT;
-                h16x8 bh[12], bl[12];
-                load_b<12>(Wf, KS_D, act ? c : 0, s0, lane, bh, bl);
-                if (!waited) { wait_phase(prev); waited = true; stamp(); }
-                const int lrow = min(rt * 32 + r, R - 1), grow = row_in0 + lrow;
-                f32x4 xa[12], xb[12];
+                const int rt = t / tpr, c = (t - rt * tpr) * 4 + wave;
+                const float bv = bias[c * 32 + r];                     // (every weight-side load goes out before the wait / the operand rows)
+                h16x8 bh[24], bl[24];
+                const int tr = tid >> 3, kb = (tid & 7) * 48;
+                const int grow = row_in0 + min(rt * 32 + tr, R - 1);
+                f32x4 v[12];
+                // vector memory returns in order: where nothing has to be waited for, the operand rows (needed first) go out before
+                // the 48 weight fragments; behind a phase barrier the weights go out before the wait
+                if (waited) {
+#pragma unroll
+                    for (int e = 0; e < 12; ++e) v[e] = bx.ld(((unsigned)grow * D + kb + 4 * e) * 4u);
+                    load_b<24>(Wf, KS_D, c, 0, lane, bh, bl);
+                } else {
+                    load_b<24>(Wf, KS_D, c, 0, lane, bh, bl);
+                    stamp(8 + 8 * ph + 0);
+                    wait_phase(prev); waited = true;
+                    stamp(8 + 8 * ph + 1);
+#pragma unroll
+                    for (int e = 0; e < 12; ++e) v[e] = bx.ld(((unsigned)grow * D + kb + 4 * e) * 4u);
+                }
                 float s1 = 0.f;
 #pragma unroll
-                for (int q = 0; q < 12; ++q) {
-                    const unsigned off = ((unsigned)grow * D + 16 * (s0 + q) + 8 * g2) * 4u;
-                    xa[q] = bx.ld(off); xb[q] = bx.ld(off + 16u);
-                }
+                for (int e = 0; e < 12; ++e) s1 += (v[e][0] + v[e][1]) + (v[e][2] + v[e][3]);
+                s1 += __shfl_xor(s1, 1); s1 += __shfl_xor(s1, 2); s1 += __shfl_xor(s1, 4);
+                const float mean = s1 * (1.0f / D);
+                float s2 = 0.f;
 #pragma unroll
-                for (int q = 0; q < 12; ++q) s1 += ((xa[q][0] + xa[q][1]) + (xa[q][2] + xa[q][3])) + ((xb[q][0] + xb[q][1]) + (xb[q][2] + xb[q][3]));
-                float mean, rstd;
-                ln_stats(s1, [&](float mu) { float v = 0.f;
+                for (int e = 0; e < 12; ++e)
 #pragma unroll
-                    for (int q = 0; q < 12; ++q)
+                    for (int i = 0; i < 4; ++i) { const float a = v[e][i] - mean; s2 += a * a; }
+                s2 += __shfl_xor(s2, 1); s2 += __shfl_xor(s2, 2); s2 += __shfl_xor(s2, 4);
+                const float rstd = 1.0f / sqrtf(s2 * (1.0f / D) + 1e-5f);
+                if (!gb_ready) { __syncthreads(); gb_ready = true; }
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) { const float a = xa[q][e] - mu, b = xb[q][e] - mu; v += a * a + b * b; }
-                    return v; }, 2, mean, rstd);
-                h16x8 ah[12], al[12];
+                for (int e = 0; e < 12; ++e)
 #pragma unroll
-                for (int q = 0; q < 12; ++q) {
-                    const int k = 16 * (s0 + q) + 8 * g2;
-                    const f32x4 ga = *reinterpret_cast<const f32x4*>(sh.gam + k), gb = *reinterpret_cast<const f32x4*>(sh.gam + k + 4);
-                    const f32x4 ba = *reinterpret_cast<const f32x4*>(sh.bet + k), bb = *reinterpret_cast<const f32x4*>(sh.bet + k + 4);
-                    f32x4 ya, yb;
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        const float ia = rstd * ga[e], ib = rstd * gb[e];
-                        ya[e] = xa[q][e] * ia + (ba[e] - mean * ia);
-                        yb[e] = xb[q][e] * ib + (bb[e] - mean * ib);
-                    }
-                    split8(ya, yb, ah[q], al[q]);
-                }
+                    for (int i = 0; i < 4; ++i) { const float inv = rstd * gbs[kb + 4 * e + i]; v[e][i] = v[e][i] * inv + (gbs[D + kb + 4 * e + i] - mean * inv); }
+                stamp(8 + 8 * ph + 2);
+                write_afrag(tr, kb, v);
+                __syncthreads();
+                stamp(8 + 8 * ph + 3);
                 f32x16 acc;
-                mfma_unit<12>(ah, al, bh, bl, acc);
-                if (combine(acc, 2) && act) {
+                mfma_lds(bh, bl, acc);
+                stamp(8 + 8 * ph + 4);
+                {
                     const int col = c * 32 + r;
-                    const float bv = bias[col];
+                    if (!planes) {
 #pragma unroll
-                    for (int i = 0; i < 16; ++i) {
-                        const int lr = rt * 32 + 8 * (i >> 2) + 4 * g2 + (i & 3);
-                        const float v = acc[i] + bv;
-                        if (lr < R) outp[(size_t)(row_in0 + lr) * ldo + col] = relu ? fmaxf(v, 0.f) : v;
+                        for (int i = 0; i < 16; ++i) {
+                            const int lr = rt * 32 + 8 * (i >> 2) + 4 * g2 + (i & 3);
+                            if (lr < R) outp[(size_t)(row_in0 + lr) * ldo + col] = acc[i] + bv;
+                        }
+                    } else {
+                        _Float16* const oh = reinterpret_cast<_Float16*>(outp);
+                        _Float16* const ol = oh + (size_t)p.B * p.L_in * ldo;
+#pragma unroll
+                        for (int i = 0; i < 16; ++i) {
+                            const int lr = rt * 32 + 8 * (i >> 2) + 4 * g2 + (i & 3);
+                            const float y = fmaxf(acc[i] + bv, 0.f);
+                            const _Float16 h = h3_hi(y);
+                            if (lr < R) { const size_t o = (size_t)(row_in0 + lr) * ldo + col; oh[o] = h; ol[o] = (_Float16)((y - (float)h) * H3_SCALE); }
+                        }
                     }
                 }
-                publish(ph, t);
+                stamp(8 + 8 * ph + 5);
+                publish(ph, t);                                        // (its barrier also frees the fragments for the next task)
                 t = next_task(ph);
             }
         };
         // ================= phase 0: qkv = LN1(x) Wqkv + b =================
         ln_dense(TP_QKV, -1, 36, p.wqkv_f, p.ln1_g, p.ln1_b, p.bqkv, p.qkv, 3 * D, false);
-        // ================= phase 1: attention, one thread per (row, head), online softmax in f32 =================
+        // ================= phase 1: attention (<= MAX_L keys, exact f32).  thread = (row, head, half of the head's 48 channels): every
+        // load of a thread in one batch, q . k completed across the two halves by one shuffle; the context rows leave as the
+        // projection's A fragments (f16 hi / lo, fragment order) =================
         {
             const Sc1Buf bqkv(p.qkv);
             int t = first_task(TP_ATTN);
             bool waited = false;
             while (t < ntask[TP_ATTN]) {
-                if (!waited) { wait_phase(TP_QKV); waited = true; stamp(); }
-                const int idx = t * 256 + tid, lrow = min(idx >> 3, R - 1), hd = idx & 7;
-                const int b = lrow / p.L_in;
-                const unsigned qoff = ((unsigned)(row_in0 + lrow) * (3 * D) + hd * 48) * 4u;
-                f32x4 q[12], acc[12];
+                stamp(8 + 8 * TP_ATTN + 0);
+                if (!waited) { wait_phase(TP_QKV); waited = true; }
+                stamp(8 + 8 * TP_ATTN + 1);
+                const int lrow_u = t * 16 + (tid >> 4), hd = (tid >> 1) & 7, hf = tid & 1;
+                const int lrow = min(lrow_u, R - 1), sb = lrow / p.L_in;
+                const unsigned cb = (unsigned)(hd * 48 + hf * 24) * 4u;                    // this thread's 24 channels, bytes into q (k, v: + D, + 2 D floats)
+                f32x4 q[6], acc[6];
 #pragma unroll
-                for (int e = 0; e < 12; ++e) { q[e] = bqkv.ld(qoff + 16u * e); acc[e] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
-                float m = -INFINITY, l = 0.f;
-                const float scale = 1.44269504088896341f / sqrtf(48.f);         // logits in units of log 2
-                for (int j = 0; j < p.L_in; ++j) {
-                    const unsigned koff = ((unsigned)(row_in0 + b * p.L_in + j) * (3 * D) + D + hd * 48) * 4u;
-                    f32x4 kv[12], vv[12];
+                for (int e = 0; e < 6; ++e) q[e] = bqkv.ld((unsigned)(row_in0 + lrow) * (3 * D * 4u) + cb + 16u * e);
+                auto attend = [&](auto lk_tag) __attribute__((always_inline)) {
+                    constexpr int LK = decltype(lk_tag)::value;
+                    f32x4 kk[LK][6], vv[LK][6];
 #pragma unroll
-                    for (int e = 0; e < 12; ++e) { kv[e] = bqkv.ld(koff + 16u * e); vv[e] = bqkv.ld(koff + D * 4u + 16u * e); }
-                    float s = 0.f;
+                    for (int j = 0; j < LK; ++j) {
+                        const unsigned ro = (unsigned)(row_in0 + sb * LK + j) * (3 * D * 4u) + cb;
 #pragma unroll
-                    for (int e = 0; e < 12; ++e) s += (q[e][0] * kv[e][0] + q[e][1] * kv[e][1]) + (q[e][2] * kv[e][2] + q[e][3] * kv[e][3]);
-                    s *= scale;
-                    const float mn = fmaxf(m, s), corr = exp2f(m - mn), pj = exp2f(s - mn);
-                    l = l * corr + pj; m = mn;
+                        for (int e = 0; e < 6; ++e) { kk[j][e] = bqkv.ld(ro + D * 4u + 16u * e); vv[j][e] = bqkv.ld(ro + 2 * D * 4u + 16u * e); }
+                    }
+                    const float scale = 1.44269504088896341f / sqrtf(48.f);               // logits in units of log 2
+                    float sj[LK], m = -INFINITY;
 #pragma unroll
-                    for (int e = 0; e < 12; ++e) acc[e] = acc[e] * corr + vv[e] * pj;
+                    for (int j = 0; j < LK; ++j) {
+                        float sacc = 0.f;
+#pragma unroll
+                        for (int e = 0; e < 6; ++e) sacc += (q[e][0] * kk[j][e][0] + q[e][1] * kk[j][e][1]) + (q[e][2] * kk[j][e][2] + q[e][3] * kk[j][e][3]);
+                        sacc += __shfl_xor(sacc, 1);                                      // the other half of the head (same sum in both lanes: x + y == y + x)
+                        sj[j] = sacc * scale;
+                        m = fmaxf(m, sj[j]);
+                    }
+                    float l = 0.f;
+#pragma unroll
+                    for (int j = 0; j < LK; ++j) { sj[j] = exp2f(sj[j] - m); l += sj[j]; }
+                    const float inv = 1.0f / l;
+#pragma unroll
+                    for (int e = 0; e < 6; ++e) acc[e] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                    for (int j = 0; j < LK; ++j) {
+                        const float pj = sj[j] * inv;
+#pragma unroll
+                        for (int e = 0; e < 6; ++e) acc[e] = acc[e] + vv[j][e] * pj;
+                    }
+                };
+                switch (p.L_in) {
+                    case 1: attend(std::integral_constant<int, 1>{}); break;
+                    case 2: attend(std::integral_constant<int, 2>{}); break;
+                    case 3: attend(std::integral_constant<int, 3>{}); break;
+                    default: attend(std::integral_constant<int, 4>{}); break;
                 }
-                const float inv = 1.0f / l;
-                if ((idx >> 3) < R) {
-                    float* op = p.o + (size_t)(row_in0 + lrow) * D + hd * 48;
+                if (lrow_u < R) {
+                    // one fragment image (48 KiB) per 32-row tile of the GROUP's rows: tile index = group * tiles per group + local tile
+                    h16x8* const fo = reinterpret_cast<h16x8*>(p.o) + (size_t)(grp * RTG + (lrow >> 5)) * (24 * 2 * 64) + (lrow & 31);
 #pragma unroll
-                    for (int e = 0; e < 12; ++e) *reinterpret_cast<f32x4*>(op + 4 * e) = acc[e] * inv;
+                    for (int mm = 0; mm < 3; ++mm) {
+                        h16x8 hi, lo;
+                        split8(acc[2 * mm], acc[2 * mm + 1], hi, lo);
+                        const int k = hd * 48 + hf * 24 + 8 * mm;
+                        h16x8* d = fo + ((k >> 4) * 2) * 64 + 32 * ((k >> 3) & 1);
+                        d[0] = hi; d[64] = lo;
+                    }
                 }
                 publish(TP_ATTN, t);
                 t = next_task(TP_ATTN);
             }
         }
-        // ================= phase 2: x += o Wp + bp =================
+        // ================= phase 2: x += o Wp + bp: A fragments straight from memory, K over the 4 waves =================
         {
             const Sc1Buf bo(p.o);
             int t = first_task(TP_PROJ);
             bool waited = false;
             while (t < ntask[TP_PROJ]) {
                 const int rt = t / 12, c = t - rt * 12, s0 = wave * 6;
+                const float bias = p.bp[c * 32 + r];
                 h16x8 bh[6], bl[6];
                 load_b<6>(p.wp_f, KS_D, c, s0, lane, bh, bl);
-                if (!waited) { wait_phase(TP_ATTN); waited = true; stamp(); }
-                const int lrow = min(rt * 32 + r, R - 1), grow = row_in0 + lrow;
-                h16x8 ah[6], al[6];
-                {
-                    f32x4 xa[6], xb[6];
+                float old[16];                                                           // the residual rows (wave 0 stores the tile): not written by
+                if (wave == 0) {                                                         // anybody before this task, so they go out before the wait too
 #pragma unroll
-                    for (int q = 0; q < 6; ++q) {
-                        const unsigned off = ((unsigned)grow * D + 16 * (s0 + q) + 8 * g2) * 4u;
-                        xa[q] = bo.ld(off); xb[q] = bo.ld(off + 16u);
-                    }
-#pragma unroll
-                    for (int q = 0; q < 6; ++q) split8(xa[q], xb[q], ah[q], al[q]);
+                    for (int i = 0; i < 16; ++i) old[i] = p.x[(size_t)(row_in0 + min(rt * 32 + 8 * (i >> 2) + 4 * g2 + (i & 3), R - 1)) * D + c * 32 + r];
                 }
-                f32x16 acc;
-                mfma_unit<6>(ah, al, bh, bl, acc);
-                if (combine(acc, 4)) {
+                stamp(8 + 8 * TP_PROJ + 0);
+                if (!waited) { wait_phase(TP_ATTN); waited = true; }
+                stamp(8 + 8 * TP_PROJ + 1);
+                h16x8 ah[6], al[6];
+#pragma unroll
+                for (int q = 0; q < 6; ++q) {
+                    const unsigned off = ((unsigned)(grp * RTG + rt) * (24 * 2 * 64) + (unsigned)((s0 + q) * 2) * 64 + lane) * 16u;
+                    ah[q] = __builtin_bit_cast(h16x8, bo.ld(off)); al[q] = __builtin_bit_cast(h16x8, bo.ld(off + 1024u));
+                }
+                f32x16 out;
+                mfma_unit<6>(ah, al, bh, bl, out);
+                stamp(8 + 8 * TP_PROJ + 4);
+                if (combine4(out)) {
                     const int col = c * 32 + r;
-                    const float bias = p.bp[col];
 #pragma unroll
                     for (int i = 0; i < 16; ++i) {
                         const int lr = rt * 32 + 8 * (i >> 2) + 4 * g2 + (i & 3);
-                        if (lr < R) { float* xp = p.x + (size_t)(row_in0 + lr) * D + col; *xp = *xp + (acc[i] + bias); }
+                        if (lr < R) p.x[(size_t)(row_in0 + lr) * D + col] = old[i] + (out[i] + bias);
                     }
                 }
                 publish(TP_PROJ, t);
                 t = next_task(TP_PROJ);
             }
         }
-        // ================= phase 3: hb = relu(LN2(x) W1 + b1) =================
+        // ================= phase 3: hb = relu(LN2(x) W1 + b1), as f16 hi / lo planes (the convolution's A operand) =================
         ln_dense(TP_FC1, TP_PROJ, 24, p.w1_f, p.ln2_g, p.ln2_b, p.b1, p.hb, H, true);
-        // ================= phase 4: partial sums of the strided 3-tap convolution (ZeroPadding1D + Conv1D, u_u_t.py:126-131) =================
+        // ================= phase 4: partial sums of the strided 3-tap convolution (ZeroPadding1D + Conv1D, u_u_t.py:126-131); the A
+        // operand = 16 bytes per lane and k-slice of the hidden activations' f16 planes, no arithmetic =================
         {
             const Sc1Buf bhb(p.hb);
+            const unsigned lo_off = (unsigned)p.B * p.L_in * H * 2u;             // bytes from the hi plane to the lo plane
             int t = first_task(TP_CONV);
             bool waited = false;
             while (t < ntask[TP_CONV]) {
@@ -398,31 +480,27 @@ strided_tail_kernel_t(const TailParams p)
                 const int s0 = hf * (KS_C / 2) + wave * 18;                      // absolute k-slice of K = 2304
                 h16x8 bh[18], bl[18];
                 load_b<18>(p.wc_f, KS_C, c, s0, lane, bh, bl);
-                if (!waited) { wait_phase(TP_FC1); waited = true; stamp(); }
+                stamp(8 + 8 * TP_CONV + 0);
+                if (!waited) { wait_phase(TP_FC1); waited = true; }
+                stamp(8 + 8 * TP_CONV + 1);
                 const int lro = min(rt * 32 + r, Ro - 1);                        // output row (b, tt) of the group
                 const int b = lro / p.L_out, tt = lro - b * p.L_out;
                 const int t0 = tt * p.stride - p.pad_left;
                 h16x8 ah[18], al[18];
-                {
-                    f32x4 xa[18], xb[18];
-                    bool ok[18];
 #pragma unroll
-                    for (int q = 0; q < 18; ++q) {
-                        const int k = 16 * (s0 + q) + 8 * g2, j = k / H, cc = k - j * H;
-                        const int src = t0 + j;
-                        ok[q] = src >= 0 && src < p.L_in;
-                        const unsigned off = ((unsigned)(row_in0 + b * p.L_in + min(max(src, 0), p.L_in - 1)) * H + cc) * 4u;
-                        xa[q] = bhb.ld(off); xb[q] = bhb.ld(off + 16u);
-                    }
-#pragma unroll
-                    for (int q = 0; q < 18; ++q) {
-                        const f32x4 z = {0.f, 0.f, 0.f, 0.f};
-                        split8(ok[q] ? xa[q] : z, ok[q] ? xb[q] : z, ah[q], al[q]);
-                    }
+                for (int q = 0; q < 18; ++q) {
+                    const int k = 16 * (s0 + q) + 8 * g2, j = k / H, cc = k - j * H;
+                    const int src = t0 + j;
+                    const bool ok = src >= 0 && src < p.L_in;
+                    const unsigned off = ((unsigned)(row_in0 + b * p.L_in + min(max(src, 0), p.L_in - 1)) * H + cc) * 2u;
+                    const f32x4 vh = bhb.ld(off), vl = bhb.ld(lo_off + off);
+                    const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+                    ah[q] = __builtin_bit_cast(h16x8, ok ? vh : z); al[q] = __builtin_bit_cast(h16x8, ok ? vl : z);
                 }
                 f32x16 acc;
                 mfma_unit<18>(ah, al, bh, bl, acc);
-                if (combine(acc, 4)) {
+                stamp(8 + 8 * TP_CONV + 4);
+                if (combine4(acc)) {
                     const int col = c * 32 + r;
                     float* pp = p.part + (size_t)hf * p.B * p.L_out * D;
 #pragma unroll
@@ -443,9 +521,12 @@ strided_tail_kernel_t(const TailParams p)
             bool waited = false;
             while (t < ntask[TP_HEAD]) {
                 const int rt = t / hchunks, c = t - rt * hchunks, s0 = wave * 6;
+                const float hbias = p.bh[min(c * 32 + r, p.n_out - 1)];
                 h16x8 bh[6], bl[6];
                 load_b<6>(p.wh_f, KS_D, c, s0, lane, bh, bl);
-                if (!waited) { wait_phase(TP_CONV); waited = true; stamp(); }
+                stamp(8 + 8 * TP_HEAD + 0);
+                if (!waited) { wait_phase(TP_CONV); waited = true; }
+                stamp(8 + 8 * TP_HEAD + 1);
                 const int lro = min(rt * 32 + r, Ro - 1);
                 const int b = lro / p.L_out, tt = lro - b * p.L_out;
                 const unsigned xrow = (unsigned)(row_in0 + b * p.L_in + tt * p.stride + p.res_lo);
@@ -470,10 +551,10 @@ strided_tail_kernel_t(const TailParams p)
                 }
                 f32x16 acc;
                 mfma_unit<6>(ah, al, bh, bl, acc);
-                if (combine(acc, 4)) {
+                if (combine4(acc)) {
                     const int col = c * 32 + r;
                     if (col < p.n_out) {
-                        const float bias = p.bh[col];
+                        const float bias = hbias;
 #pragma unroll
                         for (int i = 0; i < 16; ++i) {
                             const int lr = rt * 32 + 8 * (i >> 2) + 4 * g2 + (i & 3);
@@ -485,7 +566,19 @@ strided_tail_kernel_t(const TailParams p)
                 t = next_task(TP_HEAD);
             }
         }
+        // Stay until the group is complete.  A workgroup without tasks would otherwise go looking for unowned groups at once and take
+        // the group of an XCD whose workgroups merely started a few microseconds late (seen in tools/tail_exp: that group then ran on
+        // the idle workgroups of a foreign XCD alone, 20 us late).  Stealing is for XCDs that never show up.
+        if (wave == 0) {
+            unsigned spins = 0;
+            while (ld_u32_agent(&ctl->done[grp].v[TP_HEAD]) < (unsigned)ntask[TP_HEAD]) {
+                __builtin_amdgcn_s_sleep(64);
+                if (++spins > SPIN_LIMIT) { if (lane == 0) atomicOr(&ctl->err, (unsigned)TAIL_ERR_TIMEOUT); break; }
+            }
+        }
+        __syncthreads();
     }
+    if (tid == 0) atomicAdd(&ctl->census[xcc & 7u], 1u);             // diagnostics (uu3d_tail_status): workgroups seen per XCC id
 }
 
 }  // namespace uu3d
