@@ -1073,7 +1073,8 @@ int uu3d_forward(uu3d_model* m, const float* kp2d, const uint8_t* mask, int32_t 
     // `pend` != nullptr: the previous temporal block ended in the fused MLP -- its fc2 result still sits in w.mslab; this
     // block's first LayerNorm launch adds it to the residual stream (for the first strided block: to w.X, and x = w.XA = X + pe).
     // `fuse_mlp`: stop after the second LayerNorm (its fragments in Ph feed mlp_fused).
-    auto block_head = [&](const char* tag, int i, const BlockDev& b, float* x, int L, const uint8_t* kmask, const BlockDev* pend, bool fuse_mlp) {
+    // returns the fragment-ordered LayerNorm-2 output when `fuse_mlp` stopped the block in front of the MLP (else nullptr)
+    auto block_head = [&](const char* tag, int i, const BlockDev& b, float* x, int L, const uint8_t* kmask, const BlockDev* pend, bool fuse_mlp) -> const _Float16* {
         const int Mr = B * L;
         auto name = [&](const char* what) { snprintf(nm, sizeof nm, "%s%d.%s", tag, i + 1, what); return nm; };
         _Float16* const Pl = Ph + (size_t)Mr * dt; _Float16* const Hl = Hh + (size_t)Mr * ht;
@@ -1095,7 +1096,7 @@ int uu3d_forward(uu3d_model* m, const float* kp2d, const uint8_t* mask, int32_t 
             { GLoadPlain gl{Ph, Pl, dt, Mr}; Lh.gemm_g(name("proj_res"), gl, b.wp_t, Mr, dt, dt, EpBiasResidual{x, b.bp, dt, nullptr, nullptr, 1}, 4.0 * Mr * dt); }
             WtLoadF32 l2{x, dt, Mr, dt, b.ln2_g, b.ln2_b, 1e-5f, 1};
             Lh.gemm_wt(name("ln_fc1"), l2, b.w1_t, Mr, ht, dt, EpBiasReluSplit{Hh, Hl, b.b1, ht});
-            return;
+            return nullptr;
         }
         if (pend != nullptr) {                                     // (same row count as the block that left it: the panel path holds)
             if (x == w.X) Lh.ln_res_split_frag(name("ln1_split"), w.X, Mr, pend->b2, w.mslab, nullptr, nullptr, 1, b.ln1_g, b.ln1_b, Ph);
@@ -1120,7 +1121,7 @@ int uu3d_forward(uu3d_model* m, const float* kp2d, const uint8_t* mask, int32_t 
         }
         if (planes && Lh.panel_ok(Mr, ht, dt, b.w1_pf)) {
             Lh.ln_split_frag(name("ln2_split"), x, Mr, b.ln2_g, b.ln2_b, Ph);
-            if (fuse_mlp) return;
+            if (fuse_mlp) return Ph;
             Lh.gemm_panel(name("ln_fc1"), Ph, b.w1_pf, b.b1, Mr, ht, PanelEpBiasReluSplit{Hh, Hl, ht});
         } else {
             Lh.row_stats(name("stats2"), x, dt, Mr, w.stats);
@@ -1128,6 +1129,7 @@ int uu3d_forward(uu3d_model* m, const float* kp2d, const uint8_t* mask, int32_t 
             if (planes) { EpBiasReluSplit ep{Hh, Hl, b.b1, ht}; Lh.gemm(name("ln_fc1"), al, b.w1_t, Mr, ht, dt, ep); }
             else { EpBiasRelu ep{w.Hb, b.b1, ht}; Lh.gemm(name("ln_fc1"), al, b.w1_t, Mr, ht, dt, ep); }
         }
+        return nullptr;
     };
 
     // 3. temporal blocks.  With >= 1024 token rows the MLP is one launch (uu3d_mlp_fused.h): its three partial fc2 sums are
@@ -1139,11 +1141,11 @@ int uu3d_forward(uu3d_model* m, const float* kp2d, const uint8_t* mask, int32_t 
         const bool last = (i + 1 == c.temporal_depth);
         const bool fuse = planes && Lh.mlpf_ok(M, b) && Lh.panel_ok(M, 3 * dt, dt, m->sblocks[0].wqkv_pf) &&
                           (last || Lh.panel_ok(M, 3 * dt, dt, m->tblocks[i + 1].wqkv_pf));
-        block_head("t", i, b, w.X, N, masked ? mask : nullptr, pend, fuse);
+        const _Float16* const a2 = block_head("t", i, b, w.X, N, masked ? mask : nullptr, pend, fuse);
         pend = nullptr;
         if (fuse) {
             snprintf(nm, sizeof nm, "t%d.mlp", i + 1);
-            Lh.mlp_fused(nm, Ph, b, M, w.mslab);
+            Lh.mlp_fused(nm, a2, b, M, w.mslab);
             pend = &b;
             continue;
         }

@@ -82,15 +82,13 @@ struct Sc1Buf {
 };
 __device__ __forceinline__ unsigned ld_u32_agent(const unsigned* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 
-// LDS (all dynamic, 16-byte aligned pieces): [0, BIG): the K | V rows of the attention, then the A fragments (aliased: a barrier
-// between the last K / V read and the first fragment write); red: partial tiles of a unit whose K is split over waves
+// LDS (all dynamic, 16-byte aligned pieces): [0, BIG): the A fragments of the task's row tile; red: partial tiles of a unit whose
+// K is split over waves
 constexpr int AFRAG_BYTES = 24 * 2 * 1024;               // A fragments of one 32-row tile, K = 384: [k-slice][plane][lane][8 halfs]
-constexpr int KV_HS = 52, KV_LD = 2 * 8 * KV_HS + 8;     // staged key | value rows (f32): [k | v][head][48 + 4 pad] (+ 8): conflict-free 16-byte reads of 8 heads
-constexpr int KV_ROWS = 40;
-constexpr int BIG_BYTES = KV_ROWS * KV_LD * 4;           // 124 160
+constexpr int BIG_BYTES = AFRAG_BYTES;
 constexpr int RED_BYTES = 4 * 16 * 64 * 4;
+constexpr int MAX_L = 4;                                 // keys per sequence the unrolled attention holds in registers
 constexpr int LDS_BYTES = BIG_BYTES + RED_BYTES + 256 + 2 * 384 * 4;   // + broadcast words + LayerNorm gamma | beta
-constexpr int MAX_L = 4;                                 // tokens per sequence the staged attention holds (KV_ROWS >= 32 + 2 MAX_L)
 
 // ---- the product of one unit: rows (lane & 31) of a 32-row tile x 32 columns, k-slices [0, SPW) of this wave -------------------
 template <int SPW>
@@ -134,7 +132,6 @@ strided_tail_kernel_t(const TailParams p)
     using namespace tail;
     h3_flush_f16_denormals();
     extern __shared__ __attribute__((aligned(16))) unsigned char tsm[];
-    float* const kvs = reinterpret_cast<float*>(tsm);                               // [KV_ROWS][KV_LD]
     h16x8* const afr = reinterpret_cast<h16x8*>(tsm);                               // [24][2][64]
     float (*red)[16][64] = reinterpret_cast<float (*)[16][64]>(tsm + BIG_BYTES);
     int* const ish = reinterpret_cast<int*>(tsm + BIG_BYTES + RED_BYTES);           // [0]: broadcast, [8 ..]: first tickets
