@@ -128,6 +128,115 @@ def train_bench(args, world, rank, local_rank, use_dist):
 
 
 
+def quick_forward_bench(cfgname, batch, s_in=None, streams=1, graph=True, steps=40, warmup=10, precision="f16x3", attention=False):
+    """A short timing of another workload for the `secondary` block of the bench line (same process, same GPU): sequences/s and
+    ms per step of the forward + error kernel, `streams` batches in flight; attention=True adds the temporal-attention launch's
+    HIP-event time and its fraction of the MFMA peak."""
+    import numpy as np
+    import torch
+    import uplift_upsample_3dhpe_amd as pkg
+    from uplift_upsample_3dhpe_amd import synthetic as util
+    from uplift_upsample_3dhpe_amd.harness import per_joint_error
+    cfg = util.load_config(cfgname)
+    arch = pkg.arch_from_config(cfg)
+    model = pkg.build_uplift_upsample_transformer(cfg, weights=pkg.init_weights(arch, seed=0), precision=precision)
+    s_in = s_in or (cfg.MASK_STRIDE[0] if isinstance(cfg.MASK_STRIDE, list) else cfg.MASK_STRIDE)
+    x_np, m_np = util.synthetic_batch(cfg, batch, seed=1000, mask_specs=[(s_in, 0)])
+    x = torch.from_numpy(x_np * m_np[:, :, None, None].astype(np.float32)).cuda()
+    m = torch.from_numpy(m_np).cuda()
+    J = arch.num_keypoints
+    gt = torch.cat([torch.randn(batch, J, 3, device="cuda") * 0.3, torch.ones(batch, J, 1, device="cuda")], -1)
+    errs = [torch.empty((batch, J), dtype=torch.float64, device="cuda") for _ in range(streams)]
+    pipe = model.pipeline(batch, depth=streams, graph=graph, post=lambda f, c, i: per_joint_error(c, gt, cfg.ROOT_KEYTPOINT, out=errs[i]))
+
+    def run(n):
+        tickets = []
+        for _ in range(n):
+            tickets.append(pipe.submit(x, m))
+            if len(tickets) == streams:
+                pipe.result(tickets.pop(0))
+        for t in tickets:
+            pipe.result(t)
+    run(warmup)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    run(steps)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    out = {"workload": f"config/{cfgname}.json, batch {batch}, s_in {s_in}" if cfgname != "dense_351" else f"synthetic dense-351 (NOT a shipped config), batch {batch}",
+           "value": round(batch * steps / dt, 1), "unit": "pose-sequences/s", "ms_per_step": round(1e3 * dt / steps, 4), "steps": steps,
+           "batches_in_flight": streams, "hipgraph": bool(graph)}
+    if attention:
+        model.set_profiling(True)
+        agg = {}
+        for _ in range(3):
+            model([x, m], training=False)
+            for e in model.read_profile():
+                nm = e["name"]
+                key = ("t." + nm.split(".", 1)[1]) if (nm[0] == "t" and "." in nm) else nm
+                a = agg.setdefault(key, dict(ms=0.0, flops=0.0, bytes=0.0, n=0, kernel=e["kernel"]))
+                a["ms"] += e["ms"]; a["flops"] += e["flops"]; a["n"] += 1
+        model.set_profiling(False)
+        out["attention"] = attention_roofline(agg, arch.num_frames, out["workload"])
+    del pipe, model
+    torch.cuda.empty_cache()
+    return out
+
+
+def quick_train_bench(steps=50, warmup=10, batch=64):
+    """BASELINE config 5 (config/h36m_351_pt.json train step: fwd + bwd + AdamW) at world size 1, for the `secondary` block."""
+    import numpy as np
+    import torch
+    import uplift_upsample_3dhpe_amd as pkg
+    from uplift_upsample_3dhpe_amd import synthetic as util
+    from uplift_upsample_3dhpe_amd import harness
+    from uplift_upsample_3dhpe_amd.trainer import Trainer
+    cfg = util.load_config("h36m_351_pt")
+    cfg.BATCH_SIZE = batch
+    arch = pkg.arch_from_config(cfg)
+    model = pkg.build_uplift_upsample_transformer(cfg, weights=pkg.init_weights(arch, seed=0))
+    tr = Trainer(model, cfg, seed=100)
+    rng = np.random.default_rng(3000)
+    N, J = arch.num_frames, arch.num_keypoints
+    x = torch.from_numpy(rng.uniform(-1, 1, size=(batch, N, J, 2)).astype(np.float32)).cuda()
+    gt = torch.from_numpy(rng.normal(0, 0.3, size=(batch, N, J, 3)).astype(np.float32)).cuda()
+    m = torch.from_numpy(harness.stride_masks_train(N, cfg.SEQUENCE_STRIDE, cfg.MASK_STRIDE, batch, rng, cfg.STRIDE_MASK_RAND_SHIFT)).cuda()
+    for _ in range(warmup):
+        tr.train_step(x, gt, m)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        loss = tr.train_step(x, gt, m)
+    enqueue = time.perf_counter() - t0
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    out = {"workload": f"config/h36m_351_pt.json train step (fwd + bwd + AdamW), batch {batch}, DropPath {cfg.DROP_PATH_RATE}",
+           "value": round(batch * steps / dt, 1), "unit": "pose-sequences/s", "ms_per_step": round(1e3 * dt / steps, 3), "steps": steps,
+           "host_enqueue_ms_per_step": round(1e3 * enqueue / steps, 3), "loss": float(loss[0].item())}
+    del tr, model
+    torch.cuda.empty_cache()
+    return out
+
+
+def secondary_benchmarks(args):
+    """The other claims of DESIGN.md in the same driver-run JSON line: ~20 steps each."""
+    out = {}
+    jobs = [("latency_one_batch_in_flight", lambda: quick_forward_bench(args.config, args.batch, streams=1, graph=True)),
+            ("eager_one_batch_in_flight", lambda: quick_forward_bench(args.config, args.batch, streams=1, graph=False)),
+            ("eager_pipelined", lambda: quick_forward_bench(args.config, args.batch, streams=max(2, args.streams), graph=False)),
+            ("h36m_81_batch256", lambda: quick_forward_bench("h36m_81", 256, streams=max(1, args.streams))),
+            ("s_in_10", lambda: quick_forward_bench(args.config, args.batch, s_in=10, streams=max(1, args.streams))),
+            ("s_in_20", lambda: quick_forward_bench(args.config, args.batch, s_in=20, streams=max(1, args.streams))),
+            ("dense_351_batch32", lambda: quick_forward_bench("dense_351", 32, streams=1, attention=True)),
+            ("train_step", lambda: quick_train_bench())]
+    for name, fn in jobs:
+        try:
+            out[name] = fn()
+        except Exception as e:  # pragma: no cover
+            out[name] = {"error": f"{type(e).__name__}: {e}"}
+    return out
+
+
 def pmc_summary_for(config, batch):
     """The committed --pmc summary that was collected on THIS workload (config, per-GPU batch), or None: counters of another
     shape say nothing about this one."""
@@ -197,7 +306,9 @@ def main():
     ap.add_argument("--config", default="h36m_351")
     ap.add_argument("--mask-stride", type=int, default=None, help="s_in; default = first MASK_STRIDE")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the short secondary workloads (other configs, eager, train step) appended to the JSON line at N = 1")
     ap.add_argument("--no-graph", action="store_true", help="launch eagerly instead of replaying a hipGraph")
+    ap.add_argument("--streams", type=int, default=2, help="independent batches in flight (pipeline.ForwardPipeline: one HIP stream, workspace and hipGraph each); 1 = one batch after the other")
     ap.add_argument("--precision", default="f16x3", choices=["f16x3", "f32"], help="GEMM arithmetic of the forward (both hold the 1e-4 parity bar)")
     ap.add_argument("--mode", default="infer", choices=["infer", "train"], help="train = fwd + bwd + grad all-reduce + AdamW (BASELINE config 5)")
     ap.add_argument("--halves", action="store_true", help="two concurrent half-batch chains on two streams instead of one chain of kernels per batch")
@@ -252,21 +363,30 @@ def main():
     gathered = torch.empty((world * B, J), dtype=torch.float64, device="cuda") if use_dist else None
     from uplift_upsample_3dhpe_amd.harness import per_joint_error
 
-    def compute():
-        full, central = model([x, m], training=False)
-        per_joint_error(central, gt, cfg.ROOT_KEYTPOINT, out=err)
-
     def sync_all():
         torch.cuda.synchronize()
         if use_dist:
             dist.barrier()
             torch.cuda.synchronize()
 
-    # the forward + error kernel replay from a hipGraph; the RCCL all-gather stays outside the graph
+    # A step = one batch through the forward + the per-joint error kernel (+ the all-gather of its (B, J) block with N > 1).
+    # `--streams S` batches are in flight at once (pipeline.ForwardPipeline: each on its own HIP stream with its own workspace,
+    # static buffers and hipGraph of forward + error kernel); S = 1 is one batch after the other.  The RCCL all-gather stays
+    # outside the graphs, on the caller's stream.
+    S = 1 if (args.halves and not args.no_halves) else max(1, args.streams)
+    pipe = None
     use_graph = not args.no_graph
-    run_compute = compute
-    if use_graph:
-        try:
+    errs = [torch.empty((B, J), dtype=torch.float64, device="cuda") for _ in range(S)]
+
+    def post(full, central, i):
+        return per_joint_error(central, gt, cfg.ROOT_KEYTPOINT, out=errs[i])
+
+    if args.halves and not args.no_halves:             # legacy option: two half-batch chains inside one call (no pipeline object)
+        def compute():
+            full, central = model([x, m], training=False)
+            per_joint_error(central, gt, cfg.ROOT_KEYTPOINT, out=err)
+        run_compute = compute
+        if use_graph:
             for _ in range(2):
                 compute()
             torch.cuda.synchronize()
@@ -274,22 +394,38 @@ def main():
             with torch.cuda.graph(g):
                 compute()
             run_compute = g.replay
+
+        def run_steps(n):
+            for _ in range(n):
+                run_compute()
+                if use_dist:
+                    dist.all_gather_into_tensor(gathered, err)
+    else:
+        try:
+            pipe = model.pipeline(B, depth=S, graph=use_graph, post=post)
         except Exception as e:  # pragma: no cover
             print(f"[bench] graph capture failed ({e}); running eagerly", file=sys.stderr)
             use_graph = False
-            run_compute = compute
+            pipe = model.pipeline(B, depth=S, graph=False, post=post)
 
-    def run():
-        run_compute()
-        if use_dist:
-            dist.all_gather_into_tensor(gathered, err)
+        def run_steps(n):
+            tickets = []
 
-    for _ in range(args.warmup):
-        run()
+            def consume(t):
+                e = pipe.result(t)[2]
+                if use_dist:
+                    dist.all_gather_into_tensor(gathered, e)
+            for _ in range(n):
+                tickets.append(pipe.submit(x, m))
+                if len(tickets) == S:
+                    consume(tickets.pop(0))
+            for t in tickets:
+                consume(t)
+
+    run_steps(args.warmup)
     sync_all()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        run()
+    run_steps(args.steps)
     sync_all()
     elapsed = time.perf_counter() - t0
     if use_dist:
@@ -338,7 +474,11 @@ def main():
                                    f"{(N - 1) * cfg.SEQUENCE_STRIDE + 1}), J={J}, batch {B}/GPU, s_in={s_in}, "
                                    f"seeded Keras-default weights", "global_batch": world * B,
                        "parallelism": f"batch-sharded x{world}", "hipgraph": bool(use_graph),
-                       "concurrent_half_batches": bool(args.halves and not args.no_halves and B >= 64)},
+                       "concurrent_half_batches": bool(args.halves and not args.no_halves and B >= 64),
+                       "batches_in_flight": S,
+                       "pipelining": (f"{S} independent batches in flight on {S} HIP streams, each replaying its own hipGraph of forward + error "
+                                      "kernel with its own workspace (uplift-upsample-3dhpe_amd/pipeline.py; the same path eval.run_eval uses)") if S > 1
+                                     else "one batch after the other"},
             "roofline": {"bound": "mfma", "kernel": f"{gk} [{dom_key}]",
                          "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s",
                          "frac": round(ach / peak, 4), "traffic": pmc_traffic(gk, dom_key, pmc_summary_for(args.config, B)),
@@ -362,6 +502,9 @@ def main():
             out["cpu_baseline"] = cpu_baseline(cfg, arch, weights, x_np, m_np)
         else:
             out["cpu_baseline"] = None
+        if world == 1 and not args.no_secondary and args.config == "h36m_351":
+            pipe = None
+            out["secondary"] = secondary_benchmarks(args)
         print(json.dumps(out), flush=True)
     if use_dist:
         dist.destroy_process_group()

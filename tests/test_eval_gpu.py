@@ -72,3 +72,54 @@ def test_run_eval_matches_the_reference_protocol(cfgname, action_wise):
     assert bfull["num_forwarded"] == bfull["num_windows"] > a["num_forwarded"]
     for k in a["all_frames"]:
         assert abs(a["all_frames"][k] - bfull["all_frames"][k]) <= 1e-3       # mm: identical windows, batches composed differently
+
+
+def test_pipelined_forwards_are_bit_identical():
+    """pipeline.ForwardPipeline (several batches in flight on several streams, hipGraph replay) = the same launches on the same
+    data as model(...): bit-identical outputs, ragged last batch included, with and without graphs, depth 1 .. 3; model.capture
+    (the single-stream graph replay) likewise."""
+    cfg = util.load_config("h36m_351")
+    arch = pkg.arch_from_config(cfg)
+    w = pkg.init_weights(arch, seed=3, perturb=0.1)
+    model = pkg.build_uplift_upsample_transformer(cfg, weights=w)
+    B = 24
+    batches = []
+    for i, n in enumerate([B, B, B, B, 7]):
+        x, m = util.synthetic_batch(cfg, n, seed=10 + i)
+        batches.append((torch.from_numpy(x * m[:, :, None, None].astype(np.float32)).cuda(), torch.from_numpy(m).cuda()))
+    want = [tuple(t.clone() for t in model([x, m], training=False)) for x, m in batches]
+    for depth, graph in [(1, True), (2, True), (3, True), (2, False)]:
+        pipe = model.pipeline(B, depth=depth, graph=graph)
+        for rep in range(2):                                   # the second pass reuses every slot
+            got = [(f.clone(), c.clone()) for f, c in pipe.run(batches)]
+            assert len(got) == len(want)
+            for (f, c), (fw, cw) in zip(got, want):
+                assert torch.equal(f, fw) and torch.equal(c, cw), (depth, graph, rep)
+    f = model.capture(B)
+    for (x, m), (fw, cw) in zip(batches[:4], want[:4]):
+        full, cen = f([x, m])
+        assert torch.equal(full, fw) and torch.equal(cen, cw)
+    # protocol misuse is reported, not silently wrong
+    pipe = model.pipeline(B, depth=2, graph=False)
+    t0 = pipe.submit(*batches[0]); pipe.submit(*batches[1])
+    with pytest.raises(RuntimeError):
+        pipe.submit(*batches[2])                               # slot 0 still holds an unread result
+    pipe.result(t0)
+    with pytest.raises(RuntimeError):
+        pipe.result(t0)
+
+
+def test_run_eval_with_and_without_pipelining():
+    """run_eval's default (2 batches in flight, hipGraph replay) against the reference's loop shape (depth 1, eager): identical reports."""
+    from uplift_upsample_3dhpe_amd import eval as ev
+    cfg = util.load_config("h36m_351")
+    cfg.BATCH_SIZE = 16
+    cfg.MASK_STRIDE = cfg.MASK_STRIDE[0]
+    arch = pkg.arch_from_config(cfg)
+    model = pkg.build_uplift_upsample_transformer(cfg, weights=pkg.init_weights(arch, seed=2, perturb=0.1))
+    args = (cfg, "h36m", os.path.join(G, "h36m_tiny_3d.npz"), os.path.join(G, "h36m_tiny_2d.npz"), "S9")
+    a = ev.run_eval(*args, model=model, action_wise=False, log=lambda *a: None)
+    b = ev.run_eval(*args, model=model, action_wise=False, log=lambda *a: None, depth=1, graph=False)
+    c = ev.run_eval(*args, model=model, action_wise=False, log=lambda *a: None, depth=3, graph=True)
+    for k in a["all_frames"]:
+        assert a["all_frames"][k] == b["all_frames"][k] == c["all_frames"][k]

@@ -194,7 +194,7 @@ def test_concurrent_half_batches_option(cfgname, batch):
     assert np.abs(f1 - f2).max() <= 2e-5 and np.abs(c1 - c2).max() <= 2e-5
 
 
-@pytest.mark.parametrize("env", ["UU3D_NO_PANEL", "UU3D_NO_PLANES", "UU3D_ATTN_WG", "UU3D_NO_WT", "UU3D_ATTN_F32", "UU3D_NO_MLPF", "UU3D_NO_TAIL"])
+@pytest.mark.parametrize("env", ["UU3D_NO_PANEL", "UU3D_NO_PLANES", "UU3D_ATTN_WG", "UU3D_NO_WT", "UU3D_ATTN_F32", "UU3D_NO_MLPF", "UU3D_TAIL"])
 def test_optional_kernel_paths_agree(env, monkeypatch):
     """The opt-out switches kept for A/B measurements at the full h36m_351 batch, where every one of them
     changes the kernels that run: same results as the product path to rounding.  (The round-1 experiments that measured
@@ -205,8 +205,6 @@ def test_optional_kernel_paths_agree(env, monkeypatch):
     w = pkg.init_weights(arch, seed=5, perturb=0.1)
     x, m = util.synthetic_batch(cfg, 128, seed=5)
     x = x * m[:, :, None, None]
-    if env == "UU3D_NO_WT":            # the few-row kernel only runs where the cooperative tail kernel (round 3) does not: compare on the launch chain
-        monkeypatch.setenv("UU3D_NO_TAIL", "1")
     f0, c0 = _call(pkg.build_uplift_upsample_transformer(cfg, weights=w), x, m)
     monkeypatch.setenv(env, "1")
     f1, c1 = _call(pkg.build_uplift_upsample_transformer(cfg, weights=w), x, m)

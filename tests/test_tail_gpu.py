@@ -1,6 +1,6 @@
 """GPU: the XCD-cooperative tail kernel (csrc/uu3d_tail.h: the last StridedTransformerBlock + strided_temporal_fc of
 common/net/uplift_upsample_transformer.py:93-160,414-416 as one launch) against the CPU oracle, against the launch chain it
-replaces (UU3D_NO_TAIL=1), and its own protocol diagnostics: no bounded spin may give up and no workgroup may ever observe
+replaces (the default), and its own protocol diagnostics: no bounded spin may give up and no workgroup may ever observe
 data stamped by a foreign XCC id."""
 import numpy as np
 import pytest
@@ -12,8 +12,18 @@ torch = pytest.importorskip("torch")
 pytestmark = pytest.mark.gpu
 
 
-def _model(cfg, w):
-    return pkg.build_uplift_upsample_transformer(cfg, weights=w, precision="f16x3")
+def _model(cfg, w, tail=True, **kw):
+    """The tail kernel is opt-in (UU3D_TAIL=1 when the model is created; DESIGN.md: it ties with the launch chain)."""
+    import os
+    old = os.environ.get("UU3D_TAIL")
+    os.environ["UU3D_TAIL"] = "1" if tail else "0"
+    try:
+        return pkg.build_uplift_upsample_transformer(cfg, weights=w, precision="f16x3", **kw)
+    finally:
+        if old is None:
+            del os.environ["UU3D_TAIL"]
+        else:
+            os.environ["UU3D_TAIL"] = old
 
 
 def _forward(model, x, m):
@@ -46,11 +56,9 @@ def test_tail_matches_oracle_and_chain(cfgname, batch, monkeypatch):
     # every owner word names an XCD that really had workgroups
     for o in st["owner"][:groups]:
         assert st["census"][o - 1] > 0
-    monkeypatch.setenv("UU3D_NO_TAIL", "1")
-    chain = _model(cfg, w)
-    monkeypatch.delenv("UU3D_NO_TAIL")
+    chain = _model(cfg, w, tail=False)
     full_c, central_c, _ = _forward(chain, x, m)
-    assert all(o == 0 for o in chain.tail_status(batch)["owner"]), "UU3D_NO_TAIL=1 still ran the tail kernel"
+    assert all(o == 0 for o in chain.tail_status(batch)["owner"]), "the launch-chain model ran the tail kernel"
     n_oracle = min(batch, 12)                    # the oracle on the first sequences (sequences are independent)
     f32, c32 = O.forward(util.hp_from_arch(arch), w, xm[:n_oracle], m[:n_oracle], torch.float32)
     err = np.abs(central[:n_oracle] - c32).max()
@@ -76,8 +84,8 @@ def test_tail_under_concurrent_streams():
     arch = pkg.arch_from_config(cfg)
     w = pkg.init_weights(arch, seed=7, perturb=0.1)
     x, m = util.synthetic_batch(cfg, batch=128, seed=11)
-    one = pkg.build_uplift_upsample_transformer(cfg, weights=w, precision="f16x3")
-    two = pkg.build_uplift_upsample_transformer(cfg, weights=w, precision="f16x3", concurrent_halves=True)
+    one = _model(cfg, w)
+    two = _model(cfg, w, concurrent_halves=True)
     _, c1, _ = _forward(one, x, m)
     for _ in range(10):
         _, c2, _ = _forward(two, x, m)

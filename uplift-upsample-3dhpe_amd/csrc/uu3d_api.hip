@@ -103,7 +103,7 @@ struct uu3d_model {
     bool attn_f32 = false;         // UU3D_ATTN_F32=1: sequences of 49-128 tokens stay on the exact-f32 attention kernels (A/B measurements, tests)
     bool attn_wg = false;          // UU3D_ATTN_WG=1: attention with one workgroup per (sequence, head) (attn_f32_kernel) instead of one wave per item (A/B measurements, tests)
     bool no_panel = false;         // UU3D_NO_PANEL=1: LayerNorm-fed GEMMs stay on the tiled kernels (A/B measurements, tests)
-    bool no_tail = false;          // UU3D_NO_TAIL=1: the last strided block + head2 stay a chain of launches instead of strided_tail_kernel (A/B measurements, tests)
+    bool no_tail = true;           // UU3D_TAIL=1 (opt-in): the last strided block + head2 as ONE XCD-cooperative launch (strided_tail_kernel) instead of a chain of 9 -- measured equal for one batch at a time and 0.7 % slower with two batches in flight (its 256 spinning workgroups hold every CU), profiles/r03_tail_ab.txt
     size_t h2_pf = 0;              // fragment-ordered head2 operand (uu3d_tail.h), offset in harena, 0 = none
     int num_cus = 256;
     bool no_planes = false;        // UU3D_NO_PLANES=1: keep the on-the-fly split GEMMs in f16x3 mode (A/B measurements, tests)
@@ -317,7 +317,7 @@ int uu3d_create(const uu3d_config* c, int device, uu3d_model** out) {
     { const char* e = getenv("UU3D_NO_WT"); m->no_wt = (e != nullptr && e[0] == '1'); }
     { const char* e = getenv("UU3D_ATTN_F32"); m->attn_f32 = (e != nullptr && e[0] == '1'); }
     { const char* e = getenv("UU3D_NO_PANEL"); m->no_panel = (e != nullptr && e[0] == '1'); }
-    { const char* e = getenv("UU3D_NO_TAIL"); m->no_tail = (e != nullptr && e[0] == '1'); }
+    { const char* e = getenv("UU3D_TAIL"); m->no_tail = !(e != nullptr && e[0] == '1'); }
     { hipDeviceProp_t pr; if (hipGetDeviceProperties(&pr, device) == hipSuccess && pr.multiProcessorCount > 0) m->num_cus = pr.multiProcessorCount; }
     *out = m;
     return UU3D_OK;

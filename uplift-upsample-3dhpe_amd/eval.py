@@ -42,14 +42,32 @@ def needed_windows(frame_indices, config):
     return np.equal(np.mod(idx, stride), 0)
 
 
-def predict_windows(model, generator, descriptors, config, batch_size, flip=True):
+def predict_windows(model, generator, descriptors, config, batch_size, flip=True, depth=2, graph=True):
     """Central 3D predictions (W, J, 3) float32 on the device for the given window descriptors: batches of ``batch_size``
-    windows, each forwarded together with its mirrored copy when ``flip`` (one launch chain over 2B sequences)."""
+    windows, each forwarded together with its mirrored copy when ``flip`` (one launch chain over 2B sequences).
+
+    ``depth`` batches are in flight at once, each on its own HIP stream and -- with ``graph`` -- replayed from its own hipGraph
+    (pipeline.ForwardPipeline: batch k + 1's big kernels run beside batch k's latency-bound tail; the window gather of the next
+    batch runs on the caller's stream meanwhile).  depth = 1, graph = False is the reference's loop: one eager call after the other.
+    The predictions are bit-identical either way."""
     import torch
     W = len(descriptors)
     J = generator.table.J
     out = torch.empty((W, J, 3), dtype=torch.float32, device=generator.table.device)
     order = torch.as_tensor(np.asarray(config.AUGM_FLIP_KEYPOINT_ORDER), dtype=torch.long, device=out.device)
+    if W == 0:
+        return out
+    rows = min(batch_size, W) * (2 if flip else 1)
+    pipe = model.pipeline(rows, depth=depth, graph=graph) if (depth > 1 or graph) else None
+
+    def finish(lo, n, cen):
+        if flip:
+            f = cen[n:]
+            f = torch.cat([f[..., :1] * -1.0, f[..., 1:]], dim=-1).index_select(1, order)      # eval.py:163-166
+            cen = (cen[:n] + f) / 2.0
+        out[lo:lo + n] = cen
+
+    pending = []
     for lo in range(0, W, batch_size):
         d = np.ascontiguousarray(descriptors[lo:lo + batch_size])
         n = len(d)
@@ -57,23 +75,31 @@ def predict_windows(model, generator, descriptors, config, batch_size, flip=True
             df = d.copy(); df[:, 5] = 1 - df[:, 5]                 # the generator's flip = negate x + permute joints (= eval.py:154-158)
             d = np.concatenate([d, df], 0)
         b = generator.gather(d, zero_masked=True, with_3d=False)
-        if model.has_strided_input:
-            _, cen = model([b["kp2d"], b["stride_mask"]], training=False)
-        else:
-            _, cen = model(b["kp2d"], training=False)
-        if flip:
-            f = cen[n:]
-            f = torch.cat([f[..., :1] * -1.0, f[..., 1:]], dim=-1).index_select(1, order)      # eval.py:163-166
-            cen = (cen[:n] + f) / 2.0
-        out[lo:lo + n] = cen
+        if pipe is None:
+            if model.has_strided_input:
+                _, cen = model([b["kp2d"], b["stride_mask"]], training=False)
+            else:
+                _, cen = model(b["kp2d"], training=False)
+            finish(lo, n, cen)
+            continue
+        pending.append((lo, n, pipe.submit(b["kp2d"], b["stride_mask"] if model.has_strided_input else None)))
+        if len(pending) == depth:
+            plo, pn, t = pending.pop(0)
+            finish(plo, pn, pipe.result(t)[1])
+    for plo, pn, t in pending:
+        finish(plo, pn, pipe.result(t)[1])
+    if pipe is not None:
+        torch.cuda.current_stream(out.device).synchronize()        # the slots' buffers go away with the pipeline
+        pipe.close()
     return out
 
 
 def run_eval(config, dataset_name, dataset_path, dataset2d_path, test_subset, weights_path=None, model=None, action_wise=True,
-             batch_size=None, skip_unused_windows=True, log=_log):
+             batch_size=None, skip_unused_windows=True, log=_log, depth=2, graph=True):
     """eval.py:34-253.  Returns ``evaluation.evaluate_predictions``'s dict (+ "num_windows", "num_forwarded", "seconds").
 
-    ``batch_size`` defaults to ``config.BATCH_SIZE``.  With torch.distributed initialised, the windows to run are split
+    ``batch_size`` defaults to ``config.BATCH_SIZE``; ``depth`` / ``graph``: batches in flight and hipGraph replay of the forward
+    (``predict_windows``; depth 1 without graph = the reference's eager loop, same numbers).  With torch.distributed initialised, the windows to run are split
     contiguously over the ranks and the predictions all-gathered; every rank returns the same report."""
     import torch
     from .net.uplift_upsample_transformer_constructor import build_uplift_upsample_transformer
@@ -110,7 +136,7 @@ def run_eval(config, dataset_name, dataset_path, dataset2d_path, test_subset, we
         rank, world = tdist.get_rank(), tdist.get_world_size()
     lo, hi = udist.shard_bounds(len(run), rank, world)
     bs = int(batch_size or config.BATCH_SIZE)
-    local = predict_windows(model, gen, desc[run[lo:hi]], config, bs, flip=bool(config.EVAL_FLIP))
+    local = predict_windows(model, gen, desc[run[lo:hi]], config, bs, flip=bool(config.EVAL_FLIP), depth=depth, graph=graph)
     allp = udist.allgather_errors(local)                             # (len(run), J, 3) in rank order: the payload is a few KB per rank
     pred = np.zeros((W, table.J, 3), np.float64)
     pred[run] = allp.detach().cpu().numpy().astype(np.float64)

@@ -335,6 +335,24 @@ class UpliftUpsampleTransformer(object):
         main.wait_stream(side)
         return full, central
 
+    # ---- graph replay / several batches in flight ------------------------------------------------
+    def pipeline(self, batch, depth=2, graph=True, post=None):
+        """``depth`` independent batches in flight on ``depth`` HIP streams, each replaying its own hipGraph of the forward
+        (pipeline.ForwardPipeline): the throughput path of an evaluation loop (eval.py:147-152)."""
+        from ..pipeline import ForwardPipeline
+        return ForwardPipeline(self, batch, depth=depth, graph=graph, post=post)
+
+    def capture(self, batch):
+        """One forward at a fixed batch size as a hipGraph: ``f = model.capture(128); full, central = f([x, mask])`` replays
+        it (one launch instead of ~50; outputs are static buffers, overwritten by the next call)."""
+        pipe = self.pipeline(batch, depth=1, graph=True)
+
+        def replay(inputs):
+            x, m = (inputs[0], inputs[1]) if self.has_strided_input else (inputs, None)
+            return pipe.result(pipe.submit(x, m))
+        replay.pipeline = pipe
+        return replay
+
     def tail_status(self, batch, slot=0):
         """Diagnostics of the XCD-cooperative tail kernel after the last forward of ``batch`` sequences (uu3d_tail_status):
         dict(err, owner[8], census[8]); err must be 0 (bit 0: spin timeout, bit 1: foreign XCC id observed)."""
