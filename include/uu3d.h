@@ -76,6 +76,9 @@ typedef struct uu3d_config {
     int32_t first_strided_token_attention_layer; /* FIRST_STRIDED_TOKEN_ATTENTION_LAYER */
     int32_t full_output;         /* not USE_REFINE                                      */
     int32_t precision;           /* uu3d_precision                                      */
+    int32_t output_bn;           /* OUTPUT_BN: BatchNormalization(momentum 0.1, eps 1e-5) in front of both heads
+                                    (uplift_upsample_transformer.py:275-285); INFERENCE form only: moving statistics,
+                                    folded into the head operands at commit time                                      */
 } uu3d_config;
 
 typedef struct uu3d_model uu3d_model;

@@ -106,12 +106,14 @@ def transformer_block(p, prefix, x, num_heads, activation, mask=None, dp=None):
     return x, attn
 
 
-def strided_transformer_block(p, prefix, x, pe, num_heads, stride, pad):
-    """uplift_upsample_transformer.py:122-160 with StridedMLP :81-90."""
+def strided_transformer_block(p, prefix, x, pe, num_heads, stride, pad, dp=None):
+    """uplift_upsample_transformer.py:122-160 with StridedMLP :81-90.  dp = (rate, u_attn, u_mlp): DropPath on both branches (:132-137)."""
     assert x.shape[1] == pe.shape[0]                                    # :127
     x = x + pe                                                          # :128
     y = layer_norm(x, p[f"{prefix}/norm1/gamma"], p[f"{prefix}/norm1/beta"], 1e-5)
     y, attn = mha(p, f"{prefix}/attn", y, num_heads, None)
+    if dp is not None:
+        y = drop_path(y, dp[0], dp[1])                                  # :132-133
     x = x + y
     z = layer_norm(x, p[f"{prefix}/norm2/gamma"], p[f"{prefix}/norm2/beta"], 1e-5)
     # fc1: Conv1D k=1
@@ -128,6 +130,8 @@ def strided_transformer_block(p, prefix, x, pe, num_heads, stride, pad):
         rows = zp[:, j:j + (Lout - 1) * stride + 1:stride]              # (b, Lout, h)
         taps.append(torch.matmul(rows, wk[j]))
     z = taps[0] + taps[1] + taps[2] + p[f"{prefix}/mlp/strided_conv/bias"]
+    if dp is not None:
+        z = drop_path(z, dp[0], dp[2])                                  # :136-137
     # residual path :138-156
     if stride > 1:
         identity = x
@@ -151,7 +155,7 @@ def hp_from_arch(a):
                 strides=tuple(a.strides), paddings=tuple(a.paddings), num_heads=a.num_heads,
                 has_strided_input=a.has_strided_input,
                 first_strided_token_attention_layer=a.first_strided_token_attention_layer,
-                full_output=a.full_output)
+                full_output=a.full_output, output_bn=bool(getattr(a, "output_bn", False)))
 
 
 def forward(hp, weights, x, stride_mask=None, dtype=torch.float32, return_attention=False):
@@ -168,7 +172,8 @@ def forward_torch(hp, p, x, stride_mask=None, dtype=torch.float32, drop_path_cfg
     """Differentiable core on torch tensors (weights `p` may require grad).
 
     drop_path_cfg (training mode, vision_transformer.py:31-43): dict(rates=(spatial, temporal, strided),
-    u_spatial (Ls, 2, B*N), u_temporal (Lt, 2, B)) with explicit U[0,1) draws; None = inference.
+    u_spatial (Ls, 2, B*N), u_temporal (Lt, 2, B), u_strided (len(strides), 2, B) -- the last only when rates[2] > 0) with explicit
+    U[0,1) draws; None = inference.
 
     hp: dict with num_frames, num_keypoints, d_spatial, d_temporal, spatial_depth,
         temporal_depth, strides, paddings, num_heads, has_strided_input,
@@ -186,7 +191,7 @@ def forward_torch(hp, p, x, stride_mask=None, dtype=torch.float32, drop_path_cfg
         rate = float(np.linspace(0, drop_path_cfg["rates"][stack], depth)[i])
         if rate == 0:
             return None                                               # no DropPath layer (vision_transformer.py:170)
-        u = drop_path_cfg["u_spatial" if stack == 0 else "u_temporal"]
+        u = drop_path_cfg[("u_spatial", "u_temporal", "u_strided")[stack]]
         return (rate, torch.as_tensor(u[i, 0]).to(dtype), torch.as_tensor(u[i, 1]).to(dtype))
 
     # spatial_transformation :313-333
@@ -218,9 +223,16 @@ def forward_torch(hp, p, x, stride_mask=None, dtype=torch.float32, drop_path_cfg
         x, att = transformer_block(p, f"temporal_block_{i + 1}", x, H, torch.relu, mask, dp_for(1, i, hp["temporal_depth"]))
         att_list.append(att)
 
+    def batch_norm_inference(t, name):
+        # kl.BatchNormalization(momentum=0.1, epsilon=1e-5, axis=-1) with training=False (u_u_t.py:275-285,400-404,414-416):
+        # tf.nn.batch_normalization with the moving statistics: x * (gamma * rsqrt(var + eps)) + (beta - mean * gamma * rsqrt(var + eps))
+        inv = p[f"{name}/gamma"] * torch.rsqrt(p[f"{name}/moving_variance"] + 1e-5)
+        return t * inv + (p[f"{name}/beta"] - p[f"{name}/moving_mean"] * inv)
+
     full = None
     if hp["full_output"] and hp["temporal_depth"] > 0:
-        full = dense(x, p["temporal_fc/kernel"], p["temporal_fc/bias"])
+        full = batch_norm_inference(x, "temporal_norm") if hp.get("output_bn") else x
+        full = dense(full, p["temporal_fc/kernel"], p["temporal_fc/bias"])
         full = full.reshape(B, N, J, 3)                                 # "b n (p c) -> b n p c"
 
     # strided_temporal_transformation :369-386
@@ -231,10 +243,12 @@ def forward_torch(hp, p, x, stride_mask=None, dtype=torch.float32, drop_path_cfg
                 raise NotImplementedError("temporal_depth == 0 masked strided attention (dead for shipped configs)")
             pe_i = p[f"strided_temporal_pe_{i + 1}/positional_encoding_weights"]
             x, _ = strided_transformer_block(p, f"strided_temporal_block_{i + 1}", x, pe_i, H,
-                                             s, hp["paddings"][i])
+                                             s, hp["paddings"][i], dp_for(2, i, len(hp["strides"])))
         central = x
     else:
         central = x[:, N // 2: N // 2 + 1, :]
+    if hp.get("output_bn"):
+        central = batch_norm_inference(central, "strided_temporal_norm")
     central = dense(central, p["strided_temporal_fc/kernel"], p["strided_temporal_fc/bias"])
     assert central.shape[1] == 1                                        # einops n=1 at :416
     central = central.reshape(B, J, 3)

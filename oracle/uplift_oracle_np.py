@@ -109,9 +109,13 @@ def forward(hp, weights, x, stride_mask=None, dtype=np.float64):
         kp = penalty if (hp["has_strided_input"] and i < hp["first_strided_token_attention_layer"]) else None
         t = _block(w, f"temporal_block_{i + 1}", t, H, relu, kp)
 
+    def bn(v, name):          # BatchNormalization at inference (u_u_t.py:275-285): moving statistics, eps 1e-5
+        return (v - w[f"{name}/moving_mean"]) / np.sqrt(w[f"{name}/moving_variance"] + 1e-5) * w[f"{name}/gamma"] + w[f"{name}/beta"]
+
     full = None
     if hp["full_output"] and hp["temporal_depth"] > 0:
-        full = (t @ w["temporal_fc/kernel"] + w["temporal_fc/bias"]).reshape(B, N, J, 3)
+        f = bn(t, "temporal_norm") if hp.get("output_bn") else t
+        full = (f @ w["temporal_fc/kernel"] + w["temporal_fc/bias"]).reshape(B, N, J, 3)
 
     if len(hp["strides"]) > 0:
         for i, s in enumerate(hp["strides"]):
@@ -121,5 +125,7 @@ def forward(hp, weights, x, stride_mask=None, dtype=np.float64):
         c = t[:, 0]
     else:
         c = t[:, N // 2]
+    if hp.get("output_bn"):
+        c = bn(c, "strided_temporal_norm")
     central = (c @ w["strided_temporal_fc/kernel"] + w["strided_temporal_fc/bias"]).reshape(B, J, 3)
     return full, central

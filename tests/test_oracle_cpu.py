@@ -46,6 +46,39 @@ def test_oracle_matches_numpy_twin(cfgname):
     assert np.abs(f64 - fn).max() < 1e-11 and np.abs(c64 - cn).max() < 1e-11
 
 
+def test_output_bn_heads_in_both_oracles():
+    """OUTPUT_BN = true (u_u_t.py:275-285): BatchNormalization in front of both heads, inference form.  The torch restatement
+    against the independently written numpy twin, and against the algebra the HIP library uses (the affine folded into the
+    Dense head: W' = s W, b' = b + (beta - mean s) W)."""
+    cfg = util.load_config("h36m_81")
+    cfg.OUTPUT_BN = True
+    arch = pkg.arch_from_config(cfg)
+    hp = util.hp_from_arch(arch)
+    assert hp["output_bn"] is True
+    w = pkg.init_weights(arch, seed=8, perturb=0.2)
+    names = [n for n, _ in pkg.weight_spec(arch)]
+    assert names[-4:] == ["temporal_norm/moving_mean", "temporal_norm/moving_variance",
+                          "strided_temporal_norm/moving_mean", "strided_temporal_norm/moving_variance"]        # non-trainable weights last (Keras model.weights)
+    assert names.index("temporal_norm/gamma") + 2 == names.index("temporal_fc/kernel")
+    x, m = util.synthetic_batch(cfg, 2, seed=8)
+    xm = x * m[:, :, None, None]
+    f64, c64 = O.forward(hp, w, xm, m, torch.float64)
+    fn, cn = ON.forward(hp, w, xm, m, np.float64)
+    assert np.abs(f64 - fn).max() < 1e-11 and np.abs(c64 - cn).max() < 1e-11
+    # folded form: a model WITHOUT the BatchNorm layers and with rewritten head weights gives the same outputs
+    cfg0 = util.load_config("h36m_81")
+    hp0 = util.hp_from_arch(pkg.arch_from_config(cfg0))
+    w0 = {k: v for k, v in w.items() if "_norm/" not in k or k.startswith("spatial_norm")}
+    for fc, bn in (("temporal_fc", "temporal_norm"), ("strided_temporal_fc", "strided_temporal_norm")):
+        s = w[f"{bn}/gamma"].astype(np.float64) / np.sqrt(w[f"{bn}/moving_variance"].astype(np.float64) + 1e-5)
+        sh = w[f"{bn}/beta"] - w[f"{bn}/moving_mean"] * s
+        w0[f"{fc}/kernel"] = s[:, None] * w[f"{fc}/kernel"]
+        w0[f"{fc}/bias"] = w[f"{fc}/bias"] + sh @ w[f"{fc}/kernel"]
+    f0, c0 = O.forward(hp0, w0, xm, m, torch.float64)
+    assert np.abs(f64 - f0).max() < 1e-10 and np.abs(c64 - c0).max() < 1e-10
+    assert np.abs(c64 - O.forward(hp0, {k: v for k, v in w.items() if k in w0}, xm, m, torch.float64)[1]).max() > 1e-3      # the layers do something
+
+
 def test_masked_frame_content_is_irrelevant():
     cfg, arch, hp, w = _setup("h36m_81", seed=1)
     x, m = util.synthetic_batch(cfg, 2, seed=1, mask_specs=[(10, 0), (20, 2)])

@@ -145,3 +145,36 @@ def test_f16x3_attention_agrees_with_the_f32_kernels(monkeypatch):
     dev = max(np.abs(full - full_f).max(), np.abs(central - central_f).max())
     print(f"f16x3 attention vs exact-f32 attention: {dev:.3e}")
     assert 0.0 < dev <= 3e-5
+
+
+@pytest.mark.parametrize("cfgname,batch", [("h36m_81", 5), ("h36m_351", 17)])
+def test_output_bn_heads_match_oracle(cfgname, batch, tmp_path):
+    """OUTPUT_BN = true (BatchNormalization in front of temporal_fc / strided_temporal_fc, u_u_t.py:275-285) at inference: the
+    library folds the per-channel affine of the moving statistics into the head operands at commit time.  Against the oracle's
+    explicit BatchNorm; a checkpoint with the 8 extra tensors round-trips through the Keras .h5 walk; training is refused."""
+    from oracle import uplift_oracle as O
+    from uplift_upsample_3dhpe_amd.trainer import Trainer
+    cfg = util.load_config(cfgname)
+    cfg.OUTPUT_BN = True
+    arch = pkg.arch_from_config(cfg)
+    w = pkg.init_weights(arch, seed=4, perturb=0.2)
+    x, m = util.synthetic_batch(cfg, batch=batch, seed=4)
+    full, central, xm = _run_hip(cfg, w, x, m, "f16x3")
+    n = min(batch, 6)
+    f32, c32 = O.forward(util.hp_from_arch(arch), w, xm[:n], m[:n], torch.float32)
+    err = max(np.abs(full[:n] - f32).max(), np.abs(central[:n] - c32).max())
+    print(f"{cfgname} OUTPUT_BN: max-abs vs oracle {err:.3e}")
+    assert err <= util.TOL_MAX_ABS
+    model = pkg.build_uplift_upsample_transformer(cfg, weights=w)
+    assert len(model.weights) == len(model.trainable_variables) + 4
+    path = str(tmp_path / "bn.h5")
+    model.save_weights(path)
+    other = pkg.build_uplift_upsample_transformer(cfg, weights=pkg.init_weights(arch, seed=9))
+    other.load_weights(path)
+    xt, mt = torch.from_numpy(xm).cuda(), torch.from_numpy(m).cuda()
+    a, b = model([xt, mt], training=False), other([xt, mt], training=False)
+    assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
+    with pytest.raises(NotImplementedError, match="OUTPUT_BN"):
+        Trainer(model, cfg)
+    with pytest.raises(NotImplementedError, match="OUTPUT_BN"):
+        model([xt, mt], training=True)

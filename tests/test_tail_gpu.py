@@ -58,7 +58,12 @@ def test_tail_matches_oracle_and_chain(cfgname, batch, monkeypatch):
         assert st["census"][o - 1] > 0
     chain = _model(cfg, w, tail=False)
     full_c, central_c, _ = _forward(chain, x, m)
-    assert all(o == 0 for o in chain.tail_status(batch)["owner"]), "the launch-chain model ran the tail kernel"
+    for mdl, want_tail in ((model, True), (chain, False)):     # which launches ran: per-launch profile of one more forward
+        mdl.set_profiling(True)
+        _forward(mdl, x, m)
+        names = [e["kernel"] for e in mdl.read_profile()]
+        mdl.set_profiling(False)
+        assert ("strided_tail" in names) == want_tail, names
     n_oracle = min(batch, 12)                    # the oracle on the first sequences (sequences are independent)
     f32, c32 = O.forward(util.hp_from_arch(arch), w, xm[:n_oracle], m[:n_oracle], torch.float32)
     err = np.abs(central[:n_oracle] - c32).max()

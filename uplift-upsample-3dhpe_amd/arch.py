@@ -33,6 +33,7 @@ class UpliftArch:
     drop_rate: float = 0.0
     attention_drop_rate: float = 0.0
     token_mask_rate: float = 0.0
+    output_bn: bool = False      # BatchNormalization in front of both heads (u_u_t.py:275-285); inference form only
     # derived
     strided_lengths: Tuple[int, ...] = field(default=())   # L_0 .. L_len(strides)
 
@@ -76,16 +77,13 @@ def training_unsupported(a: "UpliftArch"):
         out.append(f"ATTENTION_DROP_RATE = {a.attention_drop_rate} (Dropout on the attention probabilities)")
     if a.token_mask_rate > 0.0:
         out.append(f"TOKEN_MASK_RATE = {a.token_mask_rate} (random token masking in training)")
-    if a.drop_path_rate[2] != 0.0:
-        out.append(f"DROP_PATH_RATE[2] = {a.drop_path_rate[2]} (DropPath inside the strided blocks)")
+    if a.output_bn:
+        out.append("OUTPUT_BN = true (training-mode BatchNormalization: batch statistics and the moving-average update)")
     return out
 
 
 def arch_from_config(config) -> UpliftArch:
     # Options that would build a DIFFERENT model than the one the HIP path computes are rejected, not ignored.
-    if bool(getattr(config, "OUTPUT_BN", False)):
-        raise NotImplementedError("OUTPUT_BN = true (BatchNormalization in front of both heads, u_u_t.py:275-285) is not "
-                                  "implemented by the HIP path; the shipped configs use OUTPUT_BN = false")
     if float(getattr(config, "TOKEN_MASK_RATE", 0.0)) > 0.0 and bool(getattr(config, "LEARNABLE_MASKED_TOKEN", False)):
         raise NotImplementedError("TOKEN_MASK_RATE > 0 with LEARNABLE_MASKED_TOKEN = true adds a trainable masked-token "
                                   "layer (u_u_t.py:219-220) that is not implemented")
@@ -149,6 +147,7 @@ def arch_from_config(config) -> UpliftArch:
         drop_rate=float(getattr(config, "DROP_RATE", 0.0)),
         attention_drop_rate=float(getattr(config, "ATTENTION_DROP_RATE", 0.0)),
         token_mask_rate=float(getattr(config, "TOKEN_MASK_RATE", 0.0)),
+        output_bn=bool(getattr(config, "OUTPUT_BN", False)),
         strided_lengths=tuple(conv_len),
     )
 

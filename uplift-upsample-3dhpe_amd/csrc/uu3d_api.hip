@@ -18,6 +18,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -202,12 +203,19 @@ void build_inventory(uu3d_model* m) {
         add_block(m, "temporal_block_" + std::to_string(i + 1), dt, c.h_temporal, false, c.qkv_bias != 0);
     for (int i = 0; i < c.num_strided; ++i)
         add_block(m, "strided_temporal_block_" + std::to_string(i + 1), dt, c.h_temporal, true, c.qkv_bias != 0);
+    // Keras' model.weights = trainable weights in creation order, then the non-trainable ones (the BatchNorm moving statistics)
     if (c.full_output && c.temporal_depth > 0) {
+        if (c.output_bn) { add_weight(m, "temporal_norm/gamma", {dt}); add_weight(m, "temporal_norm/beta", {dt}); }
         add_weight(m, "temporal_fc/kernel", {dt, 3 * J});
         add_weight(m, "temporal_fc/bias", {3 * J});
     }
+    if (c.output_bn) { add_weight(m, "strided_temporal_norm/gamma", {dt}); add_weight(m, "strided_temporal_norm/beta", {dt}); }
     add_weight(m, "strided_temporal_fc/kernel", {dt, 3 * J});
     add_weight(m, "strided_temporal_fc/bias", {3 * J});
+    if (c.output_bn) {
+        if (c.full_output && c.temporal_depth > 0) { add_weight(m, "temporal_norm/moving_mean", {dt}); add_weight(m, "temporal_norm/moving_variance", {dt}); }
+        add_weight(m, "strided_temporal_norm/moving_mean", {dt}); add_weight(m, "strided_temporal_norm/moving_variance", {dt});
+    }
 }
 
 // ---- host-side packing ------------------------------------------------------------------
@@ -501,14 +509,34 @@ int uu3d_commit_weights(uu3d_model* m, void* stream_) {
     const int Nph = round_up(3 * J, 128);
     size_t o_h1 = 0, o_h1b = 0;
     const bool has_h1 = c.full_output && c.temporal_depth > 0;
+    // OUTPUT_BN at inference (u_u_t.py:275-285, Keras BatchNormalization with training=False): y = gamma (x - mean) / sqrt(var + eps) + beta
+    // is a per-channel affine in front of the Dense head, so it is folded into the head's operands here:
+    //   W'[k][n] = s[k] W[k][n],  b'[n] = b[n] + sum_k (beta[k] - mean[k] s[k]) W[k][n],  s = gamma / sqrt(var + 1e-5)
+    auto pack_head = [&](size_t o_w, size_t o_b, const std::string& fc, const std::string& bn) {
+        const float* Wk = W(m, fc + "/kernel"); const float* bk = W(m, fc + "/bias");
+        if (!c.output_bn) {
+            pack_dense_t(P.buf, o_w, Wk, dt, 3 * J, Kdt, 0);
+            std::copy_n(bk, 3 * J, P.buf.begin() + o_b);
+            return;
+        }
+        const float *g = W(m, bn + "/gamma"), *be = W(m, bn + "/beta"), *mu = W(m, bn + "/moving_mean"), *var = W(m, bn + "/moving_variance");
+        std::vector<float> Wf((size_t)dt * 3 * J);
+        std::vector<double> bf(3 * J);
+        for (int n = 0; n < 3 * J; ++n) bf[n] = bk[n];
+        for (int k = 0; k < dt; ++k) {
+            const float s = g[k] / std::sqrt(var[k] + 1e-5f);
+            const double sh = (double)be[k] - (double)mu[k] * s;
+            for (int n = 0; n < 3 * J; ++n) { Wf[(size_t)k * 3 * J + n] = s * Wk[(size_t)k * 3 * J + n]; bf[n] += sh * Wk[(size_t)k * 3 * J + n]; }
+        }
+        pack_dense_t(P.buf, o_w, Wf.data(), dt, 3 * J, Kdt, 0);
+        for (int n = 0; n < 3 * J; ++n) P.buf[o_b + n] = (float)bf[n];
+    };
     if (has_h1) {
         o_h1 = P.alloc_dense((size_t)Nph * Kdt); o_h1b = P.alloc(Nph);
-        pack_dense_t(P.buf, o_h1, W(m, "temporal_fc/kernel"), dt, 3 * J, Kdt, 0);
-        std::copy_n(W(m, "temporal_fc/bias"), 3 * J, P.buf.begin() + o_h1b);
+        pack_head(o_h1, o_h1b, "temporal_fc", "temporal_norm");
     }
     const size_t o_h2 = P.alloc_dense((size_t)Nph * Kdt), o_h2b = P.alloc(Nph);
-    pack_dense_t(P.buf, o_h2, W(m, "strided_temporal_fc/kernel"), dt, 3 * J, Kdt, 0);
-    std::copy_n(W(m, "strided_temporal_fc/bias"), 3 * J, P.buf.begin() + o_h2b);
+    pack_head(o_h2, o_h2b, "strided_temporal_fc", "strided_temporal_norm");
 
     // ---- upload ----
     if (m->arena_floats < P.buf.size()) {

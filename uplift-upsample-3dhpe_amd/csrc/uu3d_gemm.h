@@ -192,6 +192,7 @@ struct EpConvResidual {
     float* __restrict__ out; const float* __restrict__ bias; int ld;
     const float* __restrict__ xin; int L_in, L_out, stride, lo;
     const float* __restrict__ pe_next;    // (L_out, ld) or nullptr
+    const float* __restrict__ gate = nullptr; float keep = 1.f;      // training: DropPath on the MLP branch, one gate per sequence (u_u_t.py:136-137)
     __device__ __forceinline__ float2 colv(int col) const { return make_float2(bias[col], 0.f); }
     __device__ __forceinline__ float2 pre(int rowc, int col) const {
         const int b = rowc / L_out; const int t = rowc - b * L_out;
@@ -200,7 +201,9 @@ struct EpConvResidual {
         return p;
     }
     __device__ __forceinline__ void store(int row, int col, float v, float2 cv, float2 p) const {
-        float y = p.x + (v + cv.x);
+        float z = v + cv.x;
+        if (gate != nullptr) z = (z / keep) * gate[row / L_out];
+        float y = p.x + z;
         if (pe_next != nullptr) y += p.y;
         out[(size_t)row * ld + col] = y;
     }

@@ -78,6 +78,7 @@ class BucketedAllReduce(object):
         self.works = []
         self.ranges = []
         self.error = None
+        self.force = False          # issue the collectives at world size 1 as well (tests: the RCCL / ExternalStream path on one GPU)
 
     def begin(self):
         """Start of a backward pass: wait for collectives a previous pass left outstanding (gradient inspection, a step that
@@ -94,7 +95,7 @@ class BucketedAllReduce(object):
 
     def _active(self):
         import torch.distributed as dist
-        return dist.is_available() and dist.is_initialized() and dist.get_world_size(self.group) > 1
+        return dist.is_available() and dist.is_initialized() and (dist.get_world_size(self.group) > 1 or self.force)
 
     def ready(self, first, count, stream=None):
         import torch

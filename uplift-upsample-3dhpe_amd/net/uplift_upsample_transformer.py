@@ -87,6 +87,7 @@ class UpliftUpsampleTransformer(object):
         cfg.has_strided_input = int(arch.has_strided_input)
         cfg.first_strided_token_attention_layer = arch.first_strided_token_attention_layer
         cfg.full_output = int(arch.full_output)
+        cfg.output_bn = int(bool(getattr(arch, "output_bn", False)))
         # "f16x3": forward GEMMs as three f16 MFMA passes on hi/lo-split operands (f32-grade error);
         # "f32": exact f32-input MFMA everywhere
         if precision not in ("f32", "f16x3"):
@@ -170,7 +171,10 @@ class UpliftUpsampleTransformer(object):
     def weights(self):
         return [WeightView(self, n, s) for n, s in self._spec]
 
-    trainable_variables = weights          # every weight of this model is trainable (no BatchNorm statistics: OUTPUT_BN is rejected)
+    @property
+    def trainable_variables(self):
+        """model.trainable_variables: everything but the BatchNorm moving statistics of OUTPUT_BN."""
+        return [v for v in self.weights if not v.name.endswith(("/moving_mean", "/moving_variance"))]
 
     def set_weights_dict(self, weights):
         for name, shape in self._spec:
@@ -278,6 +282,8 @@ class UpliftUpsampleTransformer(object):
                 self._rng.manual_seed(int(self._seed))
             params, rng, rates = self._train_params, self._rng, np.asarray(a.drop_path_rate, np.float32)
         n_draws = a.spatial_depth * 2 * B * a.num_frames + a.temporal_depth * 2 * B
+        if float(rates[2]) > 0.0:
+            n_draws += len(a.strides) * 2 * B
         u = torch.rand(n_draws, generator=rng, device=self.device, dtype=torch.float32)
         nbytes = int(self._lib.uu3d_train_workspace_bytes(self._h, B))
         if self._train_ws is None or self._train_ws.numel() < nbytes:

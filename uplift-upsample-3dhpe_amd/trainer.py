@@ -74,7 +74,10 @@ class Trainer(object):
 
     def drop_path_size(self, batch):
         a = self.model.arch
-        return a.spatial_depth * 2 * batch * a.num_frames + a.temporal_depth * 2 * batch
+        n = a.spatial_depth * 2 * batch * a.num_frames + a.temporal_depth * 2 * batch
+        if float(self.drop_path_rates[2]) > 0.0:                              # strided blocks: two gates per sequence and block (u_u_t.py:132-137)
+            n += len(a.strides) * 2 * batch
+        return n
 
     def forward_backward(self, keypoints2d, keypoints3d, stride_masks, drop_path_uniform="draw"):
         """Training-mode forward + loss + backward.  Returns (loss[3] tensor, full, central); gradients in self.grads.

@@ -60,9 +60,19 @@ def weight_spec(a: UpliftArch):
         spec += _block_spec(f"temporal_block_{i + 1}", dt, a.h_temporal, False, a.qkv_bias)
     for i in range(len(a.strides)):
         spec += _block_spec(f"strided_temporal_block_{i + 1}", dt, a.h_temporal, True, a.qkv_bias)
-    if a.full_output and a.temporal_depth > 0:
+    bn = bool(getattr(a, "output_bn", False))
+    h1 = a.full_output and a.temporal_depth > 0
+    if h1:
+        if bn:
+            spec += [("temporal_norm/gamma", (dt,)), ("temporal_norm/beta", (dt,))]
         spec += [("temporal_fc/kernel", (dt, a.out_dim)), ("temporal_fc/bias", (a.out_dim,))]
+    if bn:
+        spec += [("strided_temporal_norm/gamma", (dt,)), ("strided_temporal_norm/beta", (dt,))]
     spec += [("strided_temporal_fc/kernel", (dt, a.out_dim)), ("strided_temporal_fc/bias", (a.out_dim,))]
+    if bn:      # Keras' model.weights lists the non-trainable weights (BatchNorm moving statistics) after all trainable ones
+        if h1:
+            spec += [("temporal_norm/moving_mean", (dt,)), ("temporal_norm/moving_variance", (dt,))]
+        spec += [("strided_temporal_norm/moving_mean", (dt,)), ("strided_temporal_norm/moving_variance", (dt,))]
     return spec
 
 
@@ -108,10 +118,14 @@ def init_weights(a: UpliftArch, seed: int = 0, perturb: float = 0.0) -> "Ordered
             w[name] = np.ones(shape, np.float32)
             if perturb > 0:
                 w[name] += (rng.standard_normal(size=shape) * perturb).astype(np.float32)
-        elif leaf in ("beta", "bias"):
+        elif leaf in ("beta", "bias", "moving_mean"):
             w[name] = np.zeros(shape, np.float32)
             if perturb > 0:
                 w[name] += (rng.standard_normal(size=shape) * perturb).astype(np.float32)
+        elif leaf == "moving_variance":                    # Keras: ones; perturbed upwards only (a variance)
+            w[name] = np.ones(shape, np.float32)
+            if perturb > 0:
+                w[name] += np.abs(rng.standard_normal(size=shape) * perturb).astype(np.float32)
         else:
             raise KeyError(name)
     return w
