@@ -10,8 +10,8 @@ its own workspace, static input / output buffers and (optionally) its own hipGra
     for full, central in pipe.run(batches):                    # batches: iterable of (x, stride_mask) or x
         ...                                                    # outputs are valid until `depth` more batches were submitted
 
-Measured on MI355X (tools/streams_exp.py, h36m_351, batch 128, hipGraph replay): 1 stream 141 k sequences/s, 2 streams 171 k
-(+21 %), 3 streams 174 k.  Results are bit-identical to ``model(...)``: the same launches on the same data, only on another
+Measured on MI355X (tools/streams_exp.py, h36m_351, batch 128, hipGraph replay, three runs each): 1 / 2 / 3 / 4 / 5 / 6 / 8 batches in
+flight = 141.5 / 172 / 177 / 184-186 / 171-173 / 181 / 183 k sequences/s (+30 % at 4; odd counts above 3 lose again).  Results are bit-identical to ``model(...)``: the same launches on the same data, only on another
 stream.  Latency of ONE batch does not improve (0.9 ms); use ``model(...)`` for that.
 """
 import ctypes as C
