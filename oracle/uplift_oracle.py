@@ -106,12 +106,12 @@ def transformer_block(p, prefix, x, num_heads, activation, mask=None, dp=None):
     return x, attn
 
 
-def strided_transformer_block(p, prefix, x, pe, num_heads, stride, pad, dp=None):
+def strided_transformer_block(p, prefix, x, pe, num_heads, stride, pad, dp=None, mask=None):
     """uplift_upsample_transformer.py:122-160 with StridedMLP :81-90.  dp = (rate, u_attn, u_mlp): DropPath on both branches (:132-137)."""
     assert x.shape[1] == pe.shape[0]                                    # :127
     x = x + pe                                                          # :128
     y = layer_norm(x, p[f"{prefix}/norm1/gamma"], p[f"{prefix}/norm1/beta"], 1e-5)
-    y, attn = mha(p, f"{prefix}/attn", y, num_heads, None)
+    y, attn = mha(p, f"{prefix}/attn", y, num_heads, mask)
     if dp is not None:
         y = drop_path(y, dp[0], dp[1])                                  # :132-133
     x = x + y
@@ -238,12 +238,13 @@ def forward_torch(hp, p, x, stride_mask=None, dtype=torch.float32, drop_path_cfg
     # strided_temporal_transformation :369-386
     if len(hp["strides"]) > 0:
         for i, s in enumerate(hp["strides"]):
+            smask = None
             if hp["temporal_depth"] == 0 and hp["has_strided_input"] and \
                     i < hp["first_strided_token_attention_layer"]:
-                raise NotImplementedError("temporal_depth == 0 masked strided attention (dead for shipped configs)")
+                smask = inv[:, None, None, :]                           # :372-377 (broadcasts against the keys: right for the first block only)
             pe_i = p[f"strided_temporal_pe_{i + 1}/positional_encoding_weights"]
             x, _ = strided_transformer_block(p, f"strided_temporal_block_{i + 1}", x, pe_i, H,
-                                             s, hp["paddings"][i], dp_for(2, i, len(hp["strides"])))
+                                             s, hp["paddings"][i], dp_for(2, i, len(hp["strides"])), smask)
         central = x
     else:
         central = x[:, N // 2: N // 2 + 1, :]

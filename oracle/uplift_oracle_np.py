@@ -53,9 +53,9 @@ def _block(w, pre, x, H, act, key_penalty=None):
     return x + (z @ w[f"{pre}/mlp/fc2/kernel"] + w[f"{pre}/mlp/fc2/bias"])
 
 
-def _strided_block(w, pre, x, pe, H, s, pad):
+def _strided_block(w, pre, x, pe, H, s, pad, key_penalty=None):
     x = x + pe[None]
-    x = x + _attention(w, f"{pre}/attn", _ln(x, w[f"{pre}/norm1/gamma"], w[f"{pre}/norm1/beta"], 1e-5), H)
+    x = x + _attention(w, f"{pre}/attn", _ln(x, w[f"{pre}/norm1/gamma"], w[f"{pre}/norm1/beta"], 1e-5), H, key_penalty)
     z = _ln(x, w[f"{pre}/norm2/gamma"], w[f"{pre}/norm2/beta"], 1e-5)
     z = np.maximum(z @ w[f"{pre}/mlp/fc1/kernel"][0] + w[f"{pre}/mlp/fc1/bias"], 0.0)
     B, L, hdim = z.shape
@@ -119,9 +119,10 @@ def forward(hp, weights, x, stride_mask=None, dtype=np.float64):
 
     if len(hp["strides"]) > 0:
         for i, s in enumerate(hp["strides"]):
+            kp = penalty if (hp["temporal_depth"] == 0 and hp["has_strided_input"] and i < hp["first_strided_token_attention_layer"]) else None
             t = _strided_block(w, f"strided_temporal_block_{i + 1}", t,
                                w[f"strided_temporal_pe_{i + 1}/positional_encoding_weights"], H, s,
-                               hp["paddings"][i])
+                               hp["paddings"][i], kp)
         c = t[:, 0]
     else:
         c = t[:, N // 2]

@@ -178,3 +178,43 @@ def test_output_bn_heads_match_oracle(cfgname, batch, tmp_path):
         Trainer(model, cfg)
     with pytest.raises(NotImplementedError, match="OUTPUT_BN"):
         model([xt, mt], training=True)
+
+
+@pytest.mark.parametrize("variant", ["no_temporal_blocks", "no_strided_blocks", "neither", "no_temporal_blocks_no_mask"])
+def test_structural_variants_match_oracle(variant):
+    """TEMPORAL_TRANSFORMER_BLOCKS = 0 and / or STRIDES = [] (u_u_t.py:356,372-380,411-413; no shipped config uses them): without
+    temporal blocks the FIRST strided block takes the key mask and there is no full-sequence head; without strided blocks the central
+    token x[:, N // 2] feeds strided_temporal_fc.  Against the oracle (fp32 and, where no row is all-masked, float64)."""
+    from oracle import uplift_oracle as O
+    cfg = util.load_config("h36m_81")
+    if variant in ("no_temporal_blocks", "neither", "no_temporal_blocks_no_mask"):
+        cfg.TEMPORAL_TRANSFORMER_BLOCKS = 0
+    if variant in ("no_strided_blocks", "neither"):
+        cfg.STRIDES, cfg.PADDINGS = [], []
+    if variant == "no_temporal_blocks_no_mask":
+        cfg.MASK_STRIDE = None
+    arch = pkg.arch_from_config(cfg)
+    assert arch.temporal_depth == (0 if "temporal" in variant or variant == "neither" else 4)
+    w = pkg.init_weights(arch, seed=6, perturb=0.1)
+    for batch in (3, 40):                       # 40 x 41 = 1640 token rows: the row-panel / fused-MLP path where temporal blocks exist
+        if arch.has_strided_input:
+            x, m = util.synthetic_batch(cfg, batch=batch, seed=6)
+        else:
+            x, m = np.random.default_rng(6).uniform(-1, 1, size=(batch, arch.num_frames, 17, 2)).astype(np.float32), None
+        model = pkg.build_uplift_upsample_transformer(cfg, weights=w)
+        n = min(batch, 6)
+        if arch.has_strided_input:
+            xin = x * m[:, :, None, None].astype(np.float32)
+            full, central = model([torch.from_numpy(xin).cuda(), torch.from_numpy(m).cuda()], training=False)
+            f32, c32 = O.forward(util.hp_from_arch(arch), w, xin[:n], m[:n], torch.float32)
+        else:
+            xin = x
+            full, central = model(torch.from_numpy(xin).cuda(), training=False)
+            f32, c32 = O.forward(util.hp_from_arch(arch), w, xin[:n], None, torch.float32)
+        torch.cuda.synchronize()
+        assert (full is None) == (f32 is None) == (arch.temporal_depth == 0)
+        err = np.abs(central.cpu().numpy()[:n] - c32).max()
+        if full is not None:
+            err = max(err, np.abs(full.cpu().numpy()[:n] - f32).max())
+        print(f"{variant} batch {batch}: max-abs vs oracle {err:.3e}")
+        assert np.isfinite(central.cpu().numpy()).all() and err <= util.TOL_MAX_ABS

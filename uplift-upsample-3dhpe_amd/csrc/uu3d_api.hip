@@ -281,8 +281,12 @@ int uu3d_create(const uu3d_config* c, int device, uu3d_model** out) {
         return fail(nullptr, UU3D_ERR_UNSUPPORTED, "temporal attention is compiled for head dim 48 (d_t = 384)");
     if (c->h_temporal % 4 != 0 || c->h_temporal < 4)
         return fail(nullptr, UU3D_ERR_UNSUPPORTED, "h_temporal must be a positive multiple of 4");
-    if (c->temporal_depth < 1) return fail(nullptr, UU3D_ERR_UNSUPPORTED, "temporal_depth >= 1 required");
-    if (c->num_strided < 1) return fail(nullptr, UU3D_ERR_UNSUPPORTED, "at least one strided block required");
+    if (c->temporal_depth < 0) return fail(nullptr, UU3D_ERR_INVALID_ARGUMENT, "temporal_depth < 0");
+    // temporal_depth == 0 (u_u_t.py:356,372-380): the strided blocks follow the token blend directly and the FIRST one takes the key
+    // mask; the reference hands the same (B, 1, 1, N) mask to every strided block below FIRST_STRIDED_TOKEN_ATTENTION_LAYER, which only
+    // has the right shape for the first (N keys)
+    if (c->temporal_depth == 0 && c->has_strided_input && c->num_strided > 0 && c->first_strided_token_attention_layer > 1)
+        return fail(nullptr, UU3D_ERR_INVALID_ARGUMENT, "temporal_depth == 0 with FIRST_STRIDED_TOKEN_ATTENTION_LAYER > 1: the reference's key mask has N entries, strided block 2 has fewer keys");
     if (c->d_temporal > 64 * 4 * 4)
         return fail(nullptr, UU3D_ERR_UNSUPPORTED, "d_temporal > 1024");
 
@@ -312,7 +316,7 @@ int uu3d_create(const uu3d_config* c, int device, uu3d_model** out) {
         }
         m->L.push_back(Lout);
     }
-    if (m->L.back() != 1) {
+    if (c->num_strided > 0 && m->L.back() != 1) {
         delete m;   // einops "b n (p c) -> (b n) p c", n=1 fails in the reference (u_u_t.py:416)
         return fail(nullptr, UU3D_ERR_INVALID_ARGUMENT, "STRIDES/PADDINGS must reduce the sequence to one token");
     }
@@ -1167,8 +1171,9 @@ int uu3d_forward(uu3d_model* m, const float* kp2d, const uint8_t* mask, int32_t 
         const BlockDev& b = m->tblocks[i];
         const bool masked = c.has_strided_input && i < c.first_strided_token_attention_layer;
         const bool last = (i + 1 == c.temporal_depth);
-        const bool fuse = planes && Lh.mlpf_ok(M, b) && Lh.panel_ok(M, 3 * dt, dt, m->sblocks[0].wqkv_pf) &&
-                          (last || Lh.panel_ok(M, 3 * dt, dt, m->tblocks[i + 1].wqkv_pf));
+        // (the fused MLP leaves its result for the NEXT block's first LayerNorm launch: without strided blocks the last temporal block has none)
+        const bool fuse = planes && Lh.mlpf_ok(M, b) && (last ? (c.num_strided > 0 && Lh.panel_ok(M, 3 * dt, dt, m->sblocks[0].wqkv_pf))
+                                                              : Lh.panel_ok(M, 3 * dt, dt, m->tblocks[i + 1].wqkv_pf));
         const _Float16* const a2 = block_head("t", i, b, w.X, N, masked ? mask : nullptr, pend, fuse);
         pend = nullptr;
         if (fuse) {
@@ -1177,14 +1182,24 @@ int uu3d_forward(uu3d_model* m, const float* kp2d, const uint8_t* mask, int32_t 
             pend = &b;
             continue;
         }
-        EpBiasResidual ep_fc2{w.X, b.b2, dt, last ? w.XA : nullptr, last ? m->sblocks[0].pe : nullptr, N};
+        const bool to_strided = last && c.num_strided > 0;
+        EpBiasResidual ep_fc2{w.X, b.b2, dt, to_strided ? w.XA : nullptr, to_strided ? m->sblocks[0].pe : nullptr, N};
         snprintf(nm, sizeof nm, "t%d.fc2_res", i + 1);
         if (planes) { GLoadPlain gl{Hh, Hh + (size_t)M * ht, ht, M}; Lh.gemm_g(nm, gl, b.w2_t, M, dt, ht, ep_fc2, 4.0 * M * dt); }
         else { ALoadPlain al{w.Hb, ht, M, ht}; Lh.gemm(nm, al, b.w2_t, M, dt, ht, ep_fc2, 4.0 * M * dt); }
     }
+    if (c.num_strided == 0 && has_h1) {                    // 4. head1 without strided blocks (otherwise launched inside strided block 1, below)
+        ALoadPlain al{w.X, dt, M, dt}; EpBias ep{full_out, m->h1_b, 3 * J};
+        Lh.gemm("head1", al, m->h1_wt, M, 3 * J, dt, ep);
+    }
     // 5. strided blocks
     float* xa = w.XA; float* xb = w.XB;
     bool tail_done = false;
+    if (c.temporal_depth == 0 && c.num_strided > 0) {      // no temporal block whose epilogue adds the first strided PE (u_u_t.py:382-383)
+        Lh.begin("s1.add_pe", "add_pe", 0.0, 12.0 * M * dt);
+        hipLaunchKernelGGL(add_period_kernel, dim3((unsigned)(((size_t)M * dt / 4 + 255) / 256)), dim3(256), 0, Lh.stream, w.X, m->sblocks[0].pe, M, dt, N, w.XA);
+        Lh.end();
+    }
     for (int i = 0; i < c.num_strided; ++i) {
         const BlockDev& b = m->sblocks[i];
         const int Li = m->L[i], Lo = m->L[i + 1], Mi = B * Li, Mo = B * Lo;
@@ -1217,7 +1232,9 @@ int uu3d_forward(uu3d_model* m, const float* kp2d, const uint8_t* mask, int32_t 
         const int lo = (c.strides[i] > 1 && c.pad_left[i] == 0) ? 1 : 0;
         const EpConvResidual ep_conv{xb, b.b2, dt, xa, Li, Lo, c.strides[i], lo,
                                      (i + 1 < c.num_strided) ? m->sblocks[i + 1].pe : nullptr};
-        block_head("s", i, b, xa, Li, nullptr, i == 0 ? pend : nullptr, false);
+        // (without temporal blocks the first strided block is the one that must not attend to the upsampling tokens, u_u_t.py:372-376)
+        const bool smask = c.temporal_depth == 0 && c.has_strided_input && i < c.first_strided_token_attention_layer;
+        block_head("s", i, b, xa, Li, smask ? mask : nullptr, i == 0 ? pend : nullptr, false);
         if (i == 0 && has_h1) {
             // 4. head1 (after strided block 1's first LayerNorm launch, which completes w.X when the last MLP was fused).  Nothing
             // downstream reads it, but a side stream next to the strided blocks measured SLOWER (1.085 vs 1.040 ms per forward
@@ -1235,7 +1252,9 @@ int uu3d_forward(uu3d_model* m, const float* kp2d, const uint8_t* mask, int32_t 
     }
     // 6. head2
     if (!tail_done) {
-        ALoadPlain al{xa, dt, B, dt}; EpBias ep{central_out, m->h2_b, 3 * J};
+        // no strided blocks: the central token x[:, N // 2] (u_u_t.py:411-413) = row N / 2 of every sequence, leading dimension N d_t
+        ALoadPlain al{c.num_strided > 0 ? xa : w.X + (size_t)(N / 2) * dt, c.num_strided > 0 ? dt : N * dt, B, dt};
+        EpBias ep{central_out, m->h2_b, 3 * J};
         Lh.gemm("head2", al, m->h2_wt, B, 3 * J, dt, ep);
     }
     if (Lh.status != UU3D_OK) return Lh.status;

@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <math.h>
+#include "uu3d_gemm.h"
 
 namespace uu3d {
 
@@ -103,6 +104,16 @@ mpjpe_kernel(const float* __restrict__ pred, const float* __restrict__ gt, const
 // on this list -- an exact, output-preserving saving.  One workgroup, ascending order, deterministic.
 //   list[0 .. count) = indices of valid frames, count stored in list[total]
 // Each thread owns kCompactPerThread consecutive frames (one 16-byte load), so up to 1024 * 16 frames take a
+// out[row] = x[row] + pe[row % period]  (rows of D floats, D % 4 == 0): the strided positional encoding of a model without temporal blocks
+static __global__ void __launch_bounds__(256)
+add_period_kernel(const float* __restrict__ x, const float* __restrict__ pe, const int rows, const int D, const int period, float* __restrict__ out)
+{
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x, per_row = (size_t)D / 4;
+    if (i >= (size_t)rows * per_row) return;
+    const size_t row = i / per_row, c = (i - row * per_row) * 4;
+    *reinterpret_cast<f32x4*>(out + row * D + c) = *reinterpret_cast<const f32x4*>(x + row * D + c) + *reinterpret_cast<const f32x4*>(pe + (row % period) * D + c);
+}
+
 // single pass: in-thread count, wave-level shuffle scan, one barrier for the 16 wave totals.
 static constexpr int kCompactPerThread = 16;
 static __global__ void __launch_bounds__(1024)
