@@ -134,6 +134,14 @@ size_t uu3d_workspace_bytes(const uu3d_model* model, int32_t batch);
 int uu3d_forward(uu3d_model* model, const float* kp2d_dev, const uint8_t* stride_mask_dev,
                  int32_t batch, float* full_out_dev, float* central_out_dev,
                  void* workspace_dev, size_t workspace_bytes, void* stream);
+/* The same forward with return_attention=True (uplift_upsample_transformer.py:365,418-419: `att_list`, the softmax weights every temporal
+ * block's MHA returns, vision_transformer.py:117-130): attn_out_dev_ptrs is a HOST array of temporal_depth device pointers, each
+ * (B, num_heads, N, N) f32 (or NULL to skip that block); NULL = uu3d_forward.  The maps are recomputed from the block's q | k by a
+ * separate kernel -- the attention kernels of the hot path never materialise them.  Sequences of up to ~800 tokens (K of one head in LDS). */
+int uu3d_forward_attention(uu3d_model* model, const float* kp2d_dev, const uint8_t* stride_mask_dev, int32_t batch,
+                           float* full_out_dev, float* central_out_dev, float* const* attn_out_dev_ptrs,
+                           void* workspace, size_t workspace_bytes, void* stream);
+
 
 /*
  * Replaces: metrics.mpjpe(pred, gt, root_index, normalize=False)

@@ -218,3 +218,34 @@ def test_structural_variants_match_oracle(variant):
             err = max(err, np.abs(full.cpu().numpy()[:n] - f32).max())
         print(f"{variant} batch {batch}: max-abs vs oracle {err:.3e}")
         assert np.isfinite(central.cpu().numpy()).all() and err <= util.TOL_MAX_ABS
+
+
+@pytest.mark.parametrize("cfgname,batch", [("h36m_81", 3), ("h36m_351", 17)])
+def test_return_attention_matches_oracle(cfgname, batch):
+    """return_attention=True (u_u_t.py:176,365,418-419): (full, central, att_list) with the softmax weights of every temporal block,
+    the masked block's keys included (probability exactly 0 for masked keys of a row with at least one valid key)."""
+    from oracle import uplift_oracle as O
+    cfg = util.load_config(cfgname)
+    arch = pkg.arch_from_config(cfg)
+    w = pkg.init_weights(arch, seed=2, perturb=0.1)
+    x, m = util.synthetic_batch(cfg, batch=batch, seed=2)
+    xm = x * m[:, :, None, None].astype(np.float32)
+    model = pkg.build_uplift_upsample_transformer(cfg, weights=w, return_attention=True)
+    full, central, att = model([torch.from_numpy(xm).cuda(), torch.from_numpy(m).cuda()], training=False)
+    torch.cuda.synchronize()
+    plain = pkg.build_uplift_upsample_transformer(cfg, weights=w)
+    f0, c0 = plain([torch.from_numpy(xm).cuda(), torch.from_numpy(m).cuda()], training=False)
+    assert torch.equal(full, f0) and torch.equal(central, c0)            # the maps are a side output
+    n = min(batch, 4)
+    f32, c32, a32 = O.forward(util.hp_from_arch(arch), w, xm[:n], m[:n], torch.float32, return_attention=True)
+    assert len(att) == len(a32) == arch.temporal_depth
+    for i, (got, want) in enumerate(zip(att, a32)):
+        g = got.cpu().numpy()
+        assert g.shape == (batch, arch.num_heads, arch.num_frames, arch.num_frames)
+        assert np.abs(g.sum(-1) - 1.0).max() <= 1e-5
+        err = np.abs(g[:n] - want).max()
+        print(f"{cfgname} temporal block {i + 1}: attention maps max-abs vs oracle {err:.2e}")
+        assert err <= 2e-5
+    rows = m.any(axis=1)
+    masked_keys = att[0].cpu().numpy()[rows][:, :, :, :] * (~m[rows])[:, None, None, :]
+    assert masked_keys.max() == 0.0

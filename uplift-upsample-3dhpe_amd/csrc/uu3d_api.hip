@@ -1020,6 +1020,11 @@ struct Launcher {
 
 int uu3d_forward(uu3d_model* m, const float* kp2d, const uint8_t* mask, int32_t B, float* full_out,
                  float* central_out, void* workspace, size_t workspace_bytes, void* stream_) {
+    return uu3d_forward_attention(m, kp2d, mask, B, full_out, central_out, nullptr, workspace, workspace_bytes, stream_);
+}
+
+int uu3d_forward_attention(uu3d_model* m, const float* kp2d, const uint8_t* mask, int32_t B, float* full_out,
+                           float* central_out, float* const* attn_out, void* workspace, size_t workspace_bytes, void* stream_) {
     if (!m) return UU3D_ERR_INVALID_ARGUMENT;
     if (!m->committed) return fail(m, UU3D_ERR_NOT_READY, "uu3d_commit_weights has not been called");
     if (!kp2d || !central_out || !workspace || B < 1) return fail(m, UU3D_ERR_INVALID_ARGUMENT, "null buffer or batch < 1");
@@ -1120,10 +1125,21 @@ int uu3d_forward(uu3d_model* m, const float* kp2d, const uint8_t* mask, int32_t 
         _Float16* const Qh = reinterpret_cast<_Float16*>(w.QKV); _Float16* const Ql = Qh + (size_t)Mr * 3 * dt;
         const EpBiasSplitQ ep_qs{Qh, Ql, b.bqkv, 3 * dt, dt, Lh.attn_qscale()};
         const bool few = planes && Mr <= kFewRows && Lh.wt_ok(b.wqkv_t, dt) && Lh.wt_ok(b.w1_t, dt);
+        auto maps = [&]() {
+            if (attn_out != nullptr && tag[0] == 't' && attn_out[i] != nullptr) {        // return_attention=True: the block's attention maps, recomputed from q | k
+                Lh.begin(name("attn_maps"), "attn_probs", 2.0 * B * (double)c.num_heads * L * L * kDH, 4.0 * B * (double)c.num_heads * L * L);
+                const size_t lds = (size_t)L * (kDH + 1) * sizeof(float);
+                static const bool once = (hipFuncSetAttribute((const void*)attn_probs_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256) == hipSuccess); (void)once;
+                if (qsplit) hipLaunchKernelGGL(attn_probs_kernel, dim3(B * c.num_heads), dim3(256), lds, Lh.stream, (const void*)Qh, (const _Float16*)Ql, 3 * dt, dt, L, c.num_heads, kDH, kmask, 1.0f, 1, attn_out[i]);
+                else hipLaunchKernelGGL(attn_probs_kernel, dim3(B * c.num_heads), dim3(256), lds, Lh.stream, (const void*)w.QKV, (const _Float16*)nullptr, 3 * dt, dt, L, c.num_heads, kDH, kmask, 1.0f / sqrtf((float)kDH), 0, attn_out[i]);
+                Lh.end();
+            }
+        };
         if (few) {
             WtLoadF32 l1{x, dt, Mr, dt, b.ln1_g, b.ln1_b, 1e-5f, 1};
             if (qsplit) Lh.gemm_wt(name("ln_qkv"), l1, b.wqkv_t, Mr, 3 * dt, dt, ep_qs);
             else Lh.gemm_wt(name("ln_qkv"), l1, b.wqkv_t, Mr, 3 * dt, dt, EpBias{w.QKV, b.bqkv, 3 * dt});
+            maps();
             Lh.attn(name("attn"), w.QKV, B, L, kmask, w.O, (size_t)Mr * dt);
             { GLoadPlain gl{Ph, Pl, dt, Mr}; Lh.gemm_g(name("proj_res"), gl, b.wp_t, Mr, dt, dt, EpBiasResidual{x, b.bp, dt, nullptr, nullptr, 1}, 4.0 * Mr * dt); }
             WtLoadF32 l2{x, dt, Mr, dt, b.ln2_g, b.ln2_b, 1e-5f, 1};
@@ -1145,6 +1161,7 @@ int uu3d_forward(uu3d_model* m, const float* kp2d, const uint8_t* mask, int32_t 
             if (qsplit) Lh.gemm(name("ln_qkv"), al, b.wqkv_t, Mr, 3 * dt, dt, ep_qs);
             else { EpBias ep{w.QKV, b.bqkv, 3 * dt}; Lh.gemm(name("ln_qkv"), al, b.wqkv_t, Mr, 3 * dt, dt, ep); }
         }
+        maps();
         Lh.attn(name("attn"), w.QKV, B, L, kmask, w.O, planes ? (size_t)Mr * dt : 0);
         {
             EpBiasResidual ep{x, b.bp, dt, nullptr, nullptr, 1};

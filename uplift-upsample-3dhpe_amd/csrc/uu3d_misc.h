@@ -114,6 +114,46 @@ add_period_kernel(const float* __restrict__ x, const float* __restrict__ pe, con
     *reinterpret_cast<f32x4*>(out + row * D + c) = *reinterpret_cast<const f32x4*>(x + row * D + c) + *reinterpret_cast<const f32x4*>(pe + (row % period) * D + c);
 }
 
+// Attention maps for return_attention=True (vision_transformer.py:117-130: softmax(q k^T / sqrt(d_h) + mask * -1e9), what MHA returns
+// next to its output and UpliftUpsampleTransformer.call collects per temporal block, u_u_t.py:365,418-419).  NOT on the hot path: the
+// forward's attention kernels never materialise the (L, L) tile; this kernel recomputes it from the block's q | k.  One workgroup per
+// (sequence, head), K staged in LDS as f32, one thread per query row at a time; three passes over the row in the output buffer (raw
+// logits and their maximum, exponentials and their sum, normalisation).  q / k either f32 [rows][ld] (planes_lo == nullptr) or f16 hi / lo
+// planes with q already multiplied by log2(e) / sqrt(d_h) (the QKV epilogue of the f16x3 path): `qscale` and `base2` say which.
+static __global__ void __launch_bounds__(256)
+attn_probs_kernel(const void* __restrict__ qkv_hi, const _Float16* __restrict__ planes_lo, const int ld, const int D, const int L, const int H,
+                  const int DH, const uint8_t* __restrict__ key_mask, const float qscale, const int base2, float* __restrict__ out)
+{
+    extern __shared__ float kls[];                                   // [L][DH + 1]
+    const int b = blockIdx.x / H, h = blockIdx.x - b * H;
+    const size_t tok0 = (size_t)b * L;
+    const int KL = DH + 1;
+    auto val = [&](size_t row, int col) -> float {
+        const size_t o = row * ld + col;
+        if (planes_lo == nullptr) return reinterpret_cast<const float*>(qkv_hi)[o];
+        return (float)reinterpret_cast<const _Float16*>(qkv_hi)[o] + (float)planes_lo[o] * (1.0f / 2048.0f);
+    };
+    for (int i = threadIdx.x; i < L * DH; i += 256) { const int j = i / DH, c = i - j * DH; kls[j * KL + c] = val(tok0 + j, D + h * DH + c); }
+    __syncthreads();
+    const float neg = base2 ? -1e9f * 1.44269504088896341f : -1e9f;  // the mask term in the units of the logits
+    for (int i = threadIdx.x; i < L; i += 256) {
+        float* row = out + (((size_t)b * H + h) * L + i) * L;
+        float q[64];
+        for (int c = 0; c < DH; ++c) q[c] = val(tok0 + i, h * DH + c) * qscale;
+        float mx = -INFINITY;
+        for (int j = 0; j < L; ++j) {
+            float s = 0.f;
+            for (int c = 0; c < DH; ++c) s += q[c] * kls[j * KL + c];
+            if (key_mask != nullptr && key_mask[tok0 + j] == 0) s += neg;
+            row[j] = s; mx = fmaxf(mx, s);
+        }
+        float sum = 0.f;
+        for (int j = 0; j < L; ++j) { const float e = base2 ? exp2f(row[j] - mx) : expf(row[j] - mx); row[j] = e; sum += e; }
+        const float inv = 1.0f / sum;
+        for (int j = 0; j < L; ++j) row[j] *= inv;
+    }
+}
+
 // single pass: in-thread count, wave-level shuffle scan, one barrier for the 16 wave totals.
 static constexpr int kCompactPerThread = 16;
 static __global__ void __launch_bounds__(1024)

@@ -57,9 +57,9 @@ class UpliftUpsampleTransformer(object):
     def __init__(self, arch: UpliftArch, device=None, seed=0, weights=None, return_attention=False, precision="f16x3",
                  concurrent_halves=False):
         import torch
-        if return_attention:
-            # never used by the reference's scripts (eval.py:70, train.py:478,520)
-            raise NotImplementedError("return_attention=True: attention maps are never materialised")
+        # return_attention=True (u_u_t.py:176,418-419; never used by the reference's scripts): model(...) returns (full, central, att_list),
+        # att_list = the (B, heads, N, N) softmax weights of every temporal block, recomputed by a separate kernel (uu3d_forward_attention)
+        self.return_attention = bool(return_attention)
         if not torch.cuda.is_available():
             raise _capi.Uu3dLibraryError("no ROCm device visible: the uplift path has no CPU fallback")
         self._torch = torch
@@ -238,9 +238,18 @@ class UpliftUpsampleTransformer(object):
             self._ws[slot] = ws
         return ws
 
-    def _forward(self, x, stride_mask, full, central, slot, stream):
+    def _forward(self, x, stride_mask, full, central, slot, stream, attn=None):
         B = x.shape[0]
         ws = self._workspace(B, slot)
+        if attn is not None:
+            ptrs = (C.c_void_p * max(len(attn), 1))(*[t.data_ptr() for t in attn])
+            st = self._lib.uu3d_forward_attention(self._h, C.c_void_p(x.data_ptr()),
+                                                  C.c_void_p(stride_mask.data_ptr()) if stride_mask is not None else None, B,
+                                                  C.c_void_p(full.data_ptr()) if full is not None else None,
+                                                  C.c_void_p(central.data_ptr()), ptrs, C.c_void_p(ws.data_ptr()),
+                                                  C.c_size_t(ws.numel()), C.c_void_p(stream.cuda_stream))
+            _capi.check(self._lib, st, self._h)
+            return
         st = self._lib.uu3d_forward(self._h, C.c_void_p(x.data_ptr()),
                                     C.c_void_p(stride_mask.data_ptr()) if stride_mask is not None else None, B,
                                     C.c_void_p(full.data_ptr()) if full is not None else None,
@@ -317,11 +326,18 @@ class UpliftUpsampleTransformer(object):
             if self._returns_full else None
         central = torch.empty((B, a.num_keypoints, 3), dtype=torch.float32, device=self.device)
         if training:
+            if self.return_attention:
+                raise NotImplementedError("return_attention=True with training=True")
             self._flush_assigns()
             self._training_forward(x, stride_mask, full, central)
             return full, central
         self._sync_from_trainer()
         main = torch.cuda.current_stream(self.device)
+        if self.return_attention:
+            att = [torch.empty((B, a.num_heads, a.num_frames, a.num_frames), dtype=torch.float32, device=self.device)
+                   for _ in range(a.temporal_depth)]
+            self._forward(x, stride_mask, full, central, 0, main, attn=att)
+            return full, central, att
         if not (self._halves and B >= self.SPLIT_MIN_BATCH and not self._profiling):
             self._forward(x, stride_mask, full, central, 0, main)
             return full, central
