@@ -10,8 +10,11 @@ its own workspace, static input / output buffers and (optionally) its own hipGra
     for full, central in pipe.run(batches):                    # batches: iterable of (x, stride_mask) or x
         ...                                                    # outputs are valid until `depth` more batches were submitted
 
-Measured on MI355X (tools/streams_exp.py, h36m_351, batch 128, hipGraph replay, three runs each): 1 / 2 / 3 / 4 / 5 / 6 / 8 batches in
-flight = 141.5 / 172 / 177 / 184-186 / 171-173 / 181 / 183 k sequences/s (+30 % at 4; odd counts above 3 lose again).  Results are bit-identical to ``model(...)``: the same launches on the same data, only on another
+Measured on MI355X, h36m_351, batch 128, hipGraph replay (one box each; box to box +-10 %): `bench.py` (s_in = 5: every frame real)
+1 / 2 / 3 / 4 / 6 batches in flight = 126 / 162 / 168-169 / 152 / 167-169 k sequences/s; `tools/streams_exp.py` (mixed eval masks: the
+spatial stack skips masked frames) 1 / 2 / 3 / 4 / 5 / 6 / 8 = 141.5 / 172 / 177 / 184-186 / 171-173 / 181 / 183 k.  The gain is +28-34 %; which
+depth is best above 2 depends on how the chains' big kernels happen to interleave (depth 3 is the default of bench.py / run_eval).
+Results are bit-identical to ``model(...)``: the same launches on the same data, only on another
 stream.  Latency of ONE batch does not improve (0.9 ms); use ``model(...)`` for that.
 """
 import ctypes as C
