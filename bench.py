@@ -240,7 +240,7 @@ def secondary_benchmarks(args):
 def pmc_summary_for(config, batch):
     """The committed --pmc summary that was collected on THIS workload (config, per-GPU batch), or None: counters of another
     shape say nothing about this one."""
-    name = {("h36m_351", 128): "r02_final_pmc_summary.csv", ("dense_351", 32): "r02_final_dense351_pmc_summary.csv",
+    name = {("h36m_351", 128): "r03_final_pmc_summary.csv", ("dense_351", 32): "r02_final_dense351_pmc_summary.csv",
             ("h36m_81", 256): "r02_final_h36m81_pmc_summary.csv"}.get((config, batch))
     return None if name is None else os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", name)
 
