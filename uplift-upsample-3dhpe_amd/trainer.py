@@ -85,6 +85,7 @@ class Trainer(object):
         drop_path_uniform: "draw" = fresh U[0,1) draws, None = DropPath disabled, or a flat tensor of draws."""
         torch = self._torch
         a, cfg = self.model.arch, self.config
+        self.model._flush_assigns()                                          # WeightView.assign() since the last step: into the master buffer first
         B = keypoints2d.shape[0]
         dev = self.model.device
         x = keypoints2d.to(device=dev, dtype=torch.float32)
