@@ -308,7 +308,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true", help="skip the short secondary workloads (other configs, eager, train step) appended to the JSON line at N = 1")
     ap.add_argument("--no-graph", action="store_true", help="launch eagerly instead of replaying a hipGraph")
-    ap.add_argument("--streams", type=int, default=3, help="independent batches in flight (pipeline.ForwardPipeline: one HIP stream, workspace and hipGraph each); 1 = one batch after the other")
+    ap.add_argument("--streams", type=int, default=6, help="independent batches in flight (pipeline.ForwardPipeline: one HIP stream, workspace and hipGraph each); 1 = one batch after the other")
     ap.add_argument("--precision", default="f16x3", choices=["f16x3", "f32"], help="GEMM arithmetic of the forward (both hold the 1e-4 parity bar)")
     ap.add_argument("--mode", default="infer", choices=["infer", "train"], help="train = fwd + bwd + grad all-reduce + AdamW (BASELINE config 5)")
     ap.add_argument("--halves", action="store_true", help="two concurrent half-batch chains on two streams instead of one chain of kernels per batch")

@@ -16,6 +16,8 @@ def main():
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--streams", default="1,2,3")
     ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--s-in", type=int, default=0, help="mask stride of every sequence (bench.py uses 5 = every frame real); 0 = the mixed evaluation masks")
+    ap.add_argument("--prio", default="", help="comma list of stream priorities, cycled (0 / -1)")
     args = ap.parse_args()
     import numpy as np
     import torch
@@ -26,13 +28,14 @@ def main():
     arch = pkg.arch_from_config(cfg)
     w = pkg.init_weights(arch, seed=0)
     B, J = args.batch, arch.num_keypoints
-    x_np, m_np = util.synthetic_batch(cfg, B, seed=1000)
+    x_np, m_np = util.synthetic_batch(cfg, B, seed=1000, mask_specs=[(args.s_in, 0)] if args.s_in else None)
     x = torch.from_numpy(x_np * m_np[:, :, None, None].astype(np.float32)).cuda()
     m = torch.from_numpy(m_np).cuda()
     gt = torch.randn(B, J, 4, device="cuda")
     for S in [int(s) for s in args.streams.split(",")]:
         models = [pkg.build_uplift_upsample_transformer(cfg, weights=w) for _ in range(S)]
-        streams = [torch.cuda.Stream() for _ in range(S)]
+        pr = [int(p) for p in args.prio.split(",")] if args.prio else [0]
+        streams = [torch.cuda.Stream(priority=pr[i % len(pr)]) for i in range(S)]
         errs = [torch.empty((B, J), dtype=torch.float64, device="cuda") for _ in range(S)]
         runs = []
         for i in range(S):
@@ -61,7 +64,7 @@ def main():
         loop(args.steps)
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0
-        print(f"streams {S} tail {'on' if os.environ.get('UU3D_TAIL') == '1' else 'off'} graph {not args.no_graph}: {B * args.steps / dt:9.0f} sequences/s, {1e3 * dt / args.steps:.4f} ms per step", flush=True)
+        print(f"s_in {args.s_in} prio {args.prio or '-'} queues {os.environ.get('GPU_MAX_HW_QUEUES', '-')} streams {S} tail {'on' if os.environ.get('UU3D_TAIL') == '1' else 'off'} graph {not args.no_graph}: {B * args.steps / dt:9.0f} sequences/s, {1e3 * dt / args.steps:.4f} ms per step", flush=True)
         del models, runs
 
 

@@ -42,7 +42,7 @@ def needed_windows(frame_indices, config):
     return np.equal(np.mod(idx, stride), 0)
 
 
-def predict_windows(model, generator, descriptors, config, batch_size, flip=True, depth=3, graph=True):
+def predict_windows(model, generator, descriptors, config, batch_size, flip=True, depth=6, graph=True):
     """Central 3D predictions (W, J, 3) float32 on the device for the given window descriptors: batches of ``batch_size``
     windows, each forwarded together with its mirrored copy when ``flip`` (one launch chain over 2B sequences).
 
@@ -95,7 +95,7 @@ def predict_windows(model, generator, descriptors, config, batch_size, flip=True
 
 
 def run_eval(config, dataset_name, dataset_path, dataset2d_path, test_subset, weights_path=None, model=None, action_wise=True,
-             batch_size=None, skip_unused_windows=True, log=_log, depth=3, graph=True):
+             batch_size=None, skip_unused_windows=True, log=_log, depth=6, graph=True):
     """eval.py:34-253.  Returns ``evaluation.evaluate_predictions``'s dict (+ "num_windows", "num_forwarded", "seconds").
 
     ``batch_size`` defaults to ``config.BATCH_SIZE``; ``depth`` / ``graph``: batches in flight and hipGraph replay of the forward

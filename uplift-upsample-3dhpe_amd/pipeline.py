@@ -11,9 +11,10 @@ its own workspace, static input / output buffers and (optionally) its own hipGra
         ...                                                    # outputs are valid until `depth` more batches were submitted
 
 Measured on MI355X, h36m_351, batch 128, hipGraph replay (one box each; box to box +-10 %): `bench.py` (s_in = 5: every frame real)
-1 / 2 / 3 / 4 / 6 batches in flight = 126 / 162 / 168-169 / 152 / 167-169 k sequences/s; `tools/streams_exp.py` (mixed eval masks: the
-spatial stack skips masked frames) 1 / 2 / 3 / 4 / 5 / 6 / 8 = 141.5 / 172 / 177 / 184-186 / 171-173 / 181 / 183 k.  The gain is +28-34 %; which
-depth is best above 2 depends on how the chains' big kernels happen to interleave (depth 3 is the default of bench.py / run_eval).
+1 / 2 / 3 / 4 / 6 / 8 batches in flight = 126 / 162 / 166-169 / 152 / 167-169 / 155 k sequences/s; `tools/streams_exp.py` (same workload,
+another process layout) 2 / 3 / 4 / 6 = 166 / 151 / 170 / 168 k.  The gain is +28-34 %; the depths that lose ~10 % differ between the two
+programs -- HIP deals streams to its 4 hardware queues in creation order, and a depth whose slots collide on a queue serialises them --
+while 6 slots were at the top in every run of both (the default of bench.py / run_eval; h36m_81 batch 256: 305 / 322-324 / 326 k at 2 / 3 / 6).
 Results are bit-identical to ``model(...)``: the same launches on the same data, only on another
 stream.  Latency of ONE batch does not improve (0.9 ms); use ``model(...)`` for that.
 """
