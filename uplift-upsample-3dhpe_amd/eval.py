@@ -42,7 +42,7 @@ def needed_windows(frame_indices, config):
     return np.equal(np.mod(idx, stride), 0)
 
 
-def predict_windows(model, generator, descriptors, config, batch_size, flip=True, depth=6, graph=True):
+def predict_windows(model, generator, descriptors, config, batch_size, flip=True, depth=2, graph=True):
     """Central 3D predictions (W, J, 3) float32 on the device for the given window descriptors: batches of ``batch_size``
     windows, each forwarded together with its mirrored copy when ``flip`` (one launch chain over 2B sequences).
 
@@ -53,19 +53,17 @@ def predict_windows(model, generator, descriptors, config, batch_size, flip=True
     import torch
     W = len(descriptors)
     J = generator.table.J
-    out = torch.empty((W, J, 3), dtype=torch.float32, device=generator.table.device)
-    order = torch.as_tensor(np.asarray(config.AUGM_FLIP_KEYPOINT_ORDER), dtype=torch.long, device=out.device)
+    dev = generator.table.device
     if W == 0:
-        return out
+        return torch.empty((0, J, 3), dtype=torch.float32, device=dev)
+    # raw central predictions of the windows (and of their mirrored copies): the un-flip / average of eval.py:163-166 runs ONCE over
+    # all windows at the end instead of five small launches per batch
+    raw = torch.empty((2 if flip else 1, W, J, 3), dtype=torch.float32, device=dev)
     rows = min(batch_size, W) * (2 if flip else 1)
     pipe = model.pipeline(rows, depth=depth, graph=graph) if (depth > 1 or graph) else None
 
     def finish(lo, n, cen):
-        if flip:
-            f = cen[n:]
-            f = torch.cat([f[..., :1] * -1.0, f[..., 1:]], dim=-1).index_select(1, order)      # eval.py:163-166
-            cen = (cen[:n] + f) / 2.0
-        out[lo:lo + n] = cen
+        raw[:, lo:lo + n].copy_(cen.view(raw.shape[0], n, J, 3))
 
     pending = []
     for lo in range(0, W, batch_size):
@@ -89,13 +87,18 @@ def predict_windows(model, generator, descriptors, config, batch_size, flip=True
     for plo, pn, t in pending:
         finish(plo, pn, pipe.result(t)[1])
     if pipe is not None:
-        torch.cuda.current_stream(out.device).synchronize()        # the slots' buffers go away with the pipeline
+        torch.cuda.current_stream(dev).synchronize()               # the slots' buffers go away with the pipeline
         pipe.close()
-    return out
+    if not flip:
+        return raw[0]
+    order = torch.as_tensor(np.asarray(config.AUGM_FLIP_KEYPOINT_ORDER), dtype=torch.long, device=dev)
+    f = raw[1]
+    f = torch.cat([f[..., :1] * -1.0, f[..., 1:]], dim=-1).index_select(1, order)              # eval.py:163-166
+    return (raw[0] + f) / 2.0
 
 
 def run_eval(config, dataset_name, dataset_path, dataset2d_path, test_subset, weights_path=None, model=None, action_wise=True,
-             batch_size=None, skip_unused_windows=True, log=_log, depth=6, graph=True):
+             batch_size=None, skip_unused_windows=True, log=_log, depth=2, graph=True):
     """eval.py:34-253.  Returns ``evaluation.evaluate_predictions``'s dict (+ "num_windows", "num_forwarded", "seconds").
 
     ``batch_size`` defaults to ``config.BATCH_SIZE``; ``depth`` / ``graph``: batches in flight and hipGraph replay of the forward
