@@ -223,10 +223,10 @@ def secondary_benchmarks(args):
     out = {}
     jobs = [("latency_one_batch_in_flight", lambda: quick_forward_bench(args.config, args.batch, streams=1, graph=True)),
             ("eager_one_batch_in_flight", lambda: quick_forward_bench(args.config, args.batch, streams=1, graph=False)),
-            ("eager_pipelined", lambda: quick_forward_bench(args.config, args.batch, streams=max(2, args.streams), graph=False)),
-            ("h36m_81_batch256", lambda: quick_forward_bench("h36m_81", 256, streams=max(1, args.streams))),
-            ("s_in_10", lambda: quick_forward_bench(args.config, args.batch, s_in=10, streams=max(1, args.streams))),
-            ("s_in_20", lambda: quick_forward_bench(args.config, args.batch, s_in=20, streams=max(1, args.streams))),
+            ("eager_pipelined", lambda: quick_forward_bench(args.config, args.batch, streams=max(2, args.streams_used), graph=False)),
+            ("h36m_81_batch256", lambda: quick_forward_bench("h36m_81", 256, streams=max(1, args.streams_used))),
+            ("s_in_10", lambda: quick_forward_bench(args.config, args.batch, s_in=10, streams=max(1, args.streams_used))),
+            ("s_in_20", lambda: quick_forward_bench(args.config, args.batch, s_in=20, streams=max(1, args.streams_used))),
             ("dense_351_batch32", lambda: quick_forward_bench("dense_351", 32, streams=1, attention=True)),
             ("train_step", lambda: quick_train_bench())]
     for name, fn in jobs:
@@ -308,7 +308,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true", help="skip the short secondary workloads (other configs, eager, train step) appended to the JSON line at N = 1")
     ap.add_argument("--no-graph", action="store_true", help="launch eagerly instead of replaying a hipGraph")
-    ap.add_argument("--streams", type=int, default=6, help="independent batches in flight (pipeline.ForwardPipeline: one HIP stream, workspace and hipGraph each); 1 = one batch after the other")
+    ap.add_argument("--streams", type=int, default=0, help="independent batches in flight (pipeline.ForwardPipeline: one HIP stream, workspace and hipGraph each); 1 = one batch after the other; 0 (default) = tried before the timed region: 2, 3, 4 and 6 slots for 40 untimed steps each, the fastest is used (pipeline.tune_depth)")
     ap.add_argument("--precision", default="f16x3", choices=["f16x3", "f32"], help="GEMM arithmetic of the forward (both hold the 1e-4 parity bar)")
     ap.add_argument("--mode", default="infer", choices=["infer", "train"], help="train = fwd + bwd + grad all-reduce + AdamW (BASELINE config 5)")
     ap.add_argument("--halves", action="store_true", help="two concurrent half-batch chains on two streams instead of one chain of kernels per batch")
@@ -373,10 +373,12 @@ def main():
     # `--streams S` batches are in flight at once (pipeline.ForwardPipeline: each on its own HIP stream with its own workspace,
     # static buffers and hipGraph of forward + error kernel); S = 1 is one batch after the other.  The RCCL all-gather stays
     # outside the graphs, on the caller's stream.
-    S = 1 if (args.halves and not args.no_halves) else max(1, args.streams)
+    S = 1 if (args.halves and not args.no_halves) else max(0, args.streams)
     pipe = None
+    tuned = None
+    auto = (S == 0)
     use_graph = not args.no_graph
-    errs = [torch.empty((B, J), dtype=torch.float64, device="cuda") for _ in range(S)]
+    errs = [torch.empty((B, J), dtype=torch.float64, device="cuda") for _ in range(max(S, 6))]
 
     def post(full, central, i):
         return per_joint_error(central, gt, cfg.ROOT_KEYTPOINT, out=errs[i])
@@ -402,10 +404,16 @@ def main():
                     dist.all_gather_into_tensor(gathered, err)
     else:
         try:
-            pipe = model.pipeline(B, depth=S, graph=use_graph, post=post)
+            if auto:                                    # which depth collides on a hardware queue depends on the process: try them (untimed), keep the fastest
+                from uplift_upsample_3dhpe_amd.pipeline import tune_depth
+                pipe, tuned = tune_depth(model, B, candidates=(2, 3, 4, 6), steps=40, graph=use_graph, post=post)
+                S = pipe.depth
+            else:
+                pipe = model.pipeline(B, depth=S, graph=use_graph, post=post)
         except Exception as e:  # pragma: no cover
             print(f"[bench] graph capture failed ({e}); running eagerly", file=sys.stderr)
             use_graph = False
+            S = S or 2
             pipe = model.pipeline(B, depth=S, graph=False, post=post)
 
         def run_steps(n):
@@ -476,6 +484,7 @@ def main():
                        "parallelism": f"batch-sharded x{world}", "hipgraph": bool(use_graph),
                        "concurrent_half_batches": bool(args.halves and not args.no_halves and B >= 64),
                        "batches_in_flight": S,
+                       "batches_in_flight_tried_ms_per_step": None if tuned is None else {str(k): round(v * 1e3, 4) for k, v in tuned.items()},
                        "pipelining": (f"{S} independent batches in flight on {S} HIP streams, each replaying its own hipGraph of forward + error "
                                       "kernel with its own workspace (uplift-upsample-3dhpe_amd/pipeline.py; the same path eval.run_eval uses)") if S > 1
                                      else "one batch after the other"},
@@ -504,6 +513,7 @@ def main():
             out["cpu_baseline"] = None
         if world == 1 and not args.no_secondary and args.config == "h36m_351":
             pipe = None
+            args.streams_used = S
             out["secondary"] = secondary_benchmarks(args)
         print(json.dumps(out), flush=True)
     if use_dist:

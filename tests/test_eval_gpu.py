@@ -95,6 +95,12 @@ def test_pipelined_forwards_are_bit_identical():
             assert len(got) == len(want)
             for (f, c), (fw, cw) in zip(got, want):
                 assert torch.equal(f, fw) and torch.equal(c, cw), (depth, graph, rep)
+    from uplift_upsample_3dhpe_amd.pipeline import tune_depth
+    pipe, timings = tune_depth(model, B, candidates=(2, 3), steps=6)      # the measured pipeline itself comes back, the other is closed
+    assert pipe.depth in (2, 3) and set(timings) == {2, 3} and len(model._ws) <= 1 + pipe.depth
+    for (f, c), (fw, cw) in zip(pipe.run(batches), want):
+        assert torch.equal(f, fw) and torch.equal(c, cw)
+    pipe.close()
     f = model.capture(B)
     for (x, m), (fw, cw) in zip(batches[:4], want[:4]):
         full, cen = f([x, m])

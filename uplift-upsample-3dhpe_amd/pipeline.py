@@ -14,7 +14,8 @@ Measured on MI355X, h36m_351, batch 128, hipGraph replay (one box each; box to b
 1 / 2 / 3 / 4 / 6 / 8 batches in flight = 126 / 162 / 166-169 / 152 / 167-169 / 155 k sequences/s; `tools/streams_exp.py` (same workload,
 another process layout) 2 / 3 / 4 / 6 = 166 / 151 / 170 / 168 k.  The gain is +28-34 %; the depths that lose ~10 % differ between the two
 programs -- HIP deals streams to its 4 hardware queues in creation order, and a depth whose slots collide on a queue serialises them --
-while 6 slots were at the top in every run of both (the default of bench.py / run_eval; h36m_81 batch 256: 305 / 322-324 / 326 k at 2 / 3 / 6).
+hence ``tune_depth`` below (bench.py's default): try 2, 3, 4 and 6 slots, keep the fastest pipeline object.  h36m_81 batch 256: 305 /
+322-324 / 326 k at 2 / 3 / 6.
 Results are bit-identical to ``model(...)``: the same launches on the same data, only on another
 stream.  Latency of ONE batch does not improve (0.9 ms); use ``model(...)`` for that.
 """
@@ -151,3 +152,39 @@ class ForwardPipeline(object):
                 yield self.result(pending.pop(0))
         while pending:
             yield self.result(pending.pop(0))
+
+
+def tune_depth(model, batch, candidates=(2, 3, 4, 6), steps=40, graph=True, post=None):
+    """Pick the number of slots by trying them: HIP deals streams to its hardware queues in creation order, and which depths collide on
+    a queue (and lose ~10 %) depends on what else the process has created -- measured, not predictable.  Builds
+    one pipeline per candidate, runs ``steps`` forwards of its (zero) static inputs, keeps the fastest and closes the others: the
+    pipeline that is returned is the very object that was measured (same streams, same queues).
+    Returns ``(pipeline, {depth: seconds per step})``."""
+    import time
+    import torch
+    timings, best = {}, None
+    for d in candidates:
+        pipe = ForwardPipeline(model, batch, depth=d, graph=graph, post=post)
+        x, m = pipe._slots[0].x, pipe._slots[0].m
+
+        def run(n):
+            t = []
+            for _ in range(n):
+                t.append(pipe.submit(x, m))
+                if len(t) == d:
+                    pipe.result(t.pop(0))
+            for q in t:
+                pipe.result(q)
+        run(max(4, steps // 4))
+        torch.cuda.synchronize(model.device)
+        t0 = time.perf_counter()
+        run(steps)
+        torch.cuda.synchronize(model.device)
+        timings[d] = (time.perf_counter() - t0) / steps
+        if best is None or timings[d] < timings[best.depth]:
+            if best is not None:
+                best.close()
+            best = pipe
+        else:
+            pipe.close()
+    return best, timings
