@@ -296,6 +296,19 @@ int uu3d_train_forward_backward(uu3d_model* model, const float* params_dev, cons
                                 float* loss_out_dev, float* full_out_dev, float* central_out_dev,
                                 float* grads_dev, void* workspace_dev, size_t workspace_bytes, void* stream);
 
+/* The same step with random token masking (uplift_upsample_transformer.py:287-311, 336-338; TOKEN_MASK_RATE > 0 with
+ * LEARNABLE_MASKED_TOKEN = false): token (b, n) entering the temporal transformer -- spatial_to_temporal_fc's output, before the
+ * strided-input token blend and the positional encoding -- is replaced by 0 where token_mask_uniform_dev[b * N + n] <
+ * token_mask_rate, never at the central frame n = N / 2.  token_mask_uniform_dev: B * N draws of U[0, 1) (the caller's generator,
+ * like drop_path_uniform_dev); NULL or rate 0: no masking (= uu3d_train_forward_backward). */
+int uu3d_train_forward_backward_masked(uu3d_model* model, const float* params_dev, const float* kp2d_dev,
+                                       const uint8_t* stride_mask_dev, const float* gt3d_dev, int32_t batch,
+                                       int32_t batch_size_norm, float w_center, float w_seq, int32_t root_index,
+                                       const float* drop_path_rates, const float* drop_path_uniform_dev,
+                                       const float* token_mask_uniform_dev, float token_mask_rate,
+                                       float* loss_out_dev, float* full_out_dev, float* central_out_dev,
+                                       float* grads_dev, void* workspace_dev, size_t workspace_bytes, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

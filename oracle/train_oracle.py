@@ -89,7 +89,7 @@ def ema_update(ema, w, decay):
 
 
 def train_step_grads(hp, weights, keypoints2d, stride_masks, keypoints3d, root, w_center, w_seq, batch_size_norm,
-                     drop_path_cfg=None, dtype=torch.float64):
+                     drop_path_cfg=None, dtype=torch.float64, token_mask_cfg=None):
     """Loss and d loss / d weights of train_step (train.py:464-498) by autograd through the forward oracle.
 
     keypoints2d (B,N,J,2) raw, stride_masks (B,N) bool, keypoints3d (B,N,J,3) absolute.  Returns
@@ -100,7 +100,7 @@ def train_step_grads(hp, weights, keypoints2d, stride_masks, keypoints3d, root, 
     x = torch.tensor(np.asarray(keypoints2d), dtype=dtype)
     if hp["has_strided_input"]:
         x = x * torch.tensor(np.asarray(stride_masks).astype(np.float64), dtype=dtype)[:, :, None, None]   # train.py:474
-    full, central, _ = O.forward_torch(hp, p, x, stride_masks if hp["has_strided_input"] else None, dtype, drop_path_cfg)
+    full, central, _ = O.forward_torch(hp, p, x, stride_masks if hp["has_strided_input"] else None, dtype, drop_path_cfg, token_mask_cfg)
     gt = torch.tensor(np.asarray(keypoints3d), dtype=dtype)
     gt = gt - gt[:, :, root:root + 1, :]
     N, J = gt.shape[1], gt.shape[2]

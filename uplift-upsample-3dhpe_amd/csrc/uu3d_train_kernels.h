@@ -142,6 +142,19 @@ droppath_gate_kernel(const float* __restrict__ u, const int n, const float keep,
     if (i < n) gate[i] = (u != nullptr) ? floorf(u[i] + keep) : 1.0f;
 }
 
+// random token masking (u_u_t.py:287-311): keep[b, n] = 1 where the token entering the temporal transformer is spatial_to_temporal_fc's
+// output, 0 where it is replaced -- by the strided-input token (stride_mask == 0) or by the masked-token value 0 (u < rate, never the
+// central frame).  One array serves the forward epilogue and the backward row mask (d s2t_out = dX * keep).
+static __global__ void __launch_bounds__(256)
+token_keep_kernel(const float* __restrict__ u, const float rate, const uint8_t* __restrict__ stride_mask, const int rows, const int N,
+                  uint8_t* __restrict__ keep)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= rows) return;
+    const bool masked = (u[i] < rate) && (i % N != N / 2);
+    keep[i] = (uint8_t)((stride_mask == nullptr || stride_mask[i] != 0) && !masked);
+}
+
 // every layer's gates of both stacks in one launch: layer i of the spatial stack has ns gates (u and gate at i * ns), the
 // temporal stack's follow (u at Ls * ns + i * nt, gates in their own array); keep[i] >= 1 or u == nullptr: gate = 1
 struct GateKeeps { float s[16], t[16]; };

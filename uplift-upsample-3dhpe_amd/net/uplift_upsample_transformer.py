@@ -298,10 +298,12 @@ class UpliftUpsampleTransformer(object):
         if self._train_ws is None or self._train_ws.numel() < nbytes:
             self._train_ws = torch.empty(nbytes, dtype=torch.uint8, device=self.device)
         r3 = (C.c_float * 3)(*[float(r) for r in rates])
-        st = self._lib.uu3d_train_forward_backward(
+        tm = torch.rand((B, a.num_frames), generator=rng, device=self.device, dtype=torch.float32) if a.token_mask_rate > 0.0 else None   # u_u_t.py:299
+        st = self._lib.uu3d_train_forward_backward_masked(
             self._h, C.c_void_p(params.data_ptr()), C.c_void_p(x.data_ptr()),
             C.c_void_p(stride_mask.data_ptr()) if stride_mask is not None else None, None, B, int(a.batch_size), 0.0, 0.0, 0,
-            r3, C.c_void_p(u.data_ptr()), None, C.c_void_p(full.data_ptr()) if full is not None else None,
+            r3, C.c_void_p(u.data_ptr()), C.c_void_p(tm.data_ptr()) if tm is not None else None, float(a.token_mask_rate),
+            None, C.c_void_p(full.data_ptr()) if full is not None else None,
             C.c_void_p(central.data_ptr()), None, C.c_void_p(self._train_ws.data_ptr()), self._train_ws.numel(), stream)
         _capi.check(self._lib, st, self._h)
 

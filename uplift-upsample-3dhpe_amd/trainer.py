@@ -79,10 +79,11 @@ class Trainer(object):
             n += len(a.strides) * 2 * batch
         return n
 
-    def forward_backward(self, keypoints2d, keypoints3d, stride_masks, drop_path_uniform="draw"):
+    def forward_backward(self, keypoints2d, keypoints3d, stride_masks, drop_path_uniform="draw", token_mask_uniform="draw"):
         """Training-mode forward + loss + backward.  Returns (loss[3] tensor, full, central); gradients in self.grads.
 
-        drop_path_uniform: "draw" = fresh U[0,1) draws, None = DropPath disabled, or a flat tensor of draws."""
+        drop_path_uniform: "draw" = fresh U[0,1) draws, None = DropPath disabled, or a flat tensor of draws.
+        token_mask_uniform (TOKEN_MASK_RATE > 0, u_u_t.py:287-311): "draw", None = no token masking, or a (B, N) tensor of draws."""
         torch = self._torch
         a, cfg = self.model.arch, self.config
         self.model._flush_assigns()                                          # WeightView.assign() since the last step: into the master buffer first
@@ -100,15 +101,20 @@ class Trainer(object):
             u = torch.rand(self.drop_path_size(B), generator=self._rng, device=dev, dtype=torch.float32)
         else:
             u = drop_path_uniform
+        tm = None
+        if a.token_mask_rate > 0.0 and token_mask_uniform is not None:
+            tm = (torch.rand((B, a.num_frames), generator=self._rng, device=dev, dtype=torch.float32) if isinstance(token_mask_uniform, str)
+                  else token_mask_uniform.to(device=dev, dtype=torch.float32).contiguous())
         full = torch.empty((B, a.num_frames, a.num_keypoints, 3), dtype=torch.float32, device=dev)
         central = torch.empty((B, a.num_keypoints, 3), dtype=torch.float32, device=dev)
         ws = self._workspace(B)
         rates = (C.c_float * 3)(*[float(r) for r in self.drop_path_rates])
         self._buckets.begin()                                               # a previous pass without apply_gradients leaves nothing behind
-        st = self._lib.uu3d_train_forward_backward(
+        st = self._lib.uu3d_train_forward_backward_masked(
             self.model._h, C.c_void_p(self.params.data_ptr()), C.c_void_p(x.data_ptr()), m_ptr, C.c_void_p(gt.data_ptr()), B,
             int(cfg.BATCH_SIZE), float(cfg.LOSS_WEIGHT_CENTER), float(cfg.LOSS_WEIGHT_SEQUENCE), int(cfg.ROOT_KEYTPOINT),
-            rates, None if u is None else C.c_void_p(u.data_ptr()), C.c_void_p(self.loss.data_ptr()),
+            rates, None if u is None else C.c_void_p(u.data_ptr()),
+            None if tm is None else C.c_void_p(tm.data_ptr()), float(a.token_mask_rate), C.c_void_p(self.loss.data_ptr()),
             C.c_void_p(full.data_ptr()), C.c_void_p(central.data_ptr()), C.c_void_p(self.grads.data_ptr()),
             C.c_void_p(ws.data_ptr()), self._ws_bytes, self._stream())
         _capi.check(self._lib, st, self.model._h)
@@ -135,8 +141,8 @@ class Trainer(object):
         _capi.check(self._lib, self._lib.uu3d_train_nonfinite(self.model._h, C.byref(out)), self.model._h)
         return out.value != 0
 
-    def train_step(self, keypoints2d, keypoints3d, stride_masks, drop_path_uniform="draw"):
-        loss, _, _ = self.forward_backward(keypoints2d, keypoints3d, stride_masks, drop_path_uniform)
+    def train_step(self, keypoints2d, keypoints3d, stride_masks, drop_path_uniform="draw", token_mask_uniform="draw"):
+        loss, _, _ = self.forward_backward(keypoints2d, keypoints3d, stride_masks, drop_path_uniform, token_mask_uniform)
         self.apply_gradients()
         return loss
 
