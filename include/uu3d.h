@@ -190,6 +190,19 @@ int uu3d_world_to_cam_2d(const float* world_dev, const float* cams_dev, int32_t 
                          float* cam3d_dev, float* kp2d_dev, void* stream);
 
 /*
+ * What the launch shapes of the following uu3d_forward calls are chosen for (a host-side attribute, read when a forward is
+ * enqueued or captured; the results are bit-identical either way):
+ *   UU3D_SCHEDULE_LATENCY (default): one batch at a time -- every launch spreads over as many CUs as pays for ITS duration;
+ *   UU3D_SCHEDULE_THROUGHPUT: several independent batches in flight on different streams (pipeline.ForwardPipeline sets it around
+ *     its launches) -- the chip is shared between forwards, so a launch is shaped for the fewest CU-microseconds instead: the
+ *     attention projection runs as 71 workgroups x 12 column chunks instead of 213 x 4 (27 instead of 16 us alone, +2.4 %
+ *     sequences/s with four batches in flight).
+ */
+#define UU3D_SCHEDULE_LATENCY 0
+#define UU3D_SCHEDULE_THROUGHPUT 1
+int uu3d_set_schedule(uu3d_model* model, int32_t schedule);
+
+/*
  * Per-kernel timing of the next uu3d_forward calls with HIP events on the launch stream.
  * When enabled, uu3d_forward records an event pair around every launch; uu3d_profile_read
  * synchronises those events and returns the per-launch records of the LAST forward.

@@ -26,14 +26,15 @@ SRC = r'''
 using namespace uu3d;
 template __global__ void uu3d::attn_head_wave_kernel<5, 48, true>(const float*, int, int, int, int, const uint8_t*, float*, int, size_t, int);
 template __global__ void uu3d::attn_f32_kernel<3, 48, true>(const float*, int, int, int, int, const uint8_t*, float*, int, size_t);
-template __global__ void uu3d::attn_h3_kernel<48, 3, 3, false>(const _Float16*, const _Float16*, int, int, int, int, const uint8_t*, _Float16*, size_t, int);
-template __global__ void uu3d::attn_h3_kernel<48, 12, 3, true>(const _Float16*, const _Float16*, int, int, int, int, const uint8_t*, _Float16*, size_t, int);
+template __global__ void uu3d::attn_h3_kernel<48, 3, 3, false>(const _Float16*, const _Float16*, int, int, int, int, const uint8_t*, _Float16*, size_t, int, int);
+template __global__ void uu3d::attn_h3_kernel<48, 12, 3, true>(const _Float16*, const _Float16*, int, int, int, int, const uint8_t*, _Float16*, size_t, int, int);
 template __global__ void uu3d::gemm_tn_h3_kernel<TnLoadLayerNorm, EpSlab>(const TnLoadLayerNorm, const float*, int, int, int, int, int, int, int, const EpSlab);
 template __global__ void uu3d::gemm_tn_kernel<TnLoadLayerNorm, EpSlab>(const TnLoadLayerNorm, const float*, int, int, int, int, int, int, int, const EpSlab);
 template __global__ void uu3d::spatial_stack_h3_kernel<17, 3, 1, false>(const float*, const SpatialParams, const _Float16*, float*, _Float16*, _Float16*, const SpatialTrainIO);
 template __global__ void uu3d::spatial_stack_h3_kernel<17, 3, 1, true>(const float*, const SpatialParams, const _Float16*, float*, _Float16*, _Float16*, const SpatialTrainIO);
 template __global__ void uu3d::gemm_h3_panel_kernel<24, PanelEpBias>(const _Float16*, const _Float16*, const float*, int, int, int, int, const PanelEpBias);
 template __global__ void uu3d::gemm_h3_panel_kernel<24, PanelEpBiasReluSplit>(const _Float16*, const _Float16*, const float*, int, int, int, int, const PanelEpBiasReluSplit);
+template __global__ void uu3d::gemm_h3_panel_kernel<24, PanelEpBiasResidual, 4>(const _Float16*, const _Float16*, const float*, int, int, int, int, const PanelEpBiasResidual);
 template __global__ void uu3d::ln_split_frag_kernel<24, 8>(const float*, int, int, float, const float*, const float*, _Float16*);
 template __global__ void uu3d::gemm_h3g_kernel<1, 1, GLoadConv3, EpSlab, 3>(const GLoadConv3, const _Float16*, const _Float16*, int, int, int, int, int, int, const EpSlab);
 template __global__ void uu3d::gemm_h3g_kernel<1, 2, GLoadPlain, EpBiasResidual, 3>(const GLoadPlain, const _Float16*, const _Float16*, int, int, int, int, int, int, const EpBiasResidual);
@@ -93,6 +94,17 @@ def test_row_panel_gemm_code_shape(asm):
         assert n_dma % 12 == 0 and n_dma >= 2 * 12 + 4 * 12, n_dma
         assert body.count("v_mfma_f32_32x32x16_f16") == (n_dma // 12 - 2) * 72
         assert re.search(r"ds_read_b128 v\[\d+:\d+\], v\d+ offset:\d+\n\tds_read_b128", body)     # the asm fragment reads survived
+    # the in-place residual form (attention projection, chunk loop unrolled: CPW = 4): every residual value is requested straight into
+    # an accumulation register by name, and nothing but the prologue / the ends of the two panel variants drains the ring -- a load
+    # hipcc can see brought a vmcnt(0) per chunk (parked in an AGPR at once) or per loop iteration (in flight across the back edge)
+    body = next(v for k, v in ks.items() if "gemm_h3_panel_kernel" in k and "PanelEpBiasResidual" in k)
+    assert "scratch_" not in body
+    n_dma = body.count("global_load_lds_dwordx4")
+    assert n_dma % 12 == 0 and body.count("v_mfma_f32_32x32x16_f16") == (n_dma // 12 - 2) * 72
+    res = re.findall(r"global_load_dword (\w+), v\d+, s\[\d+:\d+\]", body)
+    assert len(res) == 2 * 4 * 16 and all(r.startswith("a") for r in res), res[:4]
+    assert len(re.findall(r"s_waitcnt vmcnt\(0\)", body)) <= 5
+    assert len(re.findall(r"s_waitcnt vmcnt\(12\) lgkmcnt\(0\)", body)) == 2 * 4
 
 
 def test_no_packed_fp32_valu_ops(asm):

@@ -104,6 +104,8 @@ struct uu3d_model {
     bool attn_f32 = false;         // UU3D_ATTN_F32=1: sequences of 49-128 tokens stay on the exact-f32 attention kernels (A/B measurements, tests)
     bool attn_wg = false;          // UU3D_ATTN_WG=1: attention with one workgroup per (sequence, head) (attn_f32_kernel) instead of one wave per item (A/B measurements, tests)
     bool no_panel = false;         // UU3D_NO_PANEL=1: LayerNorm-fed GEMMs stay on the tiled kernels (A/B measurements, tests)
+    bool no_panel_proj = false;    // UU3D_NO_PANEL_PROJ=1: the attention projection stays on the tiled LDS-DMA kernel
+    bool throughput = false;       // uu3d_set_schedule: launches shaped for CU-microseconds (several forwards share the chip) instead of latency
     bool no_tail = true;           // UU3D_TAIL=1 (opt-in): the last strided block + head2 as ONE XCD-cooperative launch (strided_tail_kernel) instead of a chain of 9 -- measured equal for one batch at a time and 0.7 % slower with two batches in flight (its 256 spinning workgroups hold every CU), profiles/r03_tail_ab.txt
     size_t h2_pf = 0;              // fragment-ordered head2 operand (uu3d_tail.h), offset in harena, 0 = none
     int num_cus = 256;
@@ -329,6 +331,7 @@ int uu3d_create(const uu3d_config* c, int device, uu3d_model** out) {
     { const char* e = getenv("UU3D_NO_WT"); m->no_wt = (e != nullptr && e[0] == '1'); }
     { const char* e = getenv("UU3D_ATTN_F32"); m->attn_f32 = (e != nullptr && e[0] == '1'); }
     { const char* e = getenv("UU3D_NO_PANEL"); m->no_panel = (e != nullptr && e[0] == '1'); }
+    { const char* e = getenv("UU3D_NO_PANEL_PROJ"); m->no_panel_proj = (e != nullptr && e[0] == '1'); }
     { const char* e = getenv("UU3D_TAIL"); m->no_tail = !(e != nullptr && e[0] == '1'); }
     { hipDeviceProp_t pr; if (hipGetDeviceProperties(&pr, device) == hipSuccess && pr.multiProcessorCount > 0) m->num_cus = pr.multiProcessorCount; }
     *out = m;
@@ -602,7 +605,7 @@ int uu3d_commit_weights(uu3d_model* m, void* stream_) {
                 panel_pack_operand(hb.data() + it->second.first, hb.data() + it->second.second, Nn, K, Kp, hb.data() + at);
                 m->panel_off[bt_off] = at;
             };
-            for (auto& o : toff) { add_panel(o.wqkv, 3 * dt); add_panel(o.w1, ht); }
+            for (auto& o : toff) { add_panel(o.wqkv, 3 * dt); add_panel(o.w1, ht); add_panel(o.wp, dt); }
             // fused MLP (uu3d_mlp_fused.h): fc2 fragments in the k order fc1's accumulator registers have
             m->mlpf_off.clear();
             if (dt == 32 * MLPF_OC && ht == 256 * MLPF_SLICES)
@@ -614,10 +617,10 @@ int uu3d_commit_weights(uu3d_model* m, void* stream_) {
                     mlpf_pack_w2(hb.data() + it->second.first, hb.data() + it->second.second, Kht, hb.data() + at);
                     m->mlpf_off[o.w2] = at;
                 }
-            for (auto& o : soff) { add_panel(o.wqkv, 3 * dt); add_panel(o.w1, ht); }
+            for (auto& o : soff) { add_panel(o.wqkv, 3 * dt); add_panel(o.w1, ht); add_panel(o.wp, dt); }
             // the cooperative tail kernel (uu3d_tail.h) reads every operand of the last strided block and of head2 in fragment order
             if (!soff.empty() && ht == 2 * dt) {
-                add_panel(soff.back().wp, dt); add_panel(soff.back().w2, dt, 3 * ht, round_up(3 * ht, 32));
+                add_panel(soff.back().w2, dt, 3 * ht, round_up(3 * ht, 32));
                 add_panel(o_h2, round_up(3 * J, 32));
             }
         }
@@ -835,12 +838,39 @@ struct Launcher {
     }
     template <class EP>
     void gemm_panel(const char* name, const _Float16* Af, size_t pf, const float* colv, int M, int N, const EP& ep) {
-        const int K = 384, S = panel_splits(M, N), mt = (M + 127) / 128;
+        const int K = 384, mt = (M + 127) / 128;
+        int S = panel_splits(M, N);
+        { static const char* e = getenv("UU3D_PANEL_S"); if (e != nullptr && e[0] >= '1' && e[0] <= '3' && (N / 32) % (e[0] - '0') == 0 && (N / 32) / (e[0] - '0') <= PANEL_COLV_FLOATS / 32) S = e[0] - '0'; }   // (A/B measurements)
         begin(name, "gemm_panel", 2.0 * M * (double)N * K, 4.0 * ((double)M * K + (double)N * K + (double)M * N));
         auto kern = gemm_h3_panel_kernel<24, EP>;
         static bool attr_done = false;
         if (!attr_done) { (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)PANEL_LDS_TOTAL); attr_done = true; }
         hipLaunchKernelGGL(kern, dim3(8 * S, ((mt * S + 7) / 8 + S - 1) / S), dim3(256), PANEL_LDS_TOTAL, stream, Af, m->harena + pf, colv, M, mt, S, (N / 32) / S, ep);
+        end();
+    }
+    // x[M][384] += A B + colv in place (the attention projection on the residual stream): N = K = 384, the kernel's chunk loop unrolled
+    // (CPW = 4 / 6 / 12 chunks per workgroup for 3 / 2 / 1 column ranges per row tile -- uu3d_gemm_panel.h says why)
+    void gemm_panel_residual(const char* name, const _Float16* Af, size_t pf, const float* colv, int M, float* x) {
+        const int K = 384, N = 384, mt = (M + 127) / 128;
+        int S = 1; double best = 1e30;
+        for (int s : {1, 2, 3}) {                                  // same cost model as panel_splits
+            const int per_xcd = (mt * s + 7) / 8;
+            const double cost = (double)((per_xcd + 31) / 32) * (2.5 + 12.0 / s);
+            if (cost < best) { best = cost; S = s; }
+        }
+        // several forwards in flight: the fewest CU-microseconds win, not the shortest launch (h36m_351 batch 128, 9088 rows: S = 3 / 2 / 1
+        // = 213 / 142 / 71 workgroups, 16.3 / 18.9 / 27.5 us per launch; one batch at a time 127.7 / 126.2 / 121.2 k sequences/s, four in
+        // flight 167.3 / 169.2 / 171.3 k on the same box)
+        if (m->throughput) S = 1;
+        { static const char* e = getenv("UU3D_PANEL_PROJ_S"); if (e != nullptr && e[0] >= '1' && e[0] <= '3') S = e[0] - '0'; }   // (A/B measurements)
+        begin(name, "gemm_panel", 2.0 * M * (double)N * K, 4.0 * ((double)M * K + (double)N * K + 2.0 * (double)M * N));
+        const PanelEpBiasResidual ep{x, N};
+        const dim3 grid(8 * S, ((mt * S + 7) / 8 + S - 1) / S);
+#define UU3D_PANEL_RES(CPW) { auto kern = gemm_h3_panel_kernel<24, PanelEpBiasResidual, CPW>; \
+            static const bool once = (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)PANEL_LDS_TOTAL) == hipSuccess); (void)once; \
+            hipLaunchKernelGGL(kern, grid, dim3(256), PANEL_LDS_TOTAL, stream, Af, m->harena + pf, colv, M, mt, S, CPW, ep); }
+        if (S == 3) UU3D_PANEL_RES(4) else if (S == 2) UU3D_PANEL_RES(6) else UU3D_PANEL_RES(12)
+#undef UU3D_PANEL_RES
         end();
     }
     // the same with the operand given by address (training: the packs regenerated from the master buffer) -- K = 384, N % 32 == 0
@@ -963,7 +993,8 @@ struct Launcher {
     bool attn_is_h3(int L, bool planes_out) const { return planes_out && L <= ATTN_H3_MAX_L && (L > 128 || (L > 48 && !m->attn_f32)); }
     float attn_qscale() const { return 1.44269504088896341f / sqrtf((float)kDH); }
     // split_lo_off != 0: the context rows go out as f16 planes (hi at out, lo split_lo_off halfs further)
-    void attn(const char* name, const float* qkv, int B, int L, const uint8_t* mask, float* out, size_t split_lo_off = 0) {
+    // frag (attn_h3_kernel only): the context rows in the row-panel GEMM's A-fragment order instead of row-major planes
+    void attn(const char* name, const float* qkv, int B, int L, const uint8_t* mask, float* out, size_t split_lo_off = 0, bool frag = false) {
         const int D = m->cfg.d_temporal, H = m->cfg.num_heads;
         const int NT = (L + 15) / 16;
         const bool h3a = attn_is_h3(L, split_lo_off != 0);
@@ -977,7 +1008,7 @@ struct Launcher {
             const _Float16* qh = reinterpret_cast<const _Float16*>(qkv); const _Float16* ql = qh + (size_t)B * L * 3 * D;
 #define UU3D_ATTN_H3(MW, WPE, MASKED, waves) { auto k = attn_h3_kernel<kDH, MW, WPE, MASKED>; \
                 static const bool once = (hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)attn_h3_lds_bytes(ATTN_H3_MAX_L, kDH)) == hipSuccess); (void)once; \
-                hipLaunchKernelGGL(k, grid, dim3(64 * (waves)), lds, stream, qh, ql, 3 * D, D, L, H, mask, oh, split_lo_off, D); }
+                hipLaunchKernelGGL(k, grid, dim3(64 * (waves)), lds, stream, qh, ql, 3 * D, D, L, H, mask, oh, frag ? (size_t)512 : split_lo_off, D, frag ? 1 : 0); }
             if (nt <= 3) { if (mask) UU3D_ATTN_H3(3, 3, true, nt) else UU3D_ATTN_H3(3, 3, false, nt) }
             else if (nt <= 12) { if (mask) UU3D_ATTN_H3(12, 3, true, nt) else UU3D_ATTN_H3(12, 3, false, nt) }     // one wave per query tile, three per SIMD (dense-351: 35.4 vs 36.8 us with 8 waves x 2 tiles)
             else { if (mask) UU3D_ATTN_H3(8, 2, true, std::min(nt, 8)) else UU3D_ATTN_H3(8, 2, false, std::min(nt, 8)) }
@@ -1162,8 +1193,12 @@ int uu3d_forward_attention(uu3d_model* m, const float* kp2d, const uint8_t* mask
             else { EpBias ep{w.QKV, b.bqkv, 3 * dt}; Lh.gemm(name("ln_qkv"), al, b.wqkv_t, Mr, 3 * dt, dt, ep); }
         }
         maps();
-        Lh.attn(name("attn"), w.QKV, B, L, kmask, w.O, planes ? (size_t)Mr * dt : 0);
-        {
+        // projection on the row-panel GEMM (round 3): attn_h3_kernel writes the context rows in A-fragment order, the residual is
+        // added in the epilogue from values requested a chunk earlier (UU3D_NO_PANEL_PROJ=1: the tiled LDS-DMA kernel)
+        const bool pproj = qsplit && !m->no_panel_proj && Lh.panel_ok(Mr, dt, dt, b.wp_pf);
+        Lh.attn(name("attn"), w.QKV, B, L, kmask, w.O, planes ? (size_t)Mr * dt : 0, pproj);
+        if (pproj) Lh.gemm_panel_residual(name("proj_res"), Ph, b.wp_pf, b.bp, Mr, x);
+        else {
             EpBiasResidual ep{x, b.bp, dt, nullptr, nullptr, 1};
             if (planes) { GLoadPlain gl{Ph, Pl, dt, Mr}; Lh.gemm_g(name("proj_res"), gl, b.wp_t, Mr, dt, dt, ep, 4.0 * Mr * dt); }
             else { ALoadPlain al{w.O, dt, Mr, dt}; Lh.gemm(name("proj_res"), al, b.wp_t, Mr, dt, dt, ep, 4.0 * Mr * dt); }
@@ -1312,6 +1347,13 @@ int uu3d_world_to_cam_2d(const float* world, const float* cams, int32_t B, int32
     const long per = (long)N * J, total = per * B;
     hipLaunchKernelGGL(world_to_cam_2d_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, world, cams, per, total, cam3d, kp2d);
     return hipGetLastError() == hipSuccess ? UU3D_OK : UU3D_ERR_HIP;
+}
+
+int uu3d_set_schedule(uu3d_model* m, int32_t schedule) {
+    if (!m) return UU3D_ERR_INVALID_ARGUMENT;
+    if (schedule != UU3D_SCHEDULE_LATENCY && schedule != UU3D_SCHEDULE_THROUGHPUT) return fail(m, UU3D_ERR_INVALID_ARGUMENT, "unknown schedule");
+    m->throughput = (schedule == UU3D_SCHEDULE_THROUGHPUT);
+    return UU3D_OK;
 }
 
 int uu3d_set_profiling(uu3d_model* m, int32_t enabled) {

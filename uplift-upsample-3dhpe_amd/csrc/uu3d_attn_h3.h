@@ -29,7 +29,8 @@
 //     Masked keys add -1e9 (finite, like the reference: an all-masked row stays uniform -- there the mask term is added in
 //     f32 BEFORE the maximum is subtracted, as the reference does), keys past L add -inf.
 //   * O^T has the query on the lane: 1 / l is a per-lane scalar; the two f16 planes the projection GEMM reads leave as
-//     16-byte stores after a v_permlane32_swap pairs the 8-byte groups of lanes l and l ^ 32.
+//     16-byte stores after a v_permlane32_swap pairs the 8-byte groups of lanes l and l ^ 32 -- row-major planes for the tiled
+//     LDS-DMA GEMM, or (frag) the fragment order the row-panel GEMM reads: the same pieces at other addresses.
 // The head dim 48 is 1.5 MFMA rows: the second 32-row tile of O^T is a third padding (25 % of the P V MFMAs).
 #pragma once
 #include <hip/hip_runtime.h>
@@ -57,7 +58,8 @@ template <int DH, int MAXW, int WPE, bool MASKED>
 __global__ void __launch_bounds__(64 * MAXW) __attribute__((amdgpu_waves_per_eu(WPE, WPE)))
 attn_h3_kernel(const _Float16* __restrict__ qkv_h, const _Float16* __restrict__ qkv_l, const int ld, const int D, const int L, const int H,
                const uint8_t* __restrict__ key_mask,   // (B, L) 1 = attend; nullptr = no mask
-               _Float16* __restrict__ out, const size_t lo_off, const int ldo)
+               _Float16* __restrict__ out, const size_t lo_off, const int ldo,
+               const int frag)                         // 1: the context rows leave in the row-panel GEMM's A-fragment order (uu3d_gemm_panel.h, K = ldo); lo_off = 512
 {
     static_assert(DH == 48, "operand layouts below are written for a head dim of 48 (3 k-slices, 1.5 output row tiles)");
     constexpr int KS = DH / 16;                        // k-slices of Q K^T
@@ -221,7 +223,11 @@ attn_h3_kernel(const _Float16* __restrict__ qkv_h, const _Float16* __restrict__ 
         // tile (register 8) are the ones-row product = the row sum l, with the same 2^14 factor as every other row ----
         const float rl = 1.0f / (oB0[8] + oB1[8] * (1.0f / H3_SCALE));
         const int q = 32 * qt + q31;
-        _Float16* orow = out + (tok0 + min(q, L - 1)) * ldo + h * DH;
+        // row-major planes: row * ldo + channel.  Fragment order: a 16-byte piece = 8 consecutive channels of one row, the pieces of 32
+        // consecutive rows are contiguous (512 B): [32-row panel][16-channel slice][plane][channel half][row & 31][8]
+        const size_t grow = tok0 + min(q, L - 1);
+        _Float16* orow = frag ? out + (size_t)(grow >> 5) * (size_t)(ldo >> 4) * 1024 + (grow & 31) * 8
+                              : out + grow * ldo + h * DH;
         auto pack4 = [&](const f32x16& a0, const f32x16& a1, int j, unsigned (&hi2)[2], unsigned (&lo2)[2]) {
             _Float16 hh[4], ll[4];
 #pragma unroll
@@ -246,7 +252,8 @@ attn_h3_kernel(const _Float16* __restrict__ qkv_h, const _Float16* __restrict__ 
             }
             if (q < L) {
                 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-                _Float16* d = orow + ch0 + 8 * (j + g);
+                const int chn = h * DH + ch0 + 8 * (j + g);         // first of the piece's 8 channels
+                _Float16* d = frag ? orow + (size_t)(chn >> 4) * 1024 + ((chn >> 3) & 1) * 256 : orow + ch0 + 8 * (j + g);
                 *reinterpret_cast<u32x4*>(d) = (u32x4){oh[0], oh[1], oh[2], oh[3]};
                 *reinterpret_cast<u32x4*>(d + lo_off) = (u32x4){ol[0], ol[1], ol[2], ol[3]};
             }

@@ -69,6 +69,7 @@ inline void panel_pack_operand(const _Float16* Bh, const _Float16* Bl, int N, in
 // Addresses are a scalar base + a 32-bit BYTE offset per lane (global_store ... saddr): a 64-bit address pair per unrolled
 // output register cost the fc1 kernel its register budget (512 + scratch).  The launcher keeps M * ldo * 4 below 2^32.
 struct PanelEpBias {           // out[row][col] = v
+    static constexpr bool kResidual = false;
     float* __restrict__ out; int ldo;
     __device__ __forceinline__ void store(int row, int col, float v) const {
         const unsigned b = ((unsigned)row * (unsigned)ldo + (unsigned)col) * 4u;
@@ -76,6 +77,7 @@ struct PanelEpBias {           // out[row][col] = v
     }
 };
 struct PanelEpBiasRelu {       // out[row][col] = max(v, 0)   (training-mode forward: the hidden activations stay f32 for the backward pass)
+    static constexpr bool kResidual = false;
     float* __restrict__ out; int ldo;
     __device__ __forceinline__ void store(int row, int col, float v) const {
         const unsigned b = ((unsigned)row * (unsigned)ldo + (unsigned)col) * 4u;
@@ -83,6 +85,7 @@ struct PanelEpBiasRelu {       // out[row][col] = max(v, 0)   (training-mode for
     }
 };
 struct PanelEpBiasSplitQ {     // [q | k | v] as row-major hi / lo planes for attn_h3_kernel; q (columns < qcols) times qscale = log2(e) / sqrt(d_h)
+    static constexpr bool kResidual = false;
     _Float16* __restrict__ Oh; _Float16* __restrict__ Ol; int ldo, qcols; float qscale;
     __device__ __forceinline__ void store(int row, int col, float x) const {
         const float v = col < qcols ? x * qscale : x;
@@ -93,6 +96,7 @@ struct PanelEpBiasSplitQ {     // [q | k | v] as row-major hi / lo planes for at
     }
 };
 struct PanelEpBiasReluSplit {  // ReLU(v) as row-major hi / lo planes [M][ldo] (the A operand of the tiled LDS-DMA kernel)
+    static constexpr bool kResidual = false;
     _Float16* __restrict__ Oh; _Float16* __restrict__ Ol; int ldo;
     __device__ __forceinline__ void store(int row, int col, float x) const {
         const float v = fmaxf(x, 0.f);
@@ -100,6 +104,22 @@ struct PanelEpBiasReluSplit {  // ReLU(v) as row-major hi / lo planes [M][ldo] (
         const unsigned b = ((unsigned)row * (unsigned)ldo + (unsigned)col) * 2u;
         *reinterpret_cast<_Float16*>(reinterpret_cast<char*>(Oh) + b) = h;
         *reinterpret_cast<_Float16*>(reinterpret_cast<char*>(Ol) + b) = (_Float16)((v - (float)h) * H3_SCALE);
+    }
+};
+struct PanelEpBiasResidual {   // x[row][col] += v   (the attention projection on the residual stream, in place: every element is read and written by one lane)
+    static constexpr bool kResidual = true;
+    float* __restrict__ x; int ldo;
+    // Requests x[row][col] into an ACCUMULATION register and returns at once: the value is valid only after a counted vmcnt wait
+    // that names the register (gemm_h3_panel_kernel does both).  Written as asm because (a) a load hipcc can see gets its own
+    // s_waitcnt, and with the arch registers full it parks the value in an AGPR right away -- a vmcnt(0) directly behind the load,
+    // which drains the weight ring; (b) "=a" puts it where the kernel has room (one wave per SIMD: 256 + 256 registers).
+    __device__ __forceinline__ void request(int row, int col, float& dst) const {
+        const unsigned b = ((unsigned)row * (unsigned)ldo + (unsigned)col) * 4u;
+        asm volatile("global_load_dword %0, %1, %2" : "=a"(dst) : "v"(b), "s"(x) : "memory");
+    }
+    __device__ __forceinline__ void store(int row, int col, float v) const {
+        const unsigned b = ((unsigned)row * (unsigned)ldo + (unsigned)col) * 4u;
+        *reinterpret_cast<float*>(reinterpret_cast<char*>(x) + b) = v;
     }
 };
 #ifdef UU3D_PANEL_STAMP
@@ -115,11 +135,15 @@ __device__ unsigned long long panel_clk[8];   // tools/gemm_panel_exp: s_memtime
 constexpr int panel_wait_count(const int g) { return g + 2 < PANEL_SS ? 4 : (g + 1 < PANEL_SS ? 2 : 0); }
 
 // C[M][N] = A[M][K] B + colv,  K = 16 KS (KS % 24 == 0), A / B fragment ordered (see top).
-template <int KS, class EP>
+// CPW > 0: chunks per workgroup known at compile time -- the chunk loop is unrolled completely.  Needed by epilogues that LOAD
+// (EP::kResidual): with a loop, hipcc's wait insertion puts s_waitcnt vmcnt(0) at the loop header for the loads in flight across
+// the back edge, which drains the weight ring once per iteration; in straight-line code it counts exactly.
+template <int KS, class EP, int CPW = 0>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1)))
 gemm_h3_panel_kernel(const _Float16* __restrict__ Af, const _Float16* __restrict__ Bf, const float* __restrict__ colv,
-                     const int M, const int m_tiles, const int splits, const int chunks_per_wg, const EP ep)
+                     const int M, const int m_tiles, const int splits, const int chunks_per_wg_, const EP ep)
 {
+    const int chunks_per_wg = CPW > 0 ? CPW : chunks_per_wg_;
     constexpr int SPC = KS / PANEL_SS;                           // k-steps per chunk
     h3_flush_f16_denormals();                              // the epilogue may split its result
     extern __shared__ __attribute__((aligned(16))) unsigned char psm[];
@@ -182,17 +206,35 @@ gemm_h3_panel_kernel(const _Float16* __restrict__ Af, const _Float16* __restrict
     const int valid = min(32, M - row0);                   // wave-uniform: rows of this panel that exist (<= 0: none)
     PANEL_STAMP(asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); const long long c_pro = clock64();)
 
-    auto emit = [&](int c, int r, const f32x16& p0, const f32x16& p1, float cv) __attribute__((always_inline)) {
-        ep.store(row0 + 8 * (r >> 2) + crow + (r & 3), (chunk0 + c) * 32 + ccol, p0[r] + p1[r] * (1.0f / H3_SCALE) + cv);
+    auto emit = [&](int c, int r, const f32x16& p0, const f32x16& p1, float cv, float res) __attribute__((always_inline)) {
+        float v = p0[r] + p1[r] * (1.0f / H3_SCALE) + cv;
+        if constexpr (EP::kResidual) v += res;
+        ep.store(row0 + 8 * (r >> 2) + crow + (r & 3), (chunk0 + c) * 32 + ccol, v);
     };
+    // kResidual: the 16 residual values of chunk c are requested when chunk c STARTS and added when it is emitted, a whole chunk
+    // (>= 72 MFMAs) later: read at the point of use, the wait for them would also wait for every weight piece issued before them
+    // -- the whole ring -- since vector memory returns in order.  They are covered by the SAME counted wait as the ring: chunk c's
+    // requests are older than its 12 refill pieces, so "all but the newest 12 have landed" at the start of chunk c + 1 includes
+    // them.  Rows past M: clamped (read, never stored).
+    auto fetch = [&](int c, float (&res)[16]) __attribute__((always_inline)) {
+        if constexpr (EP::kResidual) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) ep.request(min(row0 + 8 * (r >> 2) + crow + (r & 3), M - 1), (chunk0 + c) * 32 + ccol, res[r]);
+        }
+    };
+    // the residual registers become values here: `asm` names them so that nothing reads them earlier
+#define UU3D_PANEL_RES16(r) "+a"(r[0]), "+a"(r[1]), "+a"(r[2]), "+a"(r[3]), "+a"(r[4]), "+a"(r[5]), "+a"(r[6]), "+a"(r[7]), \
+                            "+a"(r[8]), "+a"(r[9]), "+a"(r[10]), "+a"(r[11]), "+a"(r[12]), "+a"(r[13]), "+a"(r[14]), "+a"(r[15])
     // WHOLE = every row of the panel exists: the 16 stores of chunk c-1 are spread over the first 16 k-slices of chunk c
     // (an MFMA holds the vector issue port for 8 of its 32 cycles).  Otherwise they are predicated and issued as a block.
-    auto chunk = [&](auto whole_tag, int c, f32x16& acc0, f32x16& acc1, const f32x16& p0, const f32x16& p1) __attribute__((always_inline)) {
+    auto chunk = [&](auto whole_tag, int c, f32x16& acc0, f32x16& acc1, const f32x16& p0, const f32x16& p1, float (&rcur)[16], float (&rprev)[16]) __attribute__((always_inline)) {
         constexpr bool WHOLE = decltype(whole_tag)::value;
         const bool prev = c > 0;
         const float pcv = colv_s[max(c - 1, 0) * 32 + ccol];                       // the previous chunk's bias
 #pragma unroll
         for (int st = 0; st < SPC; ++st) {
+            if (EP::kResidual && st == 0) asm volatile("s_waitcnt vmcnt(%16) lgkmcnt(0)" : UU3D_PANEL_RES16(rprev) : "i"(PANEL_PIECES * (PANEL_SLOTS - 2)) : "memory");
+            else
             asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" :: "i"(PANEL_PIECES * (PANEL_SLOTS - 2)) : "memory");   // k-step t landed (this wave's pieces); own reads of t-1 returned
             __builtin_amdgcn_sched_barrier(0);
             __builtin_amdgcn_s_barrier();                                  // ... everybody's; the slot refilled below was last read in t-1
@@ -200,12 +242,13 @@ gemm_h3_panel_kernel(const _Float16* __restrict__ Af, const _Float16* __restrict
             if (!WHOLE && st == 0 && prev) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r)
-                    if (8 * (r >> 2) + crow + (r & 3) < valid) emit(c - 1, r, p0, p1, pcv);
+                    if (8 * (r >> 2) + crow + (r & 3) < valid) emit(c - 1, r, p0, p1, pcv, rprev[r]);
                 __builtin_amdgcn_sched_barrier(0);
             }
             if (st == 0) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) { acc0[r] = 0.f; acc1[r] = 0.f; }
+                fetch(c, rcur);
             }
             const unsigned sb = (unsigned)(uintptr_t)(h3_lds_void*)(psm + slot_r * PANEL_STEP_BYTES + lane * 16);
             h16x8 bh[3], bl[3];
@@ -221,7 +264,7 @@ gemm_h3_panel_kernel(const _Float16* __restrict__ Af, const _Float16* __restrict
                 acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[st * PANEL_SS + kk], bh[kk % 3], acc0, 0, 0, 0);
                 acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[st * PANEL_SS + kk], bl[kk % 3], acc1, 0, 0, 0);
                 acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[st * PANEL_SS + kk], bh[kk % 3], acc1, 0, 0, 0);
-                if (WHOLE && st * PANEL_SS + kk < 16 && prev) emit(c - 1, st * PANEL_SS + kk, p0, p1, pcv);
+                if (WHOLE && st * PANEL_SS + kk < 16 && prev) emit(c - 1, st * PANEL_SS + kk, p0, p1, pcv, rprev[(st * PANEL_SS + kk) & 15]);
                 if (kk & 1) dma1(c * SPC + st + PANEL_SLOTS - 1, slot_w, kk >> 1);   // the refill of the slot read in step t-1, spread over the step (-2 %)
             }
 #undef UU3D_PANEL_READ
@@ -230,12 +273,21 @@ gemm_h3_panel_kernel(const _Float16* __restrict__ Af, const _Float16* __restrict
         }
     };
     f32x16 a0, a1, b0, b1;
+    float ra[16], rb[16];                                  // residual values of the chunk in a / b (dead unless EP::kResidual)
 #pragma unroll
-    for (int r = 0; r < 16; ++r) { b0[r] = 0.f; b1[r] = 0.f; }
+    for (int r = 0; r < 16; ++r) { b0[r] = 0.f; b1[r] = 0.f; ra[r] = 0.f; rb[r] = 0.f; }
     auto run = [&](auto whole_tag) __attribute__((always_inline)) {
-        for (int c = 0; c < chunks_per_wg; c += 2) {
-            chunk(whole_tag, c, a0, a1, b0, b1);
-            if (c + 1 < chunks_per_wg) chunk(whole_tag, c + 1, b0, b1, a0, a1);
+        if constexpr (CPW > 0) {
+#pragma unroll
+            for (int c = 0; c < CPW; c += 2) {
+                chunk(whole_tag, c, a0, a1, b0, b1, ra, rb);
+                if (c + 1 < CPW) chunk(whole_tag, c + 1, b0, b1, a0, a1, rb, ra);
+            }
+        } else {
+            for (int c = 0; c < chunks_per_wg; c += 2) {
+                chunk(whole_tag, c, a0, a1, b0, b1, ra, rb);
+                if (c + 1 < chunks_per_wg) chunk(whole_tag, c + 1, b0, b1, a0, a1, rb, ra);
+            }
         }
     };
     if (valid == 32) run(std::true_type{}); else run(std::false_type{});
@@ -243,16 +295,21 @@ gemm_h3_panel_kernel(const _Float16* __restrict__ Af, const _Float16* __restrict
     {   // last chunk
         const int c = chunks_per_wg - 1;
         const float cv = colv_s[c * 32 + ccol];
+        if constexpr (EP::kResidual) {
+            if (c & 1) asm volatile("s_waitcnt vmcnt(0)" : UU3D_PANEL_RES16(rb) :: "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" : UU3D_PANEL_RES16(ra) :: "memory");
+        }
         if (c & 1) {
 #pragma unroll
             for (int r = 0; r < 16; ++r)
-                if (8 * (r >> 2) + crow + (r & 3) < valid) emit(c, r, b0, b1, cv);
+                if (8 * (r >> 2) + crow + (r & 3) < valid) emit(c, r, b0, b1, cv, rb[r]);
         } else {
 #pragma unroll
             for (int r = 0; r < 16; ++r)
-                if (8 * (r >> 2) + crow + (r & 3) < valid) emit(c, r, a0, a1, cv);
+                if (8 * (r >> 2) + crow + (r & 3) < valid) emit(c, r, a0, a1, cv, ra[r]);
         }
     }
+#undef UU3D_PANEL_RES16
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // the clamped tail DMAs must not outlive the LDS allocation
     PANEL_STAMP(if (tid == 0) { atomicAdd(&panel_clk[0], (unsigned long long)(c_pro - c_start)); atomicAdd(&panel_clk[1], (unsigned long long)(c_loop - c_pro));
         atomicAdd(&panel_clk[4], (unsigned long long)(clock64() - c_loop)); atomicAdd(&panel_clk[5], 1ull); })

@@ -68,8 +68,16 @@ class ForwardPipeline(object):
 
     def _launch(self, i, n):
         s = self._slots[i]
-        self.model._forward(s.x[:n], s.m[:n] if s.m is not None else None, s.full[:n] if s.full is not None else None,
-                            s.central[:n], self._keys[i], s.stream)
+        lib, h = self.model._lib, self.model._h
+        # launches shaped for CU-microseconds, not latency: the forwards in flight share the chip (include/uu3d.h, uu3d_set_schedule)
+        if self.depth > 1:
+            lib.uu3d_set_schedule(h, 1)
+        try:
+            self.model._forward(s.x[:n], s.m[:n] if s.m is not None else None, s.full[:n] if s.full is not None else None,
+                                s.central[:n], self._keys[i], s.stream)
+        finally:
+            if self.depth > 1:
+                lib.uu3d_set_schedule(h, 0)
         if self.post is not None:
             s.extra = self.post(s.full[:n] if s.full is not None else None, s.central[:n], i)
 
