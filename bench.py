@@ -308,7 +308,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true", help="skip the short secondary workloads (other configs, eager, train step) appended to the JSON line at N = 1")
     ap.add_argument("--no-graph", action="store_true", help="launch eagerly instead of replaying a hipGraph")
-    ap.add_argument("--streams", type=int, default=0, help="independent batches in flight (pipeline.ForwardPipeline: one HIP stream, workspace and hipGraph each); 1 = one batch after the other; 0 (default) = tried before the timed region: 2, 3, 4 and 6 slots for 40 untimed steps each, the fastest is used (pipeline.tune_depth)")
+    ap.add_argument("--streams", type=int, default=0, help="independent batches in flight (pipeline.ForwardPipeline: one HIP stream, workspace and hipGraph each); 1 = one batch after the other; 0 (default) = one per HIP hardware queue (4; pipeline.distinct_queue_streams)")
     ap.add_argument("--precision", default="f16x3", choices=["f16x3", "f32"], help="GEMM arithmetic of the forward (both hold the 1e-4 parity bar)")
     ap.add_argument("--mode", default="infer", choices=["infer", "train"], help="train = fwd + bwd + grad all-reduce + AdamW (BASELINE config 5)")
     ap.add_argument("--halves", action="store_true", help="two concurrent half-batch chains on two streams instead of one chain of kernels per batch")
@@ -375,7 +375,6 @@ def main():
     # outside the graphs, on the caller's stream.
     S = 1 if (args.halves and not args.no_halves) else max(0, args.streams)
     pipe = None
-    tuned = None
     auto = (S == 0)
     use_graph = not args.no_graph
     errs = [torch.empty((B, J), dtype=torch.float64, device="cuda") for _ in range(max(S, 6))]
@@ -404,9 +403,8 @@ def main():
                     dist.all_gather_into_tensor(gathered, err)
     else:
         try:
-            if auto:                                    # which depth collides on a hardware queue depends on the process: try them (untimed), keep the fastest
-                from uplift_upsample_3dhpe_amd.pipeline import tune_depth
-                pipe, tuned = tune_depth(model, B, candidates=(2, 3, 4, 6), steps=40, graph=use_graph, post=post)
+            if auto:                                    # one slot per HIP hardware queue (pipeline.distinct_queue_streams finds which streams share one)
+                pipe = model.pipeline(B, depth=None, graph=use_graph, post=post)
                 S = pipe.depth
             else:
                 pipe = model.pipeline(B, depth=S, graph=use_graph, post=post)
@@ -484,8 +482,8 @@ def main():
                        "parallelism": f"batch-sharded x{world}", "hipgraph": bool(use_graph),
                        "concurrent_half_batches": bool(args.halves and not args.no_halves and B >= 64),
                        "batches_in_flight": S,
-                       "batches_in_flight_tried_ms_per_step": None if tuned is None else {str(k): round(v * 1e3, 4) for k, v in tuned.items()},
-                       "pipelining": (f"{S} independent batches in flight on {S} HIP streams, each replaying its own hipGraph of forward + error "
+                       "pipelining": (f"{S} independent batches in flight on {S} HIP streams" + (" on pairwise different hardware queues (probed)" if auto else "") +
+                                      ", each replaying its own hipGraph of forward + error "
                                       "kernel with its own workspace (uplift-upsample-3dhpe_amd/pipeline.py; the same path eval.run_eval uses)") if S > 1
                                      else "one batch after the other"},
             "roofline": {"bound": "mfma", "kernel": f"{gk} [{dom_key}]",

@@ -76,7 +76,8 @@ def test_run_eval_matches_the_reference_protocol(cfgname, action_wise):
 
 def test_pipelined_forwards_are_bit_identical():
     """pipeline.ForwardPipeline (several batches in flight on several streams, hipGraph replay) = the same launches on the same
-    data as model(...): bit-identical outputs, ragged last batch included, with and without graphs, depth 1 .. 3; model.capture
+    data as model(...): bit-identical outputs, ragged last batch included, with and without graphs, depth 1 .. 3 and the default (one slot per
+    hardware queue); model.capture
     (the single-stream graph replay) likewise."""
     cfg = util.load_config("h36m_351")
     arch = pkg.arch_from_config(cfg)
@@ -95,11 +96,33 @@ def test_pipelined_forwards_are_bit_identical():
             assert len(got) == len(want)
             for (f, c), (fw, cw) in zip(got, want):
                 assert torch.equal(f, fw) and torch.equal(c, cw), (depth, graph, rep)
-    from uplift_upsample_3dhpe_amd.pipeline import tune_depth
-    pipe, timings = tune_depth(model, B, candidates=(2, 3), steps=6)      # the measured pipeline itself comes back, the other is closed
-    assert pipe.depth in (2, 3) and set(timings) == {2, 3} and len(model._ws) <= 1 + pipe.depth
-    for (f, c), (fw, cw) in zip(pipe.run(batches), want):
-        assert torch.equal(f, fw) and torch.equal(c, cw)
+    # the default: one slot per HIP hardware queue.  distinct_queue_streams finds them by blocking one stream and timing the other;
+    # its answer must hold up under the same probe run the other way round (work on stream b must not wait for a spin on stream a)
+    from uplift_upsample_3dhpe_amd.pipeline import distinct_queue_streams
+    qs = distinct_queue_streams(model.device)
+    assert 2 <= len(qs) <= 4 and len({s.cuda_stream for s in qs}) == len(qs)
+    tiny = torch.zeros(8, device="cuda")
+    torch.cuda.synchronize()
+    t0, t1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    t0.record(); torch.cuda._sleep(2_000_000); t1.record(); t1.synchronize()
+    spin_ms = t0.elapsed_time(t1)
+    for a in qs:
+        for b in qs:
+            if a is b:
+                continue
+            e0, ea, eb = (torch.cuda.Event(enable_timing=True) for _ in range(3))
+            torch.cuda.synchronize()
+            with torch.cuda.stream(a):
+                e0.record(a); torch.cuda._sleep(2_000_000); ea.record(a)
+            with torch.cuda.stream(b):
+                tiny.add_(1.0); eb.record(b)
+            torch.cuda.synchronize()
+            assert e0.elapsed_time(eb) < 0.5 * spin_ms, (e0.elapsed_time(eb), spin_ms)
+    pipe = model.pipeline(B)
+    assert pipe.depth == len(qs) and len(model._ws) <= 1 + pipe.depth
+    for rep in range(2):
+        for (f, c), (fw, cw) in zip(pipe.run(batches), want):
+            assert torch.equal(f, fw) and torch.equal(c, cw)
     pipe.close()
     f = model.capture(B)
     for (x, m), (fw, cw) in zip(batches[:4], want[:4]):

@@ -42,11 +42,11 @@ def needed_windows(frame_indices, config):
     return np.equal(np.mod(idx, stride), 0)
 
 
-def predict_windows(model, generator, descriptors, config, batch_size, flip=True, depth=2, graph=True):
+def predict_windows(model, generator, descriptors, config, batch_size, flip=True, depth=None, graph=True):
     """Central 3D predictions (W, J, 3) float32 on the device for the given window descriptors: batches of ``batch_size``
     windows, each forwarded together with its mirrored copy when ``flip`` (one launch chain over 2B sequences).
 
-    ``depth`` batches are in flight at once, each on its own HIP stream and -- with ``graph`` -- replayed from its own hipGraph
+    ``depth`` batches (None: one per HIP hardware queue, i.e. 4) are in flight at once, each on its own HIP stream and -- with ``graph`` -- replayed from its own hipGraph
     (pipeline.ForwardPipeline: batch k + 1's big kernels run beside batch k's latency-bound tail; the window gather of the next
     batch runs on the caller's stream meanwhile).  depth = 1, graph = False is the reference's loop: one eager call after the other.
     The predictions are bit-identical either way."""
@@ -60,7 +60,11 @@ def predict_windows(model, generator, descriptors, config, batch_size, flip=True
     # all windows at the end instead of five small launches per batch
     raw = torch.empty((2 if flip else 1, W, J, 3), dtype=torch.float32, device=dev)
     rows = min(batch_size, W) * (2 if flip else 1)
-    pipe = model.pipeline(rows, depth=depth, graph=graph) if (depth > 1 or graph) else None
+    if depth is None and rows > 512:
+        depth = 2            # big batches fill the chip by themselves: two in flight measured best there (1024 sequences: 167 k vs 163 k with four)
+    pipe = model.pipeline(rows, depth=depth, graph=graph) if (depth is None or depth > 1 or graph) else None
+    if pipe is not None:
+        depth = pipe.depth
 
     def finish(lo, n, cen):
         raw[:, lo:lo + n].copy_(cen.view(raw.shape[0], n, J, 3))
@@ -98,7 +102,7 @@ def predict_windows(model, generator, descriptors, config, batch_size, flip=True
 
 
 def run_eval(config, dataset_name, dataset_path, dataset2d_path, test_subset, weights_path=None, model=None, action_wise=True,
-             batch_size=None, skip_unused_windows=True, log=_log, depth=2, graph=True):
+             batch_size=None, skip_unused_windows=True, log=_log, depth=None, graph=True):
     """eval.py:34-253.  Returns ``evaluation.evaluate_predictions``'s dict (+ "num_windows", "num_forwarded", "seconds").
 
     ``batch_size`` defaults to ``config.BATCH_SIZE``; ``depth`` / ``graph``: batches in flight and hipGraph replay of the forward

@@ -360,7 +360,7 @@ class UpliftUpsampleTransformer(object):
         return full, central
 
     # ---- graph replay / several batches in flight ------------------------------------------------
-    def pipeline(self, batch, depth=2, graph=True, post=None):
+    def pipeline(self, batch, depth=None, graph=True, post=None):
         """``depth`` independent batches in flight on ``depth`` HIP streams, each replaying its own hipGraph of the forward
         (pipeline.ForwardPipeline): the throughput path of an evaluation loop (eval.py:147-152)."""
         from ..pipeline import ForwardPipeline

@@ -6,20 +6,68 @@ latency-bound kernels on a few CUs) leaves the chip almost idle; batches are ind
 temporal blocks can run beside batch k's tail.  ``ForwardPipeline`` keeps ``depth`` batches in flight, each on its own stream with
 its own workspace, static input / output buffers and (optionally) its own hipGraph of the whole forward:
 
-    pipe = ForwardPipeline(model, batch=128, depth=2)          # model.pipeline(128)
+    pipe = ForwardPipeline(model, batch=128)                   # model.pipeline(128): one slot per hardware queue (4)
     for full, central in pipe.run(batches):                    # batches: iterable of (x, stride_mask) or x
         ...                                                    # outputs are valid until `depth` more batches were submitted
 
-Measured on MI355X, h36m_351, batch 128, hipGraph replay (one box each; box to box +-10 %): `bench.py` (s_in = 5: every frame real)
-1 / 2 / 3 / 4 / 6 / 8 batches in flight = 126 / 162 / 166-169 / 152 / 167-169 / 155 k sequences/s; `tools/streams_exp.py` (same workload,
-another process layout) 2 / 3 / 4 / 6 = 166 / 151 / 170 / 168 k.  The gain is +28-34 %; the depths that lose ~10 % differ between the two
-programs -- HIP deals streams to its 4 hardware queues in creation order, and a depth whose slots collide on a queue serialises them --
-hence ``tune_depth`` below (bench.py's default): try 2, 3, 4 and 6 slots, keep the fastest pipeline object.  h36m_81 batch 256: 305 /
-322-324 / 326 k at 2 / 3 / 6.
+How many batches in flight, and on which streams: HIP deals a process's streams to 4 hardware queues (GPU_MAX_HW_QUEUES) in an order that
+is not the creation order (24 pool streams on one box: 0 1 2 2 1 0 3 2 1 0 3 2 ...), two streams on one queue run in order, and what the
+pipeline reaches depends on the number of DISTINCT queues under its slots and on nothing else (`tools/queue_map_exp.py`, h36m_351, batch
+128, one box): 1 / 2 / 3 / 4 queues = 120-126 / 157 / 165 / 172 k sequences/s; second slots on the same queues add nothing (ABAB = AB, ABCDABCD =
+ABCD), an uneven deal loses (ABCA 147 k, ABCDAB 166 k) -- which is what made plain "depth = 2 / 3 / 4 / 6" lose 10 % here and there.  Raising
+GPU_MAX_HW_QUEUES does not help: with 6 / 8 / 12 queues, 4 slots on 4 of them reach 118-121 k and 8-12 slots 145 k.  So the default
+(``depth=None``) asks ``distinct_queue_streams`` for one stream per hardware queue: it finds out which streams share a queue by blocking one
+with a spin kernel and timing a tiny kernel on the other with HIP events (~50 ms once per process).
 Results are bit-identical to ``model(...)``: the same launches on the same data, only on another
 stream.  Latency of ONE batch does not improve (0.9 ms); use ``model(...)`` for that.
 """
 import ctypes as C
+
+
+_QUEUE_STREAMS = {}
+
+
+def distinct_queue_streams(device, want=4, pool=16, spin_ms=2.0):
+    """Up to ``want`` torch streams that sit on pairwise DIFFERENT HIP hardware queues (found once per process and device).
+
+    Two streams share a queue iff work on one waits for work on the other: a spin kernel of ``spin_ms`` goes to stream a, a tiny kernel to
+    stream b, and HIP events tell when b's kernel ran -- behind the spin (same queue) or at once.  Streams come from torch's pool; the
+    first of every new queue class is kept."""
+    import torch
+    key = (str(device), want)
+    if key in _QUEUE_STREAMS:
+        return list(_QUEUE_STREAMS[key])
+    torch.cuda.synchronize(device)
+    with torch.cuda.device(device):
+        tiny = torch.zeros(64, device=device)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        cycles = 4_000_000                                      # calibrate the spin (its clock is not the shader clock)
+        e0.record(); torch.cuda._sleep(cycles); e1.record(); e1.synchronize()
+        per_ms = cycles / max(e0.elapsed_time(e1), 1e-3)
+
+        def same_queue(a, b):
+            t0, ta, tb = (torch.cuda.Event(enable_timing=True) for _ in range(3))
+            b.wait_stream(a)                                    # (both idle and ordered before the probe)
+            with torch.cuda.stream(a):
+                t0.record(a)
+                torch.cuda._sleep(int(spin_ms * per_ms))
+                ta.record(a)
+            with torch.cuda.stream(b):
+                tiny.add_(1.0)
+                tb.record(b)
+            ta.synchronize(); tb.synchronize()
+            return t0.elapsed_time(tb) > 0.5 * t0.elapsed_time(ta)
+
+        reps = []
+        for _ in range(pool):
+            s = torch.cuda.Stream(device=device)
+            if not any(same_queue(r, s) for r in reps):
+                reps.append(s)
+                if len(reps) == want:
+                    break
+        torch.cuda.synchronize(device)
+    _QUEUE_STREAMS[key] = list(reps)
+    return list(reps)
 
 
 class _Slot(object):
@@ -28,12 +76,23 @@ class _Slot(object):
 
 class ForwardPipeline(object):
 
-    def __init__(self, model, batch, depth=2, graph=True, post=None):
-        """``post(full, central, slot_index)``: optional device work appended to every forward ON THE SLOT'S STREAM (and into its
-        graph), e.g. the per-joint error kernel; what it returns is handed out by ``result`` as a third element."""
+    def __init__(self, model, batch, depth=None, graph=True, post=None, streams=None):
+        """``depth``: batches in flight; None = one per HIP hardware queue (``distinct_queue_streams``: 4), an int up to that number takes
+        that many of those streams, more than that falls back to fresh pool streams (slots then share queues).
+        ``post(full, central, slot_index)``: optional device work appended to every forward ON THE SLOT'S STREAM (and into its
+        graph), e.g. the per-joint error kernel; what it returns is handed out by ``result`` as a third element.
+        ``streams``: the slots' streams (``depth`` of them), whatever queues they are on."""
         import torch
-        if depth < 1:
+        if depth is not None and depth < 1:
             raise ValueError("depth >= 1")
+        if streams is None and (depth is None or depth > 1):
+            q = distinct_queue_streams(model.device)
+            if depth is None:
+                depth = len(q)
+            if depth <= len(q):
+                streams = q[:depth]
+        if streams is not None and depth is None:
+            depth = len(streams)
         self._torch = torch
         self.model, self.batch, self.depth, self.post = model, int(batch), int(depth), post
         a = model.arch
@@ -47,7 +106,7 @@ class ForwardPipeline(object):
         cur = torch.cuda.current_stream(dev)
         for i in range(depth):
             s = _Slot()
-            s.stream = torch.cuda.Stream(device=dev)
+            s.stream = streams[i] if streams is not None else torch.cuda.Stream(device=dev)
             s.stream.wait_stream(cur)
             s.x = torch.zeros((batch, a.num_frames, a.num_keypoints, 2), dtype=torch.float32, device=dev)
             s.m = torch.ones((batch, a.num_frames), dtype=torch.uint8, device=dev) if model.has_strided_input else None
@@ -160,39 +219,3 @@ class ForwardPipeline(object):
                 yield self.result(pending.pop(0))
         while pending:
             yield self.result(pending.pop(0))
-
-
-def tune_depth(model, batch, candidates=(2, 3, 4, 6), steps=40, graph=True, post=None):
-    """Pick the number of slots by trying them: HIP deals streams to its hardware queues in creation order, and which depths collide on
-    a queue (and lose ~10 %) depends on what else the process has created -- measured, not predictable.  Builds
-    one pipeline per candidate, runs ``steps`` forwards of its (zero) static inputs, keeps the fastest and closes the others: the
-    pipeline that is returned is the very object that was measured (same streams, same queues).
-    Returns ``(pipeline, {depth: seconds per step})``."""
-    import time
-    import torch
-    timings, best = {}, None
-    for d in candidates:
-        pipe = ForwardPipeline(model, batch, depth=d, graph=graph, post=post)
-        x, m = pipe._slots[0].x, pipe._slots[0].m
-
-        def run(n):
-            t = []
-            for _ in range(n):
-                t.append(pipe.submit(x, m))
-                if len(t) == d:
-                    pipe.result(t.pop(0))
-            for q in t:
-                pipe.result(q)
-        run(max(4, steps // 4))
-        torch.cuda.synchronize(model.device)
-        t0 = time.perf_counter()
-        run(steps)
-        torch.cuda.synchronize(model.device)
-        timings[d] = (time.perf_counter() - t0) / steps
-        if best is None or timings[d] < timings[best.depth]:
-            if best is not None:
-                best.close()
-            best = pipe
-        else:
-            pipe.close()
-    return best, timings
