@@ -1,5 +1,6 @@
 // uu3d_misc.h -- small row-wise kernels: LayerNorm statistics and per-joint MPJPE.
 #pragma once
+#include <vector>
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <math.h>
@@ -270,6 +271,55 @@ world_to_cam_2d_kernel(const float* __restrict__ world, const float* __restrict_
     const float tan = in[9] * a + in[10] * b;
     kp2d[idx * 2] = in[2] * (a * (radial + tan) + in[9] * r2) + in[4];
     kp2d[idx * 2 + 1] = in[3] * (b * (radial + tan) + in[10] * r2) + in[5];
+}
+
+// ---- which HIP streams share a hardware queue -------------------------------------------------------------------------------
+// HIP deals the streams of a process to GPU_MAX_HW_QUEUES (4) hardware queues, not in creation order, and two streams on one queue
+// run in order -- a "side stream" on the caller's queue overlaps nothing.  The probe: a spin kernel on a, a tiny kernel on b, and
+// HIP events tell whether b's kernel ran at once or behind the spin.
+static __global__ void spin_kernel(const long long ticks)      // wall_clock64: 100 MHz
+{
+    const long long t0 = wall_clock64();
+    while (wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(32);
+}
+static __global__ void touch_kernel() {}
+
+inline bool streams_share_queue(hipStream_t a, hipStream_t b)
+{
+    hipEvent_t e0, ea, eb;
+    if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&ea) != hipSuccess || hipEventCreate(&eb) != hipSuccess) return false;
+    (void)hipStreamSynchronize(a); (void)hipStreamSynchronize(b);
+    (void)hipEventRecord(e0, a);
+    hipLaunchKernelGGL(spin_kernel, dim3(1), dim3(64), 0, a, 150000LL);          // 1.5 ms
+    (void)hipEventRecord(ea, a);
+    hipLaunchKernelGGL(touch_kernel, dim3(1), dim3(64), 0, b);
+    (void)hipEventRecord(eb, b);
+    (void)hipEventSynchronize(ea); (void)hipEventSynchronize(eb);
+    float ta = 0.f, tb = 0.f;
+    const bool ok = hipEventElapsedTime(&ta, e0, ea) == hipSuccess && hipEventElapsedTime(&tb, e0, eb) == hipSuccess;
+    (void)hipEventDestroy(e0); (void)hipEventDestroy(ea); (void)hipEventDestroy(eb);
+    return ok && tb > 0.5f * ta;
+}
+
+// n non-blocking streams on hardware queues different from `main`'s and from each other's, as far as the device has them (up to
+// `tries` streams are created and probed; the ones not taken are destroyed; what cannot be found distinct is filled with any stream)
+inline int create_streams_on_other_queues(hipStream_t main, int n, hipStream_t* out, int tries = 12)
+{
+    std::vector<hipStream_t> spare;
+    int have = 0;
+    for (int i = 0; i < tries && have < n; ++i) {
+        hipStream_t s;
+        if (hipStreamCreateWithFlags(&s, hipStreamNonBlocking) != hipSuccess) return -1;
+        bool clash = streams_share_queue(main, s);
+        for (int k = 0; k < have && !clash; ++k) clash = streams_share_queue(out[k], s);
+        if (clash) spare.push_back(s); else out[have++] = s;
+    }
+    const int distinct = have;
+    while (have < n && !spare.empty()) { out[have++] = spare.back(); spare.pop_back(); }
+    while (have < n) { if (hipStreamCreateWithFlags(&out[have], hipStreamNonBlocking) != hipSuccess) return -1; ++have; }
+    for (hipStream_t s : spare) (void)hipStreamDestroy(s);
+    (void)hipGetLastError();
+    return distinct;
 }
 
 }  // namespace uu3d
