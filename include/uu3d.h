@@ -79,6 +79,10 @@ typedef struct uu3d_config {
     int32_t output_bn;           /* OUTPUT_BN: BatchNormalization(momentum 0.1, eps 1e-5) in front of both heads
                                     (uplift_upsample_transformer.py:275-285); INFERENCE form only: moving statistics,
                                     folded into the head operands at commit time                                      */
+    int32_t learnable_masked_token; /* TOKEN_MASK_RATE > 0 and LEARNABLE_MASKED_TOKEN: the model owns one more weight,
+                                    "learnable_masked_token_layer/learnable_masked_token" (d_temporal,), the value random token
+                                    masking writes in training mode (uplift_upsample_transformer.py:38-50,219-220,337); unused
+                                    at inference                                                                        */
 } uu3d_config;
 
 typedef struct uu3d_model uu3d_model;
@@ -309,10 +313,10 @@ int uu3d_train_forward_backward(uu3d_model* model, const float* params_dev, cons
                                 float* loss_out_dev, float* full_out_dev, float* central_out_dev,
                                 float* grads_dev, void* workspace_dev, size_t workspace_bytes, void* stream);
 
-/* The same step with random token masking (uplift_upsample_transformer.py:287-311, 336-338; TOKEN_MASK_RATE > 0 with
- * LEARNABLE_MASKED_TOKEN = false): token (b, n) entering the temporal transformer -- spatial_to_temporal_fc's output, before the
- * strided-input token blend and the positional encoding -- is replaced by 0 where token_mask_uniform_dev[b * N + n] <
- * token_mask_rate, never at the central frame n = N / 2.  token_mask_uniform_dev: B * N draws of U[0, 1) (the caller's generator,
+/* The same step with random token masking (uplift_upsample_transformer.py:287-311, 336-338; TOKEN_MASK_RATE > 0): token (b, n) entering the temporal transformer -- spatial_to_temporal_fc's output, before the
+ * strided-input token blend and the positional encoding -- is replaced by 0 (by the learnable masked token when the model was
+ * created with uu3d_config.learnable_masked_token, whose gradient is the sum of d x over the replaced rows) where
+ * token_mask_uniform_dev[b * N + n] < token_mask_rate, never at the central frame n = N / 2.  token_mask_uniform_dev: B * N draws of U[0, 1) (the caller's generator,
  * like drop_path_uniform_dev); NULL or rate 0: no masking (= uu3d_train_forward_backward). */
 int uu3d_train_forward_backward_masked(uu3d_model* model, const float* params_dev, const float* kp2d_dev,
                                        const uint8_t* stride_mask_dev, const float* gt3d_dev, int32_t batch,

@@ -171,7 +171,7 @@ def forward(hp, weights, x, stride_mask=None, dtype=torch.float32, return_attent
 def forward_torch(hp, p, x, stride_mask=None, dtype=torch.float32, drop_path_cfg=None, token_mask_cfg=None):
     """Differentiable core on torch tensors (weights `p` may require grad).
 
-    token_mask_cfg (training mode, u_u_t.py:287-311,336-338; masked-token value 0): dict(rate=TOKEN_MASK_RATE, u=(B, N) explicit U[0,1) draws).
+    token_mask_cfg (training mode, u_u_t.py:287-311,336-338; masked-token value: the learnable token when `p` holds one, else 0): dict(rate=TOKEN_MASK_RATE, u=(B, N) explicit U[0,1) draws).
 
     drop_path_cfg (training mode, vision_transformer.py:31-43): dict(rates=(spatial, temporal, strided),
     u_spatial (Ls, 2, B*N), u_temporal (Lt, 2, B), u_strided (len(strides), 2, B) -- the last only when rates[2] > 0) with explicit
@@ -210,11 +210,12 @@ def forward_torch(hp, p, x, stride_mask=None, dtype=torch.float32, drop_path_cfg
     x = dense(x, p["spatial_to_temporal_fc/kernel"], p["spatial_to_temporal_fc/bias"])
 
     # temporal_transformation :335-367
-    if token_mask_cfg is not None and token_mask_cfg["rate"] > 0:      # random_token_masking :287-311, value 0 (LEARNABLE_MASKED_TOKEN = false)
+    if token_mask_cfg is not None and token_mask_cfg["rate"] > 0:      # random_token_masking :287-311
         tmask = torch.as_tensor(np.asarray(token_mask_cfg["u"], np.float32) < np.float32(token_mask_cfg["rate"]))
         tmask = tmask & (torch.arange(N) != N // 2)[None, :]            # the central frame is never masked :291-294,303
         tmask = tmask.to(dtype)[..., None]
-        x = x * (1.0 - tmask) + 0.0 * tmask                              # :310
+        value = p["learnable_masked_token_layer/learnable_masked_token"] if "learnable_masked_token_layer/learnable_masked_token" in p else 0.0   # :337
+        x = x * (1.0 - tmask) + value * tmask                            # :310
     pe = p["temporal_pe/positional_encoding_weights"]
     inv = None
     if hp["has_strided_input"]:

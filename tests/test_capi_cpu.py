@@ -35,7 +35,7 @@ def test_header_symbols_exported(lib):
 def test_config_struct_matches_header():
     from uplift_upsample_3dhpe_amd import _capi
     # 9 scalars + 3 arrays of 8 + 6 scalars, all int32
-    assert C.sizeof(_capi.Uu3dConfig) == 4 * (9 + 3 * 8 + 7)          # 9 scalars + 3 arrays of 8 + 7 scalars (output_bn since round 3), all int32
+    assert C.sizeof(_capi.Uu3dConfig) == 4 * (9 + 3 * 8 + 8)          # 9 scalars + 3 arrays of 8 + 8 scalars (output_bn and learnable_masked_token since round 3), all int32
     assert C.sizeof(_capi.Uu3dProfileEntry) == 48 + 32 + 4 + 4 + 8 + 8
 
 

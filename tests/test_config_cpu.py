@@ -153,10 +153,19 @@ def test_unimplemented_options_are_rejected_not_ignored(key, value, where):
 
 def test_learnable_masked_token_rule():
     """LEARNABLE_MASKED_TOKEN alone creates nothing in the reference (the layer exists only with TOKEN_MASK_RATE > 0,
-    u_u_t.py:219-220): accepted; together with a token mask rate it adds a trainable weight this build does not have."""
+    u_u_t.py:219-220); together with a token mask rate the model owns one more weight, created in front of the strided-input
+    token (Keras' default layer name: the reference passes none)."""
+    from uplift_upsample_3dhpe_amd.weights import weight_spec
     cfg = util.load_config("h36m_351")
     cfg.LEARNABLE_MASKED_TOKEN = True
-    pkg.arch_from_config(cfg)
+    a = pkg.arch_from_config(cfg)
+    assert not a.learnable_masked_token
+    names0 = [n for n, _ in weight_spec(a)]
     cfg.TOKEN_MASK_RATE = 0.1
-    with pytest.raises(NotImplementedError, match="LEARNABLE_MASKED_TOKEN"):
-        pkg.arch_from_config(cfg)
+    a = pkg.arch_from_config(cfg)
+    assert a.learnable_masked_token
+    spec = weight_spec(a)
+    names = [n for n, _ in spec]
+    i = names.index("learnable_masked_token_layer/learnable_masked_token")
+    assert names[i + 1] == "strided_input_token_layer/learnable_masked_token" and spec[i][1] == (a.d_temporal,)
+    assert names[:i] + names[i + 1:] == names0

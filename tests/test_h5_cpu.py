@@ -59,13 +59,16 @@ def test_loader_semantics_follow_the_reference(tmp_path):
         f = tmp_path / "not.h5"; f.write_bytes(b"hello world, definitely not hdf5"); weight_io.load_keras_h5(str(f), SPEC)
 
 
-@pytest.mark.parametrize("cfgname", ["h36m_81", "h36m_351", "h36m_81+bn"])
+@pytest.mark.parametrize("cfgname", ["h36m_81", "h36m_351", "h36m_81+bn", "h36m_351+mtoken"])
 def test_model_sized_roundtrip_and_h5py_reads_our_files(cfgname, tmp_path):
     cfg = util.load_config(cfgname.split("+")[0])
     if cfgname.endswith("+bn"):                        # OUTPUT_BN: two BatchNormalization layers, four weights each (gamma, beta, moving mean / variance)
         cfg.OUTPUT_BN = True
+    if cfgname.endswith("+mtoken"):                    # TOKEN_MASK_RATE > 0 with LEARNABLE_MASKED_TOKEN: one more layer with one weight
+        cfg.TOKEN_MASK_RATE, cfg.LEARNABLE_MASKED_TOKEN = 0.1, True
     arch = pkg.arch_from_config(cfg)
     spec = pkg.weight_spec(arch)
+    assert ("learnable_masked_token_layer/learnable_masked_token" in dict(spec)) == cfgname.endswith("+mtoken")
     w = pkg.init_weights(arch, seed=5, perturb=0.1)
     path = str(tmp_path / "w.h5")
     weight_io.save_keras_h5(path, w, spec)

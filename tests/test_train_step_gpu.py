@@ -28,7 +28,7 @@ _MASKS = [(0, 0), (1, 0), (2, 0)]
 
 @pytest.mark.parametrize("cfgname,droppath,batch_norm", [("h36m_81", False, 4), ("h36m_351", False, 4), ("h36m_81", True, 4), ("h36m_351", True, 4),
                                                          ("h36m_351", True, 512), ("h36m_81", False, 512), ("h36m_351", "strided", 4), ("h36m_81", "strided", 512),
-                                                         ("h36m_351", "tokenmask", 4), ("h36m_81", "tokenmask", 4)])
+                                                         ("h36m_351", "tokenmask", 4), ("h36m_81", "tokenmask", 4), ("h36m_351", "tokenmask_learnable", 4)])
 def test_gradients_match_autograd(cfgname, droppath, batch_norm):
     """Every gradient tensor against float64 autograd through the oracle, <= 1e-4 of its scale.  batch_norm = 512 is the
     PRODUCTION loss normaliser (config BATCH_SIZE): d loss / d joint is 8e-7 there, which the f16x3 gradient GEMMs only
@@ -41,9 +41,14 @@ def test_gradients_match_autograd(cfgname, droppath, batch_norm):
         cfg.DROP_PATH_RATE = [0.1, 0.1, 0.4]      # (spatial / temporal rates as shipped; with 0.2 / 0.2 and this draw one ReLU of strided block 1 sits within rounding of 0 and flips against the float64 oracle, with or without strided DropPath)
         arch = pkg.arch_from_config(cfg)
         model = pkg.build_uplift_upsample_transformer(cfg, weights=w)
-    if droppath == "tokenmask":                   # random token masking (TOKEN_MASK_RATE > 0, masked-token value 0: u_u_t.py:287-311,336-338; round 3)
-        cfg.TOKEN_MASK_RATE = 0.3
+    tokenmask = droppath in ("tokenmask", "tokenmask_learnable")
+    if tokenmask:                                 # random token masking (TOKEN_MASK_RATE > 0: u_u_t.py:287-311,336-338; round 3): masked-token value 0, or
+        cfg.TOKEN_MASK_RATE = 0.3                 # the extra trainable vector of LEARNABLE_MASKED_TOKEN (:38-50,219-220,337)
+        cfg.LEARNABLE_MASKED_TOKEN = droppath == "tokenmask_learnable"
         arch = pkg.arch_from_config(cfg)
+        if arch.learnable_masked_token:
+            w = pkg.init_weights(arch, seed=7, perturb=0.1)
+            assert "learnable_masked_token_layer/learnable_masked_token" in w
         model = pkg.build_uplift_upsample_transformer(cfg, weights=w)
     ms = cfg.MASK_STRIDE if isinstance(cfg.MASK_STRIDE, list) else [cfg.MASK_STRIDE]
     m = np.stack([util.eval_stride_mask(arch.num_frames, cfg.SEQUENCE_STRIDE, ms[i], 0) for i, _ in _MASKS])
@@ -51,7 +56,7 @@ def test_gradients_match_autograd(cfgname, droppath, batch_norm):
     rng = np.random.default_rng(11)
     u = rng.random(tr.drop_path_size(B)).astype(np.float32) if droppath else None
     tmu = None
-    if droppath == "tokenmask":
+    if tokenmask:
         tmu = rng.random((B, arch.num_frames)).astype(np.float32)
         tmu[:, arch.num_frames // 2] = 0.0        # a draw that WOULD mask the central frame: it must stay
         hit = (tmu < 0.3) & (m != 0)
@@ -230,6 +235,15 @@ def test_training_call_of_the_model_object():
     fi, ci = modelm([xm, mt], training=False)
     assert torch.equal(fi, f_inf) and torch.equal(ci, c_inf)
     assert (fm - f0).abs().max() > 1e-3 and torch.isfinite(fm).all() and torch.isfinite(cm).all()
+    cfg0.LEARNABLE_MASKED_TOKEN = True                                  # one more weight in the inventory, unused at inference
+    archl = pkg.arch_from_config(cfg0)
+    wl = dict(w); wl["learnable_masked_token_layer/learnable_masked_token"] = np.full((archl.d_temporal,), 0.5, np.float32)
+    modell = pkg.build_uplift_upsample_transformer(cfg0, weights=wl)
+    assert "learnable_masked_token_layer/learnable_masked_token" in modell.weight_names
+    fli, cli = modell([xm, mt], training=False)
+    assert torch.equal(fli, f_inf) and torch.equal(cli, c_inf)
+    fl, cl = modell([xm, mt], training=True)                            # same draws as modelm (same seed): only the masked rows' value differs
+    assert (fl - fm).abs().max() > 1e-3 and torch.isfinite(fl).all()
     names = [v.name for v in model.weights]
     assert names == model.weight_names and [v.name for v in model.trainable_variables] == names
     v = model.weights[1]

@@ -56,7 +56,7 @@ class Uu3dConfig(C.Structure):
         ("pad_right", C.c_int32 * UU3D_MAX_STRIDED),
         ("num_heads", C.c_int32), ("qkv_bias", C.c_int32), ("has_strided_input", C.c_int32),
         ("first_strided_token_attention_layer", C.c_int32), ("full_output", C.c_int32),
-        ("precision", C.c_int32), ("output_bn", C.c_int32),
+        ("precision", C.c_int32), ("output_bn", C.c_int32), ("learnable_masked_token", C.c_int32),
     ]
 
 

@@ -33,6 +33,7 @@ class UpliftArch:
     drop_rate: float = 0.0
     attention_drop_rate: float = 0.0
     token_mask_rate: float = 0.0
+    learnable_masked_token: bool = False   # TOKEN_MASK_RATE > 0 and LEARNABLE_MASKED_TOKEN: one more weight (u_u_t.py:219-220)
     output_bn: bool = False      # BatchNormalization in front of both heads (u_u_t.py:275-285); inference form only
     # derived
     strided_lengths: Tuple[int, ...] = field(default=())   # L_0 .. L_len(strides)
@@ -82,9 +83,6 @@ def training_unsupported(a: "UpliftArch"):
 
 def arch_from_config(config) -> UpliftArch:
     # Options that would build a DIFFERENT model than the one the HIP path computes are rejected, not ignored.
-    if float(getattr(config, "TOKEN_MASK_RATE", 0.0)) > 0.0 and bool(getattr(config, "LEARNABLE_MASKED_TOKEN", False)):
-        raise NotImplementedError("TOKEN_MASK_RATE > 0 with LEARNABLE_MASKED_TOKEN = true adds a trainable masked-token "
-                                  "layer (u_u_t.py:219-220) that is not implemented")
     has_strided_input = config.MASK_STRIDE is not None
     if has_strided_input:
         ms = config.MASK_STRIDE
@@ -145,6 +143,8 @@ def arch_from_config(config) -> UpliftArch:
         drop_rate=float(getattr(config, "DROP_RATE", 0.0)),
         attention_drop_rate=float(getattr(config, "ATTENTION_DROP_RATE", 0.0)),
         token_mask_rate=float(getattr(config, "TOKEN_MASK_RATE", 0.0)),
+        # the layer (and its weight) exists only with both settings (u_u_t.py:219-220)
+        learnable_masked_token=float(getattr(config, "TOKEN_MASK_RATE", 0.0)) > 0.0 and bool(getattr(config, "LEARNABLE_MASKED_TOKEN", False)),
         output_bn=bool(getattr(config, "OUTPUT_BN", False)),
         strided_lengths=tuple(conv_len),
     )

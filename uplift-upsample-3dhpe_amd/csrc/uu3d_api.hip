@@ -192,6 +192,7 @@ void build_inventory(uu3d_model* m) {
     add_weight(m, "temporal_pe/positional_encoding_weights", {N, dt});
     for (int i = 0; i < c.num_strided; ++i)
         add_weight(m, "strided_temporal_pe_" + std::to_string(i + 1) + "/positional_encoding_weights", {m->L[i], dt});
+    if (c.learnable_masked_token) add_weight(m, "learnable_masked_token_layer/learnable_masked_token", {dt});      // (u_u_t.py:219-220, in front of the strided-input token)
     if (c.has_strided_input) add_weight(m, "strided_input_token_layer/learnable_masked_token", {dt});
     if (c.spatial_depth > 0) {
         for (int i = 0; i < c.spatial_depth; ++i)

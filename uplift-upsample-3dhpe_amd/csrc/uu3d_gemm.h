@@ -173,7 +173,8 @@ struct EpSpatialToTemporal {
     float* __restrict__ x; const float* __restrict__ bias; int ld;
     const uint8_t* __restrict__ mask;     // per row (B*N), nullptr when no strided input
     const float* __restrict__ token; const float* __restrict__ pe; int period;
-    const uint8_t* __restrict__ keep = nullptr;     // training with TOKEN_MASK_RATE > 0 (token_keep_kernel): real rows with keep == 0 become 0
+    const uint8_t* __restrict__ keep = nullptr;     // training with TOKEN_MASK_RATE > 0 (token_keep_kernel): real rows with keep == 0 become the masked-token value
+    const float* __restrict__ mtoken = nullptr;     // that value: the learnable masked token (LEARNABLE_MASKED_TOKEN), nullptr = 0
     __device__ __forceinline__ float2 colv(int col) const {
         return make_float2(bias[col], mask != nullptr ? token[col] : 0.f);
     }
@@ -183,7 +184,7 @@ struct EpSpatialToTemporal {
         return p;
     }
     __device__ __forceinline__ void store(int row, int col, float v, float2 cv, float2 p) const {
-        const float t = (p.y == 1.f) ? (v + cv.x) : (p.y == 0.f ? cv.y : 0.f);
+        const float t = (p.y == 1.f) ? (v + cv.x) : (p.y == 0.f ? cv.y : (mtoken != nullptr ? mtoken[col] : 0.f));
         x[(size_t)row * ld + col] = t + p.x;
     }
 };

@@ -144,15 +144,17 @@ droppath_gate_kernel(const float* __restrict__ u, const int n, const float keep,
 
 // random token masking (u_u_t.py:287-311): keep[b, n] = 1 where the token entering the temporal transformer is spatial_to_temporal_fc's
 // output, 0 where it is replaced -- by the strided-input token (stride_mask == 0) or by the masked-token value 0 (u < rate, never the
-// central frame).  One array serves the forward epilogue and the backward row mask (d s2t_out = dX * keep).
+// central frame).  `keep` serves the forward epilogue and the backward row mask (d s2t_out = dX * keep).
 static __global__ void __launch_bounds__(256)
 token_keep_kernel(const float* __restrict__ u, const float rate, const uint8_t* __restrict__ stride_mask, const int rows, const int N,
-                  uint8_t* __restrict__ keep)
+                  uint8_t* __restrict__ keep, uint8_t* __restrict__ replaced)
 {
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= rows) return;
     const bool masked = (u[i] < rate) && (i % N != N / 2);
-    keep[i] = (uint8_t)((stride_mask == nullptr || stride_mask[i] != 0) && !masked);
+    const bool real = (stride_mask == nullptr || stride_mask[i] != 0);
+    keep[i] = (uint8_t)(real && !masked);
+    replaced[i] = (uint8_t)(real && masked);      // rows that carry the masked-token value: the rows its gradient sums (LEARNABLE_MASKED_TOKEN)
 }
 
 // every layer's gates of both stacks in one launch: layer i of the spatial stack has ns gates (u and gate at i * ns), the

@@ -88,6 +88,7 @@ class UpliftUpsampleTransformer(object):
         cfg.first_strided_token_attention_layer = arch.first_strided_token_attention_layer
         cfg.full_output = int(arch.full_output)
         cfg.output_bn = int(bool(getattr(arch, "output_bn", False)))
+        cfg.learnable_masked_token = int(bool(getattr(arch, "learnable_masked_token", False)))
         # "f16x3": forward GEMMs as three f16 MFMA passes on hi/lo-split operands (f32-grade error);
         # "f32": exact f32-input MFMA everywhere
         if precision not in ("f32", "f16x3"):

@@ -48,6 +48,8 @@ def weight_spec(a: UpliftArch):
     spec += [("temporal_pe/positional_encoding_weights", (N, dt))]
     for i in range(len(a.strides)):
         spec += [(f"strided_temporal_pe_{i + 1}/positional_encoding_weights", (a.strided_lengths[i], dt))]
+    if getattr(a, "learnable_masked_token", False):       # LearnableMaskedTokenLayer without a name argument (u_u_t.py:219-220): Keras' default layer name
+        spec += [("learnable_masked_token_layer/learnable_masked_token", (dt,))]
     if a.has_strided_input:
         spec += [("strided_input_token_layer/learnable_masked_token", (dt,))]
     if a.spatial_depth > 0:
