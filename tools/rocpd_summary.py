@@ -24,19 +24,21 @@ else:
         for name, gx, gy, gs, ctr, val in c.execute("select kernel_name, grid_size_x, grid_size_y, grid_size, counter_name, value from counters_collection"):
             a = acc[(name, gs, gx, gy)][ctr]; a[0] += float(val); a[1] += 1
     cols = ["FETCH_SIZE", "WRITE_SIZE", "SQ_VALU_MFMA_BUSY_CYCLES", "SQ_BUSY_CU_CYCLES", "GRBM_GUI_ACTIVE"]
+    extra = sorted({x for cc in acc.values() for x in cc} - set(cols))      # any other counter of the run: plain per-launch averages
     rows = []
     for k, cc in acc.items():
         n = max(v[1] for v in cc.values())
         avg = {x: (cc[x][0] / cc[x][1] if x in cc and cc[x][1] else None) for x in cols}
         # SQ_VALU_MFMA_BUSY_CYCLES sums busy cycles over the 1024 SIMDs, GRBM_GUI_ACTIVE sums active cycles over the 8 XCDs
         frac = avg["SQ_VALU_MFMA_BUSY_CYCLES"] / (avg["GRBM_GUI_ACTIVE"] / 8.0 * 1024.0) if avg["SQ_VALU_MFMA_BUSY_CYCLES"] is not None and avg["GRBM_GUI_ACTIVE"] else None
-        rows.append((-(avg["GRBM_GUI_ACTIVE"] or 0) * n, [k[0], k[1], k[2], k[3], n, avg["FETCH_SIZE"], None if avg["FETCH_SIZE"] is None else avg["FETCH_SIZE"] * 1024 * 2,
+        rows.append((-(avg["GRBM_GUI_ACTIVE"] or 0) * n - 1e-9 * sum(v[0] for v in cc.values()), [k[0], k[1], k[2], k[3], n, avg["FETCH_SIZE"], None if avg["FETCH_SIZE"] is None else avg["FETCH_SIZE"] * 1024 * 2,
                      avg["WRITE_SIZE"], None if avg["WRITE_SIZE"] is None else avg["WRITE_SIZE"] * 1024,
-                     avg["SQ_VALU_MFMA_BUSY_CYCLES"], avg["SQ_BUSY_CU_CYCLES"], avg["GRBM_GUI_ACTIVE"], frac]))
+                     avg["SQ_VALU_MFMA_BUSY_CYCLES"], avg["SQ_BUSY_CU_CYCLES"], avg["GRBM_GUI_ACTIVE"], frac] +
+                     [(cc[x][0] / cc[x][1] if x in cc and cc[x][1] else None) for x in extra]))
     with open(out, "w", newline="") as fh:
         w = csv.writer(fh)
         w.writerow(["kernel", "grid_size", "grid_x", "grid_y", "launches", "FETCH_SIZE_KB_avg_raw", "HBM_read_bytes_avg_x2_gfx950_corrected", "WRITE_SIZE_KB_avg",
-                    "HBM_write_bytes_avg", "SQ_VALU_MFMA_BUSY_CYCLES_avg", "SQ_BUSY_CU_CYCLES_avg", "GRBM_GUI_ACTIVE_avg", "mfma_pipe_busy_frac"])
+                    "HBM_write_bytes_avg", "SQ_VALU_MFMA_BUSY_CYCLES_avg", "SQ_BUSY_CU_CYCLES_avg", "GRBM_GUI_ACTIVE_avg", "mfma_pipe_busy_frac"] + [x + "_avg" for x in extra])
         for _, r in sorted(rows, key=lambda t: t[0]):
             w.writerow(["" if v is None else (round(v, 4) if isinstance(v, float) else v) for v in r])
     print("wrote", out, len(acc), "kernels")

@@ -70,6 +70,12 @@ constexpr int XLD = 40;          // halfs per row of the K = 32 operand tile (80
 constexpr int HLD = 72;          // halfs per row of the K = 64 hidden tile (144 B)
 constexpr int KLD = 36;          // floats per token row the K / V region is sized by (the hidden planes reuse it)
 constexpr int KPLD = 68;         // floats per key pair of a frame: [32 channels][2 keys] + 4 (272 B: 16-byte aligned, pairs 4 banks apart)
+#ifndef UU3D_KFPAD
+#define UU3D_KFPAD 8
+#endif
+constexpr int KFPAD = UU3D_KFPAD; // floats between the key-pair images of two frames: frame stride 9 * 68 + 8 = 620 = 44 banks -- the 9 lanes of a frame
+                                 // store one channel to banks 4 jp + parity; the three frames of a wave then land on disjoint banks (at 612 = 36 banks
+                                 // frames 0 and 2 shared five of nine: two-way conflicts on every K / V store)
 constexpr int NPARAM = 352;     // LayerNorm parameters and biases of one block (SpatialBlockLayoutV2 up to fq)
 constexpr size_t lds_bytes() { return (size_t)2 * ROWS_T * XLD * 2 + (size_t)2 * ROWS_T * KLD * 4 + NPARAM * 4; }
 static_assert(2 * ROWS_T * HLD * 2 == 2 * ROWS_T * KLD * 4, "the hidden planes reuse the K / V tiles byte for byte");
@@ -438,14 +444,15 @@ spatial_stack_h3_kernel(const float* __restrict__ kp2d, const SpatialParams p, c
     // K / V slots of this lane's two tokens in the key-pair layout (floats from TK / TV): [frame][key pair][channel][2]; padding
     // tokens go to the spare half of the last pair of their frame (never read with a non-zero probability)
     constexpr int NP = (J + 1) / 2;
-    static_assert((J & 1) == 1 && FR * NP * KPLD <= ROWS_T * KLD, "odd J: one spare key slot per frame; fits the K / V region");
+    constexpr int KFLD = NP * KPLD + KFPAD;               // floats per frame
+    static_assert((J & 1) == 1 && FR * KFLD <= ROWS_T * KLD && KFLD % 4 == 0, "odd J: one spare key slot per frame; fits the K / V region; 16-byte aligned frames");
     int kslot[MT];
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) {
         const int jp = real[mt] ? (joint[mt] >> 1) : NP - 1, par = real[mt] ? (joint[mt] & 1) : 1;
-        kslot[mt] = (fl * NP + jp) * KPLD + par;
+        kslot[mt] = fl * KFLD + jp * KPLD + par;
     }
-    const unsigned kfr = (unsigned)(fl * NP * KPLD * 4);   // LDS byte offset of the lane's frame inside TK / TV
+    const unsigned kfr = (unsigned)(fl * KFLD * 4);        // LDS byte offset of the lane's frame inside TK / TV
     const unsigned tk_a = (unsigned)(uintptr_t)(__attribute__((address_space(3))) const void*)TK;
     const unsigned tv_a = (unsigned)(uintptr_t)(__attribute__((address_space(3))) const void*)TV;
 
@@ -541,7 +548,7 @@ spatial_stack_h3_kernel(const float* __restrict__ kp2d, const SpatialParams p, c
             // the spare key slot of every frame: finite (zero) whatever the hidden planes of the previous block left there
             if (lane < 2 * DS) { const int c = lane & 31; float* T = lane < DS ? TK : TV;
 #pragma unroll
-                for (int f = 0; f < FR; ++f) T[(f * NP + NP - 1) * KPLD + 2 * c + 1] = 0.f; }
+                for (int f = 0; f < FR; ++f) T[f * KFLD + (NP - 1) * KPLD + 2 * c + 1] = 0.f; }
             bias_pairs(W + LY::bk, bp);
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt)
