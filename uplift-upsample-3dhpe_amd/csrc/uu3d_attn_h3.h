@@ -82,23 +82,23 @@ attn_h3_kernel(const _Float16* __restrict__ qkv_h, const _Float16* __restrict__ 
 
     // ---- K, V of the head: global -> LDS by LDS-DMA, 12 NT instructions shared by the waves; rows past L: a copy of the last
     // row (finite; those keys get -inf / probability 0) ----
-    if (MAXW == 3 && NT == 3 && NW == 3) {
-        // three key tiles, three waves (the shipped 71-token sequences): piece e = w + 3 i.  K (i < 6): plane i / 3, slice i % 3, key group w --
-        // one key per lane pair for all six pieces.  V (i >= 6): 16-byte piece P = 64 w + 192 (i - 6) + lane of the [key][12 pieces] image;
-        // 192 pieces = 16 keys, so key = P0 / 12 + 16 (i - 6) and the piece inside the row never changes.  ~5 instead of ~60 VALU instructions
-        // per piece in front of the last request (the generic loop below divides by 12, 3 NT and NT per piece).
+    if (NW == NT) {
+        // one wave per key tile (every launch of up to 12 tiles): piece e = w + NT i, i = 0 .. 11.  K (i < 6): plane i / 3, slice i % 3, key
+        // group w -- one key per lane pair for all six pieces.  V (i >= 6): 16-byte piece P = 64 (w + NT (i - 6)) + lane of the [key][12 pieces]
+        // image.  The generic loop below divides by 3 NT and NT (run-time values) for every piece: ~60 VALU instructions per piece in front of
+        // the last request; here the only division left is the one by 12.
         const int key = min(32 * w + (lane >> 1), L - 1);
         const size_t ko = (tok0 + key) * ld + D + h * DH + 8 * (lane & 1);
 #pragma unroll
         for (int i = 0; i < 6; ++i)
             __builtin_amdgcn_global_load_lds((h3_glb_void*)((i >= 3 ? qkv_l : qkv_h) + ko + 16 * (i % 3)),
                                              (h3_lds_void*)(Kp + ((size_t)i * Lpad + 32 * w) * 16), 16, 0, 0);
-        const int P0 = 64 * w + lane, k0 = P0 / 12, wi = P0 - 12 * k0;
-        const _Float16* vp = (wi >= 6 ? qkv_l : qkv_h) + 2 * D + h * DH + 8 * (wi >= 6 ? wi - 6 : wi);
 #pragma unroll
-        for (int i = 0; i < 6; ++i)
-            __builtin_amdgcn_global_load_lds((h3_glb_void*)(vp + (tok0 + min(k0 + 16 * i, L - 1)) * ld),
-                                             (h3_lds_void*)(Vr + (size_t)(64 * w + 192 * i) * 8), 16, 0, 0);
+        for (int i = 0; i < 6; ++i) {
+            const int j = w + NT * i, P = 64 * j + lane, k0 = P / 12, wi = P - 12 * k0;
+            const _Float16* vp = (wi >= 6 ? qkv_l : qkv_h) + 2 * D + h * DH + 8 * (wi >= 6 ? wi - 6 : wi);
+            __builtin_amdgcn_global_load_lds((h3_glb_void*)(vp + (tok0 + min(k0, L - 1)) * ld), (h3_lds_void*)(Vr + (size_t)64 * j * 8), 16, 0, 0);
+        }
     } else
     for (int e = w; e < 12 * NT; e += NW) {
         const _Float16* src; _Float16* dst;
