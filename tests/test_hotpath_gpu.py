@@ -219,6 +219,30 @@ def test_optional_kernel_paths_agree(env, monkeypatch):
         assert d > 0.0, "the switch did not change the path"
 
 
+def test_throughput_schedule_is_bit_identical():
+    """uu3d_set_schedule (include/uu3d.h): launch shapes for several forwards sharing the chip (the projection as 71 workgroups x 12
+    column chunks instead of 213 x 4) compute the same products per element -- bit-identical outputs; an unknown schedule is refused."""
+    import ctypes as C
+    cfg = util.load_config("h36m_351")
+    arch = pkg.arch_from_config(cfg)
+    w = pkg.init_weights(arch, seed=9, perturb=0.1)
+    model = pkg.build_uplift_upsample_transformer(cfg, weights=w)
+    for batch in (128, 17):                        # 9088 rows (whole panels) / 1207 rows (a ragged last panel)
+        x, m = util.synthetic_batch(cfg, batch, seed=9)
+        x = x * m[:, :, None, None]
+        f0, c0 = _call(model, x, m)
+        assert model._lib.uu3d_set_schedule(model._h, 1) == 0
+        try:
+            f1, c1 = _call(model, x, m)
+        finally:
+            assert model._lib.uu3d_set_schedule(model._h, 0) == 0
+        assert np.array_equal(f0, f1) and np.array_equal(c0, c1)
+    assert model._lib.uu3d_set_schedule(model._h, 7) != 0
+    model.set_profiling(True)
+    _call(model, x, m)
+    assert any(r["name"].endswith("proj_res") and r["kernel"] == "gemm_panel" for r in model.read_profile())
+
+
 def test_mpjpe_kernel_matches_the_reference_metric():
     """uu3d_mpjpe against the reference's own metrics.mpjpe(normalize=False) (tests/golden/make_metrics_golden.py
     ran common/dataset/metrics.py in the build container): per-joint errors incl. the -1 flags of invalid joints.  The
