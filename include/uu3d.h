@@ -77,8 +77,8 @@ typedef struct uu3d_config {
     int32_t full_output;         /* not USE_REFINE                                      */
     int32_t precision;           /* uu3d_precision                                      */
     int32_t output_bn;           /* OUTPUT_BN: BatchNormalization(momentum 0.1, eps 1e-5) in front of both heads
-                                    (uplift_upsample_transformer.py:275-285); INFERENCE form only: moving statistics,
-                                    folded into the head operands at commit time                                      */
+                                    (uplift_upsample_transformer.py:275-285).  uu3d_forward: moving statistics, folded into
+                                    the head operands at commit time; the training step: batch statistics (see there)   */
     int32_t learnable_masked_token; /* TOKEN_MASK_RATE > 0 and LEARNABLE_MASKED_TOKEN: the model owns one more weight,
                                     "learnable_masked_token_layer/learnable_masked_token" (d_temporal,), the value random token
                                     masking writes in training mode (uplift_upsample_transformer.py:38-50,219-220,337); unused
@@ -293,7 +293,13 @@ int uu3d_ema_update(float* ema_dev, const float* w_dev, int64_t n, float decay, 
  *                              (two draws per block: attention branch, MLP branch); NULL disables DropPath.
  *       full_out_dev / central_out_dev may be NULL.  loss_out_dev[3] = {loss, central, sequence}.
  *       gt3d_dev == NULL: training-mode FORWARD ONLY (model(inputs, training=True) outside a tape, train.py:478);
- *       loss_out_dev / grads_dev may then be NULL.  DROP_PATH_RATE[2] != 0 is UU3D_ERR_UNSUPPORTED.
+ *       loss_out_dev / grads_dev may then be NULL.  drop_path_rates[2] != 0: DropPath inside the strided blocks, its draws behind the
+ *       temporal stack's ([strided blocks][2][B]).
+ *       uu3d_config.output_bn: the heads' BatchNormalization runs in TRAINING mode (uplift_upsample_transformer.py:275-285: batch mean
+ *       and biased variance of the head's input over all rows) and -- the one exception to `const` -- the moving statistics, the last
+ *       tensors of params_dev, are updated in place (moving = 0.1 moving + 0.9 batch), as Keras does inside the training-mode call; they are
+ *       not trainable: their slots of grads_dev are zeros and the optimizer must leave them alone (trainer.Trainer steps the prefix in
+ *       front of them).
  *   uu3d_train_set_grad_callback: `fn(user, first, count, stream)` is called on the calling host thread from inside
  *       uu3d_train_forward_backward each time the range [first, first + count) of grads_dev is final; every kernel that
  *       writes it has been enqueued on `stream` before the call (a bucketed all-reduce makes its communication stream wait

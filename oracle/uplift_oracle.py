@@ -168,9 +168,12 @@ def forward(hp, weights, x, stride_mask=None, dtype=torch.float32, return_attent
     return full_np, central.numpy()
 
 
-def forward_torch(hp, p, x, stride_mask=None, dtype=torch.float32, drop_path_cfg=None, token_mask_cfg=None):
+def forward_torch(hp, p, x, stride_mask=None, dtype=torch.float32, drop_path_cfg=None, token_mask_cfg=None, bn_train=None):
     """Differentiable core on torch tensors (weights `p` may require grad).
 
+    bn_train (training mode with OUTPUT_BN, u_u_t.py:275-285): a dict that receives the updated moving statistics
+    ("<layer>/moving_mean" / "/moving_variance"); the heads then normalise with the BATCH mean and biased variance (Keras' non-fused
+    BatchNormalization on rank-3 inputs: tf.nn.moments over every axis but the last), moving = moving * 0.1 + batch * 0.9.  None = inference.
     token_mask_cfg (training mode, u_u_t.py:287-311,336-338; masked-token value: the learnable token when `p` holds one, else 0): dict(rate=TOKEN_MASK_RATE, u=(B, N) explicit U[0,1) draws).
 
     drop_path_cfg (training mode, vision_transformer.py:31-43): dict(rates=(spatial, temporal, strided),
@@ -231,7 +234,17 @@ def forward_torch(hp, p, x, stride_mask=None, dtype=torch.float32, drop_path_cfg
         x, att = transformer_block(p, f"temporal_block_{i + 1}", x, H, torch.relu, mask, dp_for(1, i, hp["temporal_depth"]))
         att_list.append(att)
 
+    def batch_norm_training(t, name):
+        red = tuple(range(t.dim() - 1))
+        mean = t.mean(dim=red)
+        var = ((t - mean) ** 2).mean(dim=red)                           # biased, like tf.nn.moments
+        bn_train[f"{name}/moving_mean"] = (p[f"{name}/moving_mean"] * 0.1 + mean * 0.9).detach()
+        bn_train[f"{name}/moving_variance"] = (p[f"{name}/moving_variance"] * 0.1 + var * 0.9).detach()
+        return (t - mean) * torch.rsqrt(var + 1e-5) * p[f"{name}/gamma"] + p[f"{name}/beta"]
+
     def batch_norm_inference(t, name):
+        if bn_train is not None:
+            return batch_norm_training(t, name)
         # kl.BatchNormalization(momentum=0.1, epsilon=1e-5, axis=-1) with training=False (u_u_t.py:275-285,400-404,414-416):
         # tf.nn.batch_normalization with the moving statistics: x * (gamma * rsqrt(var + eps)) + (beta - mean * gamma * rsqrt(var + eps))
         inv = p[f"{name}/gamma"] * torch.rsqrt(p[f"{name}/moving_variance"] + 1e-5)

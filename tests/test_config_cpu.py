@@ -128,19 +128,18 @@ def test_config_matches_the_reference_classes(tmp_path):
 
 
 @pytest.mark.parametrize("key,value,where", [
-    ("OUTPUT_BN", True, "train"),
     ("DROP_RATE", 0.1, "train"),
     ("ATTENTION_DROP_RATE", 0.1, "train"),
 ])
 def test_unimplemented_options_are_rejected_not_ignored(key, value, where):
     """A schema-legal config the HIP path does not implement must fail loudly instead of running a different model
-    (u_u_t.py:201,219-220,275-285, vit.py:87-88): OUTPUT_BN is implemented in its inference form (round 3) and refused for
-    training like the others; Dropout rates only act with training=True and are refused by
+    (u_u_t.py:201, vit.py:87-88): Dropout rates only act with training=True and are refused by
     every training entry point (random token masking with value 0 and strided-block DropPath are implemented, round 3) (arch.training_unsupported is what Trainer / model(training=True) raise from)."""
     from uplift_upsample_3dhpe_amd.arch import training_unsupported
     cfg = util.load_config("h36m_351")
     assert training_unsupported(pkg.arch_from_config(cfg)) == []
     cfg.TOKEN_MASK_RATE = 0.2                                       # implemented: not in the list
+    cfg.OUTPUT_BN = True                                            # (inference form and training form, round 3)
     assert training_unsupported(pkg.arch_from_config(cfg)) == []
     setattr(cfg, key, value)
     if where == "build":

@@ -151,9 +151,8 @@ def test_f16x3_attention_agrees_with_the_f32_kernels(monkeypatch):
 def test_output_bn_heads_match_oracle(cfgname, batch, tmp_path):
     """OUTPUT_BN = true (BatchNormalization in front of temporal_fc / strided_temporal_fc, u_u_t.py:275-285) at inference: the
     library folds the per-channel affine of the moving statistics into the head operands at commit time.  Against the oracle's
-    explicit BatchNorm; a checkpoint with the 8 extra tensors round-trips through the Keras .h5 walk; training is refused."""
+    explicit BatchNorm; a checkpoint with the 8 extra tensors round-trips through the Keras .h5 walk."""
     from oracle import uplift_oracle as O
-    from uplift_upsample_3dhpe_amd.trainer import Trainer
     cfg = util.load_config(cfgname)
     cfg.OUTPUT_BN = True
     arch = pkg.arch_from_config(cfg)
@@ -174,10 +173,9 @@ def test_output_bn_heads_match_oracle(cfgname, batch, tmp_path):
     xt, mt = torch.from_numpy(xm).cuda(), torch.from_numpy(m).cuda()
     a, b = model([xt, mt], training=False), other([xt, mt], training=False)
     assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
-    with pytest.raises(NotImplementedError, match="OUTPUT_BN"):
-        Trainer(model, cfg)
-    with pytest.raises(NotImplementedError, match="OUTPUT_BN"):
-        model([xt, mt], training=True)
+    # (the TRAINING form -- batch statistics, moving-average update -- exists since late round 3: tests/test_train_step_gpu.py)
+    ft, ct = model([xt, mt], training=True)
+    assert torch.isfinite(ft).all() and torch.isfinite(ct).all() and (ft - a[0]).abs().max() > 1e-4
 
 
 @pytest.mark.parametrize("variant", ["no_temporal_blocks", "no_strided_blocks", "neither", "no_temporal_blocks_no_mask"])

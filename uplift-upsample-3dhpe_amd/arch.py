@@ -70,14 +70,12 @@ def _conv_length_recurrence(n: int, strides, paddings) -> List[int]:
 def training_unsupported(a: "UpliftArch"):
     """Config options that change the TRAINING-mode forward and that this build does not implement; the caller raises.
     (All are inactive in the shipped configs.)  Reference: Dropout layers u_u_t.py:201, vit.py:87-88,66-67;
-    training-mode BatchNormalization u_u_t.py:276-283.  (random_token_masking u_u_t.py:287-311 with value 0 and DropPath in all three stacks ARE implemented.)"""
+    (random_token_masking u_u_t.py:287-311, DropPath in all three stacks and training-mode BatchNormalization u_u_t.py:276-283 ARE implemented.)"""
     out = []
     if a.drop_rate != 0.0:
         out.append(f"DROP_RATE = {a.drop_rate} (Dropout after the embedding, in MHA.projection and the MLPs)")
     if a.attention_drop_rate != 0.0:
         out.append(f"ATTENTION_DROP_RATE = {a.attention_drop_rate} (Dropout on the attention probabilities)")
-    if a.output_bn:
-        out.append("OUTPUT_BN = true (training-mode BatchNormalization: batch statistics and the moving-average update)")
     return out
 
 

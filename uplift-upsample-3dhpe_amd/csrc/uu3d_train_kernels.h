@@ -238,6 +238,63 @@ identity_bwd_kernel(const float* __restrict__ dout, const int B, const int L_in,
     if (q >= 0 && q % stride == 0 && q / stride < L_out) v = dout[((size_t)b * L_out + q / stride) * D + c];
     dmid[idx] = v;
 }
+// ---- BatchNormalization in training mode (OUTPUT_BN heads, u_u_t.py:275-285,400-404,414-416; kl.BatchNormalization(momentum=0.1,
+// epsilon=1e-5) on rank-3 / rank-2 inputs = Keras' non-fused path: batch mean and BIASED variance over every axis but the last, the same
+// biased variance in the moving-average update, moving = moving * momentum + batch * (1 - momentum)).  Column statistics are two
+// launch_colsum passes (sum, then sum of squared deviations: two-pass like tf.nn.moments) around these elementwise kernels.
+static __global__ void __launch_bounds__(256)
+bn_sqdev_kernel(const float* __restrict__ x, const float* __restrict__ sum, const float inv_rows, const long long n, const int D, float* __restrict__ out)
+{
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const float d = x[i] - sum[i % D] * inv_rows;
+    out[i] = d * d;
+}
+// mean, 1 / sqrt(var + eps) of the batch; moving statistics updated in place (the only weights a training-mode forward writes)
+static __global__ void __launch_bounds__(256)
+bn_stats_kernel(const float* __restrict__ sum, const float* __restrict__ sumsq, const float inv_rows, const float eps, const float momentum, const int D,
+                float* __restrict__ mean, float* __restrict__ rstd, float* __restrict__ moving_mean, float* __restrict__ moving_var)
+{
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= D) return;
+    const float m = sum[c] * inv_rows, v = sumsq[c] * inv_rows;
+    mean[c] = m; rstd[c] = 1.0f / sqrtf(v + eps);
+    moving_mean[c] = moving_mean[c] * momentum + m * (1.0f - momentum);
+    moving_var[c] = moving_var[c] * momentum + v * (1.0f - momentum);
+}
+static __global__ void __launch_bounds__(256)
+bn_apply_kernel(const float* __restrict__ x, const float* __restrict__ mean, const float* __restrict__ rstd, const float* __restrict__ gamma,
+                const float* __restrict__ beta, const long long n, const int D, float* __restrict__ y)
+{
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const int c = (int)(i % D);
+    y[i] = (x[i] - mean[c]) * rstd[c] * gamma[c] + beta[c];
+}
+// out = dy * xhat  (its column sum is d gamma; the column sum of dy is d beta)
+static __global__ void __launch_bounds__(256)
+bn_bwd_prod_kernel(const float* __restrict__ dy, const float* __restrict__ x, const float* __restrict__ mean, const float* __restrict__ rstd,
+                   const long long n, const int D, float* __restrict__ out)
+{
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const int c = (int)(i % D);
+    out[i] = dy[i] * ((x[i] - mean[c]) * rstd[c]);
+}
+// dx (+)= gamma * rstd * (dy - dbeta / R - xhat * dgamma / R)
+static __global__ void __launch_bounds__(256)
+bn_bwd_dx_kernel(const float* __restrict__ dy, const float* __restrict__ x, const float* __restrict__ mean, const float* __restrict__ rstd,
+                 const float* __restrict__ gamma, const float* __restrict__ dgamma, const float* __restrict__ dbeta, const float inv_rows,
+                 const long long n, const int D, const int accumulate, float* __restrict__ dx)
+{
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const int c = (int)(i % D);
+    const float xh = (x[i] - mean[c]) * rstd[c];
+    const float v = gamma[c] * rstd[c] * (dy[i] - dbeta[c] * inv_rows - xh * dgamma[c] * inv_rows);
+    dx[i] = accumulate ? dx[i] + v : v;
+}
+
 // out[r][0..ldo) = in[r][0..C) followed by zeros   (head gradients: 51 -> 64 columns)
 static __global__ void __launch_bounds__(256)
 pad_cols_kernel(const float* __restrict__ in, const int rows, const int C, const int ldo, float* __restrict__ out)

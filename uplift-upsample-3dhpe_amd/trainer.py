@@ -52,7 +52,11 @@ class Trainer(object):
             if "epsilon" in extra:                            # tfa.optimizers.AdamW(..., epsilon=1e-8, **OPTIMIZER_PARAMS): duplicate keyword
                 raise TypeError("AdamW() got multiple values for keyword argument 'epsilon'")
             extra["epsilon"] = 1e-8
-        self.optimizer = optim.AdamW(self.params, weight_decay=wd, learning_rate=lr, **extra)
+        # the optimizer sees the TRAINABLE prefix of the flat buffer: BatchNorm's moving statistics (OUTPUT_BN) are the last tensors of the
+        # inventory, updated by the training-mode forward itself (Keras: non-trainable weights), never decayed or stepped
+        from .weights import weight_spec
+        self.n_trainable = self.n_params - sum(int(np.prod(shape)) for name, shape in weight_spec(model.arch) if "/moving_" in name)
+        self.optimizer = optim.AdamW(self.params[:self.n_trainable], weight_decay=wd, learning_rate=lr, **extra)
         self.ema = self.params.clone() if config.EMA_ENABLED else None
         self.global_step = 0
         self._rng = torch.Generator(device=dev)
@@ -127,7 +131,7 @@ class Trainer(object):
         self._buckets.wait()                                                 # loss normaliser is the GLOBAL batch size: sums, no rescale
         # a backward pass that produced non-finite gradients (loss-scaled f16x3 overflow) leaves weights and moments alone:
         # the flag is read on the device, the host never waits (nonfinite() reads it back for logging)
-        self.optimizer.apply_gradients(self.grads, skip_flag_ptr=self._lib.uu3d_train_nonfinite_flag(self.model._h))
+        self.optimizer.apply_gradients(self.grads[:self.n_trainable], skip_flag_ptr=self._lib.uu3d_train_nonfinite_flag(self.model._h))
         if self.ema is not None:
             optim.ema_update(self.ema, self.params, optim.ema_decay_value(self.config.EMA_DECAY, self.global_step))
         _capi.check(self._lib, self._lib.uu3d_train_repack(self.model._h, C.c_void_p(self.params.data_ptr()), self._stream()), self.model._h)
@@ -206,6 +210,16 @@ class Trainer(object):
     def grads_dict(self):
         out, o = {}, 0
         flat = self.grads.cpu().numpy()
+        for name, shape in self.model._spec:
+            n = int(np.prod(shape))
+            out[name] = flat[o:o + n].reshape(shape)
+            o += n
+        return out
+
+    def params_dict(self):
+        """The live master weights by name (Keras layouts), moving statistics of OUTPUT_BN included."""
+        out, o = {}, 0
+        flat = self.params.cpu().numpy()
         for name, shape in self.model._spec:
             n = int(np.prod(shape))
             out[name] = flat[o:o + n].reshape(shape)
