@@ -499,3 +499,22 @@ def test_batchnorm_heads_through_a_whole_training_step(tmp_path):
     # model(training=True) (train.py:478) takes the batch statistics too
     f_tr, c_tr = model([xm, mt], training=True)
     assert torch.isfinite(f_tr).all() and (f_tr - full).abs().max() > 1e-4
+
+
+def test_pipeline_sees_the_trainers_weights():
+    """A ForwardPipeline built before training keeps working while a Trainer changes the weights (validation inside a training loop,
+    train.py:517-536): every submit after an optimizer step runs on the freshly exported weights -- the same numbers as model(...)."""
+    from uplift_upsample_3dhpe_amd.trainer import Trainer
+    cfg, arch, w, model, x, m, gt = _setup("h36m_81", 6, seed=12, batch_norm=6)
+    xm = torch.from_numpy(x * m[:, :, None, None]).cuda(); mt = torch.from_numpy(m).cuda()
+    pipe = model.pipeline(6)                                        # one slot per hardware queue, hipGraphs captured with the initial weights
+    f0, c0 = [t.clone() for t in next(iter(pipe.run([(xm, mt)])))]
+    tr = Trainer(model, cfg, seed=2)
+    for step in range(2):
+        tr.train_step(torch.from_numpy(x).cuda(), torch.from_numpy(gt).cuda(), mt)
+        got = [(f.clone(), c.clone()) for f, c in pipe.run([(xm, mt)] * 5)]      # more batches than slots: every slot replays
+        want = model([xm, mt], training=False)
+        for f, c in got:
+            assert torch.equal(f, want[0]) and torch.equal(c, want[1]), step
+        assert (want[1] - c0).abs().max() > 1e-6                    # ... and they are not the initial weights' numbers
+    pipe.close()
