@@ -994,7 +994,7 @@ struct Launcher {
     bool attn_is_h3(int L, bool planes_out) const { return planes_out && L <= ATTN_H3_MAX_L && (L > 128 || (L > 48 && !m->attn_f32)); }
     float attn_qscale() const { return 1.44269504088896341f / sqrtf((float)kDH); }
     // split_lo_off != 0: the context rows go out as f16 planes (hi at out, lo split_lo_off halfs further)
-    // frag (attn_h3_kernel only): the context rows in the row-panel GEMM's A-fragment order instead of row-major planes
+    // frag: the context rows in the row-panel GEMM's A-fragment order instead of row-major planes (split_lo_off != 0 only)
     void attn(const char* name, const float* qkv, int B, int L, const uint8_t* mask, float* out, size_t split_lo_off = 0, bool frag = false) {
         const int D = m->cfg.d_temporal, H = m->cfg.num_heads;
         const int NT = (L + 15) / 16;
@@ -1025,7 +1025,7 @@ struct Launcher {
 #define UU3D_ATTN_HW(nt) case nt: { \
             constexpr size_t lds = attn_head_wave_lds_bytes<nt, kDH>(); \
             if (split_lo_off) { auto k = attn_head_wave_kernel<nt, kDH, true>; static const bool once = (hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) == hipSuccess); (void)once; \
-                hipLaunchKernelGGL(k, hgrid, dim3(256), lds, stream, qkv, 3 * D, D, L, H, mask, out, D, split_lo_off, items); } \
+                hipLaunchKernelGGL(k, hgrid, dim3(256), lds, stream, qkv, 3 * D, D, L, H, mask, out, D, frag ? (size_t)512 : split_lo_off, items); } \
             else { auto k = attn_head_wave_kernel<nt, kDH, false>; static const bool once = (hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) == hipSuccess); (void)once; \
                 hipLaunchKernelGGL(k, hgrid, dim3(256), lds, stream, qkv, 3 * D, D, L, H, mask, out, D, (size_t)0, items); } \
             } break;
@@ -1035,7 +1035,7 @@ struct Launcher {
             return;
         }
 #define UU3D_ATTN_CASE(nt) case nt: \
-        if (split_lo_off) hipLaunchKernelGGL((attn_f32_kernel<nt, kDH, true>), grid, dim3(64 * nt), 0, stream, qkv, 3 * D, D, L, H, mask, out, D, split_lo_off); \
+        if (split_lo_off) hipLaunchKernelGGL((attn_f32_kernel<nt, kDH, true>), grid, dim3(64 * nt), 0, stream, qkv, 3 * D, D, L, H, mask, out, D, frag ? (size_t)512 : split_lo_off); \
         else hipLaunchKernelGGL((attn_f32_kernel<nt, kDH, false>), grid, dim3(64 * nt), 0, stream, qkv, 3 * D, D, L, H, mask, out, D, (size_t)0); \
         break;
         switch (NT) {
@@ -1196,7 +1196,7 @@ int uu3d_forward_attention(uu3d_model* m, const float* kp2d, const uint8_t* mask
         maps();
         // projection on the row-panel GEMM (round 3): attn_h3_kernel writes the context rows in A-fragment order, the residual is
         // added in the epilogue from values requested a chunk earlier (UU3D_NO_PANEL_PROJ=1: the tiled LDS-DMA kernel)
-        const bool pproj = qsplit && !m->no_panel_proj && Lh.panel_ok(Mr, dt, dt, b.wp_pf);
+        const bool pproj = planes && !m->no_panel_proj && Lh.panel_ok(Mr, dt, dt, b.wp_pf);      // (every attention kernel writes either layout)
         Lh.attn(name("attn"), w.QKV, B, L, kmask, w.O, planes ? (size_t)Mr * dt : 0, pproj);
         if (pproj) Lh.gemm_panel_residual(name("proj_res"), Ph, b.wp_pf, b.bp, Mr, x);
         else {

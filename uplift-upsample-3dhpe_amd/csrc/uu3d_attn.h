@@ -185,7 +185,11 @@ attn_f32_kernel(const float* __restrict__ qkv, const int ld, const int D, const 
             if (pc < PIECES && q < L) {
                 const h16x8v piece = *reinterpret_cast<const h16x8v*>(&Ow[(plane * 16 + row) * DH + 8 * c8]);
                 const int grow = b * L + q, k = h * DH + 8 * c8;
-                *reinterpret_cast<h16x8v*>(oh + (size_t)plane * lo_off + (size_t)grow * ldo + k) = piece;
+                // lo_off == 512 (no row-major plane pair is that small): the row-panel GEMM's A-fragment order (uu3d_gemm_panel.h, K = ldo) --
+                // the same 16-byte pieces at [32-row panel][16-channel slice][plane][channel half][row & 31][8]
+                _Float16* dst = lo_off == 512 ? oh + ((size_t)(grow >> 5) * (size_t)(ldo >> 4) + (size_t)(k >> 4)) * 1024 + (size_t)plane * 512 + ((k >> 3) & 1) * 256 + (grow & 31) * 8
+                                              : oh + (size_t)plane * lo_off + (size_t)grow * ldo + k;
+                *reinterpret_cast<h16x8v*>(dst) = piece;
             }
         }
     } else {
@@ -417,7 +421,9 @@ attn_head_wave_kernel(const float* __restrict__ qkv, const int ld, const int D, 
                 if (pc < PIECES && q < L) {
                     const h16x8v piece = *reinterpret_cast<const h16x8v*>(&Os[(plane * 16 + row) * DH + 8 * c8]);
                     const int grow = b * L + q, k = h * DH + 8 * c8;
-                    *reinterpret_cast<h16x8v*>(oh + (size_t)plane * lo_off_s + (size_t)grow * ldo_s + k) = piece;
+                    _Float16* dst = lo_off_s == 512 ? oh + ((size_t)(grow >> 5) * (size_t)(ldo_s >> 4) + (size_t)(k >> 4)) * 1024 + (size_t)plane * 512 + ((k >> 3) & 1) * 256 + (grow & 31) * 8
+                                                    : oh + (size_t)plane * lo_off_s + (size_t)grow * ldo_s + k;      // (lo_off == 512: A-fragment order, see attn_f32_kernel)
+                    *reinterpret_cast<h16x8v*>(dst) = piece;
                 }
             }
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
