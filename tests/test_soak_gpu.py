@@ -55,3 +55,28 @@ def test_training_pass_is_bitwise_repeatable_over_many_steps():
         loss, _, _ = tr.forward_backward(x, gt, m, drop_path_uniform=u)
         torch.cuda.synchronize()
         assert torch.equal(tr.grads, g0) and torch.equal(loss, l0), f"pass {i} differs from the first"
+
+
+def test_pipelined_forwards_stay_bitwise_right_over_many_batches():
+    """Four forwards in flight on four hardware queues (pipeline.ForwardPipeline, the bench's and run_eval's path), 1200 batches cycling through
+    six different inputs: every result equals what model(...) returned for that input -- a slot reading another slot's workspace, a graph
+    replayed before its inputs landed, or the throughput schedule's launch shapes computing something else would show up here."""
+    cfg = util.load_config("h36m_351")
+    arch = pkg.arch_from_config(cfg)
+    model = pkg.build_uplift_upsample_transformer(cfg, weights=pkg.init_weights(arch, seed=0, perturb=0.1), device="cuda:0")
+    B = 128
+    inputs, want = [], []
+    for k in range(6):
+        x, m = util.synthetic_batch(cfg, batch=B, seed=20 + k)
+        xt = torch.from_numpy(x * m[:, :, None, None].astype(np.float32)).cuda(); mt = torch.from_numpy(m).cuda()
+        inputs.append((xt, mt))
+        want.append(tuple(t.clone() for t in model([xt, mt], training=False)))
+    pipe = model.pipeline(B)
+    assert pipe.depth >= 2
+    n = 0
+    for full, cen in pipe.run(inputs[i % 6] for i in range(1200)):
+        fw, cw = want[n % 6]
+        assert torch.equal(full, fw) and torch.equal(cen, cw), f"batch {n} differs"
+        n += 1
+    assert n == 1200
+    pipe.close()
