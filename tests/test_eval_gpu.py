@@ -152,3 +152,31 @@ def test_run_eval_with_and_without_pipelining():
     c = ev.run_eval(*args, model=model, action_wise=False, log=lambda *a: None, depth=3, graph=True)
     for k in a["all_frames"]:
         assert a["all_frames"][k] == b["all_frames"][k] == c["all_frames"][k]
+
+
+def test_pipeline_adapts_to_the_number_of_hardware_queues():
+    """GPU_MAX_HW_QUEUES = 2 (read by the HIP runtime at start-up: a process of its own): distinct_queue_streams finds two queues, the default
+    pipeline takes two slots, results stay bit-identical to model(...)."""
+    import os
+    import subprocess
+    import sys
+    code = (
+        "import numpy as np, torch\n"
+        "import uplift_upsample_3dhpe_amd as pkg\n"
+        "from uplift_upsample_3dhpe_amd import synthetic as util\n"
+        "from uplift_upsample_3dhpe_amd.pipeline import distinct_queue_streams\n"
+        "cfg = util.load_config('h36m_81'); arch = pkg.arch_from_config(cfg)\n"
+        "model = pkg.build_uplift_upsample_transformer(cfg, weights=pkg.init_weights(arch, seed=1, perturb=0.1))\n"
+        "qs = distinct_queue_streams(model.device)\n"
+        "x, m = util.synthetic_batch(cfg, 16, seed=3)\n"
+        "xt = torch.from_numpy(x * m[:, :, None, None].astype(np.float32)).cuda(); mt = torch.from_numpy(m).cuda()\n"
+        "want = [t.clone() for t in model([xt, mt], training=False)]\n"
+        "pipe = model.pipeline(16)\n"
+        "ok = all(torch.equal(f, want[0]) and torch.equal(c, want[1]) for f, c in pipe.run([(xt, mt)] * 7))\n"
+        "print('RESULT', len(qs), pipe.depth, ok)\n")
+    env = dict(os.environ, GPU_MAX_HW_QUEUES="2", PYTHONPATH=util.ROOT + os.pathsep + os.environ.get("PYTHONPATH", ""))
+    out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
+    line = [l for l in out.stdout.splitlines() if l.startswith("RESULT")]
+    assert line, out.stderr[-2000:]
+    n, depth, ok = line[0].split()[1:]
+    assert int(n) == 2 and int(depth) == 2 and ok == "True", line[0]
