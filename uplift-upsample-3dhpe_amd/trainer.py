@@ -56,6 +56,9 @@ class Trainer(object):
         # inventory, updated by the training-mode forward itself (Keras: non-trainable weights), never decayed or stepped
         from .weights import weight_spec
         self.n_trainable = self.n_params - sum(int(np.prod(shape)) for name, shape in weight_spec(model.arch) if "/moving_" in name)
+        tail = [name for name, _ in model._spec if "/moving_" in name]
+        if [name for name, _ in model._spec][len(model._spec) - len(tail):] != tail:
+            raise RuntimeError("the non-trainable weights are expected at the end of the inventory")
         self.optimizer = optim.AdamW(self.params[:self.n_trainable], weight_decay=wd, learning_rate=lr, **extra)
         self.ema = self.params.clone() if config.EMA_ENABLED else None
         self.global_step = 0
