@@ -69,7 +69,7 @@ inline void panel_pack_operand(const _Float16* Bh, const _Float16* Bl, int N, in
 // Addresses are a scalar base + a 32-bit BYTE offset per lane (global_store ... saddr): a 64-bit address pair per unrolled
 // output register cost the fc1 kernel its register budget (512 + scratch).  The launcher keeps M * ldo * 4 below 2^32.
 struct PanelEpBias {           // out[row][col] = v
-    static constexpr bool kResidual = false;
+    static constexpr bool kResidual = false; static constexpr int kStores = 1;
     float* __restrict__ out; int ldo;
     __device__ __forceinline__ void store(int row, int col, float v) const {
         const unsigned b = ((unsigned)row * (unsigned)ldo + (unsigned)col) * 4u;
@@ -77,7 +77,7 @@ struct PanelEpBias {           // out[row][col] = v
     }
 };
 struct PanelEpBiasRelu {       // out[row][col] = max(v, 0)   (training-mode forward: the hidden activations stay f32 for the backward pass)
-    static constexpr bool kResidual = false;
+    static constexpr bool kResidual = false; static constexpr int kStores = 1;
     float* __restrict__ out; int ldo;
     __device__ __forceinline__ void store(int row, int col, float v) const {
         const unsigned b = ((unsigned)row * (unsigned)ldo + (unsigned)col) * 4u;
@@ -85,7 +85,7 @@ struct PanelEpBiasRelu {       // out[row][col] = max(v, 0)   (training-mode for
     }
 };
 struct PanelEpBiasSplitQ {     // [q | k | v] as row-major hi / lo planes for attn_h3_kernel; q (columns < qcols) times qscale = log2(e) / sqrt(d_h)
-    static constexpr bool kResidual = false;
+    static constexpr bool kResidual = false; static constexpr int kStores = 2;
     _Float16* __restrict__ Oh; _Float16* __restrict__ Ol; int ldo, qcols; float qscale;
     __device__ __forceinline__ void store(int row, int col, float x) const {
         const float v = col < qcols ? x * qscale : x;
@@ -96,7 +96,7 @@ struct PanelEpBiasSplitQ {     // [q | k | v] as row-major hi / lo planes for at
     }
 };
 struct PanelEpBiasReluSplit {  // ReLU(v) as row-major hi / lo planes [M][ldo] (the A operand of the tiled LDS-DMA kernel)
-    static constexpr bool kResidual = false;
+    static constexpr bool kResidual = false; static constexpr int kStores = 2;
     _Float16* __restrict__ Oh; _Float16* __restrict__ Ol; int ldo;
     __device__ __forceinline__ void store(int row, int col, float x) const {
         const float v = fmaxf(x, 0.f);
@@ -107,7 +107,7 @@ struct PanelEpBiasReluSplit {  // ReLU(v) as row-major hi / lo planes [M][ldo] (
     }
 };
 struct PanelEpBiasResidual {   // x[row][col] += v   (the attention projection on the residual stream, in place: every element is read and written by one lane)
-    static constexpr bool kResidual = true;
+    static constexpr bool kResidual = true; static constexpr int kStores = 1;
     float* __restrict__ x; int ldo;
     // Requests x[row][col] into an ACCUMULATION register and returns at once: the value is valid only after a counted vmcnt wait
     // that names the register (gemm_h3_panel_kernel does both).  Written as asm because (a) a load hipcc can see gets its own
@@ -117,13 +117,20 @@ struct PanelEpBiasResidual {   // x[row][col] += v   (the attention projection o
         const unsigned b = ((unsigned)row * (unsigned)ldo + (unsigned)col) * 4u;
         asm volatile("global_load_dword %0, %1, %2" : "=a"(dst) : "v"(b), "s"(x) : "memory");
     }
+    __device__ __forceinline__ void request8(int row, int col, float& dst) const {          // the same into an architectural register (gemm_h3_panel8_kernel: 256 registers per wave)
+        const unsigned b = ((unsigned)row * (unsigned)ldo + (unsigned)col) * 4u;
+        asm volatile("global_load_dword %0, %1, %2" : "=v"(dst) : "v"(b), "s"(x) : "memory");
+    }
     __device__ __forceinline__ void store(int row, int col, float v) const {
         const unsigned b = ((unsigned)row * (unsigned)ldo + (unsigned)col) * 4u;
         *reinterpret_cast<float*>(reinterpret_cast<char*>(x) + b) = v;
     }
 };
+#ifndef UU3D_PANEL_LOO
+#define UU3D_PANEL_LOO 0       // tools/panel8_exp: leave-out timing builds (results wrong), bit mask: 1 no refill DMA, 2 no epilogue stores, 4 no fragment reads, 8 no barrier, 16 no MFMA
+#endif
 #ifdef UU3D_PANEL_STAMP
-__device__ unsigned long long panel_clk[8];   // tools/gemm_panel_exp: s_memtime ticks in prologue / loop / tail, summed over workgroups
+__device__ unsigned long long panel_stamps[1024 * 8];   // tools/panel8_exp: s_memrealtime (100 MHz) per work item: entry, requests issued, first k-step landed, loop done, end; [5] = s_memtime ticks of the loop
 #define PANEL_STAMP(...) __VA_ARGS__
 #else
 #define PANEL_STAMP(...)
@@ -181,7 +188,7 @@ gemm_h3_panel_kernel(const _Float16* __restrict__ Af, const _Float16* __restrict
 #pragma unroll
         for (int p = 0; p < PANEL_PIECES; ++p) dma1(t, slot, p);
     };
-    PANEL_STAMP(const long long c_start = clock64();)
+    PANEL_STAMP(const unsigned long long st_entry = __builtin_amdgcn_s_memrealtime(); unsigned long long st_first = 0;)
 
     // ---- A panel: 2 KS fragments straight into registers (panels past M: clamped to the last one, never stored) ----
     h16x8 ah[KS], al[KS];
@@ -204,11 +211,14 @@ gemm_h3_panel_kernel(const _Float16* __restrict__ Af, const _Float16* __restrict
     int slot_r = 0, slot_w = PANEL_SLOTS - 1;              // slot consumed / refilled in the current step
     const int crow = (lane >> 5) * 4, ccol = lane & 31;
     const int valid = min(32, M - row0);                   // wave-uniform: rows of this panel that exist (<= 0: none)
-    PANEL_STAMP(asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); const long long c_pro = clock64();)
+    PANEL_STAMP(const unsigned long long st_issued = __builtin_amdgcn_s_memrealtime(); const unsigned long long ck0 = __builtin_amdgcn_s_memtime();)
 
     auto emit = [&](int c, int r, const f32x16& p0, const f32x16& p1, float cv, float res) __attribute__((always_inline)) {
         float v = p0[r] + p1[r] * (1.0f / H3_SCALE) + cv;
         if constexpr (EP::kResidual) v += res;
+#if UU3D_PANEL_LOO & 2
+        if (v != 12345.678f) return;
+#endif
         ep.store(row0 + 8 * (r >> 2) + crow + (r & 3), (chunk0 + c) * 32 + ccol, v);
     };
     // kResidual: the 16 residual values of chunk c are requested when chunk c STARTS and added when it is emitted, a whole chunk
@@ -237,8 +247,11 @@ gemm_h3_panel_kernel(const _Float16* __restrict__ Af, const _Float16* __restrict
             else
             asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" :: "i"(PANEL_PIECES * (PANEL_SLOTS - 2)) : "memory");   // k-step t landed (this wave's pieces); own reads of t-1 returned
             __builtin_amdgcn_sched_barrier(0);
+#if !(UU3D_PANEL_LOO & 8)
             __builtin_amdgcn_s_barrier();                                  // ... everybody's; the slot refilled below was last read in t-1
+#endif
             __builtin_amdgcn_sched_barrier(0);
+            PANEL_STAMP(if (c == 0 && st == 0) st_first = __builtin_amdgcn_s_memrealtime();)
             if (!WHOLE && st == 0 && prev) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r)
@@ -259,13 +272,21 @@ gemm_h3_panel_kernel(const _Float16* __restrict__ Af, const _Float16* __restrict
             UU3D_PANEL_READ(1, 1);
 #pragma unroll
             for (int kk = 0; kk < PANEL_SS; ++kk) {
+#if !(UU3D_PANEL_LOO & 4)
                 if (kk + 2 < PANEL_SS) UU3D_PANEL_READ((kk + 2) % 3, kk + 2);
                 asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(bh[kk % 3]), "+v"(bl[kk % 3]) : "i"(panel_wait_count(kk)));
+#endif
+#if !(UU3D_PANEL_LOO & 16)
                 acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[st * PANEL_SS + kk], bh[kk % 3], acc0, 0, 0, 0);
                 acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[st * PANEL_SS + kk], bl[kk % 3], acc1, 0, 0, 0);
                 acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[st * PANEL_SS + kk], bh[kk % 3], acc1, 0, 0, 0);
+#else
+                asm volatile("" : "+v"(acc0), "+v"(acc1) : "v"(ah[st * PANEL_SS + kk]), "v"(al[st * PANEL_SS + kk]), "v"(bh[kk % 3]), "v"(bl[kk % 3]));
+#endif
                 if (WHOLE && st * PANEL_SS + kk < 16 && prev) emit(c - 1, st * PANEL_SS + kk, p0, p1, pcv, rprev[(st * PANEL_SS + kk) & 15]);
+#if !(UU3D_PANEL_LOO & 1)
                 if (kk & 1) dma1(c * SPC + st + PANEL_SLOTS - 1, slot_w, kk >> 1);   // the refill of the slot read in step t-1, spread over the step (-2 %)
+#endif
             }
 #undef UU3D_PANEL_READ
             slot_r = slot_r + 1 == PANEL_SLOTS ? 0 : slot_r + 1;
@@ -291,7 +312,7 @@ gemm_h3_panel_kernel(const _Float16* __restrict__ Af, const _Float16* __restrict
         }
     };
     if (valid == 32) run(std::true_type{}); else run(std::false_type{});
-    PANEL_STAMP(const long long c_loop = clock64();)
+    PANEL_STAMP(const unsigned long long st_loop = __builtin_amdgcn_s_memrealtime(); const unsigned long long ck1 = __builtin_amdgcn_s_memtime();)
     {   // last chunk
         const int c = chunks_per_wg - 1;
         const float cv = colv_s[c * 32 + ccol];
@@ -311,8 +332,7 @@ gemm_h3_panel_kernel(const _Float16* __restrict__ Af, const _Float16* __restrict
     }
 #undef UU3D_PANEL_RES16
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // the clamped tail DMAs must not outlive the LDS allocation
-    PANEL_STAMP(if (tid == 0) { atomicAdd(&panel_clk[0], (unsigned long long)(c_pro - c_start)); atomicAdd(&panel_clk[1], (unsigned long long)(c_loop - c_pro));
-        atomicAdd(&panel_clk[4], (unsigned long long)(clock64() - c_loop)); atomicAdd(&panel_clk[5], 1ull); })
+    PANEL_STAMP(if (tid == 0 && u < 1024) { unsigned long long* o = panel_stamps + u * 8; o[0] = st_entry; o[1] = st_issued; o[2] = st_first; o[3] = st_loop; o[4] = __builtin_amdgcn_s_memrealtime(); o[5] = ck1 - ck0; })
 }
 
 // ------------------------------------------------------------------------------------------------
