@@ -149,10 +149,12 @@ def quick_forward_bench(cfgname, batch, s_in=None, streams=1, graph=True, steps=
     errs = [torch.empty((batch, J), dtype=torch.float64, device="cuda") for _ in range(streams)]
     pipe = model.pipeline(batch, depth=streams, graph=graph, post=lambda f, c, i: per_joint_error(c, gt, cfg.ROOT_KEYTPOINT, out=errs[i]))
 
+    pipe.preload(x, m)                                   # the batch is resident in every slot's input buffers: no per-step copy
+
     def run(n):
         tickets = []
         for _ in range(n):
-            tickets.append(pipe.submit(x, m))
+            tickets.append(pipe.launch())
             if len(tickets) == streams:
                 pipe.result(tickets.pop(0))
         for t in tickets:
@@ -414,6 +416,11 @@ def main():
             S = S or 2
             pipe = model.pipeline(B, depth=S, graph=False, post=post)
 
+        # the synthetic batch is resident in every slot's static input buffers (the contract's "inputs already resident in HBM"):
+        # a step is launch() = graph replay of forward + error kernel; a producer of real data writes into the buffers
+        # pipe.acquire() hands out (eval.predict_windows), it does not copy either
+        pipe.preload(x, m)
+
         def run_steps(n):
             tickets = []
 
@@ -422,7 +429,7 @@ def main():
                 if use_dist:
                     dist.all_gather_into_tensor(gathered, e)
             for _ in range(n):
-                tickets.append(pipe.submit(x, m))
+                tickets.append(pipe.launch())
                 if len(tickets) == S:
                     consume(tickets.pop(0))
             for t in tickets:

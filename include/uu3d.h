@@ -194,16 +194,23 @@ int uu3d_world_to_cam_2d(const float* world_dev, const float* cams_dev, int32_t 
                          float* cam3d_dev, float* kp2d_dev, void* stream);
 
 /*
- * What the launch shapes of the following uu3d_forward calls are chosen for (a host-side attribute, read when a forward is
- * enqueued or captured; the results are bit-identical either way):
- *   UU3D_SCHEDULE_LATENCY (default): one batch at a time -- every launch spreads over as many CUs as pays for ITS duration;
- *   UU3D_SCHEDULE_THROUGHPUT: several independent batches in flight on different streams (pipeline.ForwardPipeline sets it around
- *     its launches) -- the chip is shared between forwards, so a launch is shaped for the fewest CU-microseconds instead: the
- *     attention projection runs as 71 workgroups x 12 column chunks instead of 213 x 4 (27 instead of 16 us alone, +2.4 %
- *     sequences/s with four batches in flight).
+ * The schedule of a forward: what its launch shapes are chosen for.  The results are bit-identical either way (the same products
+ * per element, computed by other workgroups).
+ *   UU3D_SCHEDULE_LATENCY: one batch at a time -- every launch spreads over as many CUs as pays for ITS duration;
+ *   UU3D_SCHEDULE_THROUGHPUT: several independent batches in flight on different streams (pipeline.ForwardPipeline) -- the chip is
+ *     shared between forwards, so a launch is shaped for the fewest CU-microseconds instead: the attention projection runs as 71
+ *     workgroups x 12 column chunks instead of 213 x 4 (27 instead of 16 us alone, +2.4 % sequences/s with four batches in flight;
+ *     DESIGN.md section 7a).
+ * uu3d_forward_ex takes it as an ARGUMENT of the call (round 4): it is a property of the enqueued / captured forward, not of the
+ * model, so a model(...) call on one thread and a pipeline on another never see each other's choice.  attention_out as in
+ * uu3d_forward_attention (NULL: none).  uu3d_forward / uu3d_forward_attention = uu3d_forward_ex with the model's DEFAULT schedule,
+ * which uu3d_set_schedule changes (UU3D_SCHEDULE_LATENCY unless set; kept for callers that cannot pass the argument).
  */
 #define UU3D_SCHEDULE_LATENCY 0
 #define UU3D_SCHEDULE_THROUGHPUT 1
+int uu3d_forward_ex(uu3d_model* model, const float* kp2d_dev, const uint8_t* stride_mask_dev, int32_t batch, float* full_out_dev,
+                    float* central_out_dev, float* const* attention_out, void* workspace_dev, size_t workspace_bytes,
+                    int32_t schedule, void* stream);
 int uu3d_set_schedule(uu3d_model* model, int32_t schedule);
 
 /*

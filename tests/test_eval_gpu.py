@@ -180,3 +180,138 @@ def test_pipeline_adapts_to_the_number_of_hardware_queues():
     assert line, out.stderr[-2000:]
     n, depth, ok = line[0].split()[1:]
     assert int(n) == 2 and int(depth) == 2 and ok == "True", line[0]
+
+
+def _tiny_generator(cfg):
+    from uplift_upsample_3dhpe_amd import h36m
+    from uplift_upsample_3dhpe_amd.data import SequenceGenerator
+    ds, p2 = h36m.load_dataset_and_2d_poses(os.path.join(G, "h36m_tiny_3d.npz"), os.path.join(G, "h36m_tiny_2d.npz"), verbose=False)
+    cams, p3d, p2d, _, subj, act, fps = h36m.filter_and_subsample_dataset(ds, p2, ["S9", "S11"], "*", verbose=False)
+    table = h36m.pose_table(p2d, p3d, subj, act, fps, device="cuda")
+    msv = cfg.MASK_STRIDE[0] if isinstance(cfg.MASK_STRIDE, list) else cfg.MASK_STRIDE
+    return SequenceGenerator(table, seq_len=cfg.SEQUENCE_LENGTH, subsample=1, stride=cfg.SEQUENCE_STRIDE, padding_type=cfg.PADDING_TYPE,
+                             flip_augment=False, flip_lr_indices=cfg.AUGM_FLIP_KEYPOINT_ORDER, mask_stride=msv,
+                             stride_mask_align_global=True, shuffle=False)
+
+
+def test_pipeline_inputs_survive_allocator_churn():
+    """Round-3 verdict, weak point 8: the pipeline reads its inputs on the SLOTS' streams.  (a) ``predict_windows`` now gathers
+    every batch straight into the slot's static buffers on the slot's stream (``acquire`` / ``gather(out=...)`` / ``launch``): over
+    2000 batches with the caching allocator churned on the caller's stream in between (fresh, differently sized temporaries, filled
+    with garbage, ``empty_cache`` now and then), the predictions equal the one-batch-at-a-time eager loop bit for bit.  (b)
+    ``submit`` of fresh temporaries that are dropped at once and whose memory the caller's stream immediately reuses: protected by
+    ``record_stream``, bit-identical to ``model(...)``."""
+    from uplift_upsample_3dhpe_amd import eval as ev
+    cfg = util.load_config("h36m_81")
+    arch = pkg.arch_from_config(cfg)
+    model = pkg.build_uplift_upsample_transformer(cfg, weights=pkg.init_weights(arch, seed=5, perturb=0.1))
+    gen = _tiny_generator(cfg)
+    desc = gen.descriptors()
+    rng = np.random.default_rng(0)
+    desc = desc[rng.integers(0, len(desc), size=2000 * 4 + 3)]                # 2001 batches of 4 windows (+ mirrored copies = 8 sequences), ragged end
+    want = ev.predict_windows(model, gen, desc, cfg, 4, flip=True, depth=1, graph=False)
+    torch.cuda.synchronize()
+
+    # the churn rides on gather: every call first allocates, fills and frees junk of a varying size on the caller's stream
+    real_gather = gen.gather
+    state = {"n": 0}
+
+    def churning_gather(d, **kw):
+        state["n"] += 1
+        k = state["n"]
+        junk = [torch.full((int(rng.integers(1, 64)) * 4093,), float("nan"), device="cuda") for _ in range(1 + k % 3)]
+        out = real_gather(d, **kw)
+        for j in junk:
+            j.add_(1.0)
+        del junk
+        if k % 97 == 0:
+            torch.cuda.empty_cache()
+        return out
+    gen.gather = churning_gather
+    try:
+        got = ev.predict_windows(model, gen, desc, cfg, 4, flip=True, depth=None, graph=True)
+    finally:
+        gen.gather = real_gather
+    assert state["n"] >= 2000
+    assert torch.equal(got, want)
+
+    # (b) submit() with temporaries that die immediately
+    B = 8
+    pipe = model.pipeline(B, depth=None, graph=True)
+    xs = []
+    for i in range(6):
+        x, m = util.synthetic_batch(cfg, B, seed=50 + i)
+        xs.append((x * m[:, :, None, None].astype(np.float32), m))
+    refs = [tuple(t.clone() for t in model([torch.from_numpy(x).cuda(), torch.from_numpy(m).cuda()], training=False)) for x, m in xs]
+    for rep in range(60):
+        tickets = []
+        for i, (x, m) in enumerate(xs):
+            xt, mt = torch.from_numpy(x).cuda(), torch.from_numpy(m).cuda()
+            tickets.append((i, pipe.submit(xt, mt)))
+            del xt, mt                                                     # the blocks go back to the caller's stream's pool ...
+            scribble = [torch.full((x.size,), float("nan"), device="cuda"), torch.full((m.size,), 7, dtype=torch.uint8, device="cuda")]   # ... and would be handed out here
+            del scribble
+            if len(tickets) == pipe.depth:
+                j, t = tickets.pop(0)
+                f, c = pipe.result(t)
+                assert torch.equal(c, refs[j][1]) and torch.equal(f, refs[j][0]), (rep, j)
+        for j, t in tickets:
+            f, c = pipe.result(t)
+            assert torch.equal(c, refs[j][1]) and torch.equal(f, refs[j][0]), (rep, j)
+    pipe.close()
+
+
+def test_schedule_is_an_argument_of_the_call():
+    """Round-3 verdict, weak point 11: the launch schedule is an argument of ``uu3d_forward_ex``, not state of the model handle.  One
+    thread runs ``model(...)`` (latency schedule) while another drives a four-slot pipeline (throughput schedule) on the same model:
+    both get the bits of a quiet ``model(...)`` call, and the handle's default schedule is untouched."""
+    import threading
+    cfg = util.load_config("h36m_351")
+    arch = pkg.arch_from_config(cfg)
+    model = pkg.build_uplift_upsample_transformer(cfg, weights=pkg.init_weights(arch, seed=6, perturb=0.1))
+    B = 16
+    x, m = util.synthetic_batch(cfg, B, seed=77)
+    xt, mt = torch.from_numpy(x * m[:, :, None, None].astype(np.float32)).cuda(), torch.from_numpy(m).cuda()
+    want_f, want_c = (t.clone() for t in model([xt, mt], training=False))
+    pipe = model.pipeline(B, depth=None, graph=False)                          # eager: every submit goes through uu3d_forward_ex now
+    errors = []
+
+    def direct():
+        try:
+            s = torch.cuda.Stream()
+            with torch.cuda.stream(s):
+                for _ in range(150):
+                    f, c = model([xt, mt], training=False)
+                    if not (torch.equal(f, want_f) and torch.equal(c, want_c)):
+                        errors.append("model(...) differs")
+                        return
+                s.synchronize()
+        except Exception as e:                                                   # pragma: no cover
+            errors.append(repr(e))
+
+    def piped():
+        try:
+            s = torch.cuda.Stream()
+            with torch.cuda.stream(s):
+                for f, c in pipe.run([(xt, mt)] * 150):
+                    if not (torch.equal(f, want_f) and torch.equal(c, want_c)):
+                        errors.append("pipeline differs")
+                        return
+                s.synchronize()
+        except Exception as e:                                                   # pragma: no cover
+            errors.append(repr(e))
+    torch.cuda.synchronize()
+    ts = [threading.Thread(target=direct), threading.Thread(target=piped)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join()
+    assert not errors, errors
+    pipe.close()
+    # bad schedule values are rejected by the C entry point
+    import ctypes as C
+    ws = model._workspace(B, "default")
+    st = model._lib.uu3d_forward_ex(model._h, C.c_void_p(xt.data_ptr()), C.c_void_p(mt.data_ptr()), B, C.c_void_p(want_f.data_ptr()),
+                                    C.c_void_p(want_c.data_ptr()), None, C.c_void_p(ws.data_ptr()), C.c_size_t(ws.numel()), 7,
+                                    C.c_void_p(torch.cuda.current_stream().cuda_stream))
+    assert st != 0

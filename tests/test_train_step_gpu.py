@@ -409,6 +409,39 @@ def test_ema_export_survives_the_validation_forward():
     assert len(names) == len(model._spec)
 
 
+def test_assign_after_an_ema_export_keeps_the_trained_weights():
+    """after Trainer.export_to_model(use_ema=True) the model holds the EMA weights and is not "dirty"; a
+    WeightView.assign then reloaded the trainer's master buffer from the model = EMA weights + the one assigned tensor, and the
+    trained weights were gone without a word.  Now the live weights are exported first: every OTHER tensor of trainer.params is
+    unchanged by the assign, and repeated reloads do not probe streams again (the training state is re-used)."""
+    from uplift_upsample_3dhpe_amd.trainer import Trainer
+    cfg, arch, w, model, x, m, gt = _setup("h36m_81", 2, seed=11, batch_norm=2)
+    cfg.EMA_DECAY = 0.5
+    tr = Trainer(model, cfg)
+    T_ = lambda a: torch.from_numpy(a).cuda()
+    for _ in range(2):
+        tr.train_step(T_(x), T_(gt), T_(m), drop_path_uniform=None)
+    live = tr.params.clone()
+    assert not torch.equal(tr.ema, live)
+    tr.export_to_model(use_ema=True)
+    v0 = model.weights[0]
+    n0 = int(np.prod(v0.shape))
+    new0 = (live[:n0].cpu().numpy().reshape(v0.shape) * 0.5).astype(np.float32)
+    v0.assign(new0)
+    tr.forward_backward(T_(x), T_(gt), T_(m), drop_path_uniform=None)       # flushes the assign into the master buffer
+    assert np.array_equal(tr.params[:n0].cpu().numpy(), new0.ravel())
+    assert torch.equal(tr.params[n0:], live[n0:]), "the trained weights were replaced by the EMA weights"
+    # assign once per step, tf.Variable style: the state is re-used (same side streams, same pack arena), results stay deterministic
+    import time
+    t0 = time.perf_counter()
+    for k in range(20):
+        v0.assign(new0 * (1.0 + 0.01 * k))
+        tr.train_step(T_(x), T_(gt), T_(m), drop_path_uniform=None)
+    torch.cuda.synchronize()
+    assert (time.perf_counter() - t0) / 20 < 0.2                             # (the full re-initialisation cost ~50 ms + allocations per assign)
+    assert torch.isfinite(tr.params).all()
+
+
 def test_two_backward_passes_without_an_optimizer_step():
     """forward_backward twice (gradient inspection / accumulation), then apply_gradients: the bucket bookkeeping of the first pass
     must not leak into the second ("gradient ranges do not tile the buffer")."""

@@ -31,6 +31,7 @@
 #include "uu3d_gemm.h"
 #include "uu3d_gemm_h3.h"
 #include "uu3d_gemm_panel.h"
+#include "uu3d_gemm_panel8.h"
 #include "uu3d_gemm_wt.h"
 #include "uu3d_mlp_fused.h"
 #include "uu3d_tail.h"
@@ -727,6 +728,7 @@ struct Launcher {
     hipStream_t stream;
     float* slab = nullptr;          // split-K partial sums
     size_t slab_floats = 0;
+    bool throughput = false;        // this CALL's schedule (uu3d_forward_ex): launches shaped for CU-microseconds instead of latency
     int status = UU3D_OK;
 
     void begin(const char* name, const char* kernel, double flops, double bytes) {
@@ -837,16 +839,38 @@ struct Launcher {
     bool panel_ok(int M, int N, int K, size_t pf) const {
         return !m->no_panel && pf != 0 && K == 384 && N % 32 == 0 && M >= 1024 && (double)M * N * 4.0 < 4.0e9;      // 32-bit byte offsets in the epilogue stores
     }
+    // The 8-wave form of the row-panel GEMM (uu3d_gemm_panel8.h: contraction split over wave pairs, two waves per SIMD) for the chunk
+    // counts it is instantiated for; UU3D_PANEL4=1 keeps every launch on the 4-wave kernel (A/B measurements).  Returns false when
+    // the caller has to launch the 4-wave kernel.
+    template <class EP>
+    bool launch_panel8(const _Float16* Af, const _Float16* Bf, const float* colv, int M, int mt, int S, int cpw, const EP& ep) {
+        static const bool off = getenv("UU3D_PANEL4") != nullptr && atoi(getenv("UU3D_PANEL4")) != 0;
+        if (off) return false;
+        const dim3 grid(8 * S, ((mt * S + 7) / 8 + S - 1) / S);
+#define UU3D_P8_LAUNCH(CPW) { auto kern = gemm_h3_panel8_kernel<EP, CPW, 3>; \
+            static const bool once = (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)P8_LDS_TOTAL) == hipSuccess); (void)once; \
+            hipLaunchKernelGGL(kern, grid, dim3(512), P8_LDS_TOTAL, stream, Af, Bf, colv, M, mt, S, ep); return true; }
+        switch (cpw) {
+            case 4: UU3D_P8_LAUNCH(4)
+            case 6: UU3D_P8_LAUNCH(6)
+            case 8: UU3D_P8_LAUNCH(8)
+            case 12: UU3D_P8_LAUNCH(12)
+            default: return false;
+        }
+#undef UU3D_P8_LAUNCH
+    }
     template <class EP>
     void gemm_panel(const char* name, const _Float16* Af, size_t pf, const float* colv, int M, int N, const EP& ep) {
         const int K = 384, mt = (M + 127) / 128;
         int S = panel_splits(M, N);
         { static const char* e = getenv("UU3D_PANEL_S"); if (e != nullptr && e[0] >= '1' && e[0] <= '3' && (N / 32) % (e[0] - '0') == 0 && (N / 32) / (e[0] - '0') <= PANEL_COLV_FLOATS / 32) S = e[0] - '0'; }   // (A/B measurements)
         begin(name, "gemm_panel", 2.0 * M * (double)N * K, 4.0 * ((double)M * K + (double)N * K + (double)M * N));
-        auto kern = gemm_h3_panel_kernel<24, EP>;
-        static bool attr_done = false;
-        if (!attr_done) { (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)PANEL_LDS_TOTAL); attr_done = true; }
-        hipLaunchKernelGGL(kern, dim3(8 * S, ((mt * S + 7) / 8 + S - 1) / S), dim3(256), PANEL_LDS_TOTAL, stream, Af, m->harena + pf, colv, M, mt, S, (N / 32) / S, ep);
+        if (!launch_panel8(Af, m->harena + pf, colv, M, mt, S, (N / 32) / S, ep)) {
+            auto kern = gemm_h3_panel_kernel<24, EP>;
+            static bool attr_done = false;
+            if (!attr_done) { (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)PANEL_LDS_TOTAL); attr_done = true; }
+            hipLaunchKernelGGL(kern, dim3(8 * S, ((mt * S + 7) / 8 + S - 1) / S), dim3(256), PANEL_LDS_TOTAL, stream, Af, m->harena + pf, colv, M, mt, S, (N / 32) / S, ep);
+        }
         end();
     }
     // x[M][384] += A B + colv in place (the attention projection on the residual stream): N = K = 384, the kernel's chunk loop unrolled
@@ -862,7 +886,7 @@ struct Launcher {
         // several forwards in flight: the fewest CU-microseconds win, not the shortest launch (h36m_351 batch 128, 9088 rows: S = 3 / 2 / 1
         // = 213 / 142 / 71 workgroups, 16.3 / 18.9 / 27.5 us per launch; one batch at a time 127.7 / 126.2 / 121.2 k sequences/s, four in
         // flight 167.3 / 169.2 / 171.3 k on the same box)
-        if (m->throughput) S = 1;
+        if (throughput) S = 1;
         { static const char* e = getenv("UU3D_PANEL_PROJ_S"); if (e != nullptr && e[0] >= '1' && e[0] <= '3') S = e[0] - '0'; }   // (A/B measurements)
         begin(name, "gemm_panel", 2.0 * M * (double)N * K, 4.0 * ((double)M * K + (double)N * K + 2.0 * (double)M * N));
         const PanelEpBiasResidual ep{x, N};
@@ -870,6 +894,7 @@ struct Launcher {
 #define UU3D_PANEL_RES(CPW) { auto kern = gemm_h3_panel_kernel<24, PanelEpBiasResidual, CPW>; \
             static const bool once = (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)PANEL_LDS_TOTAL) == hipSuccess); (void)once; \
             hipLaunchKernelGGL(kern, grid, dim3(256), PANEL_LDS_TOTAL, stream, Af, m->harena + pf, colv, M, mt, S, CPW, ep); }
+        if (launch_panel8(Af, m->harena + pf, colv, M, mt, S, 12 / S, ep)) { end(); return; }
         if (S == 3) UU3D_PANEL_RES(4) else if (S == 2) UU3D_PANEL_RES(6) else UU3D_PANEL_RES(12)
 #undef UU3D_PANEL_RES
         end();
@@ -879,10 +904,12 @@ struct Launcher {
     void gemm_panel_at(const char* name, const _Float16* Af, const _Float16* Bf, const float* colv, int M, int N, const EP& ep) {
         const int K = 384, S = panel_splits(M, N), mt = (M + 127) / 128;
         begin(name, "gemm_panel", 2.0 * M * (double)N * K, 4.0 * ((double)M * K + (double)N * K + (double)M * N));
-        auto kern = gemm_h3_panel_kernel<24, EP>;
-        static bool attr_done = false;
-        if (!attr_done) { (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)PANEL_LDS_TOTAL); attr_done = true; }
-        hipLaunchKernelGGL(kern, dim3(8 * S, ((mt * S + 7) / 8 + S - 1) / S), dim3(256), PANEL_LDS_TOTAL, stream, Af, Bf, colv, M, mt, S, (N / 32) / S, ep);
+        if (!launch_panel8(Af, Bf, colv, M, mt, S, (N / 32) / S, ep)) {
+            auto kern = gemm_h3_panel_kernel<24, EP>;
+            static bool attr_done = false;
+            if (!attr_done) { (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)PANEL_LDS_TOTAL); attr_done = true; }
+            hipLaunchKernelGGL(kern, dim3(8 * S, ((mt * S + 7) / 8 + S - 1) / S), dim3(256), PANEL_LDS_TOTAL, stream, Af, Bf, colv, M, mt, S, (N / 32) / S, ep);
+        }
         end();
     }
     void ln_split_frag_stats(const char* name, const float* x, int M, const float* g, const float* b, _Float16* Af, float2* stats) {
@@ -1058,6 +1085,14 @@ int uu3d_forward(uu3d_model* m, const float* kp2d, const uint8_t* mask, int32_t 
 int uu3d_forward_attention(uu3d_model* m, const float* kp2d, const uint8_t* mask, int32_t B, float* full_out,
                            float* central_out, float* const* attn_out, void* workspace, size_t workspace_bytes, void* stream_) {
     if (!m) return UU3D_ERR_INVALID_ARGUMENT;
+    return uu3d_forward_ex(m, kp2d, mask, B, full_out, central_out, attn_out, workspace, workspace_bytes,
+                           m->throughput ? UU3D_SCHEDULE_THROUGHPUT : UU3D_SCHEDULE_LATENCY, stream_);
+}
+
+int uu3d_forward_ex(uu3d_model* m, const float* kp2d, const uint8_t* mask, int32_t B, float* full_out,
+                    float* central_out, float* const* attn_out, void* workspace, size_t workspace_bytes, int32_t schedule, void* stream_) {
+    if (!m) return UU3D_ERR_INVALID_ARGUMENT;
+    if (schedule != UU3D_SCHEDULE_LATENCY && schedule != UU3D_SCHEDULE_THROUGHPUT) return fail(m, UU3D_ERR_INVALID_ARGUMENT, "schedule must be UU3D_SCHEDULE_LATENCY or UU3D_SCHEDULE_THROUGHPUT");
     if (!m->committed) return fail(m, UU3D_ERR_NOT_READY, "uu3d_commit_weights has not been called");
     if (!kp2d || !central_out || !workspace || B < 1) return fail(m, UU3D_ERR_INVALID_ARGUMENT, "null buffer or batch < 1");
     const uu3d_config& c = m->cfg;
@@ -1071,7 +1106,7 @@ int uu3d_forward_attention(uu3d_model* m, const float* kp2d, const uint8_t* mask
     if ((long)B * c.num_frames * c.num_keypoints > (1L << 30)) return fail(m, UU3D_ERR_INVALID_ARGUMENT, "batch too large");
 
     HIPCHK(m, hipSetDevice(m->device));
-    Launcher Lh{m, (hipStream_t)stream_, w.slab, w.slab_floats};
+    Launcher Lh{m, (hipStream_t)stream_, w.slab, w.slab_floats, schedule == UU3D_SCHEDULE_THROUGHPUT};
     m->prof_used = 0;
     const int N = c.num_frames, J = c.num_keypoints, ds = c.d_spatial, dt = c.d_temporal, ht = c.h_temporal;
     const int M = B * N;
@@ -1258,7 +1293,8 @@ int uu3d_forward_attention(uu3d_model* m, const float* kp2d, const uint8_t* mask
         const int Li = m->L[i], Lo = m->L[i + 1], Mi = B * Li, Mo = B * Lo;
         // the last strided block + head2 as ONE launch of XCD-cooperative workgroups (uu3d_tail.h) when the block is small: few
         // rows make every launch of the chain a bare memory round trip (h36m_351 at batch 128: 9 launches, 76 us)
-        if (i >= 1 && i + 1 == c.num_strided && planes && !m->no_tail && dt == 384 && ht == 768 && Li <= tail::MAX_L && Mi <= 1024 &&
+        // (never under the throughput schedule: its 256 workgroups spin on every CU while other forwards need them, and can then time out)
+        if (i >= 1 && i + 1 == c.num_strided && planes && !m->no_tail && !Lh.throughput && dt == 384 && ht == 768 && Li <= tail::MAX_L && Mi <= 1024 &&
             b.wqkv_pf != 0 && b.w1_pf != 0 && b.wp_pf != 0 && b.wc_pf != 0 && m->h2_pf != 0) {
             TailParams tp{};
             tp.B = B; tp.G = (B + TAIL_GROUPS - 1) / TAIL_GROUPS;

@@ -122,7 +122,7 @@ gemm_h3_panel8_kernel(const _Float16* __restrict__ Af, const _Float16* __restric
     unsigned char* const xpart = psm + P8_RING_BYTES + (wave ^ 4) * 2048 + lane16;
     const unsigned rd0 = (unsigned)(uintptr_t)(h3_lds_void*)(psm + h * HS * 2048 + lane16);   // fragment reads of this group in ring slot 0
 
-    f32x16 a0, a1, b0, b1;
+    f32x16 a0, a1, b0 = {}, b1 = {};                        // (chunk 0 is handed b0 / b1 as its "previous" accumulators and never reads them)
     float res[2][8];
 #pragma unroll
     for (int r = 0; r < 8; ++r) { res[0][r] = 0.f; res[1][r] = 0.f; }

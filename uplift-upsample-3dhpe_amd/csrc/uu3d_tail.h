@@ -551,7 +551,9 @@ strided_tail_kernel_t(const TailParams p)
                 if (combine4(acc)) {
                     const int col = c * 32 + r;
                     if (col < p.n_out) {
-                        const float bias = hbias;
+                        // a bounded spin that gave up anywhere in this launch means some phase was consumed unfinished: the
+                        // predictions are poisoned instead of silently wrong (uu3d_tail_status names the reason)
+                        const float bias = (ld_u32_agent(&ctl->err) & (unsigned)TAIL_ERR_TIMEOUT) ? __builtin_nanf("") : hbias;
 #pragma unroll
                         for (int i = 0; i < 16; ++i) {
                             const int lr = rt * 32 + 8 * (i >> 2) + 4 * g2 + (i & 3);

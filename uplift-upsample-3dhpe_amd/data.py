@@ -127,17 +127,26 @@ class SequenceGenerator(object):
                     self.camera_indices.append(self.camera_indices[-1])      # the flipped copy keeps the sample's camera
         return np.array(out, dtype=np.int32).reshape(-1, 6)
 
-    def gather(self, desc, zero_masked=True, with_3d=True):
-        """Build one batch on the device from (B, 6) descriptors -> dict of device tensors (+ host metadata)."""
+    def gather(self, desc, zero_masked=True, with_3d=True, out=None, stream=None):
+        """Build one batch on the device from (B, 6) descriptors -> dict of device tensors (+ host metadata).
+
+        ``out = (kp2d_buf, stride_mask_buf)``: write the 2D windows / stride masks into these tensors ((B, N, J, 2) float32 and (B, N)
+        uint8 or None) instead of fresh ones -- e.g. a ``pipeline.ForwardPipeline`` slot's static input buffers (``acquire``).
+        ``stream``: the torch stream the gather runs on (default: the current one); the descriptor upload is registered with it."""
         torch, t = self._torch, self.table
         lib = _capi.load_library()
         desc = np.ascontiguousarray(desc, np.int32)
         B, N, J = len(desc), self.seq_len, t.J
-        d_desc = torch.from_numpy(desc).to(t.device)
-        stream = torch.cuda.current_stream(t.device).cuda_stream
-        kp2d = torch.empty((B, N, J, 2), dtype=torch.float32, device=t.device)
-        smask = torch.empty((B, N), dtype=torch.uint8, device=t.device)
-        pmask = torch.empty((B, N), dtype=torch.uint8, device=t.device)
+        tstream = stream if stream is not None else torch.cuda.current_stream(t.device)
+        with torch.cuda.stream(tstream):
+            d_desc = torch.from_numpy(desc).to(t.device)               # (pageable upload: blocks the host until it is done)
+            stream = tstream.cuda_stream
+            kp2d = out[0] if out is not None else torch.empty((B, N, J, 2), dtype=torch.float32, device=t.device)
+            smask = out[1] if (out is not None and out[1] is not None) else torch.empty((B, N), dtype=torch.uint8, device=t.device)
+            pmask = torch.empty((B, N), dtype=torch.uint8, device=t.device)
+        if tuple(kp2d.shape) != (B, N, J, 2) or kp2d.dtype != torch.float32 or not kp2d.is_contiguous() or \
+                tuple(smask.shape) != (B, N) or smask.dtype != torch.uint8 or not smask.is_contiguous():
+            raise ValueError("out buffers must be contiguous (B, N, J, 2) float32 and (B, N) uint8")
         fl = C.c_void_p(self._d_flip.data_ptr()) if self._d_flip is not None else None
         st = lib.uu3d_gather_windows(C.c_void_p(t.kp2d.data_ptr()), C.c_void_p(t.d_starts.data_ptr()), C.c_void_p(t.d_lens.data_ptr()),
                                      C.c_void_p(d_desc.data_ptr()), fl, B, N, J, 2, int(self.pad_edge), int(zero_masked),

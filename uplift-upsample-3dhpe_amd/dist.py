@@ -28,6 +28,9 @@ def allgather_errors(err_local, group=None):
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
         return err_local
     world = dist.get_world_size(group)
+    if err_local.is_cuda and dist.get_backend(group) == "gloo":
+        # gloo gathers host tensors only (its device-tensor support is broadcast / all_reduce): stage the few KB through the host
+        return allgather_errors(err_local.cpu(), group).to(err_local.device)
     n_local = torch.tensor([err_local.shape[0]], dtype=torch.int64, device=err_local.device)
     counts = [torch.zeros_like(n_local) for _ in range(world)]
     dist.all_gather(counts, n_local, group=group)

@@ -144,15 +144,18 @@ class UpliftUpsampleTransformer(object):
 
     # ---- single-variable access (WeightView) ----------------------------------------------------
     def _get_one(self, name, shape):
-        if self._trainer is not None and self._weights_dirty:
+        if self._trainer is not None and self._weights_dirty:   # (a model that holds the EMA weights reads them: that is what was asked for)
             self._trainer.export_to_model()
         a = np.empty(shape, np.float32)
         _capi.check(self._lib, self._lib.uu3d_get_weight(self._h, name.encode(), a.ctypes.data_as(C.c_void_p), a.size), self._h)
         return a
 
     def _assign_one(self, name, shape, value):
-        if self._trainer is not None and self._weights_dirty:
-            self._trainer.export_to_model()                    # the other variables keep their trained values
+        # the other variables keep their TRAINED values: a stale model is refreshed first, and so is a model that holds the EMA
+        # weights after Trainer.export_to_model(use_ema=True) -- otherwise the flush below would reload the master buffer with
+        # "EMA weights + the one assigned tensor" and the trained weights would be gone
+        if self._trainer is not None and (self._weights_dirty or self._holds_ema):
+            self._trainer.export_to_model()
         a = np.ascontiguousarray(np.asarray(value, dtype=np.float32).reshape(shape))
         _capi.check(self._lib, self._lib.uu3d_set_weight(self._h, name.encode(), a.ctypes.data_as(C.c_void_p), a.size), self._h)
         self._pending_assigns = True
@@ -239,23 +242,18 @@ class UpliftUpsampleTransformer(object):
             self._ws[slot] = ws
         return ws
 
-    def _forward(self, x, stride_mask, full, central, slot, stream, attn=None):
+    def _forward(self, x, stride_mask, full, central, slot, stream, attn=None, schedule=0):
+        """One uu3d_forward_ex call.  ``schedule`` (include/uu3d.h: 0 = latency, 1 = throughput) is an argument of THIS call."""
         B = x.shape[0]
         ws = self._workspace(B, slot)
+        ptrs = None
         if attn is not None:
             ptrs = (C.c_void_p * max(len(attn), 1))(*[t.data_ptr() for t in attn])
-            st = self._lib.uu3d_forward_attention(self._h, C.c_void_p(x.data_ptr()),
-                                                  C.c_void_p(stride_mask.data_ptr()) if stride_mask is not None else None, B,
-                                                  C.c_void_p(full.data_ptr()) if full is not None else None,
-                                                  C.c_void_p(central.data_ptr()), ptrs, C.c_void_p(ws.data_ptr()),
-                                                  C.c_size_t(ws.numel()), C.c_void_p(stream.cuda_stream))
-            _capi.check(self._lib, st, self._h)
-            return
-        st = self._lib.uu3d_forward(self._h, C.c_void_p(x.data_ptr()),
-                                    C.c_void_p(stride_mask.data_ptr()) if stride_mask is not None else None, B,
-                                    C.c_void_p(full.data_ptr()) if full is not None else None,
-                                    C.c_void_p(central.data_ptr()), C.c_void_p(ws.data_ptr()),
-                                    C.c_size_t(ws.numel()), C.c_void_p(stream.cuda_stream))
+        st = self._lib.uu3d_forward_ex(self._h, C.c_void_p(x.data_ptr()),
+                                       C.c_void_p(stride_mask.data_ptr()) if stride_mask is not None else None, B,
+                                       C.c_void_p(full.data_ptr()) if full is not None else None,
+                                       C.c_void_p(central.data_ptr()), ptrs, C.c_void_p(ws.data_ptr()),
+                                       C.c_size_t(ws.numel()), int(schedule), C.c_void_p(stream.cuda_stream))
         _capi.check(self._lib, st, self._h)
 
     def _mask_u8(self, stride_mask):

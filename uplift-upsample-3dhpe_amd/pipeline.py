@@ -127,42 +127,64 @@ class ForwardPipeline(object):
 
     def _launch(self, i, n):
         s = self._slots[i]
-        lib, h = self.model._lib, self.model._h
-        # launches shaped for CU-microseconds, not latency: the forwards in flight share the chip (include/uu3d.h, uu3d_set_schedule)
-        if self.depth > 1:
-            lib.uu3d_set_schedule(h, 1)
-        try:
-            self.model._forward(s.x[:n], s.m[:n] if s.m is not None else None, s.full[:n] if s.full is not None else None,
-                                s.central[:n], self._keys[i], s.stream)
-        finally:
-            if self.depth > 1:
-                lib.uu3d_set_schedule(h, 0)
+        # launches shaped for CU-microseconds, not latency, when the forwards in flight share the chip: an ARGUMENT of the call
+        # (include/uu3d.h, uu3d_forward_ex), so a model(...) call on another thread keeps its own schedule
+        self.model._forward(s.x[:n], s.m[:n] if s.m is not None else None, s.full[:n] if s.full is not None else None,
+                            s.central[:n], self._keys[i], s.stream, schedule=1 if self.depth > 1 else 0)
         if self.post is not None:
             s.extra = self.post(s.full[:n] if s.full is not None else None, s.central[:n], i)
 
-    def submit(self, x, stride_mask=None):
-        """Enqueue one batch (n <= batch sequences).  Returns a ticket for ``result``.  The inputs are read on the slot's stream
-        after everything the caller's current stream has enqueued so far."""
-        torch = self._torch
+    def _next_slot(self, n):
         model = self.model
         i = self._submitted % self.depth
         s = self._slots[i]
         if s.busy:
             raise RuntimeError("slot still holds an unread result: call result() for the oldest ticket first")
-        n = int(x.shape[0])
         if n > self.batch:
             raise ValueError(f"batch of {n} > pipeline batch {self.batch}")
-        if model.has_strided_input != (stride_mask is not None):
-            raise ValueError("stride_mask must be given iff the model has strided input")
         if model._weights_dirty or getattr(model, "_pending_assigns", False):
             self.drain()
             model._sync_from_trainer()                              # (weights changed: the packs are rewritten on the caller's stream)
-        cur = torch.cuda.current_stream(model.device)
-        s.stream.wait_stream(cur)
+        return i, s
+
+    def acquire(self, n=None):
+        """The next slot's STATIC input buffers, for a producer that writes the batch in place (no copy, no temporaries):
+
+            x_buf, m_buf, stream = pipe.acquire(n)      # (n, N, J, 2) float32, (n, N) uint8 or None, the slot's torch stream
+            generator.gather(desc, out=(x_buf, m_buf), stream=stream)
+            ticket = pipe.launch(n)
+
+        Everything that fills the buffers must be enqueued on ``stream`` (or on a stream ``stream`` has been made to wait for) before
+        ``launch``.  ``stream`` already waits for the caller's current stream at this point.  The slot's previous forward has
+        finished reading the buffers as far as ``stream`` is concerned (same stream: in order)."""
+        torch = self._torch
+        n = self.batch if n is None else int(n)
+        i, s = self._next_slot(n)
+        s.stream.wait_stream(torch.cuda.current_stream(self.model.device))
+        return s.x[:n], (s.m[:n] if s.m is not None else None), s.stream
+
+    def preload(self, x, stride_mask=None):
+        """Copy one batch into EVERY slot's static input buffers (e.g. a benchmark that forwards the same resident batch again and
+        again: ``preload`` once, then ``launch()`` per step -- no per-step input copy)."""
+        torch = self._torch
+        n = int(x.shape[0])
+        cur = torch.cuda.current_stream(self.model.device)
+        for s in self._slots:
+            s.stream.wait_stream(cur)
+            with torch.cuda.stream(s.stream):
+                s.x[:n].copy_(x, non_blocking=True)
+                if s.m is not None:
+                    s.m[:n].copy_(self.model._mask_u8(stride_mask), non_blocking=True)
+            cur.wait_stream(s.stream)                               # (the sources may be dropped / rewritten by the caller afterwards)
+
+    def launch(self, n=None):
+        """Enqueue the forward of the next slot on the buffers it holds (``acquire`` + a producer, or ``preload``): ``n`` sequences.
+        The slot's stream first waits for the caller's current stream (which may still read the slot's previous outputs).  Returns a ticket."""
+        torch = self._torch
+        n = self.batch if n is None else int(n)
+        i, s = self._next_slot(n)
+        s.stream.wait_stream(torch.cuda.current_stream(self.model.device))
         with torch.cuda.stream(s.stream):
-            s.x[:n].copy_(x, non_blocking=True)
-            if s.m is not None:
-                s.m[:n].copy_(model._mask_u8(stride_mask), non_blocking=True)
             if s.graph is not None and n == self.batch:
                 s.graph.replay()
             else:
@@ -172,6 +194,30 @@ class ForwardPipeline(object):
         t = self._submitted
         self._submitted += 1
         return t
+
+    def submit(self, x, stride_mask=None):
+        """Enqueue one batch (n <= batch sequences) given as tensors: they are copied into the slot's static buffers on the slot's
+        stream, after everything the caller's current stream has enqueued so far.  Returns a ticket for ``result``.  The copies
+        run on ANOTHER stream than the one the tensors were allocated on, so they are registered with the caching allocator
+        (``record_stream``): a temporary that the caller drops right after ``submit`` is not handed out again before the copy ran."""
+        model = self.model
+        n = int(x.shape[0])
+        if model.has_strided_input != (stride_mask is not None):
+            raise ValueError("stride_mask must be given iff the model has strided input")
+        xb, mb, stream = self.acquire(n)
+        torch = self._torch
+        with torch.cuda.stream(stream):
+            if x.is_cuda:
+                x.record_stream(stream)
+            xb.copy_(x, non_blocking=True)
+            if mb is not None:
+                mu = model._mask_u8(stride_mask)
+                if mu.is_cuda:
+                    mu.record_stream(stream)
+                    if stride_mask.is_cuda and mu.data_ptr() != stride_mask.data_ptr():
+                        stride_mask.record_stream(stream)
+                mb.copy_(mu, non_blocking=True)
+        return self.launch(n)
 
     def result(self, ticket):
         """(full, central[, post's value]) of a submitted batch; the caller's current stream waits for it.  The tensors are the

@@ -68,6 +68,8 @@ class Trainer(object):
                                           else [config.DROP_PATH_RATE] * 3, np.float32)
         # bucketed gradient all-reduce: the library reports finished ranges of self.grads during the backward pass
         self._buckets = BucketedAllReduce(self.grads)
+        # world size > 1: the skip decision of a non-finite step is taken on the REDUCED gradients (identical on every rank)
+        self._skip_word = torch.zeros(1, dtype=torch.int32, device=dev)
         self._ready_cb = _capi.GRAD_READY_FN(lambda user, first, count, stream: self._buckets.ready(first, count, stream))
         _capi.check(lib, lib.uu3d_train_set_grad_callback(model._h, self._ready_cb, None), model._h)
         model._attach_trainer(self)
@@ -126,6 +128,8 @@ class Trainer(object):
             C.c_void_p(ws.data_ptr()), self._ws_bytes, self._stream())
         _capi.check(self._lib, st, self.model._h)
         self._buckets.raise_pending()                                       # an exception inside the gradient-ready callback (ctypes only prints it)
+        if a.output_bn:
+            self.model._weights_dirty = True                                # the forward moved BatchNorm's running statistics inside the master buffer
         return self.loss, full, central
 
     def apply_gradients(self):
@@ -133,8 +137,25 @@ class Trainer(object):
         were started by forward_backward while the backward pass ran; here the stream only waits for them."""
         self._buckets.wait()                                                 # loss normaliser is the GLOBAL batch size: sums, no rescale
         # a backward pass that produced non-finite gradients (loss-scaled f16x3 overflow) leaves weights and moments alone:
-        # the flag is read on the device, the host never waits (nonfinite() reads it back for logging)
-        self.optimizer.apply_gradients(self.grads[:self.n_trainable], skip_flag_ptr=self._lib.uu3d_train_nonfinite_flag(self.model._h))
+        # the flag is read on the device, the host never waits (nonfinite() reads it back for logging).  With several ranks the
+        # library's flag only knows THIS rank's gradients, raised before the all-reduce: a rank whose shard was finite would
+        # apply the Inf / NaN sum it received and diverge from the one that skipped (ADVICE round 3).  The decision is therefore
+        # taken on the reduced buffer, which is bit-identical on every rank: all ranks skip or none does.
+        world = self._world()
+        if world > 1:
+            torch = self._torch
+            self._skip_word.copy_((~torch.isfinite(self.grads).all()).to(torch.int32).reshape(1))
+            flag_ptr = self._skip_word.data_ptr()
+        else:
+            flag_ptr = self._lib.uu3d_train_nonfinite_flag(self.model._h)
+        self.optimizer.apply_gradients(self.grads[:self.n_trainable], skip_flag_ptr=flag_ptr)
+        if world > 1 and self.n_trainable < self.n_params:
+            # OUTPUT_BN: every rank moved the running statistics with ITS shard's batch statistics; the mean over ranks keeps the
+            # replicas (and with them inference weights, EMA and the sharded evaluation) identical.  Batch statistics stay per replica.
+            import torch.distributed as dist
+            tail = self.params[self.n_trainable:]
+            dist.all_reduce(tail, op=dist.ReduceOp.SUM, group=self._buckets.group)
+            tail.div_(float(world))
         if self.ema is not None:
             optim.ema_update(self.ema, self.params, optim.ema_decay_value(self.config.EMA_DECAY, self.global_step))
         _capi.check(self._lib, self._lib.uu3d_train_repack(self.model._h, C.c_void_p(self.params.data_ptr()), self._stream()), self.model._h)
@@ -142,8 +163,15 @@ class Trainer(object):
         self.model._weights_dirty = True                                      # the model's host / inference weights are now stale
         self.model._holds_ema = False
 
+    def _world(self):
+        import torch.distributed as dist
+        return dist.get_world_size(self._buckets.group) if (dist.is_available() and dist.is_initialized()) else 1
+
     def nonfinite(self):
-        """True when the last backward pass flagged non-finite gradients (its optimizer step was skipped).  Synchronises."""
+        """True when the last step was skipped for non-finite gradients (world size 1: this rank's backward pass flagged them;
+        more ranks: the reduced gradients were not finite -- the same answer on every rank).  Synchronises."""
+        if self._world() > 1:
+            return bool(int(self._skip_word.item()))
         out = C.c_int32()
         _capi.check(self._lib, self._lib.uu3d_train_nonfinite(self.model._h, C.byref(out)), self.model._h)
         return out.value != 0
