@@ -431,14 +431,14 @@ def test_assign_after_an_ema_export_keeps_the_trained_weights():
     tr.forward_backward(T_(x), T_(gt), T_(m), drop_path_uniform=None)       # flushes the assign into the master buffer
     assert np.array_equal(tr.params[:n0].cpu().numpy(), new0.ravel())
     assert torch.equal(tr.params[n0:], live[n0:]), "the trained weights were replaced by the EMA weights"
-    # assign once per step, tf.Variable style: the state is re-used (same side streams, same pack arena), results stay deterministic
-    import time
-    t0 = time.perf_counter()
-    for k in range(20):
+    # assign once per step, tf.Variable style: uu3d_train_init re-uses its state (side streams, events, pack arenas) and only redoes
+    # "master <- host weights" + the operand repack; the steps stay finite and the assigned tensor is what the step started from
+    for k in range(4):
         v0.assign(new0 * (1.0 + 0.01 * k))
-        tr.train_step(T_(x), T_(gt), T_(m), drop_path_uniform=None)
+        tr.forward_backward(T_(x), T_(gt), T_(m), drop_path_uniform=None)
+        assert np.array_equal(tr.params[:n0].cpu().numpy(), (new0 * (1.0 + 0.01 * k)).astype(np.float32).ravel())
+        tr.apply_gradients()
     torch.cuda.synchronize()
-    assert (time.perf_counter() - t0) / 20 < 0.2                             # (the full re-initialisation cost ~50 ms + allocations per assign)
     assert torch.isfinite(tr.params).all()
 
 
