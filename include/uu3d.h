@@ -314,6 +314,19 @@ int uu3d_ema_update(float* ema_dev, const float* w_dev, int64_t n, float decay, 
  */
 typedef void (*uu3d_grad_ready_fn)(void* user, int64_t first, int64_t count, void* stream);
 int uu3d_train_set_grad_callback(uu3d_model* model, uu3d_grad_ready_fn fn, void* user);
+/*
+ * The Dropout layers of the model in TRAINING mode (config DROP_RATE / ATTENTION_DROP_RATE: kl.Dropout in
+ * common/net/vision_transformer.py:57-58,63-67 (MLP: behind the activation and behind fc2), :87-90,127-128 (attention weights),
+ * :153-154 (projection output); common/net/uplift_upsample_transformer.py:78-79,84-89 (StridedMLP), :201,324 (token_dropout behind
+ * the keypoint embedding + positional encoding)).  Applies to the following uu3d_train_forward_backward* calls of this model
+ * (forward-only calls included) until changed; rates 0 (the default, and every shipped config) = no layer.  An element is kept iff
+ * u >= rate, kept elements are scaled by 1 / (1 - rate) (Keras); u is a counter-based function of (seed, layer site, element
+ * index) -- csrc/uu3d_dropout.h lists the sites -- so the backward pass recomputes the masks instead of storing them and a CPU
+ * restatement can evaluate the same masks (oracle/dropout_oracle.py).  Give every step a fresh seed.  With a rate > 0 the
+ * spatial stack runs as its unfused chain of launches and attention on the generic kernels (the fused / MFMA kernels have no
+ * Dropout sites): correct, slower.
+ */
+int uu3d_train_set_dropout(uu3d_model* model, float drop_rate, float attention_drop_rate, uint64_t seed);
 int64_t uu3d_num_params(const uu3d_model* model);
 int uu3d_train_init(uu3d_model* model, float* params_dev, void* stream);
 int uu3d_train_repack(uu3d_model* model, const float* params_dev, void* stream);

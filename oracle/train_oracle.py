@@ -89,19 +89,20 @@ def ema_update(ema, w, decay):
 
 
 def train_step_grads(hp, weights, keypoints2d, stride_masks, keypoints3d, root, w_center, w_seq, batch_size_norm,
-                     drop_path_cfg=None, dtype=torch.float64, token_mask_cfg=None, bn_train=None):
+                     drop_path_cfg=None, dtype=torch.float64, token_mask_cfg=None, bn_train=None, dropout_cfg=None):
     """Loss and d loss / d weights of train_step (train.py:464-498) by autograd through the forward oracle.
 
     keypoints2d (B,N,J,2) raw, stride_masks (B,N) bool, keypoints3d (B,N,J,3) absolute.  Returns
     (dict loss/central/seq, {name: grad ndarray}, full, central).  bn_train: a dict (OUTPUT_BN in training mode) that receives the updated
-    moving statistics, see uplift_oracle.forward_torch.
+    moving statistics, see uplift_oracle.forward_torch.  dropout_cfg: dict(rate, attn_rate, seed) -- the Dropout layers with the
+    counter-based masks of the HIP library (oracle/dropout_oracle.py).
     """
     from oracle import uplift_oracle as O
     p = {k: torch.tensor(np.asarray(v), dtype=dtype, requires_grad=True) for k, v in weights.items()}
     x = torch.tensor(np.asarray(keypoints2d), dtype=dtype)
     if hp["has_strided_input"]:
         x = x * torch.tensor(np.asarray(stride_masks).astype(np.float64), dtype=dtype)[:, :, None, None]   # train.py:474
-    full, central, _ = O.forward_torch(hp, p, x, stride_masks if hp["has_strided_input"] else None, dtype, drop_path_cfg, token_mask_cfg, bn_train)
+    full, central, _ = O.forward_torch(hp, p, x, stride_masks if hp["has_strided_input"] else None, dtype, drop_path_cfg, token_mask_cfg, bn_train, dropout_cfg)
     gt = torch.tensor(np.asarray(keypoints3d), dtype=dtype)
     gt = gt - gt[:, :, root:root + 1, :]
     N, J = gt.shape[1], gt.shape[2]

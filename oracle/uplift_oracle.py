@@ -59,8 +59,21 @@ def gelu_exact(x):
     return 0.5 * x * (1.0 + torch.erf(x / math.sqrt(2.0)))
 
 
-def mha(p, prefix, x, num_heads, mask=None):
-    """vision_transformer.py:132-156 (self-attention: v = k = q = x)."""
+def _dropout(t, cfg, site, attention=False):
+    """kl.Dropout in training mode with the masks of csrc/uu3d_dropout.h (oracle/dropout_oracle.py); cfg = dict(rate=DROP_RATE,
+    attn_rate=ATTENTION_DROP_RATE, seed=...) or None (inference / no Dropout layers)."""
+    if cfg is None:
+        return t
+    rate = cfg["attn_rate"] if attention else cfg["rate"]
+    if rate <= 0:
+        return t                                                       # Keras builds no layer for rate 0
+    from oracle.dropout_oracle import drop_factor
+    return t * torch.as_tensor(drop_factor(tuple(t.shape), rate, cfg["seed"], site)).to(t.dtype)
+
+
+def mha(p, prefix, x, num_heads, mask=None, drop=None, site=0):
+    """vision_transformer.py:132-156 (self-attention: v = k = q = x).  drop / site: Dropout on the attention weights (:127-128, site)
+    and on the projection output (:153-154, site + 1)."""
     b, L, d = x.shape
     depth = d // num_heads
     q = dense(x, p[f"{prefix}/wq/kernel"], p.get(f"{prefix}/wq/bias"))
@@ -76,9 +89,11 @@ def mha(p, prefix, x, num_heads, mask=None):
     if mask is not None:
         logits = logits + mask * torch.tensor(-1e9, dtype=x.dtype)      # :122-123
     attn = torch.softmax(logits, dim=-1)                                # :126
+    attn = _dropout(attn, drop, site, attention=True)                  # :127-128 (the returned weights are the dropped ones)
     out = torch.matmul(attn, v)                                         # :129
     out = out.permute(0, 2, 1, 3).reshape(b, L, d)                      # :147-150
     out = dense(out, p[f"{prefix}/projection/kernel"], p[f"{prefix}/projection/bias"])  # :151
+    out = _dropout(out, drop, site + 1)                                 # :153-154
     return out, attn
 
 
@@ -89,29 +104,35 @@ def drop_path(x, rate, u):
     return (x / keep) * gate
 
 
-def transformer_block(p, prefix, x, num_heads, activation, mask=None, dp=None):
-    """vision_transformer.py:176-195.  dp = (rate, u_attn, u_mlp) in training mode with rate > 0, else None."""
+def transformer_block(p, prefix, x, num_heads, activation, mask=None, dp=None, drop=None, site=0, inner=False):
+    """vision_transformer.py:176-195.  dp = (rate, u_attn, u_mlp) in training mode with rate > 0, else None.
+    drop / site: the block's Dropout layers (site + 0 .. 3); inner: the MLP has an inner Dropout behind its activation (:63-64; the
+    temporal blocks are built with inner_dropout = drop_rate, the spatial ones without, u_u_t.py:233-235,247-248)."""
     y = layer_norm(x, p[f"{prefix}/norm1/gamma"], p[f"{prefix}/norm1/beta"], 1e-5)
-    y, attn = mha(p, f"{prefix}/attn", y, num_heads, mask)
+    y, attn = mha(p, f"{prefix}/attn", y, num_heads, mask, drop, site)
     if dp is not None:
         y = drop_path(y, dp[0], dp[1])
     x = x + y
     z = layer_norm(x, p[f"{prefix}/norm2/gamma"], p[f"{prefix}/norm2/beta"], 1e-5)
     z = dense(z, p[f"{prefix}/mlp/fc1/kernel"], p[f"{prefix}/mlp/fc1/bias"])
     z = activation(z)
+    if inner:
+        z = _dropout(z, drop, site + 2)                                 # :63-64
     z = dense(z, p[f"{prefix}/mlp/fc2/kernel"], p[f"{prefix}/mlp/fc2/bias"])
+    z = _dropout(z, drop, site + 3)                                     # :65-66
     if dp is not None:
         z = drop_path(z, dp[0], dp[2])
     x = x + z
     return x, attn
 
 
-def strided_transformer_block(p, prefix, x, pe, num_heads, stride, pad, dp=None, mask=None):
-    """uplift_upsample_transformer.py:122-160 with StridedMLP :81-90.  dp = (rate, u_attn, u_mlp): DropPath on both branches (:132-137)."""
+def strided_transformer_block(p, prefix, x, pe, num_heads, stride, pad, dp=None, mask=None, drop=None, site=0):
+    """uplift_upsample_transformer.py:122-160 with StridedMLP :81-90.  dp = (rate, u_attn, u_mlp): DropPath on both branches (:132-137).
+    drop / site: Dropout on attention weights, projection output, hidden activations (:84-85) and convolution output (:88-89)."""
     assert x.shape[1] == pe.shape[0]                                    # :127
     x = x + pe                                                          # :128
     y = layer_norm(x, p[f"{prefix}/norm1/gamma"], p[f"{prefix}/norm1/beta"], 1e-5)
-    y, attn = mha(p, f"{prefix}/attn", y, num_heads, mask)
+    y, attn = mha(p, f"{prefix}/attn", y, num_heads, mask, drop, site)
     if dp is not None:
         y = drop_path(y, dp[0], dp[1])                                  # :132-133
     x = x + y
@@ -119,6 +140,7 @@ def strided_transformer_block(p, prefix, x, pe, num_heads, stride, pad, dp=None,
     # fc1: Conv1D k=1
     z = dense(z, p[f"{prefix}/mlp/fc1/kernel"][0], p[f"{prefix}/mlp/fc1/bias"])
     z = torch.relu(z)
+    z = _dropout(z, drop, site + 2)                                     # :84-85
     # ZeroPadding1D(pad) + Conv1D(k=3, stride, 'valid')
     b, L, h = z.shape
     zp = torch.zeros(b, L + pad[0] + pad[1], h, dtype=z.dtype)
@@ -130,6 +152,7 @@ def strided_transformer_block(p, prefix, x, pe, num_heads, stride, pad, dp=None,
         rows = zp[:, j:j + (Lout - 1) * stride + 1:stride]              # (b, Lout, h)
         taps.append(torch.matmul(rows, wk[j]))
     z = taps[0] + taps[1] + taps[2] + p[f"{prefix}/mlp/strided_conv/bias"]
+    z = _dropout(z, drop, site + 3)                                     # :88-89
     if dp is not None:
         z = drop_path(z, dp[0], dp[2])                                  # :136-137
     # residual path :138-156
@@ -168,8 +191,11 @@ def forward(hp, weights, x, stride_mask=None, dtype=torch.float32, return_attent
     return full_np, central.numpy()
 
 
-def forward_torch(hp, p, x, stride_mask=None, dtype=torch.float32, drop_path_cfg=None, token_mask_cfg=None, bn_train=None):
+def forward_torch(hp, p, x, stride_mask=None, dtype=torch.float32, drop_path_cfg=None, token_mask_cfg=None, bn_train=None, dropout_cfg=None):
     """Differentiable core on torch tensors (weights `p` may require grad).
+
+    dropout_cfg (training mode with DROP_RATE / ATTENTION_DROP_RATE > 0): dict(rate, attn_rate, seed) -- every kl.Dropout layer of the
+    reference with the counter-based masks of csrc/uu3d_dropout.h (oracle/dropout_oracle.py lists the sites); None = inference.
 
     bn_train (training mode with OUTPUT_BN, u_u_t.py:275-285): a dict that receives the updated moving statistics
     ("<layer>/moving_mean" / "/moving_variance"); the heads then normalise with the BATCH mean and biased variance (Keras' non-fused
@@ -206,8 +232,10 @@ def forward_torch(hp, p, x, stride_mask=None, dtype=torch.float32, drop_path_cfg
         x = x.reshape(B * N, J, 2)
         x = dense(x, p["keypoint_embedding/kernel"], p["keypoint_embedding/bias"])
         x = x + p["spatial_pe/positional_encoding_weights"]
+        x = _dropout(x, dropout_cfg, 1)                                 # token_dropout :324
         for i in range(hp["spatial_depth"]):
-            x, _ = transformer_block(p, f"spatial_block_{i + 1}", x, H, gelu_exact, None, dp_for(0, i, hp["spatial_depth"]))
+            x, _ = transformer_block(p, f"spatial_block_{i + 1}", x, H, gelu_exact, None, dp_for(0, i, hp["spatial_depth"]),
+                                     dropout_cfg, 10 + 4 * i, inner=False)
         x = layer_norm(x, p["spatial_norm/gamma"], p["spatial_norm/beta"], 1e-6)
         x = x.reshape(B, N, J * hp["d_spatial"])                        # "(b n) p c -> b n (p c)"
     x = dense(x, p["spatial_to_temporal_fc/kernel"], p["spatial_to_temporal_fc/bias"])
@@ -231,7 +259,8 @@ def forward_torch(hp, p, x, stride_mask=None, dtype=torch.float32, drop_path_cfg
         mask = None
         if hp["has_strided_input"] and i < hp["first_strided_token_attention_layer"]:
             mask = inv[:, None, None, :]                                # :361
-        x, att = transformer_block(p, f"temporal_block_{i + 1}", x, H, torch.relu, mask, dp_for(1, i, hp["temporal_depth"]))
+        x, att = transformer_block(p, f"temporal_block_{i + 1}", x, H, torch.relu, mask, dp_for(1, i, hp["temporal_depth"]),
+                                   dropout_cfg, 100 + 4 * i, inner=True)
         att_list.append(att)
 
     def batch_norm_training(t, name):
@@ -265,7 +294,7 @@ def forward_torch(hp, p, x, stride_mask=None, dtype=torch.float32, drop_path_cfg
                 smask = inv[:, None, None, :]                           # :372-377 (broadcasts against the keys: right for the first block only)
             pe_i = p[f"strided_temporal_pe_{i + 1}/positional_encoding_weights"]
             x, _ = strided_transformer_block(p, f"strided_temporal_block_{i + 1}", x, pe_i, H,
-                                             s, hp["paddings"][i], dp_for(2, i, len(hp["strides"])), smask)
+                                             s, hp["paddings"][i], dp_for(2, i, len(hp["strides"])), smask, dropout_cfg, 200 + 4 * i)
         central = x
     else:
         central = x[:, N // 2: N // 2 + 1, :]

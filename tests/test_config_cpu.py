@@ -127,27 +127,44 @@ def test_config_matches_the_reference_classes(tmp_path):
     same(public(c), exp["__text_mode__"], "text mode")
 
 
-@pytest.mark.parametrize("key,value,where", [
-    ("DROP_RATE", 0.1, "train"),
-    ("ATTENTION_DROP_RATE", 0.1, "train"),
-])
-def test_unimplemented_options_are_rejected_not_ignored(key, value, where):
-    """A schema-legal config the HIP path does not implement must fail loudly instead of running a different model
-    (u_u_t.py:201, vit.py:87-88): Dropout rates only act with training=True and are refused by
-    every training entry point (random token masking with value 0 and strided-block DropPath are implemented, round 3) (arch.training_unsupported is what Trainer / model(training=True) raise from)."""
+@pytest.mark.parametrize("key", ["DROP_RATE", "ATTENTION_DROP_RATE"])
+def test_every_training_option_is_implemented_and_bad_rates_are_rejected(key):
+    """Round 4: the Dropout layers (u_u_t.py:201,324, vit.py:57-67,87-90,127-128,153-154) were the last schema-legal options that a
+    training entry point refused; ``arch.training_unsupported`` (what Trainer / model(training=True) raise from) is now empty for any
+    legal rate.  Rates Keras itself rejects (outside [0, 1)) still fail loudly instead of running a different model."""
     from uplift_upsample_3dhpe_amd.arch import training_unsupported
     cfg = util.load_config("h36m_351")
     assert training_unsupported(pkg.arch_from_config(cfg)) == []
-    cfg.TOKEN_MASK_RATE = 0.2                                       # implemented: not in the list
-    cfg.OUTPUT_BN = True                                            # (inference form and training form, round 3)
-    assert training_unsupported(pkg.arch_from_config(cfg)) == []
-    setattr(cfg, key, value)
-    if where == "build":
-        with pytest.raises(NotImplementedError, match=key):
-            pkg.arch_from_config(cfg)
-    else:
+    cfg.TOKEN_MASK_RATE = 0.2
+    cfg.OUTPUT_BN = True
+    setattr(cfg, key, 0.1)
+    a = pkg.arch_from_config(cfg)
+    assert training_unsupported(a) == [] and getattr(a, "drop_rate" if key == "DROP_RATE" else "attention_drop_rate") == pytest.approx(0.1)
+    for bad_rate in (1.0, -0.1):
+        setattr(cfg, key, bad_rate)
         bad = training_unsupported(pkg.arch_from_config(cfg))      # inference is unaffected: the arch still builds
         assert len(bad) == 1 and key in bad[0]
+
+
+def test_dropout_oracle_masks():
+    """oracle/dropout_oracle.py (the numpy twin of csrc/uu3d_dropout.h): deterministic in (seed, site, index), different per site and
+    seed, the kept fraction follows the rate, kept elements carry 1 / (1 - rate) in float32, rate 0 means no layer."""
+    import torch
+    from oracle import uplift_oracle as O
+    from oracle.dropout_oracle import drop_factor, drop_hash
+    f = drop_factor((64, 71, 384), 0.1, 987654321012345, 101)
+    assert f.dtype == np.float32 and set(np.unique(f)) == {np.float32(0.0), np.float32(1.0) / (np.float32(1.0) - np.float32(0.1))}
+    assert abs((f > 0).mean() - 0.9) < 2e-3
+    assert np.array_equal(f, drop_factor((64, 71, 384), 0.1, 987654321012345, 101))
+    assert not np.array_equal(f, drop_factor((64, 71, 384), 0.1, 987654321012345, 102))
+    assert not np.array_equal(f, drop_factor((64, 71, 384), 0.1, 987654321012346, 101))
+    # the hash sees all 64 bits of an index and of the seed
+    assert drop_hash(5, 1, np.uint64(3)) != drop_hash(5, 1, np.uint64(3 + 2 ** 32)) and drop_hash(5, 1, np.uint64(3)) != drop_hash(5 + 2 ** 32, 1, np.uint64(3))
+    x = torch.ones(4, 8)
+    assert O._dropout(x, None, 1) is x and O._dropout(x, dict(rate=0.0, attn_rate=0.0, seed=1), 1) is x
+    y = O._dropout(x, dict(rate=0.5, attn_rate=0.25, seed=1), 7)
+    ya = O._dropout(x, dict(rate=0.5, attn_rate=0.25, seed=1), 7, attention=True)
+    assert set(np.unique(y.numpy())) <= {0.0, 2.0} and set(np.unique(ya.numpy())) <= {0.0, np.float32(1.0) / np.float32(0.75)}
 
 
 def test_learnable_masked_token_rule():

@@ -29,7 +29,8 @@ _MASKS = [(0, 0), (1, 0), (2, 0)]
 @pytest.mark.parametrize("cfgname,droppath,batch_norm", [("h36m_81", False, 4), ("h36m_351", False, 4), ("h36m_81", True, 4), ("h36m_351", True, 4),
                                                          ("h36m_351", True, 512), ("h36m_81", False, 512), ("h36m_351", "strided", 4), ("h36m_81", "strided", 512),
                                                          ("h36m_351", "tokenmask", 4), ("h36m_81", "tokenmask", 4), ("h36m_351", "tokenmask_learnable", 4),
-                                                         ("h36m_351", "bn", 4), ("h36m_81", "bn", 512)])
+                                                         ("h36m_351", "bn", 4), ("h36m_81", "bn", 512),
+                                                         ("h36m_351", "dropout", 4), ("h36m_81", "dropout", 512), ("h36m_351", "dropout_all", 4)])
 def test_gradients_match_autograd(cfgname, droppath, batch_norm):
     """Every gradient tensor against float64 autograd through the oracle, <= 1e-4 of its scale.  batch_norm = 512 is the
     PRODUCTION loss normaliser (config BATCH_SIZE): d loss / d joint is 8e-7 there, which the f16x3 gradient GEMMs only
@@ -56,6 +57,19 @@ def test_gradients_match_autograd(cfgname, droppath, batch_norm):
         arch = pkg.arch_from_config(cfg)
         w = pkg.init_weights(arch, seed=7, perturb=0.1)
         model = pkg.build_uplift_upsample_transformer(cfg, weights=w)
+    dropout = None
+    if droppath in ("dropout", "dropout_all"):    # the Dropout layers (DROP_RATE / ATTENTION_DROP_RATE > 0: vit.py:57-67,87-90,127-128,153-154; u_u_t.py:78-89,201,324; round 4),
+        cfg.DROP_RATE, cfg.ATTENTION_DROP_RATE = 0.1, 0.15        # alone and ("dropout_all") together with DropPath in all three stacks and token masking
+        if droppath == "dropout_all":
+            cfg.DROP_PATH_RATE = [0.1, 0.1, 0.4]
+            cfg.TOKEN_MASK_RATE = 0.3
+        arch = pkg.arch_from_config(cfg)
+        from uplift_upsample_3dhpe_amd.arch import training_unsupported
+        assert training_unsupported(arch) == []
+        model = pkg.build_uplift_upsample_transformer(cfg, weights=w)
+        dropout = dict(rate=0.1, attn_rate=0.15, seed=0x1234567890ABCDE + batch_norm)
+        tokenmask = droppath == "dropout_all"
+        droppath = "strided" if droppath == "dropout_all" else False
     ms = cfg.MASK_STRIDE if isinstance(cfg.MASK_STRIDE, list) else [cfg.MASK_STRIDE]
     m = np.stack([util.eval_stride_mask(arch.num_frames, cfg.SEQUENCE_STRIDE, ms[_MASKS[b % len(_MASKS)][0]], 0) for b in range(B)])
     tr = Trainer(model, cfg)
@@ -70,8 +84,11 @@ def test_gradients_match_autograd(cfgname, droppath, batch_norm):
         assert hit.any() and ((tmu >= 0.3) & (m != 0)).any()      # real tokens both masked and kept
     loss, full, central = tr.forward_backward(torch.from_numpy(x).cuda(), torch.from_numpy(gt).cuda(), torch.from_numpy(m).cuda(),
                                               drop_path_uniform=None if u is None else torch.from_numpy(u).cuda(),
-                                              token_mask_uniform=None if tmu is None else torch.from_numpy(tmu).cuda())
+                                              token_mask_uniform=None if tmu is None else torch.from_numpy(tmu).cuda(),
+                                              dropout_seed=None if dropout is None else dropout["seed"])
     torch.cuda.synchronize()
+    if dropout is not None:
+        assert tr.last_dropout_seed == dropout["seed"]
     dp = None
     if droppath:
         ns = arch.spatial_depth * 2 * B * arch.num_frames
@@ -85,7 +102,7 @@ def test_gradients_match_autograd(cfgname, droppath, batch_norm):
     ref, gref, fref, cref = T.train_step_grads(util.hp_from_arch(arch), w, x, m, gt, cfg.ROOT_KEYTPOINT, cfg.LOSS_WEIGHT_CENTER,
                                                cfg.LOSS_WEIGHT_SEQUENCE, cfg.BATCH_SIZE, dp,
                                                token_mask_cfg=None if tmu is None else dict(rate=0.3, u=tmu),
-                                               bn_train=(moving := {}) if droppath == "bn" else None)
+                                               bn_train=(moving := {}) if droppath == "bn" else None, dropout_cfg=dropout)
     if droppath == "bn":
         # the training-mode forward has updated the moving statistics inside the master buffer (Keras: non-trainable weights); their
         # gradient slots are zeros and the optimizer never sees them
@@ -278,6 +295,33 @@ def test_training_call_of_the_model_object():
     u = torch.rand(tr2.drop_path_size(4), generator=tr2._rng, device="cuda", dtype=torch.float32)
     _, fb, cb = tr2.forward_backward(torch.from_numpy(x).cuda(), torch.from_numpy(gt).cuda(), mt, drop_path_uniform=u)
     assert torch.equal(a[0], fb) and torch.equal(a[1], cb)
+
+
+def test_training_call_with_dropout_layers():
+    """model(inputs, training=True) with DROP_RATE / ATTENTION_DROP_RATE > 0 (round 4): the Dropout layers act in the training-mode
+    call only, every call draws a new mask stream from the model's generator, and the output equals the oracle's forward with the
+    masks of the seed the call used (fp32, <= 1e-4)."""
+    from oracle import uplift_oracle as O
+    cfg, arch, w, model, x, m, gt = _setup("h36m_351", 3, seed=13, batch_norm=4)
+    cfg.DROP_PATH_RATE = [0.0, 0.0, 0.0]
+    cfg.DROP_RATE, cfg.ATTENTION_DROP_RATE = 0.2, 0.1
+    arch = pkg.arch_from_config(cfg)
+    model = pkg.build_uplift_upsample_transformer(cfg, weights=w)
+    ms = cfg.MASK_STRIDE if isinstance(cfg.MASK_STRIDE, list) else [cfg.MASK_STRIDE]
+    m = np.stack([util.eval_stride_mask(arch.num_frames, cfg.SEQUENCE_STRIDE, ms[0], 0) for _ in range(3)])
+    xm = torch.from_numpy(x * m[:, :, None, None].astype(np.float32)).cuda()
+    mt = torch.from_numpy(m).cuda()
+    f_inf, c_inf = model([xm, mt], training=False)
+    f1, c1 = model([xm, mt], training=True)
+    s1 = model.last_dropout_seed
+    f2, c2 = model([xm, mt], training=True)
+    assert model.last_dropout_seed != s1 and (f1 - f2).abs().max() > 1e-3       # a fresh mask stream per call
+    assert (f1 - f_inf).abs().max() > 1e-3 and torch.isfinite(f1).all() and torch.isfinite(c1).all()
+    assert torch.equal(model([xm, mt], training=False)[0], f_inf)                # inference: no Dropout layer acts
+    p = {k: torch.tensor(v, dtype=torch.float32) for k, v in w.items()}
+    fr, cr, _ = O.forward_torch(util.hp_from_arch(arch), p, torch.tensor(x * m[:, :, None, None].astype(np.float32)), m, torch.float32,
+                                dropout_cfg=dict(rate=0.2, attn_rate=0.1, seed=s1))
+    assert (f1.cpu() - fr).abs().max() <= util.TOL_MAX_ABS and (c1.cpu() - cr).abs().max() <= util.TOL_MAX_ABS
 
 
 def test_model_sees_trained_weights_without_explicit_export(tmp_path):

@@ -24,7 +24,7 @@ EXPORTED_SYMBOLS = (
     "uu3d_set_schedule", "uu3d_set_profiling", "uu3d_profile_read", "uu3d_gather_windows", "uu3d_world_to_cam_2d",
     "uu3d_mpjpe_loss", "uu3d_adamw_update", "uu3d_adamw_update_guarded", "uu3d_train_nonfinite_flag", "uu3d_train_nonfinite", "uu3d_ema_update",
     "uu3d_num_params", "uu3d_train_init", "uu3d_train_repack", "uu3d_train_export",
-    "uu3d_train_workspace_bytes", "uu3d_train_forward_backward", "uu3d_train_forward_backward_masked", "uu3d_train_set_grad_callback",
+    "uu3d_train_workspace_bytes", "uu3d_train_forward_backward", "uu3d_train_forward_backward_masked", "uu3d_train_set_grad_callback", "uu3d_train_set_dropout",
 )
 # include/uu3d_ops.h
 OPS_SYMBOLS = (
@@ -158,6 +158,8 @@ def load_library(path=None):
                                                        C.POINTER(C.c_float), vp, vp, C.c_float, vp, vp, vp, vp, vp, sz, vp]
     lib.uu3d_train_set_grad_callback.restype = C.c_int
     lib.uu3d_train_set_grad_callback.argtypes = [vp, GRAD_READY_FN, vp]
+    lib.uu3d_train_set_dropout.restype = C.c_int
+    lib.uu3d_train_set_dropout.argtypes = [vp, C.c_float, C.c_float, C.c_uint64]
     lib.uu3d_op_scratch_floats.restype = sz
     lib.uu3d_op_scratch_floats.argtypes = []
     lib.uu3d_op_gemm_tn.restype = C.c_int

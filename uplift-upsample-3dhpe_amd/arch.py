@@ -69,13 +69,15 @@ def _conv_length_recurrence(n: int, strides, paddings) -> List[int]:
 
 def training_unsupported(a: "UpliftArch"):
     """Config options that change the TRAINING-mode forward and that this build does not implement; the caller raises.
-    (All are inactive in the shipped configs.)  Reference: Dropout layers u_u_t.py:201, vit.py:87-88,66-67;
-    (random_token_masking u_u_t.py:287-311, DropPath in all three stacks and training-mode BatchNormalization u_u_t.py:276-283 ARE implemented.)"""
+    Empty since round 4: the Dropout layers (DROP_RATE: u_u_t.py:201,324, vit.py:57-58,63-67,153-154, u_u_t.py:78-79,84-89;
+    ATTENTION_DROP_RATE: vit.py:87-88,127-128) are implemented with counter-based masks (csrc/uu3d_dropout.h), like
+    random_token_masking (u_u_t.py:287-311), DropPath in all three stacks and training-mode BatchNormalization (u_u_t.py:276-283)
+    before them.  Rates outside [0, 1) are rejected, as Keras does."""
     out = []
-    if a.drop_rate != 0.0:
-        out.append(f"DROP_RATE = {a.drop_rate} (Dropout after the embedding, in MHA.projection and the MLPs)")
-    if a.attention_drop_rate != 0.0:
-        out.append(f"ATTENTION_DROP_RATE = {a.attention_drop_rate} (Dropout on the attention probabilities)")
+    if not (0.0 <= a.drop_rate < 1.0):
+        out.append(f"DROP_RATE = {a.drop_rate} (must be in [0, 1))")
+    if not (0.0 <= a.attention_drop_rate < 1.0):
+        out.append(f"ATTENTION_DROP_RATE = {a.attention_drop_rate} (must be in [0, 1))")
     return out
 
 

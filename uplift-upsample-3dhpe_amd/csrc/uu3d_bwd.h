@@ -614,7 +614,7 @@ template <int DH>
 __global__ void __launch_bounds__(128)
 attn_generic_fwd_kernel(const float* __restrict__ qkv, const int ld, const int D, const int L, const int H,
                         const uint8_t* __restrict__ key_mask, float* __restrict__ out, const int ldo,
-                        const int pack, const int total)
+                        const int pack, const int total, const DropCfg drop = DropCfg{})
 {
     // `pack` (sequence, head) pairs share a workgroup, L threads each (L = 17 leaves 119 of 128 lanes busy instead of 17)
     constexpr int LD = DH + 4;
@@ -666,8 +666,10 @@ attn_generic_fwd_kernel(const float* __restrict__ qkv, const int ld, const int D
         if (key_mask != nullptr) s += (key_mask[(size_t)b * L + j] ? 0.0f : 1.0f) * -1e9f;
         const float e = __builtin_amdgcn_exp2f((s - mx) * 1.44269504088896341f);
         sum += e;
+        // Dropout on the attention WEIGHTS (after the softmax, vision_transformer.py:126-129): the row sum is that of the full row
+        const float ed = drop.on() ? e * drop_factor(drop, ((unsigned long long)bh * L + i) * L + j) : e;
 #pragma unroll
-        for (int c = 0; c < DH; ++c) o[c] = fmaf(e, Vs[j * LD + c], o[c]);
+        for (int c = 0; c < DH; ++c) o[c] = fmaf(ed, Vs[j * LD + c], o[c]);
     }
     const float rsum = 1.0f / sum;
     if constexpr (DH == 4) {
@@ -683,8 +685,9 @@ __global__ void __launch_bounds__(128)
 attn_generic_bwd_kernel(const float* __restrict__ qkv, const float* __restrict__ dO, const int ld, const int D,
                         const int L, const int H, const uint8_t* __restrict__ key_mask,
                         float* __restrict__ dqkv /* same layout as qkv */, const int ldo,
-                        const int pack, const int total)
+                        const int pack, const int total, const DropCfg drop = DropCfg{})
 {
+    // with Dropout on the attention weights (P' = M * P, O = P' V): dV = P'^T dO, dP = M * (dO V^T), dS = P * (dP - rowsum(dP * P))
     constexpr int LD = DH + 4;
     extern __shared__ __attribute__((aligned(16))) float sm[];
     const int LP = L + 1;
@@ -737,6 +740,7 @@ attn_generic_bwd_kernel(const float* __restrict__ qkv, const float* __restrict__
             float dp = 0.f;
 #pragma unroll
             for (int c = 0; c < DH; ++c) dp = fmaf(g[c], Vs[j * LD + c], dp);
+            if (drop.on()) dp *= drop_factor(drop, ((unsigned long long)bh * L + i) * L + j);
             Pm[i * LP + j] = pij; Sm[i * LP + j] = dp;
             delta = fmaf(pij, dp, delta);
         }
@@ -762,7 +766,9 @@ attn_generic_bwd_kernel(const float* __restrict__ qkv, const float* __restrict__
 #pragma unroll
         for (int c = 0; c < DH; ++c) { dk[c] = 0.f; dv[c] = 0.f; }
         for (int r = 0; r < L; ++r) {
-            const float ds = Sm[r * LP + i], pr = Pm[r * LP + i];
+            const float ds = Sm[r * LP + i];
+            float pr = Pm[r * LP + i];
+            if (drop.on()) pr *= drop_factor(drop, ((unsigned long long)bh * L + r) * L + i);
 #pragma unroll
             for (int c = 0; c < DH; ++c) { dk[c] = fmaf(ds, Qs[r * LD + c], dk[c]); dv[c] = fmaf(pr, Gs[r * LD + c], dv[c]); }
         }

@@ -21,6 +21,7 @@
 // id % 8 selects the XCD; all N-tiles of one M-tile go to the same XCD so the A rows are
 // fetched into ONE L2 (weights are read by every XCD regardless).
 #pragma once
+#include "uu3d_dropout.h"
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -195,6 +196,7 @@ struct EpConvResidual {
     const float* __restrict__ xin; int L_in, L_out, stride, lo;
     const float* __restrict__ pe_next;    // (L_out, ld) or nullptr
     const float* __restrict__ gate = nullptr; float keep = 1.f;      // training: DropPath on the MLP branch, one gate per sequence (u_u_t.py:136-137)
+    DropCfg drop{};                                                   // training: Dropout on the convolution's output (u_u_t.py:88-89), in front of DropPath
     __device__ __forceinline__ float2 colv(int col) const { return make_float2(bias[col], 0.f); }
     __device__ __forceinline__ float2 pre(int rowc, int col) const {
         const int b = rowc / L_out; const int t = rowc - b * L_out;
@@ -204,6 +206,7 @@ struct EpConvResidual {
     }
     __device__ __forceinline__ void store(int row, int col, float v, float2 cv, float2 p) const {
         float z = v + cv.x;
+        if (drop.on()) z *= drop_factor(drop, (unsigned long long)row * (unsigned)ld + (unsigned)col);
         if (gate != nullptr) z = (z / keep) * gate[row / L_out];
         float y = p.x + z;
         if (pe_next != nullptr) y += p.y;

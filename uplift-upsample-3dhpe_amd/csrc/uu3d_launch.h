@@ -185,22 +185,24 @@ inline int launch_ln_bwd(const float* x, const float* dy, const float2* stats, c
     return hip_status();
 }
 
+// drop: Dropout on the attention weights (training with ATTENTION_DROP_RATE > 0) -- only the generic kernels implement it, so the
+// unrolled / MFMA backward kernels are not taken then
 inline int launch_attn_generic(bool backward, const float* qkv, const float* dO, int ld, int D, int B, int L, int H, int dh,
-                               const uint8_t* mask, float* out, int ldo, hipStream_t stream) {
+                               const uint8_t* mask, float* out, int ldo, hipStream_t stream, const DropCfg drop = DropCfg{}) {
     const int total = B * H;
     const dim3 block(128);
     if (dh == 4) {
         const int pack = std::max(1, 128 / L);                         // (sequence, head) pairs per workgroup
         const dim3 grid((total + pack - 1) / pack);
         const size_t lds = attn_generic_lds_bytes<4>(L, backward) * pack;
-        if (backward && L == 17 && mask == nullptr && !getenv("UU3D_ATTN_BWD_GENERIC"))     // the spatial stack's shape: unrolled, rows in registers
+        if (backward && L == 17 && mask == nullptr && !drop.on() && !getenv("UU3D_ATTN_BWD_GENERIC"))     // the spatial stack's shape: unrolled, rows in registers
             hipLaunchKernelGGL(attn_small_bwd_kernel<17>, grid, block, attn_small_bwd_lds_bytes<17>() * pack, stream, qkv, dO, ld, D, H, out, ldo, pack, total);
-        else if (backward) hipLaunchKernelGGL(attn_generic_bwd_kernel<4>, grid, block, lds, stream, qkv, dO, ld, D, L, H, mask, out, ldo, pack, total);
-        else hipLaunchKernelGGL(attn_generic_fwd_kernel<4>, grid, block, lds, stream, qkv, ld, D, L, H, mask, out, ldo, pack, total);
+        else if (backward) hipLaunchKernelGGL(attn_generic_bwd_kernel<4>, grid, block, lds, stream, qkv, dO, ld, D, L, H, mask, out, ldo, pack, total, drop);
+        else hipLaunchKernelGGL(attn_generic_fwd_kernel<4>, grid, block, lds, stream, qkv, ld, D, L, H, mask, out, ldo, pack, total, drop);
     } else {
         const dim3 grid(total);
         const size_t lds = attn_generic_lds_bytes<48>(L, backward);
-        if (backward && L <= 128 && !getenv("UU3D_ATTN_BWD_GENERIC")) {
+        if (backward && L <= 128 && !drop.on() && !getenv("UU3D_ATTN_BWD_GENERIC")) {
             // MFMA backward, tiles in registers (attn_bwd_mfma_kernel); dqkv has the layout (and leading dimension) of qkv
             const int NT = (L + 15) / 16;
             const size_t l2 = attn_bwd_mfma_lds_bytes<48>(NT);
@@ -214,9 +216,11 @@ inline int launch_attn_generic(bool backward, const float* qkv, const float* dO,
         } else if (backward) {
             static bool done = false;
             if (!done) { (void)hipFuncSetAttribute((const void*)attn_generic_bwd_kernel<48>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); done = true; }
-            hipLaunchKernelGGL(attn_generic_bwd_kernel<48>, grid, block, lds, stream, qkv, dO, ld, D, L, H, mask, out, ldo, 1, total);
+            hipLaunchKernelGGL(attn_generic_bwd_kernel<48>, grid, block, lds, stream, qkv, dO, ld, D, L, H, mask, out, ldo, 1, total, drop);
         } else {
-            hipLaunchKernelGGL(attn_generic_fwd_kernel<48>, grid, block, lds, stream, qkv, ld, D, L, H, mask, out, ldo, 1, total);
+            static bool donef = false;
+            if (!donef) { (void)hipFuncSetAttribute((const void*)attn_generic_fwd_kernel<48>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); donef = true; }
+            hipLaunchKernelGGL(attn_generic_fwd_kernel<48>, grid, block, lds, stream, qkv, ld, D, L, H, mask, out, ldo, 1, total, drop);
         }
     }
     return hip_status();

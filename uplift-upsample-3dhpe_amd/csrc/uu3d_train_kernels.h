@@ -1,6 +1,7 @@
 // uu3d_train_kernels.h -- small kernels, loaders and epilogues used only by the training step
 // (training-mode forward that keeps activations, DropPath, and the backward chain).
 #pragma once
+#include "uu3d_dropout.h"
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <math.h>
@@ -366,6 +367,7 @@ struct EpBiasResGate {
     float* __restrict__ out; const float* __restrict__ xin; const float* __restrict__ bias; int ld;
     const float* __restrict__ gate; float keep; int rps;      // gate == nullptr: no DropPath layer
     float* out2; const float* __restrict__ pe2; int period;   // optional second stream out + pe2[row % period]
+    DropCfg drop{};                                           // Dropout on (acc + bias), in front of DropPath (vision_transformer.py:153-154,65-66 then :186-193)
     __device__ __forceinline__ float2 colv(int col) const { return make_float2(bias[col], 0.f); }
     __device__ __forceinline__ float2 pre(int rowc, int col) const {
         float2 p; p.x = xin[(size_t)rowc * ld + col];
@@ -374,6 +376,7 @@ struct EpBiasResGate {
     }
     __device__ __forceinline__ void store(int row, int col, float v, float2 cv, float2 p) const {
         float y = v + cv.x;
+        if (drop.on()) y *= drop_factor(drop, (unsigned long long)row * (unsigned)ld + (unsigned)col);
         if (gate != nullptr) y = (y / keep) * gate[row / rps];
         const float o = p.x + y;
         out[(size_t)row * ld + col] = o;
@@ -386,11 +389,11 @@ struct EpAdd {              // out += acc
     __device__ __forceinline__ float2 pre(int rowc, int col) const { return make_float2(out[(size_t)rowc * ldo + col], 0.f); }
     __device__ __forceinline__ void store(int row, int col, float v, float2, float2 p) const { out[(size_t)row * ldo + col] = p.x + v; }
 };
-struct EpReluMask {         // out = acc * (H > 0)
-    float* __restrict__ out; const float* __restrict__ H; int ldo;
+struct EpReluMask {         // out = acc * (H > 0) * scale   (scale: 1 / (1 - rate) of an inner Dropout behind the ReLU -- H is stored AFTER it, so H > 0 = kept and active)
+    float* __restrict__ out; const float* __restrict__ H; int ldo; float scale = 1.f;
     __device__ __forceinline__ float2 colv(int) const { return make_float2(0.f, 0.f); }
     __device__ __forceinline__ float2 pre(int rowc, int col) const { return make_float2(H[(size_t)rowc * ldo + col], 0.f); }
-    __device__ __forceinline__ void store(int row, int col, float v, float2, float2 p) const { out[(size_t)row * ldo + col] = p.x > 0.f ? v : 0.f; }
+    __device__ __forceinline__ void store(int row, int col, float v, float2, float2 p) const { out[(size_t)row * ldo + col] = p.x > 0.f ? v * scale : 0.f; }
 };
 struct EpGeluGrad {         // out = acc * gelu'(Hpre)
     float* __restrict__ out; const float* __restrict__ Hpre; int ldo;

@@ -269,6 +269,19 @@ class UpliftUpsampleTransformer(object):
             return m.contiguous()
         return (m != 0).contiguous().view(torch.uint8)
 
+    def _set_dropout(self, rng, seed=None):
+        """The Dropout layers of this training-mode call (uu3d_train_set_dropout): the config's rates and a fresh seed of the mask
+        stream drawn from ``rng`` (or the given ``seed``); with both rates 0 nothing is drawn."""
+        a = self.arch
+        if a.drop_rate > 0.0 or a.attention_drop_rate > 0.0:
+            if seed is None:
+                seed = int(self._torch.randint(0, 2 ** 62, (1,), generator=rng, device=self.device, dtype=self._torch.int64).item())
+        else:
+            seed = 0
+        _capi.check(self._lib, self._lib.uu3d_train_set_dropout(self._h, float(a.drop_rate), float(a.attention_drop_rate), int(seed)), self._h)
+        self.last_dropout_seed = seed                           # (what a test needs to evaluate the same masks on the CPU)
+        return seed
+
     def _training_forward(self, x, stride_mask, full, central):
         """model(inputs, training=True) (train.py:478): DropPath active, live weights.  Without a Trainer the model keeps
         its own master buffer (uu3d_train_init) and generator."""
@@ -298,6 +311,7 @@ class UpliftUpsampleTransformer(object):
             self._train_ws = torch.empty(nbytes, dtype=torch.uint8, device=self.device)
         r3 = (C.c_float * 3)(*[float(r) for r in rates])
         tm = torch.rand((B, a.num_frames), generator=rng, device=self.device, dtype=torch.float32) if a.token_mask_rate > 0.0 else None   # u_u_t.py:299
+        self._set_dropout(rng)
         st = self._lib.uu3d_train_forward_backward_masked(
             self._h, C.c_void_p(params.data_ptr()), C.c_void_p(x.data_ptr()),
             C.c_void_p(stride_mask.data_ptr()) if stride_mask is not None else None, None, B, int(a.batch_size), 0.0, 0.0, 0,

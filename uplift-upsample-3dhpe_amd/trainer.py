@@ -88,11 +88,13 @@ class Trainer(object):
             n += len(a.strides) * 2 * batch
         return n
 
-    def forward_backward(self, keypoints2d, keypoints3d, stride_masks, drop_path_uniform="draw", token_mask_uniform="draw"):
+    def forward_backward(self, keypoints2d, keypoints3d, stride_masks, drop_path_uniform="draw", token_mask_uniform="draw", dropout_seed=None):
         """Training-mode forward + loss + backward.  Returns (loss[3] tensor, full, central); gradients in self.grads.
 
         drop_path_uniform: "draw" = fresh U[0,1) draws, None = DropPath disabled, or a flat tensor of draws.
-        token_mask_uniform (TOKEN_MASK_RATE > 0, u_u_t.py:287-311): "draw", None = no token masking, or a (B, N) tensor of draws."""
+        token_mask_uniform (TOKEN_MASK_RATE > 0, u_u_t.py:287-311): "draw", None = no token masking, or a (B, N) tensor of draws.
+        dropout_seed (DROP_RATE / ATTENTION_DROP_RATE > 0): the seed of this step's Dropout masks; None = drawn from the trainer's
+        generator.  ``self.last_dropout_seed`` keeps what was used."""
         torch = self._torch
         a, cfg = self.model.arch, self.config
         self.model._flush_assigns()                                          # WeightView.assign() since the last step: into the master buffer first
@@ -118,6 +120,7 @@ class Trainer(object):
         central = torch.empty((B, a.num_keypoints, 3), dtype=torch.float32, device=dev)
         ws = self._workspace(B)
         rates = (C.c_float * 3)(*[float(r) for r in self.drop_path_rates])
+        self.last_dropout_seed = self.model._set_dropout(self._rng, dropout_seed)
         self._buckets.begin()                                               # a previous pass without apply_gradients leaves nothing behind
         st = self._lib.uu3d_train_forward_backward_masked(
             self.model._h, C.c_void_p(self.params.data_ptr()), C.c_void_p(x.data_ptr()), m_ptr, C.c_void_p(gt.data_ptr()), B,
@@ -176,8 +179,8 @@ class Trainer(object):
         _capi.check(self._lib, self._lib.uu3d_train_nonfinite(self.model._h, C.byref(out)), self.model._h)
         return out.value != 0
 
-    def train_step(self, keypoints2d, keypoints3d, stride_masks, drop_path_uniform="draw", token_mask_uniform="draw"):
-        loss, _, _ = self.forward_backward(keypoints2d, keypoints3d, stride_masks, drop_path_uniform, token_mask_uniform)
+    def train_step(self, keypoints2d, keypoints3d, stride_masks, drop_path_uniform="draw", token_mask_uniform="draw", dropout_seed=None):
+        loss, _, _ = self.forward_backward(keypoints2d, keypoints3d, stride_masks, drop_path_uniform, token_mask_uniform, dropout_seed)
         self.apply_gradients()
         return loss
 
