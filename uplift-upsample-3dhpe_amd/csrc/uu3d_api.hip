@@ -875,7 +875,11 @@ struct Launcher {
     }
     // x[M][384] += A B + colv in place (the attention projection on the residual stream): N = K = 384, the kernel's chunk loop unrolled
     // (CPW = 4 / 6 / 12 chunks per workgroup for 3 / 2 / 1 column ranges per row tile -- uu3d_gemm_panel.h says why)
-    void gemm_panel_residual(const char* name, const _Float16* Af, size_t pf, const float* colv, int M, float* x) {
+    // ln_g / ln_b / ln_out (optional): LayerNorm 2 (eps 1e-5) of the finished rows as the next panel GEMM's A fragments, by the same launch
+    // when it owns whole rows (throughput schedule, 8-wave kernel) -- returns true when it did, false when the caller still has to
+    // launch ln_split_frag
+    bool gemm_panel_residual(const char* name, const _Float16* Af, size_t pf, const float* colv, int M, float* x,
+                             const float* ln_g = nullptr, const float* ln_b = nullptr, _Float16* ln_out = nullptr) {
         const int K = 384, N = 384, mt = (M + 127) / 128;
         int S = 1; double best = 1e30;
         for (int s : {1, 2, 3}) {                                  // same cost model as panel_splits
@@ -891,13 +895,19 @@ struct Launcher {
         begin(name, "gemm_panel", 2.0 * M * (double)N * K, 4.0 * ((double)M * K + (double)N * K + 2.0 * (double)M * N));
         const PanelEpBiasResidual ep{x, N};
         const dim3 grid(8 * S, ((mt * S + 7) / 8 + S - 1) / S);
+        static const bool no_ln_tail = getenv("UU3D_NO_LN_TAIL") != nullptr;      // (A/B measurements)
+        if (S == 1 && ln_out != nullptr && !no_ln_tail) {
+            const PanelEpBiasResidualLn epl{{x, N}, ln_g, ln_b, 1e-5f, ln_out};
+            if (launch_panel8(Af, m->harena + pf, colv, M, mt, 1, 12, epl)) { end(); return true; }
+        }
 #define UU3D_PANEL_RES(CPW) { auto kern = gemm_h3_panel_kernel<24, PanelEpBiasResidual, CPW>; \
             static const bool once = (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)PANEL_LDS_TOTAL) == hipSuccess); (void)once; \
             hipLaunchKernelGGL(kern, grid, dim3(256), PANEL_LDS_TOTAL, stream, Af, m->harena + pf, colv, M, mt, S, CPW, ep); }
-        if (launch_panel8(Af, m->harena + pf, colv, M, mt, S, 12 / S, ep)) { end(); return; }
+        if (launch_panel8(Af, m->harena + pf, colv, M, mt, S, 12 / S, ep)) { end(); return false; }
         if (S == 3) UU3D_PANEL_RES(4) else if (S == 2) UU3D_PANEL_RES(6) else UU3D_PANEL_RES(12)
 #undef UU3D_PANEL_RES
         end();
+        return false;
     }
     // the same with the operand given by address (training: the packs regenerated from the master buffer) -- K = 384, N % 32 == 0
     template <class EP>
@@ -1233,14 +1243,17 @@ int uu3d_forward_ex(uu3d_model* m, const float* kp2d, const uint8_t* mask, int32
         // added in the epilogue from values requested a chunk earlier (UU3D_NO_PANEL_PROJ=1: the tiled LDS-DMA kernel)
         const bool pproj = planes && !m->no_panel_proj && Lh.panel_ok(Mr, dt, dt, b.wp_pf);      // (every attention kernel writes either layout)
         Lh.attn(name("attn"), w.QKV, B, L, kmask, w.O, planes ? (size_t)Mr * dt : 0, pproj);
-        if (pproj) Lh.gemm_panel_residual(name("proj_res"), Ph, b.wp_pf, b.bp, Mr, x);
+        const bool mlp_panel = planes && Lh.panel_ok(Mr, ht, dt, b.w1_pf);
+        bool ln2_done = false;
+        if (pproj) ln2_done = mlp_panel ? Lh.gemm_panel_residual(name("proj_res"), Ph, b.wp_pf, b.bp, Mr, x, b.ln2_g, b.ln2_b, Ph)
+                                        : Lh.gemm_panel_residual(name("proj_res"), Ph, b.wp_pf, b.bp, Mr, x);
         else {
             EpBiasResidual ep{x, b.bp, dt, nullptr, nullptr, 1};
             if (planes) { GLoadPlain gl{Ph, Pl, dt, Mr}; Lh.gemm_g(name("proj_res"), gl, b.wp_t, Mr, dt, dt, ep, 4.0 * Mr * dt); }
             else { ALoadPlain al{w.O, dt, Mr, dt}; Lh.gemm(name("proj_res"), al, b.wp_t, Mr, dt, dt, ep, 4.0 * Mr * dt); }
         }
-        if (planes && Lh.panel_ok(Mr, ht, dt, b.w1_pf)) {
-            Lh.ln_split_frag(name("ln2_split"), x, Mr, b.ln2_g, b.ln2_b, Ph);
+        if (mlp_panel) {
+            if (!ln2_done) Lh.ln_split_frag(name("ln2_split"), x, Mr, b.ln2_g, b.ln2_b, Ph);      // (throughput schedule: LayerNorm 2 rode in the projection's launch)
             if (fuse_mlp) return Ph;
             Lh.gemm_panel(name("ln_fc1"), Ph, b.w1_pf, b.b1, Mr, ht, PanelEpBiasReluSplit{Hh, Hl, ht});
         } else {

@@ -126,6 +126,16 @@ struct PanelEpBiasResidual {   // x[row][col] += v   (the attention projection o
         *reinterpret_cast<float*>(reinterpret_cast<char*>(x) + b) = v;
     }
 };
+// x[row][col] += v, then -- by the workgroup that owns the whole rows (one column range per row tile: gemm_h3_panel8_kernel with
+// splits == 1) -- LayerNorm 2 of the finished rows, split and written as the next panel GEMM's A fragments: the ln_split_frag launch
+// between the projection and the MLP disappears (throughput schedule; round 4).  Af may be the buffer the projection's own A
+// panels came from: a workgroup has read its rows' fragments into registers long before it rewrites them.
+struct PanelEpBiasResidualLn : PanelEpBiasResidual {
+    const float* __restrict__ gamma; const float* __restrict__ beta; float eps; _Float16* __restrict__ Af;
+};
+template <class EP> struct panel_ln_tail { static constexpr bool value = false; };
+template <> struct panel_ln_tail<PanelEpBiasResidualLn> { static constexpr bool value = true; };
+
 #ifndef UU3D_PANEL_LOO
 #define UU3D_PANEL_LOO 0       // tools/panel8_exp: leave-out timing builds (results wrong), bit mask: 1 no refill DMA, 2 no epilogue stores, 4 no fragment reads, 8 no barrier, 16 no MFMA
 #endif
@@ -341,6 +351,47 @@ gemm_h3_panel_kernel(const _Float16* __restrict__ Af, const _Float16* __restrict
 // them, so that a wave's stores for one piece index are runs of 64 contiguous bytes of the operand.  At M = 9088:
 // 6.6 us with 8 or 4 rows per workgroup, 7.0 with 16, 7.9 with 32 -- the floor of 28 MB through the Infinity Cache in
 // one short launch.
+// One row of ln_split_frag_body for the 16 threads (j = 0 .. 15) that share it: LayerNorm of x[row][0 .. 16 KS) and the fragment-ordered
+// hi / lo planes of the row (rows >= M: read clamped, nothing written).  Same arithmetic, same order as ln_split_frag_body.
+template <int KS>
+__device__ __forceinline__ void ln_split_frag_row(const float* __restrict__ x, const int ld, const int M, const float eps,
+                                                  const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                  _Float16* __restrict__ Af, const int row, const int j)
+{
+    constexpr int D = 16 * KS, NV = D / 64;
+    const float* p = x + (size_t)min(row, M - 1) * ld;
+    f32x4 v[NV];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) { v[i] = *reinterpret_cast<const f32x4*>(p + 4 * (j + 16 * i)); s += (v[i][0] + v[i][1]) + (v[i][2] + v[i][3]); }
+    s += __shfl_xor(s, 1); s += __shfl_xor(s, 2); s += __shfl_xor(s, 4); s += __shfl_xor(s, 8);
+    const float mean = s * (1.0f / D);
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const float a = v[i][0] - mean, b = v[i][1] - mean, c = v[i][2] - mean, d = v[i][3] - mean;
+        q += (a * a + b * b) + (c * c + d * d);
+    }
+    q += __shfl_xor(q, 1); q += __shfl_xor(q, 2); q += __shfl_xor(q, 4); q += __shfl_xor(q, 8);
+    const float rstd = 1.0f / sqrtf(q * (1.0f / D) + eps);
+    if (row >= M) return;
+    _Float16* base = Af + (size_t)(row >> 5) * KS * 2 * 512 + (row & 31) * 8;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int c = 4 * (j + 16 * i);
+        const f32x4 g = *reinterpret_cast<const f32x4*>(gamma + c);
+        const f32x4 bt = *reinterpret_cast<const f32x4*>(beta + c);
+        f32x4 y;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { const float inv = rstd * g[e]; y[e] = v[i][e] * inv + (bt[e] - mean * inv); }
+        h16x4 hi, lo;
+        h3_split(y, hi, lo);
+        _Float16* d = base + (size_t)(c >> 4) * 2 * 512 + ((c >> 3) & 1) * 256 + (c & 4);
+        *reinterpret_cast<h16x4*>(d) = hi;
+        *reinterpret_cast<h16x4*>(d + 512) = lo;
+    }
+}
+
 template <int KS, int ROWS>
 __device__ __forceinline__ void ln_split_frag_body(const float* __restrict__ x, const int ld, const int M, const float eps,
                                                    const float* __restrict__ gamma, const float* __restrict__ beta,

@@ -294,6 +294,15 @@ gemm_h3_panel8_kernel(const _Float16* __restrict__ Af, const _Float16* __restric
 #pragma unroll
         for (int r = 0; r < 8; ++r)
             if (decltype(whole_tag)::value || 8 * (r >> 2) + (r & 3) < valid) finish(c, r, p0, p1, rv, rl);
+        if constexpr (panel_ln_tail<EP>::value) {
+            // LayerNorm 2 of this row tile (the workgroup owns its rows: splits == 1, all 12 chunks): every store of the tile is
+            // complete and visible to the workgroup behind the wait + barrier (workgroup scope: one CU, one L1, write-through)
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+#pragma unroll 2
+            for (int pass = 0; pass < 4; ++pass)
+                ln_split_frag_row<KS>(ep.x, ep.ldo, M, ep.eps, ep.gamma, ep.beta, ep.Af, bm * 128 + pass * 32 + (tid >> 4), tid & 15);
+        }
         PANEL_STAMP(asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                     if (tid == 0 && u < 1024) { unsigned long long* o = panel_stamps + u * 8; o[0] = st_entry; o[1] = st_issued; o[2] = st_first; o[3] = st_loop; o[4] = __builtin_amdgcn_s_memrealtime(); o[5] = ck1 - ck0; })
     };
