@@ -1044,12 +1044,17 @@ struct Launcher {
             const size_t lds = attn_h3_lds_bytes(L, kDH);
             _Float16* oh = reinterpret_cast<_Float16*>(out);
             const _Float16* qh = reinterpret_cast<const _Float16*>(qkv); const _Float16* ql = qh + (size_t)B * L * 3 * D;
-#define UU3D_ATTN_H3(MW, WPE, MASKED, waves) { auto k = attn_h3_kernel<kDH, MW, WPE, MASKED>; \
+#define UU3D_ATTN_H3(MW, WPE, MASKED, PIPE, waves) { auto k = attn_h3_kernel<kDH, MW, WPE, MASKED, PIPE>; \
                 static const bool once = (hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)attn_h3_lds_bytes(ATTN_H3_MAX_L, kDH)) == hipSuccess); (void)once; \
                 hipLaunchKernelGGL(k, grid, dim3(64 * (waves)), lds, stream, qh, ql, 3 * D, D, L, H, mask, oh, frag ? (size_t)512 : split_lo_off, D, frag ? 1 : 0); }
-            if (nt <= 3) { if (mask) UU3D_ATTN_H3(3, 3, true, nt) else UU3D_ATTN_H3(3, 3, false, nt) }
-            else if (nt <= 12) { if (mask) UU3D_ATTN_H3(12, 3, true, nt) else UU3D_ATTN_H3(12, 3, false, nt) }     // one wave per query tile, three per SIMD (dense-351: 35.4 vs 36.8 us with 8 waves x 2 tiles)
-            else { if (mask) UU3D_ATTN_H3(8, 2, true, std::min(nt, 8)) else UU3D_ATTN_H3(8, 2, false, std::min(nt, 8)) }
+            // 4 .. 12 key tiles (dense-351: 11): one wave per query tile, three per SIMD.  UU3D_ATTN_PIPE=1 (round 4, measured 4 % SLOWER: 35.6 against
+            // 34.3 us at 351 tokens, batch 32): the PIPE form (operand reads by name ahead of their use, uu3d_attn_h3.h) needs ~190 registers =
+            // two waves per SIMD, so 8 waves walk the query tiles -- the exposed LDS round trips of the round-3 kernel are not what it waits for
+            static const bool no_pipe = getenv("UU3D_ATTN_PIPE") == nullptr;
+            if (nt <= 3) { if (mask) UU3D_ATTN_H3(3, 3, true, false, nt) else UU3D_ATTN_H3(3, 3, false, false, nt) }
+            else if (nt <= 12 && no_pipe) { if (mask) UU3D_ATTN_H3(12, 3, true, false, nt) else UU3D_ATTN_H3(12, 3, false, false, nt) }     // one wave per query tile, three per SIMD (dense-351: 35.4 vs 36.8 us with 8 waves x 2 tiles)
+            else if (nt <= 12) { if (mask) UU3D_ATTN_H3(8, 2, true, true, std::min(nt, 8)) else UU3D_ATTN_H3(8, 2, false, true, std::min(nt, 8)) }
+            else { if (mask) UU3D_ATTN_H3(8, 2, true, false, std::min(nt, 8)) else UU3D_ATTN_H3(8, 2, false, false, std::min(nt, 8)) }
 #undef UU3D_ATTN_H3
             end();
             return;

@@ -54,7 +54,11 @@ typedef _Float16 h16x2 __attribute__((ext_vector_type(2)));
 // MAXW = waves per workgroup the instantiation is compiled for; WPE = waves per SIMD the register budget must allow
 // (short sequences: 3 waves per workgroup, four workgroups per CU = 3 per SIMD; long ones: 8 waves = 2 per SIMD).
 // MASKED = a key mask is given (temporal block 1): the mask term is added before the running maximum is subtracted.
-template <int DH, int MAXW, int WPE, bool MASKED>
+// PIPE (round 4): the LDS operand reads of a key tile are issued BY NAME ahead of their use -- the six K fragments of S^T = K Q^T at
+// the top of the tile (hipcc emitted each read directly in front of its MFMA with a full lgkmcnt(0): five exposed LDS round trips
+// per tile), the first 16-key step's V^T fragments behind the last S^T MFMA (they land during the softmax), the second step's
+// into the K-fragment registers behind the first step's MFMAs; full key tiles skip the LDS read of the additive mask (it is 0).
+template <int DH, int MAXW, int WPE, bool MASKED, bool PIPE = false>
 __global__ void __launch_bounds__(64 * MAXW) __attribute__((amdgpu_waves_per_eu(WPE, WPE)))
 attn_h3_kernel(const _Float16* __restrict__ qkv_h, const _Float16* __restrict__ qkv_l, const int ld, const int D, const int L, const int H,
                const uint8_t* __restrict__ key_mask,   // (B, L) 1 = attend; nullptr = no mask
@@ -151,6 +155,36 @@ attn_h3_kernel(const _Float16* __restrict__ qkv_h, const _Float16* __restrict__ 
             // ---- S^T = K Q^T (32 keys x 32 queries); lane holds keys 32 kt + 8 j + 4 g + i of its query.  The hi-hi
             // accumulator starts at the key's mask term (minus the running maximum when nothing is masked) ----
             f32x16 s0, s1;
+            typedef _Float16 h16x4v __attribute__((ext_vector_type(4)));
+            h16x4v va[8], vb[8];                                   // V^T fragments of the two 16-key steps (PIPE: requested by name)
+            if constexpr (PIPE) {
+                h16x8 kf[6];                                       // K fragments: hi slices 0..2, lo slices 0..2
+                const unsigned kb = (unsigned)(uintptr_t)(h3_lds_void*)(Kp + ((size_t)32 * kt + q31) * 16 + g * 8);
+                const unsigned sl = (unsigned)Lpad * 32u;          // bytes between two slices of a plane
+#pragma unroll
+                for (int i = 0; i < 6; ++i)
+                    asm volatile("ds_read_b128 %0, %1" : "=v"(kf[i]) : "v"(kb + (unsigned)i * sl) : "memory");
+                if (!MASKED && 32 * kt + 32 <= L) {                // a full tile without a mask: the additive term is 0
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) { s0[r] = -m_off; s1[r] = 0.f; }
+                } else {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const f32x4 ma = *reinterpret_cast<const f32x4*>(madd + 32 * kt + 8 * j + 4 * g);
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) { s0[4 * j + i] = MASKED ? ma[i] : ma[i] - m_off; s1[4 * j + i] = 0.f; }
+                    }
+                }
+#pragma unroll
+                for (int s = 0; s < KS; ++s) {
+                    // LDS returns in order: the hi fragment of slice s has 5 - s younger reads behind it, the lo one 2 - s
+                    asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(kf[s]) : "i"(5 - s));
+                    s0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf[s], qh[s], s0, 0, 0, 0);
+                    s1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf[s], ql[s], s1, 0, 0, 0);
+                    asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(kf[3 + s]) : "i"(2 - s));
+                    s1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf[3 + s], qh[s], s1, 0, 0, 0);
+                }
+            } else {
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 const f32x4 ma = *reinterpret_cast<const f32x4*>(madd + 32 * kt + 8 * j + 4 * g);
@@ -166,11 +200,27 @@ attn_h3_kernel(const _Float16* __restrict__ qkv_h, const _Float16* __restrict__ 
                 s1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh, ql[s], s1, 0, 0, 0);
                 s1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(kl, qh[s], s1, 0, 0, 0);
             }
+            }
             // ---- online softmax ----
             float t[16];
             float tmax = -INFINITY;
 #pragma unroll
             for (int r = 0; r < 16; ++r) { t[r] = fmaf(s1[r], 1.0f / H3_SCALE, s0[r]); tmax = fmaxf(tmax, t[r]); }
+            if constexpr (PIPE) {
+                // the first step's V^T fragments: requested here (the cross-term accumulator is dead: 16 registers), they land while the softmax runs
+                {
+                    const unsigned ko = (unsigned)((32 * kt) * VROW * 2);
+                    const unsigned aA = vA + ko, aB = (grp ? vB_ones : vB_real) + (grp ? 0u : ko);
+                    const unsigned aB8 = aB + (grp ? 0u : (unsigned)(8 * VROW * 2));
+                    const unsigned lo_o = grp ? 32u : (unsigned)(DH * 2);
+                    asm volatile("ds_read_b64_tr_b16 %0, %4\n\tds_read_b64_tr_b16 %1, %4 offset:%6\n\t"
+                                 "ds_read_b64_tr_b16 %2, %4 offset:%5\n\tds_read_b64_tr_b16 %3, %4 offset:%7"
+                                 : "=&v"(va[0]), "=&v"(va[1]), "=&v"(va[2]), "=&v"(va[3]) : "v"(aA), "i"(DH * 2), "i"(8 * VROW * 2), "i"(8 * VROW * 2 + DH * 2) : "memory");
+                    asm volatile("ds_read_b64_tr_b16 %0, %4\n\tds_read_b64_tr_b16 %1, %5\n\t"
+                                 "ds_read_b64_tr_b16 %2, %6\n\tds_read_b64_tr_b16 %3, %7"
+                                 : "=&v"(va[4]), "=&v"(va[5]), "=&v"(va[6]), "=&v"(va[7]) : "v"(aB), "v"(aB8), "v"(aB + lo_o), "v"(aB8 + lo_o) : "memory");
+                }
+            }
             tmax = fmaxf(tmax, __shfl_xor(tmax, 32));
             if (MASKED) {
                 // t = logit + mask term, rounded in f32 like the reference's sum.  The running maximum can jump by 1e9 (first
@@ -207,6 +257,40 @@ attn_h3_kernel(const _Float16* __restrict__ qkv_h, const _Float16* __restrict__ 
                 pl[r >> 3][r & 7] = lv[0]; pl[r >> 3][(r & 7) + 1] = lv[1];
             }
             // ---- O^T += V^T P^T : two 16-key steps, A = V^T fragment (keys 16 s + 8 (j >> 2) + 4 g + (j & 3)) ----
+            if constexpr (PIPE) {
+                const bool second = 32 * kt + 16 < L;              // (else the second step holds padding keys only: p = 0)
+                if (second) {
+                    const unsigned ko = (unsigned)((32 * kt + 16) * VROW * 2);
+                    const unsigned aA = vA + ko, aB = (grp ? vB_ones : vB_real) + (grp ? 0u : ko);
+                    const unsigned aB8 = aB + (grp ? 0u : (unsigned)(8 * VROW * 2));
+                    const unsigned lo_o = grp ? 32u : (unsigned)(DH * 2);
+                    asm volatile("ds_read_b64_tr_b16 %0, %4\n\tds_read_b64_tr_b16 %1, %4 offset:%6\n\t"
+                                 "ds_read_b64_tr_b16 %2, %4 offset:%5\n\tds_read_b64_tr_b16 %3, %4 offset:%7"
+                                 : "=&v"(vb[0]), "=&v"(vb[1]), "=&v"(vb[2]), "=&v"(vb[3]) : "v"(aA), "i"(DH * 2), "i"(8 * VROW * 2), "i"(8 * VROW * 2 + DH * 2) : "memory");
+                    asm volatile("ds_read_b64_tr_b16 %0, %4\n\tds_read_b64_tr_b16 %1, %5\n\t"
+                                 "ds_read_b64_tr_b16 %2, %6\n\tds_read_b64_tr_b16 %3, %7"
+                                 : "=&v"(vb[4]), "=&v"(vb[5]), "=&v"(vb[6]), "=&v"(vb[7]) : "v"(aB), "v"(aB8), "v"(aB + lo_o), "v"(aB8 + lo_o) : "memory");
+                    asm volatile("s_waitcnt lgkmcnt(8)" : "+v"(va[0]), "+v"(va[1]), "+v"(va[2]), "+v"(va[3]), "+v"(va[4]), "+v"(va[5]), "+v"(va[6]), "+v"(va[7]) :: "memory");
+                } else
+                    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(va[0]), "+v"(va[1]), "+v"(va[2]), "+v"(va[3]), "+v"(va[4]), "+v"(va[5]), "+v"(va[6]), "+v"(va[7]) :: "memory");
+                auto step = [&](const h16x4v (&f)[8], int s) __attribute__((always_inline)) {
+                    const h16x8 vAh = (h16x8){f[0][0], f[0][1], f[0][2], f[0][3], f[1][0], f[1][1], f[1][2], f[1][3]};
+                    const h16x8 vAl = (h16x8){f[2][0], f[2][1], f[2][2], f[2][3], f[3][0], f[3][1], f[3][2], f[3][3]};
+                    const h16x8 vBh = (h16x8){f[4][0], f[4][1], f[4][2], f[4][3], f[5][0], f[5][1], f[5][2], f[5][3]};
+                    const h16x8 vBl = (h16x8){f[6][0], f[6][1], f[6][2], f[6][3], f[7][0], f[7][1], f[7][2], f[7][3]};
+                    oA0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(vAh, ph[s], oA0, 0, 0, 0);
+                    oA1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(vAh, pl[s], oA1, 0, 0, 0);
+                    oA1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(vAl, ph[s], oA1, 0, 0, 0);
+                    oB0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(vBh, ph[s], oB0, 0, 0, 0);
+                    oB1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(vBh, pl[s], oB1, 0, 0, 0);
+                    oB1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(vBl, ph[s], oB1, 0, 0, 0);
+                };
+                step(va, 0);
+                if (second) {
+                    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(vb[0]), "+v"(vb[1]), "+v"(vb[2]), "+v"(vb[3]), "+v"(vb[4]), "+v"(vb[5]), "+v"(vb[6]), "+v"(vb[7]) :: "memory");
+                    step(vb, 1);
+                }
+            } else
 #pragma unroll
             for (int s = 0; s < 2; ++s) {
                 if (s == 1 && 32 * kt + 16 >= L) break;           // the step holds padding keys only (p = 0)
