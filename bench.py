@@ -242,22 +242,29 @@ def secondary_benchmarks(args):
 def pmc_summary_for(config, batch):
     """The committed --pmc summary that was collected on THIS workload (config, per-GPU batch), or None: counters of another
     shape say nothing about this one."""
-    name = {("h36m_351", 128): "r03_final_pmc_summary.csv", ("dense_351", 32): "r02_final_dense351_pmc_summary.csv",
-            ("h36m_81", 256): "r02_final_h36m81_pmc_summary.csv"}.get((config, batch))
-    return None if name is None else os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", name)
+    name = {("h36m_351", 128): "r04_final_pmc_summary.csv", ("dense_351", 32): "r04_final_dense351_pmc_summary.csv",
+            ("h36m_81", 256): "r04_final_h36m81_pmc_summary.csv"}.get((config, batch))
+    if name is None:
+        return None
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", name)
+    return path if os.path.exists(path) else None
 
 
-def pmc_traffic(kernel_class, dom_key, summary=None):
-    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 --pmc summary (FETCH_SIZE x2 on gfx950 +
-    WRITE_SIZE, separate --pmc passes, tools/profile_r02.sh -> tools/rocpd_summary.py; one launch = the whole batch, like
-    `achieved`).  None when the summary does not hold that kernel."""
+# profile-record kernel name (csrc: Launcher::begin) -> substrings that pick the kernel SYMBOL out of a rocprofv3 summary
+def symbol_filter(symbol):
+    if symbol.startswith("gemm_panel8<") or symbol.startswith("gemm_panel<"):
+        return ("gemm_h3_panel8_kernel" if symbol.startswith("gemm_panel8<") else "gemm_h3_panel_kernel",
+                "PanelEp" + symbol[symbol.index("<") + 1:-1] + "E")
+    return {"mlp_fused": ("mlp_fused_h3_kernel",), "gemm_wt": ("gemm_h3_wt_kernel",), "gemm_f32": ("gemm_f32_kernel",),
+            "gemm_h3": ("gemm_h3",)}.get(symbol)
+
+
+def pmc_traffic(symbol, summary=None):
+    """HBM-side bytes per launch of a kernel symbol from the committed rocprofv3 --pmc summary of THIS workload (FETCH_SIZE x2 on
+    gfx950 + WRITE_SIZE, separate --pmc passes, tools/profile_r04.sh -> tools/rocpd_summary.py; one launch = the whole batch, like
+    `achieved`).  None when no summary of this workload is committed or it does not hold that symbol."""
     import csv
-    op = dom_key.split(".")[-1]
-    want = {"mlp_fused": ("mlp_fused_h3_kernel",), "gemm_wt": ("gemm_h3_wt_kernel",),
-            "gemm_panel": ("gemm_h3_panel_kernel", "PanelEpBiasSplitQ" if op == "ln_qkv" else "PanelEpBiasReluSplit"),
-            "gemm_h3": {"proj_res": ("gemm_h3g_kernel", "GLoadPlain", "EpBiasResidual"), "fc2_res": ("gemm_h3g_kernel", "GLoadPlain", "EpBiasResidual"),
-                        "conv_res": ("gemm_h3g_kernel", "GLoadConv3"), "s2t": ("gemm_h3_kernel", "EpSpatialToTemporal")}.get(op),
-            "gemm_f32": ("gemm_f32_kernel",)}.get(kernel_class)
+    want = symbol_filter(symbol)
     if want is None or summary is None or not os.path.exists(summary):
         return None
     best = None
@@ -463,15 +470,21 @@ def main():
     if rank == 0:
         fl = pkg.flops_per_sequence(arch)
         total_ms = sum(a["ms"] for a in agg.values()) / reps
-        # GEMM launch classes: the tiled f16x3 kernels ("gemm_h3"), the row-panel f16x3 kernel ("gemm_panel"), exact f32
-        gks = ("gemm_h3", "gemm_panel", "mlp_fused", "gemm_wt") if args.precision == "f16x3" else ("gemm_f32",)
+        # GEMM kernels by SYMBOL (the profile records carry the distinguishing part of the symbol: "gemm_panel8<BiasSplitQ>", "mlp_fused", ...):
+        # the dominant kernel is the symbol with the most time per forward, whatever labels its launches carry
+        is_gemm = (lambda k: k.startswith(("gemm_h3", "gemm_panel", "mlp_fused", "gemm_wt"))) if args.precision == "f16x3" else (lambda k: k.startswith("gemm_f32"))
         peak = PEAK_F16_MFMA_TFLOPS if args.precision == "f16x3" else PEAK_F32_MFMA_TFLOPS
-        dom_key = max((k for k in agg if agg[k]["kernel"] in gks), key=lambda k: agg[k]["ms"])
-        dom = agg[dom_key]
-        gk = dom["kernel"]
+        by_sym = {}
+        for k, a in agg.items():
+            if is_gemm(a["kernel"]):
+                bs = by_sym.setdefault(a["kernel"], dict(ms=0.0, flops=0.0, n=0, labels=[]))
+                bs["ms"] += a["ms"]; bs["flops"] += a["flops"]; bs["n"] += a["n"]; bs["labels"].append(k)
+        gk = max(by_sym, key=lambda k: by_sym[k]["ms"])
+        dom = by_sym[gk]
+        dom_key = "+".join(sorted(dom["labels"]))
         ach = dom["flops"] / (dom["ms"] * 1e-3) / 1e12
-        gemm_fl = sum(a["flops"] for a in agg.values() if a["kernel"] in gks)
-        gemm_ms = sum(a["ms"] for a in agg.values() if a["kernel"] in gks)
+        gemm_fl = sum(bs["flops"] for bs in by_sym.values())
+        gemm_ms = sum(bs["ms"] for bs in by_sym.values())
         seqs = world * B * args.steps
         out = {
             "metric": "pose-sequences/sec",
@@ -495,7 +508,7 @@ def main():
                                      else "one batch after the other"},
             "roofline": {"bound": "mfma", "kernel": f"{gk} [{dom_key}]",
                          "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s",
-                         "frac": round(ach / peak, 4), "traffic": pmc_traffic(gk, dom_key, pmc_summary_for(args.config, B)),
+                         "frac": round(ach / peak, 4), "traffic": pmc_traffic(gk, pmc_summary_for(args.config, B)),
                          "note": ("algorithmic 2*M*N*K FLOPs (mlp_fused: both Dense layers of the MLP, 4*M*d*h); the f16x3 kernels issue 3 f16 "
                                   "MFMA passes per product, so the matrix pipe does 3x this work (frac of pipe = 3 * frac)") if args.precision == "f16x3" else
                                  "exact f32-input MFMA",
@@ -503,10 +516,11 @@ def main():
                          "attention": attention_roofline(agg, N, "synthetic dense-351 (NOT a shipped config)" if args.config == "dense_351" else f"config/{args.config}.json"),
                          # the four largest GEMM launch classes (the first two are within a microsecond per launch of each
                          # other, so which one is "dominant" changes from box to box)
-                         "gemm_classes": [{"kernel": f"{agg[k]['kernel']} [{k}]", "ms_per_forward": round(agg[k]["ms"] / reps, 4),
-                                           "achieved": round(agg[k]["flops"] / (agg[k]["ms"] * 1e-3) / 1e12, 2),
-                                           "frac": round(agg[k]["flops"] / (agg[k]["ms"] * 1e-3) / 1e12 / peak, 4)}
-                                          for k in sorted((k for k in agg if agg[k]["kernel"] in gks), key=lambda k: -agg[k]["ms"])[:4]],
+                         "gemm_symbols": [{"kernel": f"{k} [{'+'.join(sorted(bs['labels']))}]", "ms_per_forward": round(bs["ms"] / reps, 4),
+                                           "launches_per_forward": bs["n"] // reps,
+                                           "achieved": round(bs["flops"] / (bs["ms"] * 1e-3) / 1e12, 2),
+                                           "frac": round(bs["flops"] / (bs["ms"] * 1e-3) / 1e12 / peak, 4)}
+                                          for k, bs in sorted(by_sym.items(), key=lambda kv: -kv[1]["ms"])[:4]],
                          "all_gemm_tflops": round(gemm_fl / (gemm_ms * 1e-3) / 1e12, 2),
                          "model_tflops": round(fl["total"] * seqs / world / elapsed / 1e12, 2)},
             "kernel_ms_per_forward": {k: round(a["ms"] / reps, 4) for k, a in sorted(agg.items(), key=lambda kv: -kv[1]["ms"])},

@@ -19,6 +19,7 @@ CSRC = os.path.join(util.ROOT, "uplift-upsample-3dhpe_amd", "csrc")
 SRC = r'''
 #include "uu3d_gemm_h3.h"
 #include "uu3d_gemm_panel.h"
+#include "uu3d_gemm_panel8.h"
 #include "uu3d_attn.h"
 #include "uu3d_attn_h3.h"
 #include "uu3d_bwd.h"
@@ -35,6 +36,9 @@ template __global__ void uu3d::spatial_stack_h3_kernel<17, 3, 1, true>(const flo
 template __global__ void uu3d::gemm_h3_panel_kernel<24, PanelEpBias>(const _Float16*, const _Float16*, const float*, int, int, int, int, const PanelEpBias);
 template __global__ void uu3d::gemm_h3_panel_kernel<24, PanelEpBiasReluSplit>(const _Float16*, const _Float16*, const float*, int, int, int, int, const PanelEpBiasReluSplit);
 template __global__ void uu3d::gemm_h3_panel_kernel<24, PanelEpBiasResidual, 4>(const _Float16*, const _Float16*, const float*, int, int, int, int, const PanelEpBiasResidual);
+template __global__ void uu3d::gemm_h3_panel8_kernel<PanelEpBiasSplitQ, 12, 3>(const _Float16*, const _Float16*, const float*, int, int, int, const PanelEpBiasSplitQ);
+template __global__ void uu3d::gemm_h3_panel8_kernel<PanelEpBiasResidual, 4, 3>(const _Float16*, const _Float16*, const float*, int, int, int, const PanelEpBiasResidual);
+template __global__ void uu3d::gemm_h3_panel8_kernel<PanelEpBiasResidualLn, 12, 3>(const _Float16*, const _Float16*, const float*, int, int, int, const PanelEpBiasResidualLn);
 template __global__ void uu3d::ln_split_frag_kernel<24, 8>(const float*, int, int, float, const float*, const float*, _Float16*);
 template __global__ void uu3d::gemm_h3g_kernel<1, 1, GLoadConv3, EpSlab, 3>(const GLoadConv3, const _Float16*, const _Float16*, int, int, int, int, int, int, const EpSlab);
 template __global__ void uu3d::gemm_h3g_kernel<1, 2, GLoadPlain, EpBiasResidual, 3>(const GLoadPlain, const _Float16*, const _Float16*, int, int, int, int, int, int, const EpBiasResidual);
@@ -105,6 +109,36 @@ def test_row_panel_gemm_code_shape(asm):
     assert len(res) == 2 * 4 * 16 and all(r.startswith("a") for r in res), res[:4]
     assert len(re.findall(r"s_waitcnt vmcnt\(0\)", body)) <= 5
     assert len(re.findall(r"s_waitcnt vmcnt\(12\) lgkmcnt\(0\)", body)) == 2 * 4
+
+
+def test_eight_wave_row_panel_gemm_code_shape(asm):
+    """uu3d_gemm_panel8.h (round 4): two code paths (whole row tile / ragged last tile), each a straight line of CPW chunks.  What the
+    kernel relies on: no scratch (a register that was requested by name must never be spilled or copied before its wait -- the
+    branch between the paths sits in front of the first request for that reason); per chunk and wave 36 MFMAs, 6 LDS-DMA pieces
+    (3 per half-interval) and two barriers; the A fragments requested by name (24 per path, never by a load hipcc sees); every
+    residual / bias request by name into an architectural register; 256 registers = two waves per SIMD."""
+    ks = _kernels(asm)
+    for ep, cpw, requests in (("PanelEpBiasSplitQ", 12, 1), ("PanelEpBiasResidualE", 4, 9), ("PanelEpBiasResidualLn", 12, 9)):
+        body = next(v for k, v in ks.items() if "gemm_h3_panel8_kernel" in k and ep in k)
+        assert "scratch_" not in body, ep
+        assert body.count("v_mfma_f32_32x32x16_f16") == 2 * cpw * 36, ep
+        # prologue: half-chunks 0 .. 4 = 15 pieces per path (hipcc may hoist the first 6, which do not depend on the path, above the branch:
+        # 24 instead of 30 in the text); every chunk issues 6 more, 3 per half-interval (the tail's are clamped re-reads)
+        assert body.count("global_load_lds_dwordx4") - 12 * cpw in (24, 30), ep
+        per_interval = [seg.count("global_load_lds_dwordx4") for seg in body.split("s_barrier")]
+        assert sorted(set(per_interval[1:])) in ([0, 3], [0, 3, 9]), (ep, per_interval)
+        assert body.count("s_barrier") == 2 * (2 * cpw + 2 + (1 if "Ln" in ep else 0)), ep
+        a_frag = re.findall(r"global_load_dwordx4 v\[\d+:\d+\], v\d+, s\[\d+:\d+\]", body)
+        assert len(a_frag) == 2 * 24 + (0 if "Ln" not in ep else 0), (ep, len(a_frag))
+        by_name = re.findall(r"global_load_dword (\w+), v\d+, s\[\d+:\d+\]", body)
+        assert len(by_name) == 2 * cpw * requests and all(r.startswith("v") for r in by_name), (ep, len(by_name))
+        # the waits are counted: nothing but the two ends of a path (and the LayerNorm tail) drains vector memory
+        assert len(re.findall(r"s_waitcnt vmcnt\(0\)", body)) <= (2 * 5 if "Ln" in ep else 2), ep
+    # the kernel descriptors: at most 256 registers (two waves per SIMD), all of the LDS
+    for name in (k for k in ks if "gemm_h3_panel8_kernel" in k):
+        d = asm[asm.index(".amdhsa_kernel " + name):]
+        d = d[:d.index(".end_amdhsa_kernel")]
+        assert int(re.search(r"\.amdhsa_next_free_vgpr (\d+)", d).group(1)) <= 256, name
 
 
 def test_no_packed_fp32_valu_ops(asm):

@@ -842,10 +842,22 @@ struct Launcher {
     // The 8-wave form of the row-panel GEMM (uu3d_gemm_panel8.h: contraction split over wave pairs, two waves per SIMD) for the chunk
     // counts it is instantiated for; UU3D_PANEL4=1 keeps every launch on the 4-wave kernel (A/B measurements).  Returns false when
     // the caller has to launch the 4-wave kernel.
+    static bool panel8_ok(int cpw) {
+        static const bool off = getenv("UU3D_PANEL4") != nullptr && atoi(getenv("UU3D_PANEL4")) != 0;
+        return !off && (cpw == 4 || cpw == 6 || cpw == 8 || cpw == 12);
+    }
+    // the profile records' kernel name = the kernel SYMBOL's distinguishing part (bench.py picks the dominant kernel by it)
+    template <class EP> static const char* panel_symbol(bool eight) {
+        const char* e = std::is_same<EP, PanelEpBiasSplitQ>::value ? "BiasSplitQ" : std::is_same<EP, PanelEpBiasResidual>::value ? "BiasResidual"
+                      : std::is_same<EP, PanelEpBiasResidualLn>::value ? "BiasResidualLn" : std::is_same<EP, PanelEpBiasReluSplit>::value ? "BiasReluSplit"
+                      : std::is_same<EP, PanelEpBiasRelu>::value ? "BiasRelu" : "Bias";
+        static thread_local char buf[32];
+        std::snprintf(buf, sizeof buf, "%s<%s>", eight ? "gemm_panel8" : "gemm_panel", e);
+        return buf;
+    }
     template <class EP>
     bool launch_panel8(const _Float16* Af, const _Float16* Bf, const float* colv, int M, int mt, int S, int cpw, const EP& ep) {
-        static const bool off = getenv("UU3D_PANEL4") != nullptr && atoi(getenv("UU3D_PANEL4")) != 0;
-        if (off) return false;
+        if (!panel8_ok(cpw)) return false;
         const dim3 grid(8 * S, ((mt * S + 7) / 8 + S - 1) / S);
 #define UU3D_P8_LAUNCH(CPW) { auto kern = gemm_h3_panel8_kernel<EP, CPW, 3>; \
             static const bool once = (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)P8_LDS_TOTAL) == hipSuccess); (void)once; \
@@ -864,7 +876,7 @@ struct Launcher {
         const int K = 384, mt = (M + 127) / 128;
         int S = panel_splits(M, N);
         { static const char* e = getenv("UU3D_PANEL_S"); if (e != nullptr && e[0] >= '1' && e[0] <= '3' && (N / 32) % (e[0] - '0') == 0 && (N / 32) / (e[0] - '0') <= PANEL_COLV_FLOATS / 32) S = e[0] - '0'; }   // (A/B measurements)
-        begin(name, "gemm_panel", 2.0 * M * (double)N * K, 4.0 * ((double)M * K + (double)N * K + (double)M * N));
+        begin(name, panel_symbol<EP>(panel8_ok((N / 32) / S)), 2.0 * M * (double)N * K, 4.0 * ((double)M * K + (double)N * K + (double)M * N));
         if (!launch_panel8(Af, m->harena + pf, colv, M, mt, S, (N / 32) / S, ep)) {
             auto kern = gemm_h3_panel_kernel<24, EP>;
             static bool attr_done = false;
@@ -892,11 +904,13 @@ struct Launcher {
         // flight 167.3 / 169.2 / 171.3 k on the same box)
         if (throughput) S = 1;
         { static const char* e = getenv("UU3D_PANEL_PROJ_S"); if (e != nullptr && e[0] >= '1' && e[0] <= '3') S = e[0] - '0'; }   // (A/B measurements)
-        begin(name, "gemm_panel", 2.0 * M * (double)N * K, 4.0 * ((double)M * K + (double)N * K + 2.0 * (double)M * N));
+        static const bool no_ln_tail = getenv("UU3D_NO_LN_TAIL") != nullptr;      // (A/B measurements)
+        const bool ln_tail = S == 1 && ln_out != nullptr && !no_ln_tail && panel8_ok(12);
+        begin(name, ln_tail ? panel_symbol<PanelEpBiasResidualLn>(true) : panel_symbol<PanelEpBiasResidual>(panel8_ok(12 / S)),
+              2.0 * M * (double)N * K, 4.0 * ((double)M * K + (double)N * K + 2.0 * (double)M * N));
         const PanelEpBiasResidual ep{x, N};
         const dim3 grid(8 * S, ((mt * S + 7) / 8 + S - 1) / S);
-        static const bool no_ln_tail = getenv("UU3D_NO_LN_TAIL") != nullptr;      // (A/B measurements)
-        if (S == 1 && ln_out != nullptr && !no_ln_tail) {
+        if (ln_tail) {
             const PanelEpBiasResidualLn epl{{x, N}, ln_g, ln_b, 1e-5f, ln_out};
             if (launch_panel8(Af, m->harena + pf, colv, M, mt, 1, 12, epl)) { end(); return true; }
         }
@@ -913,7 +927,7 @@ struct Launcher {
     template <class EP>
     void gemm_panel_at(const char* name, const _Float16* Af, const _Float16* Bf, const float* colv, int M, int N, const EP& ep) {
         const int K = 384, S = panel_splits(M, N), mt = (M + 127) / 128;
-        begin(name, "gemm_panel", 2.0 * M * (double)N * K, 4.0 * ((double)M * K + (double)N * K + (double)M * N));
+        begin(name, panel_symbol<EP>(panel8_ok((N / 32) / S)), 2.0 * M * (double)N * K, 4.0 * ((double)M * K + (double)N * K + (double)M * N));
         if (!launch_panel8(Af, Bf, colv, M, mt, S, (N / 32) / S, ep)) {
             auto kern = gemm_h3_panel_kernel<24, EP>;
             static bool attr_done = false;
