@@ -215,6 +215,11 @@ def quick_train_bench(steps=50, warmup=10, batch=64):
     out = {"workload": f"config/h36m_351_pt.json train step (fwd + bwd + AdamW), batch {batch}, DropPath {cfg.DROP_PATH_RATE}",
            "value": round(batch * steps / dt, 1), "unit": "pose-sequences/s", "ms_per_step": round(1e3 * dt / steps, 3), "steps": steps,
            "host_enqueue_ms_per_step": round(1e3 * enqueue / steps, 3), "loss": float(loss[0].item())}
+    # algorithmic FLOPs of a step = 3 x the forward's (forward + activation-gradient + weight-gradient products), against the f16 MFMA
+    # peak the f16x3 GEMMs of the step run on (its attention and small layers run exact f32: the fraction is an upper-level figure)
+    fl = 3.0 * pkg.flops_per_sequence(arch)["total"] * batch
+    out["achieved_tflops"] = round(fl / (dt / steps) / 1e12, 2)
+    out["frac"] = round(fl / (dt / steps) / 1e12 / PEAK_F16_MFMA_TFLOPS, 4)
     del tr, model
     torch.cuda.empty_cache()
     return out
