@@ -723,6 +723,15 @@ inline bool spatial_h3_pays(int frames) {
     return t_h3 <= t_f32;
 }
 
+// UU3D_SKIP=<bit mask> (TIMING EXPERIMENTS ONLY: the skipped launches leave garbage, results are wrong): which launch classes of the
+// forward are left out -- 1 spatial stack, 2 LayerNorm-fed panel GEMMs (QKV, fc1), 4 projection, 8 fused MLP, 16 attention, 32 ln_split_frag,
+// 64 ln_res_split_frag.  tools/marginal_exp.sh prices what each class costs the pipelined step.
+inline int skip_mask() {
+    static const int mask = [] { const char* e = getenv("UU3D_SKIP"); const int v = e ? atoi(e) : 0;
+                                 if (v) fprintf(stderr, "[uu3d] UU3D_SKIP=%d: launches are being skipped, RESULTS ARE WRONG (timing experiment)\n", v); return v; }();
+    return mask;
+}
+
 struct Launcher {
     uu3d_model* m;
     hipStream_t stream;
@@ -876,6 +885,7 @@ struct Launcher {
         const int K = 384, mt = (M + 127) / 128;
         int S = panel_splits(M, N);
         { static const char* e = getenv("UU3D_PANEL_S"); if (e != nullptr && e[0] >= '1' && e[0] <= '3' && (N / 32) % (e[0] - '0') == 0 && (N / 32) / (e[0] - '0') <= PANEL_COLV_FLOATS / 32) S = e[0] - '0'; }   // (A/B measurements)
+        if (skip_mask() & 2) return;
         begin(name, panel_symbol<EP>(panel8_ok((N / 32) / S)), 2.0 * M * (double)N * K, 4.0 * ((double)M * K + (double)N * K + (double)M * N));
         if (!launch_panel8(Af, m->harena + pf, colv, M, mt, S, (N / 32) / S, ep)) {
             auto kern = gemm_h3_panel_kernel<24, EP>;
@@ -893,6 +903,7 @@ struct Launcher {
     bool gemm_panel_residual(const char* name, const _Float16* Af, size_t pf, const float* colv, int M, float* x,
                              const float* ln_g = nullptr, const float* ln_b = nullptr, _Float16* ln_out = nullptr) {
         const int K = 384, N = 384, mt = (M + 127) / 128;
+        if (skip_mask() & 4) return false;
         int S = 1; double best = 1e30;
         for (int s : {1, 2, 3}) {                                  // same cost model as panel_splits
             const int per_xcd = (mt * s + 7) / 8;
@@ -943,6 +954,7 @@ struct Launcher {
     }
     // LayerNorm (eps 1e-5) of M rows of 384 floats, written as the fragment-ordered planes of the panel GEMM's A operand
     void ln_split_frag(const char* name, const float* x, int M, const float* g, const float* b, _Float16* Af) {
+        if (skip_mask() & 32) return;
         begin(name, "ln_split_frag", 0.0, 8.0 * (double)M * 384);
         hipLaunchKernelGGL((ln_split_frag_kernel<24, 8>), dim3((M + 7) / 8), dim3(128), 0, stream, x, 384, M, 1e-5f, g, b, Af);   // 8 rows per workgroup: 6.6 us at 9088 rows (16: 7.0, 32: 7.9, 4: 6.6)
         end();
@@ -997,6 +1009,7 @@ struct Launcher {
         return !m->no_mlpf && b.w2_mf != 0 && panel_ok(M, m->cfg.h_temporal, m->cfg.d_temporal, b.w1_pf);
     }
     void mlp_fused(const char* name, const _Float16* Af, const BlockDev& b, int M, float* mslab) {
+        if (skip_mask() & 8) return;
         const int mt = (M + 127) / 128, S = MLPF_SLICES;
         begin(name, "mlp_fused", 4.0 * M * (double)m->cfg.d_temporal * m->cfg.h_temporal, 4.0 * ((double)M * 384 + 2.0 * 384 * 768 + 3.0 * M * 384));
         static bool attr_done = false;
@@ -1008,6 +1021,7 @@ struct Launcher {
     // the fused MLP's combine (x += b2 + slabs; optionally xa = x + pe) + LayerNorm + split into A fragments
     void ln_res_split_frag(const char* name, float* x, int M, const float* bias2, const float* mslab, float* xa, const float* pe, int period,
                            const float* g, const float* b, _Float16* Af) {
+        if (skip_mask() & 64) return;
         begin(name, "ln_split_frag", 0.0, 4.0 * (double)M * 384 * (xa ? 8 : 7));
         hipLaunchKernelGGL((ln_res_split_frag_kernel<24, 8>), dim3((M + 7) / 8), dim3(128), 0, stream, x, 384, M, 1e-5f, bias2, mslab, xa, pe, period, g, b, Af);
         end();
@@ -1047,6 +1061,7 @@ struct Launcher {
     // split_lo_off != 0: the context rows go out as f16 planes (hi at out, lo split_lo_off halfs further)
     // frag: the context rows in the row-panel GEMM's A-fragment order instead of row-major planes (split_lo_off != 0 only)
     void attn(const char* name, const float* qkv, int B, int L, const uint8_t* mask, float* out, size_t split_lo_off = 0, bool frag = false) {
+        if (skip_mask() & 16) return;
         const int D = m->cfg.d_temporal, H = m->cfg.num_heads;
         const int NT = (L + 15) / 16;
         const bool h3a = attn_is_h3(L, split_lo_off != 0);
@@ -1169,6 +1184,7 @@ int uu3d_forward_ex(uu3d_model* m, const float* kp2d, const uint8_t* mask, int32
             sp.blocks = m->sp_blocks_v2;             // LayerNorm parameters and biases
             auto kern = spatial_stack_h3_kernel<kJ, kFR, kSpatialMT>;
             Lh.begin("spatial_stack", "spatial_h3", fl, 4.0 * M * J * (2.0 + ds));
+            if (!(skip_mask() & 1))
             hipLaunchKernelGGL(kern, dim3((M + kFR - 1) / kFR), dim3(64 * (2 / kSpatialMT)), sh3::lds_bytes(), Lh.stream, kp2d, sp,
                                m->harena + m->sp_frag_off, w.S, s2t_planes ? reinterpret_cast<_Float16*>(w.S) : (_Float16*)nullptr,
                                s2t_planes ? reinterpret_cast<_Float16*>(w.S) + (size_t)M * J * ds : (_Float16*)nullptr, SpatialTrainIO{});
