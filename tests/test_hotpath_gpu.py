@@ -220,27 +220,56 @@ def test_optional_kernel_paths_agree(env, monkeypatch):
 
 
 def test_throughput_schedule_is_bit_identical():
-    """uu3d_set_schedule (include/uu3d.h): launch shapes for several forwards sharing the chip (the projection as 71 workgroups x 12
-    column chunks instead of 213 x 4) compute the same products per element -- bit-identical outputs; an unknown schedule is refused."""
+    """The schedules of include/uu3d.h: launch shapes for several forwards sharing the chip (the projection as 71 workgroups x 12 column
+    chunks instead of 213 x 4, with LayerNorm 2 of its rows in the same launch) compute the same values per element -- bit-identical
+    outputs, whether the schedule arrives as the argument of uu3d_forward_ex (what the pipeline does) or as the model's default
+    (uu3d_set_schedule + uu3d_forward); an unknown schedule is refused."""
     import ctypes as C
     cfg = util.load_config("h36m_351")
     arch = pkg.arch_from_config(cfg)
     w = pkg.init_weights(arch, seed=9, perturb=0.1)
     model = pkg.build_uplift_upsample_transformer(cfg, weights=w)
+
+    def forward(x, m, schedule=None, legacy=False):
+        xt, mt = torch.as_tensor(x).cuda(), torch.as_tensor(m).cuda()
+        B = xt.shape[0]
+        full = torch.empty((B, arch.num_frames, arch.num_keypoints, 3), dtype=torch.float32, device="cuda")
+        cen = torch.empty((B, arch.num_keypoints, 3), dtype=torch.float32, device="cuda")
+        mu = model._mask_u8(mt)
+        stream = torch.cuda.current_stream()
+        if legacy:                                       # uu3d_forward: the model's default schedule
+            ws = model._workspace(B, 0)
+            st = model._lib.uu3d_forward(model._h, C.c_void_p(xt.data_ptr()), C.c_void_p(mu.data_ptr()), B, C.c_void_p(full.data_ptr()),
+                                         C.c_void_p(cen.data_ptr()), C.c_void_p(ws.data_ptr()), C.c_size_t(ws.numel()), C.c_void_p(stream.cuda_stream))
+            assert st == 0
+        else:
+            model._forward(xt, mu, full, cen, 0, stream, schedule=schedule)
+        torch.cuda.synchronize()
+        return full.cpu().numpy(), cen.cpu().numpy()
+
     for batch in (128, 17):                        # 9088 rows (whole panels) / 1207 rows (a ragged last panel)
         x, m = util.synthetic_batch(cfg, batch, seed=9)
         x = x * m[:, :, None, None]
-        f0, c0 = _call(model, x, m)
+        f0, c0 = forward(x, m, schedule=0)
+        f1, c1 = forward(x, m, schedule=1)
+        assert np.array_equal(f0, f1) and np.array_equal(c0, c1)
         assert model._lib.uu3d_set_schedule(model._h, 1) == 0
         try:
-            f1, c1 = _call(model, x, m)
+            f2, c2 = forward(x, m, legacy=True)
         finally:
             assert model._lib.uu3d_set_schedule(model._h, 0) == 0
-        assert np.array_equal(f0, f1) and np.array_equal(c0, c1)
+        assert np.array_equal(f0, f2) and np.array_equal(c0, c2)
     assert model._lib.uu3d_set_schedule(model._h, 7) != 0
+    # the throughput schedule really is another set of launches: the projection carries LayerNorm 2 (no ln2_split launch of the temporal blocks)
     model.set_profiling(True)
-    _call(model, x, m)
-    assert any(r["name"].endswith("proj_res") and r["kernel"] == "gemm_panel" for r in model.read_profile())
+    forward(x, m, schedule=1)
+    thr = model.read_profile()
+    forward(x, m, schedule=0)
+    lat = model.read_profile()
+    model.set_profiling(False)
+    assert any(r["name"].endswith("proj_res") and r["kernel"].startswith("gemm_panel") for r in lat)
+    assert any(r["kernel"] == "gemm_panel8<BiasResidualLn>" for r in thr) and not any(r["kernel"] == "gemm_panel8<BiasResidualLn>" for r in lat)
+    assert sum(r["name"].endswith("ln2_split") for r in thr) < sum(r["name"].endswith("ln2_split") for r in lat)
 
 
 def test_mpjpe_kernel_matches_the_reference_metric():
