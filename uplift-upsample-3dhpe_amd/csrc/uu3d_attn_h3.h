@@ -51,6 +51,63 @@ __host__ __device__ inline constexpr size_t attn_h3_lds_bytes(int L, int DH) {
 typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 typedef _Float16 h16x2 __attribute__((ext_vector_type(2)));
 
+// Timing builds only (tools/attn_loo_exp.hip; results are wrong by construction): UU3D_ATTN_LOO is a mask of what to leave out of the
+// kernel -- 1 the K / V LDS-DMA, 2 the S^T MFMAs, 4 the exponentials and the hi / lo conversion of the probabilities, 8 the O^T MFMAs,
+// 16 the output stores, 32 the V^T fragment reads, 64 the query fragment loads.  A left-out MFMA is replaced by one FMA on its
+// operands, so that what feeds it stays alive.
+#ifndef UU3D_ATTN_LOO
+#define UU3D_ATTN_LOO 0
+#endif
+#define UU3D_ATTN_MFMA(bit, a, b, c) (((UU3D_ATTN_LOO) & (bit)) ? attn_loo_fma(a, b, c) : __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0))
+__device__ __forceinline__ f32x16 attn_loo_fma(const h16x8& a, const h16x8& b, f32x16 c) { c[0] = fmaf((float)a[0], (float)b[0], c[0]); return c; }
+
+// The end of a query tile: normalise O^T by the row sum, split into f16 hi / lo, store (used by attn_h3_kernel and attn_h3_pp_kernel).
+template <int DH>
+__device__ __forceinline__ void attn_h3_store_tile(const f32x16& oA0, const f32x16& oA1, const f32x16& oB0, const f32x16& oB1, const int qt, const int q31, const int g,
+                                                   const int h, const int L, const size_t tok0, _Float16* __restrict__ out, const size_t lo_off, const int ldo, const int frag)
+{
+    // ---- normalise, split, store: lane (query, g) holds channels 32 t + 8 j + 4 g + (0..3); rows 16 + 4 g of the second
+    // tile (register 8) are the ones-row product = the row sum l, with the same 2^14 factor as every other row ----
+    const float rl = 1.0f / (oB0[8] + oB1[8] * (1.0f / H3_SCALE));
+    const int q = 32 * qt + q31;
+    // row-major planes: row * ldo + channel.  Fragment order: a 16-byte piece = 8 consecutive channels of one row, the pieces of 32
+    // consecutive rows are contiguous (512 B): [32-row panel][16-channel slice][plane][channel half][row & 31][8]
+    const size_t grow = tok0 + min(q, L - 1);
+    _Float16* orow = frag ? out + (size_t)(grow >> 5) * (size_t)(ldo >> 4) * 1024 + (grow & 31) * 8
+                          : out + grow * ldo + h * DH;
+    auto pack4 = [&](const f32x16& a0, const f32x16& a1, int j, unsigned (&hi2)[2], unsigned (&lo2)[2]) {
+        _Float16 hh[4], ll[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const float v = (a0[4 * j + i] + a1[4 * j + i] * (1.0f / H3_SCALE)) * rl;
+            hh[i] = h3_hi(v);
+            ll[i] = (_Float16)((v - (float)hh[i]) * H3_SCALE);
+        }
+        hi2[0] = __builtin_bit_cast(unsigned, (h16x2){hh[0], hh[1]}); hi2[1] = __builtin_bit_cast(unsigned, (h16x2){hh[2], hh[3]});
+        lo2[0] = __builtin_bit_cast(unsigned, (h16x2){ll[0], ll[1]}); lo2[1] = __builtin_bit_cast(unsigned, (h16x2){ll[2], ll[3]});
+    };
+    // blocks (j, j + 1) of 8 channels: after the swap lane g = 0 owns all 16 bytes of block j, lane g = 1 those of block j + 1
+    auto store_pair = [&](const f32x16& a0, const f32x16& a1, int j, int ch0) {
+        unsigned xh[2], xl[2], yh[2], yl[2];
+        pack4(a0, a1, j, xh, xl); pack4(a0, a1, j + 1, yh, yl);
+        unsigned oh[4], ol[4];
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+            const u32x2 sh = __builtin_amdgcn_permlane32_swap(xh[e], yh[e], false, false);
+            const u32x2 sl = __builtin_amdgcn_permlane32_swap(xl[e], yl[e], false, false);
+            oh[e] = sh[0]; oh[2 + e] = sh[1]; ol[e] = sl[0]; ol[2 + e] = sl[1];
+        }
+        if (((UU3D_ATTN_LOO) & 16) ? (oh[0] == 0x12345678u && ol[3] == 0x9abcdef0u) : q < L) {
+            typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+            const int chn = h * DH + ch0 + 8 * (j + g);         // first of the piece's 8 channels
+            _Float16* d = frag ? orow + (size_t)(chn >> 4) * 1024 + ((chn >> 3) & 1) * 256 : orow + ch0 + 8 * (j + g);
+            *reinterpret_cast<u32x4*>(d) = (u32x4){oh[0], oh[1], oh[2], oh[3]};
+            *reinterpret_cast<u32x4*>(d + lo_off) = (u32x4){ol[0], ol[1], ol[2], ol[3]};
+        }
+    };
+    store_pair(oA0, oA1, 0, 0); store_pair(oA0, oA1, 2, 0); store_pair(oB0, oB1, 0, 32);
+}
+
 // MAXW = waves per workgroup the instantiation is compiled for; WPE = waves per SIMD the register budget must allow
 // (short sequences: 3 waves per workgroup, four workgroups per CU = 3 per SIMD; long ones: 8 waves = 2 per SIMD).
 // MASKED = a key mask is given (temporal block 1): the mask term is added before the running maximum is subtracted.
@@ -86,7 +143,8 @@ attn_h3_kernel(const _Float16* __restrict__ qkv_h, const _Float16* __restrict__ 
 
     // ---- K, V of the head: global -> LDS by LDS-DMA, 12 NT instructions shared by the waves; rows past L: a copy of the last
     // row (finite; those keys get -inf / probability 0) ----
-    if (NW == NT) {
+    if ((UU3D_ATTN_LOO) & 1) {
+    } else if (NW == NT) {
         // one wave per key tile (every launch of up to 12 tiles): piece e = w + NT i, i = 0 .. 11.  K (i < 6): plane i / 3, slice i % 3, key
         // group w -- one key per lane pair for all six pieces.  V (i >= 6): 16-byte piece P = 64 (w + NT (i - 6)) + lane of the [key][12 pieces]
         // image.  The generic loop below divides by 3 NT and NT (run-time values) for every piece: ~60 VALU instructions per piece in front of
@@ -125,6 +183,12 @@ attn_h3_kernel(const _Float16* __restrict__ qkv_h, const _Float16* __restrict__ 
 #pragma unroll
         for (int s = 0; s < KS; ++s) { qh[s] = *reinterpret_cast<const h16x8*>(qkv_h + o + 16 * s); ql[s] = *reinterpret_cast<const h16x8*>(qkv_l + o + 16 * s); }
     };
+    if ((UU3D_ATTN_LOO) & 64) {
+#pragma unroll
+        for (int s = 0; s < KS; ++s)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { qh[s][e] = (_Float16)(0.01f * (float)(lane + e)); ql[s][e] = (_Float16)(float)e; }
+    } else
     load_q(w);
     for (int k = tid; k < Lpad; k += nthr) {
         const uint8_t mk = (MASKED && key_mask != nullptr) ? key_mask[tok0 + min(k, L - 1)] : (uint8_t)1;
@@ -196,9 +260,9 @@ attn_h3_kernel(const _Float16* __restrict__ qkv_h, const _Float16* __restrict__ 
                 const _Float16* kp = Kp + ((size_t)s * Lpad + 32 * kt + q31) * 16 + g * 8;
                 const h16x8 kh = *reinterpret_cast<const h16x8*>(kp);
                 const h16x8 kl = *reinterpret_cast<const h16x8*>(kp + (size_t)KS * Lpad * 16);
-                s0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh, qh[s], s0, 0, 0, 0);
-                s1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh, ql[s], s1, 0, 0, 0);
-                s1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(kl, qh[s], s1, 0, 0, 0);
+                s0 = UU3D_ATTN_MFMA(2, kh, qh[s], s0);
+                s1 = UU3D_ATTN_MFMA(2, kh, ql[s], s1);
+                s1 = UU3D_ATTN_MFMA(2, kl, qh[s], s1);
             }
             }
             // ---- online softmax ----
@@ -250,6 +314,11 @@ attn_h3_kernel(const _Float16* __restrict__ qkv_h, const _Float16* __restrict__ 
             h16x8 ph[2], pl[2];
 #pragma unroll
             for (int r = 0; r < 16; r += 2) {
+                if ((UU3D_ATTN_LOO) & 4) {
+                    const h16x2 hv = __builtin_bit_cast(h16x2, __builtin_amdgcn_cvt_pkrtz(t[r], t[r + 1]));
+                    ph[r >> 3][r & 7] = hv[0]; ph[r >> 3][(r & 7) + 1] = hv[1]; pl[r >> 3][r & 7] = hv[1]; pl[r >> 3][(r & 7) + 1] = hv[0];
+                    continue;
+                }
                 const float p0 = __builtin_amdgcn_exp2f(t[r]), p1 = __builtin_amdgcn_exp2f(t[r + 1]);
                 const h16x2 hv = __builtin_bit_cast(h16x2, __builtin_amdgcn_cvt_pkrtz(p0, p1));      // hi: any rounding will do, lo takes the rest
                 const h16x2 lv = __builtin_bit_cast(h16x2, __builtin_amdgcn_cvt_pkrtz((p0 - (float)hv[0]) * H3_SCALE, (p1 - (float)hv[1]) * H3_SCALE));
@@ -298,6 +367,7 @@ attn_h3_kernel(const _Float16* __restrict__ qkv_h, const _Float16* __restrict__ 
                 const unsigned aA = vA + ko, aB = (grp ? vB_ones : vB_real) + (grp ? 0u : ko);
                 typedef _Float16 h16x4v __attribute__((ext_vector_type(4)));
                 h16x4v a0, a1, a2, a3, b0, b1, b2, b3;             // tile A: hi keys 0-3 / 8-11, lo likewise; tile B the same
+                if ((UU3D_ATTN_LOO) & 32) { a0 = a1 = a2 = a3 = b0 = b1 = b2 = b3 = (h16x4v){ph[s][0], ph[s][1], pl[s][2], pl[s][3]}; } else {
                 asm volatile("ds_read_b64_tr_b16 %0, %4\n\tds_read_b64_tr_b16 %1, %4 offset:%6\n\t"
                              "ds_read_b64_tr_b16 %2, %4 offset:%5\n\tds_read_b64_tr_b16 %3, %4 offset:%7"
                              : "=&v"(a0), "=&v"(a1), "=&v"(a2), "=&v"(a3) : "v"(aA), "i"(DH * 2), "i"(8 * VROW * 2), "i"(8 * VROW * 2 + DH * 2) : "memory");
@@ -308,59 +378,21 @@ attn_h3_kernel(const _Float16* __restrict__ qkv_h, const _Float16* __restrict__ 
                              "ds_read_b64_tr_b16 %2, %6\n\tds_read_b64_tr_b16 %3, %7"
                              : "=&v"(b0), "=&v"(b1), "=&v"(b2), "=&v"(b3) : "v"(aB), "v"(aB8), "v"(aB + lo_off), "v"(aB8 + lo_off) : "memory");
                 asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(b0), "+v"(b1), "+v"(b2), "+v"(b3) :: "memory");
+                }
                 const h16x8 vAh = (h16x8){a0[0], a0[1], a0[2], a0[3], a1[0], a1[1], a1[2], a1[3]};
                 const h16x8 vAl = (h16x8){a2[0], a2[1], a2[2], a2[3], a3[0], a3[1], a3[2], a3[3]};
                 const h16x8 vBh = (h16x8){b0[0], b0[1], b0[2], b0[3], b1[0], b1[1], b1[2], b1[3]};
                 const h16x8 vBl = (h16x8){b2[0], b2[1], b2[2], b2[3], b3[0], b3[1], b3[2], b3[3]};
-                oA0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(vAh, ph[s], oA0, 0, 0, 0);
-                oA1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(vAh, pl[s], oA1, 0, 0, 0);
-                oA1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(vAl, ph[s], oA1, 0, 0, 0);
-                oB0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(vBh, ph[s], oB0, 0, 0, 0);
-                oB1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(vBh, pl[s], oB1, 0, 0, 0);
-                oB1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(vBl, ph[s], oB1, 0, 0, 0);
+                oA0 = UU3D_ATTN_MFMA(8, vAh, ph[s], oA0);
+                oA1 = UU3D_ATTN_MFMA(8, vAh, pl[s], oA1);
+                oA1 = UU3D_ATTN_MFMA(8, vAl, ph[s], oA1);
+                oB0 = UU3D_ATTN_MFMA(8, vBh, ph[s], oB0);
+                oB1 = UU3D_ATTN_MFMA(8, vBh, pl[s], oB1);
+                oB1 = UU3D_ATTN_MFMA(8, vBl, ph[s], oB1);
             }
         }
         if (MAXW == 8 && qt + NW < NT) load_q(qt + NW);         // (the other instantiations are launched with one wave per tile)
-        // ---- normalise, split, store: lane (query, g) holds channels 32 t + 8 j + 4 g + (0..3); rows 16 + 4 g of the second
-        // tile (register 8) are the ones-row product = the row sum l, with the same 2^14 factor as every other row ----
-        const float rl = 1.0f / (oB0[8] + oB1[8] * (1.0f / H3_SCALE));
-        const int q = 32 * qt + q31;
-        // row-major planes: row * ldo + channel.  Fragment order: a 16-byte piece = 8 consecutive channels of one row, the pieces of 32
-        // consecutive rows are contiguous (512 B): [32-row panel][16-channel slice][plane][channel half][row & 31][8]
-        const size_t grow = tok0 + min(q, L - 1);
-        _Float16* orow = frag ? out + (size_t)(grow >> 5) * (size_t)(ldo >> 4) * 1024 + (grow & 31) * 8
-                              : out + grow * ldo + h * DH;
-        auto pack4 = [&](const f32x16& a0, const f32x16& a1, int j, unsigned (&hi2)[2], unsigned (&lo2)[2]) {
-            _Float16 hh[4], ll[4];
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const float v = (a0[4 * j + i] + a1[4 * j + i] * (1.0f / H3_SCALE)) * rl;
-                hh[i] = h3_hi(v);
-                ll[i] = (_Float16)((v - (float)hh[i]) * H3_SCALE);
-            }
-            hi2[0] = __builtin_bit_cast(unsigned, (h16x2){hh[0], hh[1]}); hi2[1] = __builtin_bit_cast(unsigned, (h16x2){hh[2], hh[3]});
-            lo2[0] = __builtin_bit_cast(unsigned, (h16x2){ll[0], ll[1]}); lo2[1] = __builtin_bit_cast(unsigned, (h16x2){ll[2], ll[3]});
-        };
-        // blocks (j, j + 1) of 8 channels: after the swap lane g = 0 owns all 16 bytes of block j, lane g = 1 those of block j + 1
-        auto store_pair = [&](const f32x16& a0, const f32x16& a1, int j, int ch0) {
-            unsigned xh[2], xl[2], yh[2], yl[2];
-            pack4(a0, a1, j, xh, xl); pack4(a0, a1, j + 1, yh, yl);
-            unsigned oh[4], ol[4];
-#pragma unroll
-            for (int e = 0; e < 2; ++e) {
-                const u32x2 sh = __builtin_amdgcn_permlane32_swap(xh[e], yh[e], false, false);
-                const u32x2 sl = __builtin_amdgcn_permlane32_swap(xl[e], yl[e], false, false);
-                oh[e] = sh[0]; oh[2 + e] = sh[1]; ol[e] = sl[0]; ol[2 + e] = sl[1];
-            }
-            if (q < L) {
-                typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-                const int chn = h * DH + ch0 + 8 * (j + g);         // first of the piece's 8 channels
-                _Float16* d = frag ? orow + (size_t)(chn >> 4) * 1024 + ((chn >> 3) & 1) * 256 : orow + ch0 + 8 * (j + g);
-                *reinterpret_cast<u32x4*>(d) = (u32x4){oh[0], oh[1], oh[2], oh[3]};
-                *reinterpret_cast<u32x4*>(d + lo_off) = (u32x4){ol[0], ol[1], ol[2], ol[3]};
-            }
-        };
-        store_pair(oA0, oA1, 0, 0); store_pair(oA0, oA1, 2, 0); store_pair(oB0, oB1, 0, 32);
+        attn_h3_store_tile<DH>(oA0, oA1, oB0, oB1, qt, q31, g, h, L, tok0, out, lo_off, ldo, frag);
     }
 }
 
