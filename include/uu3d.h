@@ -34,7 +34,7 @@ extern "C" {
 typedef enum uu3d_status {
     UU3D_OK = 0,
     UU3D_ERR_INVALID_ARGUMENT = 1, /* NULL pointer, bad size, unknown weight name ...        */
-    UU3D_ERR_UNSUPPORTED = 2,      /* config is schema-legal but outside the compiled kernels */
+    UU3D_ERR_UNSUPPORTED = 2,      /* config is schema-legal but outside the compiled / generic kernels */
     UU3D_ERR_SHAPE = 3,            /* tensor element count does not match the model           */
     UU3D_ERR_NOT_READY = 4,        /* forward before every weight was set and committed       */
     UU3D_ERR_WORKSPACE = 5,        /* workspace too small / misaligned                        */
@@ -98,6 +98,10 @@ const char* uu3d_last_error(const uu3d_model* model);
  * Replaces: build_uplift_upsample_transformer(config) -> model
  * (uplift_upsample_transformer_constructor.py:14-50).  Creates the model on HIP device
  * `device` with all weight storage allocated but unset.
+ * The specialised kernels are compiled for J = 17, SPATIAL_EMBED_DIM 32, TEMPORAL_EMBED_DIM 384, NUM_HEADS 8, MLP_RATIO 2 (every
+ * shipped config).  Other dims the constructor accepts (:26-32) give a handle whose forward (uu3d_forward_ex) runs on generic,
+ * untuned kernels: head dims in {2, 4, 8, 12, 16, 24, 32, 48, 64}, <= 128 keypoints, <= 96 frames, >= 1 temporal and strided
+ * block, the full-sequence head, no OUTPUT_BN; no attention-weight output, no backward pass.  Outside that: UU3D_ERR_UNSUPPORTED.
  */
 int uu3d_create(const uu3d_config* config, int device, uu3d_model** out_model);
 void uu3d_destroy(uu3d_model* model);

@@ -98,6 +98,11 @@ struct uu3d_model {
     std::map<std::string, int> index;
     std::vector<int> L;            // strided lengths L_0 .. L_ns
     bool committed = false;
+    // Dims other than the compiled ones (J = 17, d_s = 32, h_s = 64, 8 heads, d_t = 384): the forward runs on the GENERIC kernels of the
+    // training-mode chain (uu3d_train_step.inc: tiled GEMMs with LayerNorm / GELU loaders, attn_generic_fwd_kernel, one launch per layer)
+    // from a master buffer the model owns -- correct and an order of magnitude slower than the specialised path; no backward pass.
+    bool generic = false;
+    float* gparams = nullptr;      // generic: master parameter buffer (uu3d_train_init layout)
     float* arena = nullptr;        // packed device weights
     size_t arena_floats = 0;
     bool no_mlpf = false;          // UU3D_NO_MLPF=1: fc1 and fc2 of the temporal blocks as two GEMM launches (A/B measurements, tests)
@@ -276,16 +281,27 @@ int uu3d_create(const uu3d_config* c, int device, uu3d_model** out) {
     if (c->num_frames < 1 || c->num_keypoints < 1 || c->num_strided < 0 || c->num_strided > UU3D_MAX_STRIDED)
         return fail(nullptr, UU3D_ERR_INVALID_ARGUMENT, "bad num_frames/num_keypoints/num_strided");
     if (c->precision != UU3D_PREC_F32 && c->precision != UU3D_PREC_F16X3) return fail(nullptr, UU3D_ERR_UNSUPPORTED, "unknown precision");
-    // limits of the compiled kernels (all shipped configs satisfy them)
-    if (c->spatial_depth < 1 || c->num_keypoints != kJ || c->d_spatial != kDS || c->h_spatial != kHS ||
-        c->num_heads != kHeads)
-        return fail(nullptr, UU3D_ERR_UNSUPPORTED,
-                    "spatial stack is compiled for J=17, d_s=32, h_s=64, 8 heads, depth>=1");
-    if (c->d_temporal != kDH * kHeads)
-        return fail(nullptr, UU3D_ERR_UNSUPPORTED, "temporal attention is compiled for head dim 48 (d_t = 384)");
+    if (c->spatial_depth < 1) return fail(nullptr, UU3D_ERR_UNSUPPORTED, "spatial_depth must be >= 1");
+    if (c->temporal_depth < 0) return fail(nullptr, UU3D_ERR_INVALID_ARGUMENT, "temporal_depth < 0");
+    // the specialised kernels (all shipped configs): J = 17, d_s = 32, h_s = 64, 8 heads, d_t = 384.  Anything else the reference's constructor
+    // accepts (SPATIAL_EMBED_DIM / TEMPORAL_EMBED_DIM / NUM_HEADS / MLP ratios, u_u_t_constructor.py:26-32) runs on the generic forward.
+    const bool generic = c->num_keypoints != kJ || c->d_spatial != kDS || c->h_spatial != kHS || c->num_heads != kHeads || c->d_temporal != kDH * kHeads;
+    if (generic) {
+        if (c->num_heads < 1 || c->d_spatial < 1 || c->d_temporal < 1 || c->h_spatial < 1 || c->h_temporal < 1)
+            return fail(nullptr, UU3D_ERR_INVALID_ARGUMENT, "dims and head count must be positive");
+        if (c->d_spatial % c->num_heads != 0 || c->d_temporal % c->num_heads != 0)
+            return fail(nullptr, UU3D_ERR_INVALID_ARGUMENT, "embed dims must be divisible by NUM_HEADS (vision_transformer.py:79)");
+        if (!attn_generic_head_dim_ok(c->d_spatial / c->num_heads) || !attn_generic_head_dim_ok(c->d_temporal / c->num_heads))
+            return fail(nullptr, UU3D_ERR_UNSUPPORTED, "generic forward: head dims (embed dim / NUM_HEADS) must be one of 2, 4, 8, 12, 16, 24, 32, 48, 64");
+        if (c->num_keypoints > 128 || c->num_frames > 96)
+            return fail(nullptr, UU3D_ERR_UNSUPPORTED, "generic forward: at most 128 keypoints and 96 frames");
+        if (c->temporal_depth < 1 || c->num_strided < 1 || !c->full_output)
+            return fail(nullptr, UU3D_ERR_UNSUPPORTED, "generic forward: needs at least one temporal block, one strided block and the full-sequence head");
+        if (c->output_bn)
+            return fail(nullptr, UU3D_ERR_UNSUPPORTED, "generic forward: OUTPUT_BN is not implemented (inference-mode statistics live in the specialised path)");
+    }
     if (c->h_temporal % 4 != 0 || c->h_temporal < 4)
         return fail(nullptr, UU3D_ERR_UNSUPPORTED, "h_temporal must be a positive multiple of 4");
-    if (c->temporal_depth < 0) return fail(nullptr, UU3D_ERR_INVALID_ARGUMENT, "temporal_depth < 0");
     // temporal_depth == 0 (u_u_t.py:356,372-380): the strided blocks follow the token blend directly and the FIRST one takes the key
     // mask; the reference hands the same (B, 1, 1, N) mask to every strided block below FIRST_STRIDED_TOKEN_ATTENTION_LAYER, which only
     // has the right shape for the first (N keys)
@@ -301,6 +317,7 @@ int uu3d_create(const uu3d_config* c, int device, uu3d_model** out) {
     auto* m = new uu3d_model();
     m->cfg = *c;
     m->device = device;
+    m->generic = generic;
     m->L.push_back(c->num_frames);
     for (int i = 0; i < c->num_strided; ++i) {
         if (c->strides[i] < 1 || c->pad_left[i] < 0 || c->pad_right[i] < 0) {
@@ -341,10 +358,13 @@ int uu3d_create(const uu3d_config* c, int device, uu3d_model** out) {
 }
 
 static void train_free(uu3d_model* m);
+static int generic_forward(uu3d_model* m, const float* kp2d, const uint8_t* mask, int32_t B, float* full_out, float* central_out,
+                           void* workspace, size_t workspace_bytes, void* stream);      // uu3d_train_step.inc
 void uu3d_destroy(uu3d_model* m) {
     if (!m) return;
     (void)hipSetDevice(m->device);
     train_free(m);
+    if (m->gparams) (void)hipFree(m->gparams);
     if (m->arena) (void)hipFree(m->arena);
     if (m->harena) (void)hipFree(m->harena);
     for (auto& r : m->prof) { (void)hipEventDestroy(r.e0); (void)hipEventDestroy(r.e1); }
@@ -394,6 +414,20 @@ int uu3d_commit_weights(uu3d_model* m, void* stream_) {
         if (!r.set) return fail(m, UU3D_ERR_NOT_READY, "weight never set: " + r.name);
     hipStream_t stream = (hipStream_t)stream_;
     HIPCHK(m, hipSetDevice(m->device));
+    if (m->generic) {
+        // generic dims: the forward reads the master buffer and the operand packs of the training-mode chain (uu3d_train_init; called again it
+        // re-uploads the weights and repacks)
+        if (m->gparams == nullptr) {
+            long long n = 0;
+            for (auto& r : m->weights) n += r.numel;
+            HIPCHK(m, hipMalloc((void**)&m->gparams, (size_t)n * sizeof(float)));
+        }
+        const int r = uu3d_train_init(m, m->gparams, stream_);
+        if (r != UU3D_OK) return r;
+        HIPCHK(m, hipStreamSynchronize(stream));
+        m->committed = true;
+        return UU3D_OK;
+    }
     const uu3d_config& c = m->cfg;
     const int J = c.num_keypoints, N = c.num_frames, ds = c.d_spatial, dt = c.d_temporal, ht = c.h_temporal;
     const int Kdt = round_up(dt, 32), Kht = round_up(ht, 32), Ks2t = round_up(J * ds, 32);
@@ -706,6 +740,7 @@ Workspace carve(const uu3d_model* m, int B, char* base) {
 
 size_t uu3d_workspace_bytes(const uu3d_model* m, int32_t batch) {
     if (!m || batch < 1) return 0;
+    if (m->generic) return uu3d_train_workspace_bytes(m, batch);     // the generic forward keeps the training chain's activations
     return carve(m, batch, nullptr).bytes;
 }
 
@@ -1145,6 +1180,12 @@ int uu3d_forward_ex(uu3d_model* m, const float* kp2d, const uint8_t* mask, int32
     const bool has_h1 = c.full_output && c.temporal_depth > 0;
     if (has_h1 && !full_out) return fail(m, UU3D_ERR_INVALID_ARGUMENT, "full_out_dev is required for this model");
     if (((uintptr_t)workspace & 255) != 0) return fail(m, UU3D_ERR_WORKSPACE, "workspace must be 256-byte aligned");
+    if (m->generic) {
+        // dims other than the compiled ones: the training-mode chain, forward only, with every stochastic layer off (no DropPath draws, no token
+        // mask, Dropout rates 0): vit / u_u_t in inference mode
+        if (attn_out != nullptr) return fail(m, UU3D_ERR_UNSUPPORTED, "generic forward: attention weights are not returned");
+        return generic_forward(m, kp2d, mask, B, full_out, central_out, workspace, workspace_bytes, stream_);
+    }
     Workspace w = carve(m, B, (char*)workspace);
     if (workspace_bytes < w.bytes) return fail(m, UU3D_ERR_WORKSPACE, "workspace smaller than uu3d_workspace_bytes(batch)");
     if ((long)B * c.num_frames * c.num_keypoints > (1L << 30)) return fail(m, UU3D_ERR_INVALID_ARGUMENT, "batch too large");

@@ -185,12 +185,29 @@ inline int launch_ln_bwd(const float* x, const float* dy, const float2* stats, c
     return hip_status();
 }
 
+// head dims the generic forward kernel is instantiated for (launch_attn_generic)
+inline bool attn_generic_head_dim_ok(int dh) { return dh == 2 || dh == 4 || dh == 8 || dh == 12 || dh == 16 || dh == 24 || dh == 32 || dh == 48 || dh == 64; }
+
 // drop: Dropout on the attention weights (training with ATTENTION_DROP_RATE > 0) -- only the generic kernels implement it, so the
 // unrolled / MFMA backward kernels are not taken then
 inline int launch_attn_generic(bool backward, const float* qkv, const float* dO, int ld, int D, int B, int L, int H, int dh,
                                const uint8_t* mask, float* out, int ldo, hipStream_t stream, const DropCfg drop = DropCfg{}) {
     const int total = B * H;
     const dim3 block(128);
+    if (dh != 4 && dh != 48) {
+        // other head dims (generic-dims models, uu3d_create): forward only, thread = query row, one (sequence, head) per workgroup
+        if (backward || L > 128) return UU3D_ERR_UNSUPPORTED;
+        const dim3 grid(total);
+#define UU3D_ATTNG_CASE(d) case d: { static bool done##d = false; \
+            if (!done##d) { (void)hipFuncSetAttribute((const void*)attn_generic_fwd_kernel<d>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); done##d = true; } \
+            hipLaunchKernelGGL(attn_generic_fwd_kernel<d>, grid, block, attn_generic_lds_bytes<d>(L, false), stream, qkv, ld, D, L, H, mask, out, ldo, 1, total, drop); } break;
+        switch (dh) {
+            UU3D_ATTNG_CASE(2) UU3D_ATTNG_CASE(8) UU3D_ATTNG_CASE(12) UU3D_ATTNG_CASE(16) UU3D_ATTNG_CASE(24) UU3D_ATTNG_CASE(32) UU3D_ATTNG_CASE(64)
+            default: return UU3D_ERR_UNSUPPORTED;
+        }
+#undef UU3D_ATTNG_CASE
+        return hip_status();
+    }
     if (dh == 4) {
         const int pack = std::max(1, 128 / L);                         // (sequence, head) pairs per workgroup
         const dim3 grid((total + pack - 1) / pack);
