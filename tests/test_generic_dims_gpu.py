@@ -67,6 +67,33 @@ def test_generic_dims_forward_matches_oracle(name, precision):
     assert np.array_equal(f2.cpu().numpy(), full) and np.array_equal(c2.cpu().numpy(), central)
 
 
+@pytest.mark.parametrize("n,strides,batch", [(125, [5, 5, 5], 2), (9, [3, 3], 5)])
+def test_generic_dims_output_bn_and_long_sequences(n, strides, batch):
+    """OUTPUT_BN in inference mode (moving statistics, u_u_t.py:400-404,414-416) and the longest sequences the generic forward takes."""
+    from oracle import uplift_oracle as O
+    cfg = _config(17, 16, 96, 4, n, strides, mask_stride=[5, 25, 2])
+    cfg.OUTPUT_BN = True
+    arch = pkg.arch_from_config(cfg)
+    w = pkg.init_weights(arch, seed=4, perturb=0.1)
+    rng = np.random.default_rng(4)
+    for k in w:
+        if k.endswith("moving_mean"):
+            w[k] = rng.normal(0, 0.3, w[k].shape).astype(np.float32)
+        if k.endswith("moving_variance"):
+            w[k] = rng.uniform(0.5, 2.0, w[k].shape).astype(np.float32)
+    model = pkg.build_uplift_upsample_transformer(cfg, weights=w)
+    x, m = util.synthetic_batch(cfg, batch=batch, seed=9)
+    xin = x * m[:, :, None, None].astype(np.float32)
+    full, central = model([torch.from_numpy(xin).cuda(), torch.from_numpy(m).cuda()], training=False)
+    torch.cuda.synchronize()
+    f32, c32 = O.forward(util.hp_from_arch(arch), w, xin, m, torch.float32)
+    err = max(np.abs(full.cpu().numpy() - f32).max(), np.abs(central.cpu().numpy() - c32).max())
+    print(f"OUTPUT_BN, {n} frames: max-abs vs oracle {err:.3e}")
+    assert err <= util.TOL_MAX_ABS
+    got = model.get_weights_dict()
+    assert all(np.array_equal(got[k], w[k]) for k in w if "moving" in k)       # inference mode writes nothing
+
+
 def test_generic_dims_weights_round_trip_and_reassign():
     """set_weights / assign on a generic-dims model re-commits (master buffer re-uploaded, operands repacked): the next forward uses them."""
     from oracle import uplift_oracle as O
@@ -90,11 +117,28 @@ def test_generic_dims_weights_round_trip_and_reassign():
         assert max(np.abs(full.cpu().numpy() - f32).max(), np.abs(central.cpu().numpy() - c32).max()) <= util.TOL_MAX_ABS
 
 
+def test_generic_dims_through_the_pipeline():
+    """Several batches in flight (pipeline.ForwardPipeline: one hipGraph per slot) on a generic-dims handle: the same bits as model(...)."""
+    J, d_s, d_t, heads, n, strides, ratio, ms = CASES["small_heads4"]
+    cfg = _config(J, d_s, d_t, heads, n, strides, ratio, mask_stride=ms)
+    arch = pkg.arch_from_config(cfg)
+    model = pkg.build_uplift_upsample_transformer(cfg, weights=pkg.init_weights(arch, seed=3, perturb=0.1))
+    pipe = model.pipeline(6, depth=3)
+    batches = []
+    for i in range(7):
+        x, m = util.synthetic_batch(cfg, batch=6, seed=20 + i)
+        batches.append((torch.from_numpy(x * m[:, :, None, None].astype(np.float32)).cuda(), torch.from_numpy(m).cuda()))
+    outs = [(full.clone(), central.clone()) for full, central in pipe.run(batches)]      # results in order, three batches in flight
+    torch.cuda.synchronize()
+    for (xt, mt), (full, central) in zip(batches, outs):
+        f, c = model([xt, mt], training=False)
+        assert torch.equal(f, full) and torch.equal(c, central)
+
+
 def test_generic_dims_limits_are_stated():
     """What the generic forward does not do fails loudly at construction / at the call, never silently."""
-    cfg = _config(17, 16, 64, 4, 9, [3, 3])
-    cfg.OUTPUT_BN = True
-    with pytest.raises(Exception, match="OUTPUT_BN"):
+    cfg = _config(17, 16, 64, 4, 243, [3, 3, 3, 3, 3])        # 243 frames
+    with pytest.raises(Exception, match="128 frames"):
         pkg.build_uplift_upsample_transformer(cfg)
     cfg = _config(17, 40, 80, 8, 9, [3, 3])                   # head dims 5 / 10: no instantiation
     with pytest.raises(Exception, match="head dims"):

@@ -293,12 +293,10 @@ int uu3d_create(const uu3d_config* c, int device, uu3d_model** out) {
             return fail(nullptr, UU3D_ERR_INVALID_ARGUMENT, "embed dims must be divisible by NUM_HEADS (vision_transformer.py:79)");
         if (!attn_generic_head_dim_ok(c->d_spatial / c->num_heads) || !attn_generic_head_dim_ok(c->d_temporal / c->num_heads))
             return fail(nullptr, UU3D_ERR_UNSUPPORTED, "generic forward: head dims (embed dim / NUM_HEADS) must be one of 2, 4, 8, 12, 16, 24, 32, 48, 64");
-        if (c->num_keypoints > 128 || c->num_frames > 96)
-            return fail(nullptr, UU3D_ERR_UNSUPPORTED, "generic forward: at most 128 keypoints and 96 frames");
+        if (c->num_keypoints > 128 || c->num_frames > 128)
+            return fail(nullptr, UU3D_ERR_UNSUPPORTED, "generic forward: at most 128 keypoints and 128 frames");
         if (c->temporal_depth < 1 || c->num_strided < 1 || !c->full_output)
             return fail(nullptr, UU3D_ERR_UNSUPPORTED, "generic forward: needs at least one temporal block, one strided block and the full-sequence head");
-        if (c->output_bn)
-            return fail(nullptr, UU3D_ERR_UNSUPPORTED, "generic forward: OUTPUT_BN is not implemented (inference-mode statistics live in the specialised path)");
     }
     if (c->h_temporal % 4 != 0 || c->h_temporal < 4)
         return fail(nullptr, UU3D_ERR_UNSUPPORTED, "h_temporal must be a positive multiple of 4");

@@ -271,6 +271,15 @@ bn_stats_kernel(const float* __restrict__ sum, const float* __restrict__ sumsq, 
     moving_mean[c] = moving_mean[c] * momentum + m * (1.0f - momentum);
     moving_var[c] = moving_var[c] * momentum + v * (1.0f - momentum);
 }
+// inference-mode BatchNormalization (u_u_t.py:400-404,414-416 with training=False): mean / 1 / sqrt(var + eps) from the moving statistics
+static __global__ void __launch_bounds__(256)
+bn_moving_stats_kernel(const float* __restrict__ moving_mean, const float* __restrict__ moving_var, const float eps, const int D,
+                       float* __restrict__ mean, float* __restrict__ rstd)
+{
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= D) return;
+    mean[c] = moving_mean[c]; rstd[c] = 1.0f / sqrtf(moving_var[c] + eps);
+}
 static __global__ void __launch_bounds__(256)
 bn_apply_kernel(const float* __restrict__ x, const float* __restrict__ mean, const float* __restrict__ rstd, const float* __restrict__ gamma,
                 const float* __restrict__ beta, const long long n, const int D, float* __restrict__ y)
