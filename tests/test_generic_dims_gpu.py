@@ -144,7 +144,83 @@ def test_generic_dims_limits_are_stated():
     with pytest.raises(Exception, match="head dims"):
         pkg.build_uplift_upsample_transformer(cfg)
     cfg = _config(17, 16, 64, 4, 9, [3, 3])
-    model = pkg.build_uplift_upsample_transformer(cfg)
+    model = pkg.build_uplift_upsample_transformer(cfg, return_attention=True)
+    x = torch.zeros((1, 9, 17, 2), device="cuda")
+    with pytest.raises(Exception, match="attention weights"):
+        model(x, training=False)
+
+
+GRAD_CASES = {
+    # name: (J, d_s, d_t, heads, N, strides, mlp_ratio, mask strides, regularisers)
+    "j8_heads16": (8, 32, 192, 16, 9, [3, 3], 2.0, None, False),            # 3 J = 24: head gradients padded to 32 columns
+    "j25_heads4": (25, 16, 64, 4, 27, [3, 3, 3], 2.0, [3, 9, 2], False),    # 3 J = 75: padded to 96
+    "heads3_j13": (13, 24, 96, 3, 27, [3, 3, 3], 2.0, [3, 9, 2], True),     # DropPath in all stacks + Dropout + token masking
+    "wide_mlp": (17, 32, 192, 8, 25, [5, 5], 4.0, [5, 25, 3], False),
+    "heads2_dh64": (17, 128, 128, 2, 9, [3, 3], 1.0, None, True),
+}
+
+
+@pytest.mark.parametrize("name", sorted(GRAD_CASES))
+def test_generic_dims_gradients_match_autograd(name):
+    """The training step on dims other than the compiled ones: every gradient tensor against float64 autograd through the oracle
+    (<= 1e-4 of its scale, as tests/test_train_step_gpu.py asks of the shipped configs), then one optimizer step."""
+    from oracle import train_oracle as T
     from uplift_upsample_3dhpe_amd.trainer import Trainer
-    with pytest.raises(NotImplementedError, match="backward"):
-        Trainer(model, cfg)
+    J, d_s, d_t, heads, n, strides, ratio, ms, regularised = GRAD_CASES[name]
+    cfg = _config(J, d_s, d_t, heads, n, strides, ratio, mask_stride=ms)
+    cfg.BATCH_SIZE = 4
+    cfg.DROP_PATH_RATE = [0.1, 0.1, 0.3] if regularised else [0.0, 0.0, 0.0]
+    if regularised:
+        cfg.DROP_RATE, cfg.ATTENTION_DROP_RATE = 0.1, 0.15
+        cfg.TOKEN_MASK_RATE = 0.25 if ms is not None else 0.0
+    arch = pkg.arch_from_config(cfg)
+    # (j25_heads4 with seed 7: ONE hidden unit of temporal block 1 sits within rounding of the ReLU's zero at one token and flips against the
+    # float64 oracle -- column 100 of fc1's kernel gradient is off by 2.6e-3, everything else <= 4e-6; the same effect as documented for the
+    # shipped configs in tests/test_train_step_gpu.py.  Another draw for that case.)
+    w = pkg.init_weights(arch, seed=8 if name == "j25_heads4" else 7, perturb=0.1)
+    model = pkg.build_uplift_upsample_transformer(cfg, weights=w)
+    B = 3
+    rng = np.random.default_rng(5)
+    x = rng.uniform(-1, 1, size=(B, n, J, 2)).astype(np.float32)
+    gt = rng.normal(0, 0.3, size=(B, n, J, 3)).astype(np.float32)
+    m = np.stack([util.eval_stride_mask(n, cfg.SEQUENCE_STRIDE, ms[b % 2], 0) for b in range(B)]) if arch.has_strided_input else None
+    tr = Trainer(model, cfg)
+    u = rng.random(tr.drop_path_size(B)).astype(np.float32) if regularised else None
+    tmu = rng.random((B, n)).astype(np.float32) if arch.token_mask_rate > 0 else None
+    seed = 0x5EED5EED1234 if regularised else None
+    loss, full, central = tr.forward_backward(torch.from_numpy(x).cuda(), torch.from_numpy(gt).cuda(), None if m is None else torch.from_numpy(m).cuda(),
+                                              drop_path_uniform=None if u is None else torch.from_numpy(u).cuda(),
+                                              token_mask_uniform=None if tmu is None else torch.from_numpy(tmu).cuda(), dropout_seed=seed)
+    torch.cuda.synchronize()
+    dp = None
+    if regularised:
+        ns_, nt_ = arch.spatial_depth * 2 * B * n, arch.temporal_depth * 2 * B
+        dp = dict(rates=tuple(cfg.DROP_PATH_RATE), u_spatial=u[:ns_].reshape(arch.spatial_depth, 2, B * n), u_temporal=u[ns_:ns_ + nt_].reshape(arch.temporal_depth, 2, B),
+                  u_strided=u[ns_ + nt_:].reshape(len(arch.strides), 2, B))
+    ref, gref, fref, cref = T.train_step_grads(util.hp_from_arch(arch), w, x, m if m is not None else np.ones((B, n), bool), gt, cfg.ROOT_KEYTPOINT,
+                                               cfg.LOSS_WEIGHT_CENTER, cfg.LOSS_WEIGHT_SEQUENCE, cfg.BATCH_SIZE, dp,
+                                               token_mask_cfg=None if tmu is None else dict(rate=arch.token_mask_rate, u=tmu),
+                                               dropout_cfg=None if seed is None else dict(rate=0.1, attn_rate=0.15, seed=seed))
+    assert float(loss.cpu()[0]) == pytest.approx(ref["loss"], rel=2e-5)
+    assert max(np.abs(full.cpu().numpy() - fref).max(), np.abs(central.cpu().numpy() - cref).max()) <= util.TOL_MAX_ABS
+    g = tr.grads_dict()
+    gmax = max(np.abs(v).max() for v in gref.values())
+    worst = ("", 0.0)
+    for k in gref:
+        scale = max(np.abs(gref[k]).max(), 1e-4 * gmax)
+        if k.endswith("/attn/wk/bias") and np.abs(gref[k]).max() < 1e-12 * gmax:      # structurally zero (softmax shift invariance), see test_train_step_gpu.py
+            scale = max(scale, np.abs(gref[k.replace("/bias", "/kernel")]).max())
+        e = np.abs(g[k] - gref[k]).max() / scale
+        if e > worst[1]:
+            worst = (k, e)
+    print(f"{name}: loss {float(loss.cpu()[0]):.6f}; worst relative gradient error {worst[1]:.2e} at {worst[0]}")
+    if worst[1] > 1e-4:
+        k = worst[0]
+        d = np.abs(g[k] - gref[k]) / max(np.abs(gref[k]).max(), 1e-4 * gmax)
+        print(f"   {k}: shape {d.shape}, elements over 1e-4: {(d > 1e-4).sum()} of {d.size}, in columns {sorted(set(np.argwhere(d > 1e-4)[:, -1].tolist()))[:10]}")
+    assert worst[1] <= 1e-4, worst
+    p0 = tr.params.clone()
+    tr.train_step(torch.from_numpy(x).cuda(), torch.from_numpy(gt).cuda(), None if m is None else torch.from_numpy(m).cuda(),
+                  drop_path_uniform=None if u is None else torch.from_numpy(u).cuda(), token_mask_uniform=None if tmu is None else torch.from_numpy(tmu).cuda())
+    torch.cuda.synchronize()
+    assert tr.global_step == 1 and not torch.equal(tr.params, p0) and bool(torch.isfinite(tr.params).all())

@@ -53,8 +53,8 @@ class UpliftArch:
     @property
     def compiled_dims(self) -> bool:
         """The dims the specialised HIP kernels are compiled for (every shipped config/*.json).  Anything else the reference's
-        constructor accepts (u_u_t_constructor.py:26-32) runs the forward on the library's generic kernels -- correct, much slower,
-        no backward pass (csrc/uu3d_api.hip: uu3d_create)."""
+        constructor accepts (u_u_t_constructor.py:26-32) runs on the library's generic kernels -- forward and training step, correct
+        and untuned (csrc/uu3d_api.hip: uu3d_create)."""
         return (self.num_keypoints == 17 and self.d_spatial == 32 and self.h_spatial == 64 and self.num_heads == 8
                 and self.d_temporal == 384)
 

@@ -195,12 +195,15 @@ inline int launch_attn_generic(bool backward, const float* qkv, const float* dO,
     const int total = B * H;
     const dim3 block(128);
     if (dh != 4 && dh != 48) {
-        // other head dims (generic-dims models, uu3d_create): forward only, thread = query row, one (sequence, head) per workgroup
-        if (backward || L > 128) return UU3D_ERR_UNSUPPORTED;
+        // other head dims (generic-dims models, uu3d_create): thread = query row, one (sequence, head) per workgroup
+        if (L > 128) return UU3D_ERR_UNSUPPORTED;
         const dim3 grid(total);
 #define UU3D_ATTNG_CASE(d) case d: { static bool done##d = false; \
-            if (!done##d) { (void)hipFuncSetAttribute((const void*)attn_generic_fwd_kernel<d>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); done##d = true; } \
-            hipLaunchKernelGGL(attn_generic_fwd_kernel<d>, grid, block, attn_generic_lds_bytes<d>(L, false), stream, qkv, ld, D, L, H, mask, out, ldo, 1, total, drop); } break;
+            if (!done##d) { (void)hipFuncSetAttribute((const void*)attn_generic_fwd_kernel<d>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
+                            (void)hipFuncSetAttribute((const void*)attn_generic_bwd_kernel<d>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); done##d = true; } \
+            if (attn_generic_lds_bytes<d>(L, backward) > (size_t)160 * 1024) return UU3D_ERR_UNSUPPORTED; \
+            if (backward) hipLaunchKernelGGL(attn_generic_bwd_kernel<d>, grid, block, attn_generic_lds_bytes<d>(L, true), stream, qkv, dO, ld, D, L, H, mask, out, ldo, 1, total, drop); \
+            else hipLaunchKernelGGL(attn_generic_fwd_kernel<d>, grid, block, attn_generic_lds_bytes<d>(L, false), stream, qkv, ld, D, L, H, mask, out, ldo, 1, total, drop); } break;
         switch (dh) {
             UU3D_ATTNG_CASE(2) UU3D_ATTNG_CASE(8) UU3D_ATTNG_CASE(12) UU3D_ATTNG_CASE(16) UU3D_ATTNG_CASE(24) UU3D_ATTNG_CASE(32) UU3D_ATTNG_CASE(64)
             default: return UU3D_ERR_UNSUPPORTED;

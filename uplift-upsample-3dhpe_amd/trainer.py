@@ -23,9 +23,6 @@ class Trainer(object):
         self.model, self.config = model, config
         self._lib = model._lib
         bad = training_unsupported(model.arch)
-        if not model.arch.compiled_dims:
-            bad = bad + ["dims other than J = 17, SPATIAL_EMBED_DIM = 32, TEMPORAL_EMBED_DIM = 384, NUM_HEADS = 8, MLP_RATIO = 2 (the backward pass "
-                         "is compiled for these; the forward runs on generic kernels)"]
         if bad:
             raise NotImplementedError("training with " + "; ".join(bad) + " is not implemented (the reference would train a "
                                       "different model than this step computes)")
