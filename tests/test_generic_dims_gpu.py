@@ -18,6 +18,7 @@ def _config(J, d_s, d_t, heads, n, strides, mlp_ratio=2.0, spatial=2, temporal=2
     cfg.SEQUENCE_LENGTH, cfg.STRIDES, cfg.PADDINGS, cfg.MLP_RATIO = n, list(strides), None, mlp_ratio
     cfg.SPATIAL_TRANSFORMER_BLOCKS, cfg.TEMPORAL_TRANSFORMER_BLOCKS = spatial, temporal
     cfg.MASK_STRIDE = mask_stride
+    cfg.ROOT_KEYTPOINT = min(int(cfg.ROOT_KEYTPOINT), J - 1)         # (the loss centres the ground truth on this joint)
     return cfg
 
 
@@ -117,6 +118,101 @@ def test_generic_dims_weights_round_trip_and_reassign():
         assert max(np.abs(full.cpu().numpy() - f32).max(), np.abs(central.cpu().numpy() - c32).max()) <= util.TOL_MAX_ABS
 
 
+def _random_case(rng):
+    heads = int(rng.choice([1, 2, 3, 4, 6, 8, 12]))
+    dh_s, dh_t = (int(rng.choice([2, 4, 8, 12, 16, 24, 32])) for _ in range(2))
+    while heads * dh_t > 512 or (heads * dh_t) % 4 != 0:       # embed dims: multiples of 4 (uu3d_create)
+        dh_t = int(rng.choice([2, 4, 8, 12, 16, 24, 32]))
+    while (heads * dh_s) % 4 != 0:
+        dh_s = int(rng.choice([4, 8, 12, 16, 24, 32]))
+    n, strides = [(9, [3, 3]), (15, [3, 5]), (27, [3, 3, 3]), (45, [3, 3, 5]), (75, [5, 5, 3]), (81, [3, 3, 3, 3]), (125, [5, 5, 5]), (21, [7, 3]), (3, [3])][int(rng.integers(9))]
+    J = int(rng.integers(2, 31))
+    ratio = float(rng.choice([1.0, 2.0, 4.0]))
+    # (MLP widths int(d * ratio) are multiples of 4 for every ratio drawn, since the embed dims are)
+    ms = None if rng.random() < 0.4 else [int(strides[0]), int(np.prod(strides)), 2]
+    return dict(J=J, d_s=heads * dh_s, d_t=heads * dh_t, heads=heads, n=n, strides=strides, ratio=ratio, ms=ms,
+                spatial=int(rng.integers(1, 4)), temporal=int(rng.integers(1, 4)), bn=bool(rng.random() < 0.3), qkv_bias=bool(rng.random() < 0.8))
+
+
+@pytest.mark.parametrize("seed", range(16))
+def test_generic_dims_random_configs_match_oracle(seed):
+    """Randomised differential test of the generic forward: dims, depths, sequence lengths, joint counts (even and odd), MLP ratios,
+    QKV_BIAS, OUTPUT_BN and stride masks drawn from a seeded generator, each against the oracle."""
+    from oracle import uplift_oracle as O
+    rng = np.random.default_rng(1000 + seed)
+    c = _random_case(rng)
+    cfg = _config(c["J"], c["d_s"], c["d_t"], c["heads"], c["n"], c["strides"], c["ratio"], spatial=c["spatial"], temporal=c["temporal"], mask_stride=c["ms"])
+    cfg.OUTPUT_BN, cfg.QKV_BIAS = c["bn"], c["qkv_bias"]
+    arch = pkg.arch_from_config(cfg)
+    if arch.compiled_dims:
+        pytest.skip("drew the compiled dims")
+    w = pkg.init_weights(arch, seed=seed, perturb=0.1)
+    for k in w:
+        if k.endswith("moving_variance"):
+            w[k] = rng.uniform(0.5, 2.0, w[k].shape).astype(np.float32)
+        if k.endswith("moving_mean"):
+            w[k] = rng.normal(0, 0.3, w[k].shape).astype(np.float32)
+    model = pkg.build_uplift_upsample_transformer(cfg, weights=w, precision="f16x3" if seed % 2 == 0 else "f32")
+    batch = int(rng.integers(1, 9))
+    if arch.has_strided_input:
+        x, m = util.synthetic_batch(cfg, batch=batch, seed=seed)
+        xin = x * m[:, :, None, None].astype(np.float32)
+        full, central = model([torch.from_numpy(xin).cuda(), torch.from_numpy(m).cuda()], training=False)
+    else:
+        xin, m = rng.uniform(-1, 1, size=(batch, c["n"], c["J"], 2)).astype(np.float32), None
+        full, central = model(torch.from_numpy(xin).cuda(), training=False)
+    torch.cuda.synchronize()
+    f32, c32 = O.forward(util.hp_from_arch(arch), w, xin, m, torch.float32)
+    err = max(np.abs(full.cpu().numpy() - f32).max(), np.abs(central.cpu().numpy() - c32).max())
+    print(f"seed {seed}: {c} batch {batch}: max-abs vs oracle {err:.3e}")
+    assert np.isfinite(full.cpu().numpy()).all() and err <= util.TOL_MAX_ABS
+
+
+@pytest.mark.parametrize("seed", range(8))
+def test_generic_dims_random_configs_gradients(seed):
+    """The same draw, through the training step: loss and every gradient tensor against float64 autograd (<= 1e-4 of its scale; a
+    tensor whose error sits in a single hidden unit's column is a ReLU / GELU input within rounding of zero, reported and tolerated
+    as in tests/test_train_step_gpu.py -- at most one such unit per case)."""
+    from oracle import train_oracle as T
+    from uplift_upsample_3dhpe_amd.trainer import Trainer
+    rng = np.random.default_rng(2000 + seed)
+    c = _random_case(rng)
+    if c["n"] > 96:
+        c["n"], c["strides"] = 27, [3, 3, 3]
+        c["ms"] = None if c["ms"] is None else [3, 27, 2]
+    cfg = _config(c["J"], c["d_s"], c["d_t"], c["heads"], c["n"], c["strides"], c["ratio"], spatial=c["spatial"], temporal=c["temporal"], mask_stride=c["ms"])
+    cfg.QKV_BIAS, cfg.BATCH_SIZE, cfg.DROP_PATH_RATE = c["qkv_bias"], 4, [0.0, 0.0, 0.0]
+    arch = pkg.arch_from_config(cfg)
+    if arch.compiled_dims:
+        pytest.skip("drew the compiled dims")
+    w = pkg.init_weights(arch, seed=seed, perturb=0.1)
+    model = pkg.build_uplift_upsample_transformer(cfg, weights=w)
+    B, n, J = 3, c["n"], c["J"]
+    x = rng.uniform(-1, 1, size=(B, n, J, 2)).astype(np.float32)
+    gt = rng.normal(0, 0.3, size=(B, n, J, 3)).astype(np.float32)
+    m = np.stack([util.eval_stride_mask(n, cfg.SEQUENCE_STRIDE, c["ms"][b % 2], 0) for b in range(B)]) if arch.has_strided_input else None
+    tr = Trainer(model, cfg)
+    loss, full, central = tr.forward_backward(torch.from_numpy(x).cuda(), torch.from_numpy(gt).cuda(), None if m is None else torch.from_numpy(m).cuda(), drop_path_uniform=None)
+    torch.cuda.synchronize()
+    ref, gref, fref, cref = T.train_step_grads(util.hp_from_arch(arch), w, x, m if m is not None else np.ones((B, n), bool), gt, cfg.ROOT_KEYTPOINT,
+                                               cfg.LOSS_WEIGHT_CENTER, cfg.LOSS_WEIGHT_SEQUENCE, cfg.BATCH_SIZE, None)
+    assert float(loss.cpu()[0]) == pytest.approx(ref["loss"], rel=2e-5)
+    g = tr.grads_dict()
+    gmax = max(np.abs(v).max() for v in gref.values())
+    bad = []
+    for k in gref:
+        scale = max(np.abs(gref[k]).max(), 1e-4 * gmax)
+        if k.endswith("/attn/wk/bias") and np.abs(gref[k]).max() < 1e-12 * gmax:
+            scale = max(scale, np.abs(gref[k.replace("/bias", "/kernel")]).max())
+        d = np.abs(g[k] - gref[k]) / scale
+        if d.max() > 1e-4:
+            bad.append((k, float(d.max()), d))
+    print(f"seed {seed}: {c}: loss {float(loss.cpu()[0]):.6f}; tensors over 1e-4: {[(k, '%.1e' % e) for k, e, _ in bad]}")
+    # an activation input within rounding of zero flips one hidden unit: its fc1 column / bias entry (and what feeds it) differ, nothing else does
+    flips = [k for k, _, d in bad if d.ndim == 2 and len(set(np.argwhere(d > 1e-4)[:, -1].tolist())) == 1 or d.ndim == 1 and (d > 1e-4).sum() == 1]
+    assert len(bad) == len(flips) and len({k.split("/")[0] for k in flips}) <= 1, [(k, e) for k, e, _ in bad]
+
+
 def test_generic_dims_through_the_pipeline():
     """Several batches in flight (pipeline.ForwardPipeline: one hipGraph per slot) on a generic-dims handle: the same bits as model(...)."""
     J, d_s, d_t, heads, n, strides, ratio, ms = CASES["small_heads4"]
@@ -139,6 +235,9 @@ def test_generic_dims_limits_are_stated():
     """What the generic forward does not do fails loudly at construction / at the call, never silently."""
     cfg = _config(17, 16, 64, 4, 243, [3, 3, 3, 3, 3])        # 243 frames
     with pytest.raises(Exception, match="128 frames"):
+        pkg.build_uplift_upsample_transformer(cfg)
+    cfg = _config(17, 2, 24, 1, 9, [3, 3])                    # SPATIAL_EMBED_DIM 2: rows shorter than the loaders' 16-byte pieces
+    with pytest.raises(Exception, match="multiples of 4"):
         pkg.build_uplift_upsample_transformer(cfg)
     cfg = _config(17, 40, 80, 8, 9, [3, 3])                   # head dims 5 / 10: no instantiation
     with pytest.raises(Exception, match="head dims"):

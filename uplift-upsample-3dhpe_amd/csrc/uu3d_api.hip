@@ -293,6 +293,8 @@ int uu3d_create(const uu3d_config* c, int device, uu3d_model** out) {
             return fail(nullptr, UU3D_ERR_INVALID_ARGUMENT, "embed dims must be divisible by NUM_HEADS (vision_transformer.py:79)");
         if (!attn_generic_head_dim_ok(c->d_spatial / c->num_heads) || !attn_generic_head_dim_ok(c->d_temporal / c->num_heads))
             return fail(nullptr, UU3D_ERR_UNSUPPORTED, "generic forward: head dims (embed dim / NUM_HEADS) must be one of 2, 4, 8, 12, 16, 24, 32, 48, 64");
+        if (c->d_spatial % 4 != 0 || c->d_temporal % 4 != 0 || c->h_spatial % 4 != 0)
+            return fail(nullptr, UU3D_ERR_UNSUPPORTED, "generic forward: embed dims and MLP widths must be multiples of 4 (16-byte row pieces in every loader)");
         if (c->num_keypoints > 128 || c->num_frames > 128)
             return fail(nullptr, UU3D_ERR_UNSUPPORTED, "generic forward: at most 128 keypoints and 128 frames");
         if (c->temporal_depth < 1 || c->num_strided < 1 || !c->full_output)
