@@ -242,11 +242,38 @@ def test_generic_dims_limits_are_stated():
     cfg = _config(17, 40, 80, 8, 9, [3, 3])                   # head dims 5 / 10: no instantiation
     with pytest.raises(Exception, match="head dims"):
         pkg.build_uplift_upsample_transformer(cfg)
-    cfg = _config(17, 16, 64, 4, 9, [3, 3])
-    model = pkg.build_uplift_upsample_transformer(cfg, return_attention=True)
-    x = torch.zeros((1, 9, 17, 2), device="cuda")
-    with pytest.raises(Exception, match="attention weights"):
-        model(x, training=False)
+
+
+@pytest.mark.parametrize("name", ["small_heads4", "heads3_j13", "heads2"])
+def test_generic_dims_return_attention(name):
+    """return_attention=True on a generic-dims handle (u_u_t.py:176,365,418-419): the softmax weights of every temporal block next to
+    unchanged outputs, against the oracle's."""
+    from oracle import uplift_oracle as O
+    J, d_s, d_t, heads, n, strides, ratio, ms = CASES[name]
+    cfg = _config(J, d_s, d_t, heads, n, strides, ratio, temporal=3, mask_stride=ms)
+    arch = pkg.arch_from_config(cfg)
+    w = pkg.init_weights(arch, seed=2, perturb=0.1)
+    batch = 5
+    if arch.has_strided_input:
+        x, m = util.synthetic_batch(cfg, batch=batch, seed=2)
+        xin = x * m[:, :, None, None].astype(np.float32)
+        inputs = [torch.from_numpy(xin).cuda(), torch.from_numpy(m).cuda()]
+    else:
+        xin, m = np.random.default_rng(2).uniform(-1, 1, size=(batch, n, J, 2)).astype(np.float32), None
+        inputs = torch.from_numpy(xin).cuda()
+    model = pkg.build_uplift_upsample_transformer(cfg, weights=w, return_attention=True)
+    full, central, att = model(inputs, training=False)
+    f0, c0 = pkg.build_uplift_upsample_transformer(cfg, weights=w)(inputs, training=False)
+    torch.cuda.synchronize()
+    assert torch.equal(full, f0) and torch.equal(central, c0)            # the maps are a side output
+    f32, c32, a32 = O.forward(util.hp_from_arch(arch), w, xin, m, torch.float32, return_attention=True)
+    assert len(att) == len(a32) == arch.temporal_depth == 3
+    for i, (got, want) in enumerate(zip(att, a32)):
+        g = got.cpu().numpy()
+        assert g.shape == (batch, heads, n, n) and np.abs(g.sum(-1) - 1.0).max() <= 1e-5
+        err = np.abs(g - want).max()
+        print(f"{name} temporal block {i + 1}: attention maps max-abs vs oracle {err:.2e}")
+        assert err <= 2e-5
 
 
 GRAD_CASES = {

@@ -359,7 +359,7 @@ int uu3d_create(const uu3d_config* c, int device, uu3d_model** out) {
 
 static void train_free(uu3d_model* m);
 static int generic_forward(uu3d_model* m, const float* kp2d, const uint8_t* mask, int32_t B, float* full_out, float* central_out,
-                           void* workspace, size_t workspace_bytes, void* stream);      // uu3d_train_step.inc
+                           float* const* attn_out, void* workspace, size_t workspace_bytes, void* stream);      // uu3d_train_step.inc
 void uu3d_destroy(uu3d_model* m) {
     if (!m) return;
     (void)hipSetDevice(m->device);
@@ -1183,8 +1183,7 @@ int uu3d_forward_ex(uu3d_model* m, const float* kp2d, const uint8_t* mask, int32
     if (m->generic) {
         // dims other than the compiled ones: the training-mode chain, forward only, with every stochastic layer off (no DropPath draws, no token
         // mask, Dropout rates 0): vit / u_u_t in inference mode
-        if (attn_out != nullptr) return fail(m, UU3D_ERR_UNSUPPORTED, "generic forward: attention weights are not returned");
-        return generic_forward(m, kp2d, mask, B, full_out, central_out, workspace, workspace_bytes, stream_);
+        return generic_forward(m, kp2d, mask, B, full_out, central_out, attn_out, workspace, workspace_bytes, stream_);
     }
     Workspace w = carve(m, B, (char*)workspace);
     if (workspace_bytes < w.bytes) return fail(m, UU3D_ERR_WORKSPACE, "workspace smaller than uu3d_workspace_bytes(batch)");
