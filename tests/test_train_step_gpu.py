@@ -595,3 +595,33 @@ def test_pipeline_sees_the_trainers_weights():
             assert torch.equal(f, want[0]) and torch.equal(c, want[1]), step
         assert (want[1] - c0).abs().max() > 1e-6                    # ... and they are not the initial weights' numbers
     pipe.close()
+
+
+@pytest.mark.parametrize("n,strides", [(125, [5, 5, 5]), (128, [4, 4, 8])])
+def test_gradients_at_the_longest_sequences(n, strides):
+    """The training step at 97 .. 128 tokens (round 4: the limit was 96, set by the Dropout path's LDS-resident attention backward; without
+    ATTENTION_DROP_RATE the MFMA backward holds 8 x 16 tokens in registers): every gradient tensor against float64 autograd."""
+    from oracle import train_oracle as T
+    from uplift_upsample_3dhpe_amd.trainer import Trainer
+    cfg = util.load_config("h36m_351")
+    cfg.SEQUENCE_LENGTH, cfg.STRIDES, cfg.PADDINGS, cfg.BATCH_SIZE = n, strides, None, 4
+    cfg.SPATIAL_TRANSFORMER_BLOCKS, cfg.TEMPORAL_TRANSFORMER_BLOCKS, cfg.DROP_PATH_RATE = 1, 2, [0.0, 0.0, 0.0]
+    arch = pkg.arch_from_config(cfg)
+    w = pkg.init_weights(arch, seed=3, perturb=0.1)
+    model = pkg.build_uplift_upsample_transformer(cfg, weights=w)
+    B = 2
+    rng = np.random.default_rng(8)
+    x = rng.uniform(-1, 1, size=(B, n, 17, 2)).astype(np.float32)
+    gt = rng.normal(0, 0.3, size=(B, n, 17, 3)).astype(np.float32)
+    ms = cfg.MASK_STRIDE if isinstance(cfg.MASK_STRIDE, list) else [cfg.MASK_STRIDE]
+    m = np.stack([util.eval_stride_mask(n, cfg.SEQUENCE_STRIDE, ms[b % 2], 0) for b in range(B)])
+    tr = Trainer(model, cfg)
+    loss, full, central = tr.forward_backward(torch.from_numpy(x).cuda(), torch.from_numpy(gt).cuda(), torch.from_numpy(m).cuda(), drop_path_uniform=None)
+    torch.cuda.synchronize()
+    ref, gref, fref, cref = T.train_step_grads(util.hp_from_arch(arch), w, x, m, gt, cfg.ROOT_KEYTPOINT, cfg.LOSS_WEIGHT_CENTER, cfg.LOSS_WEIGHT_SEQUENCE, cfg.BATCH_SIZE, None)
+    assert float(loss.cpu()[0]) == pytest.approx(ref["loss"], rel=2e-5)
+    g = tr.grads_dict()
+    gmax = max(np.abs(v).max() for v in gref.values())
+    worst = max(((np.abs(g[k] - gref[k]).max() / max(np.abs(gref[k]).max(), 1e-4 * gmax), k) for k in gref if not k.endswith("/attn/wk/bias")), key=lambda t: t[0])
+    print(f"{n} tokens: worst relative gradient error {worst[0]:.2e} at {worst[1]}")
+    assert worst[0] <= 1e-4, worst
