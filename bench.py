@@ -67,6 +67,74 @@ def cpu_baseline(cfg, arch, weights, x, m, budget_s=60.0):
                       f"PyTorch-CPU fp32 oracle (oracle/uplift_oracle.py) on {best} of {ncpu} hardware threads (fastest of the sweep)"}
 
 
+class ErrorGather:
+    """The multi-GPU payload of a step: its (B_local, J) float64 per-joint error block, all-gathered over the ranks.
+
+    mode "end" (default): every step's block is kept in a (steps, B, J) buffer (one small device copy per step, enqueued behind the
+    step's result) and ONE collective of the whole buffer runs after the loop's last result, inside the timed region -- nothing of the
+    data path waits for a collective.  mode "step": one all-gather per step on the caller's stream (the round-4 behaviour, kept for
+    A/B runs).  Without a process group both modes only keep the blocks."""
+
+    def __init__(self, mode, steps, B, J, world, device, use_dist):
+        import torch
+        if mode not in ("end", "step"):
+            raise ValueError("gather mode: end | step")
+        self.mode, self.world, self.use_dist = mode, int(world), bool(use_dist)
+        self.local = torch.empty((max(steps, 1), B, J), dtype=torch.float64, device=device)
+        self.gathered = torch.empty((self.world * self.local.shape[0],) + tuple(self.local.shape[1:]), dtype=torch.float64, device=device) if use_dist else None   # rank-major: (world * steps, B, J)
+        self.step_out = torch.empty((self.world * B, J), dtype=torch.float64, device=device) if (use_dist and mode == "step") else None
+        self.k = 0
+
+    def reset(self):
+        self.k = 0
+
+    def step(self, e):
+        import torch.distributed as dist
+        self.local[self.k % self.local.shape[0]].copy_(e, non_blocking=True)
+        self.k += 1
+        if self.use_dist and self.mode == "step":
+            dist.all_gather_into_tensor(self.step_out, e)
+
+    def finish(self):
+        """mode "end": the one collective; returns the (world, steps, B, J) blocks (or None without a process group)."""
+        import torch.distributed as dist
+        if self.use_dist and self.mode == "end":
+            dist.all_gather_into_tensor(self.gathered, self.local)
+        return None if self.gathered is None else self.gathered.view((self.world,) + tuple(self.local.shape))
+
+
+def run_pipelined_steps(pipe, n, depth, gather):
+    """n steps with `depth` batches in flight: launch() a slot, take the oldest result when `depth` are out, hand its error block to
+    `gather`; the collective of gather mode "end" closes the loop.  (`pipe`: launch() -> ticket, result(ticket) -> (full, central, err).)"""
+    gather.reset()
+    tickets = []
+    for _ in range(n):
+        tickets.append(pipe.launch())
+        if len(tickets) == depth:
+            gather.step(pipe.result(tickets.pop(0))[2])
+    for t in tickets:
+        gather.step(pipe.result(t)[2])
+    gather.finish()
+
+
+def parity_vs_oracle(cfg, arch, weights, x, m, full, central, gt, n=8):
+    """BASELINE's metric names "MPJPE vs ref": the HIP outputs of the bench batch (what the timed pipeline produced) against the CPU oracle on
+    its first `n` sequences, OUTSIDE the timed region -- max-abs over both outputs and the difference of the two MPJPEs against the synthetic
+    ground truth (mm; the north_star's budget is 0.05 mm).  The oracle is the checker here, never the thing measured."""
+    import numpy as np
+    import torch
+    from oracle import uplift_oracle as O
+    n = min(n, x.shape[0])
+    f32, c32 = O.forward(O.hp_from_arch(arch), weights, x[:n], m[:n], torch.float32)
+    e = float(np.abs(central[:n] - c32).max())
+    if full is not None and f32 is not None:
+        e = max(e, float(np.abs(full[:n] - f32).max()))
+    _, a = O.frame_mpjpe_mm(central[:n], gt[:n, :, :3], cfg.ROOT_KEYTPOINT)
+    _, b = O.frame_mpjpe_mm(c32, gt[:n, :, :3], cfg.ROOT_KEYTPOINT)
+    return {"max_abs_vs_oracle": e, "mpjpe_delta_mm": float(abs(a - b)), "n_sequences": int(n), "tolerance_max_abs": 1e-4, "budget_mpjpe_mm": 0.05,
+            "reference": "oracle/uplift_oracle.py (PyTorch-CPU fp32 restatement; parity UNPINNED against TensorFlow, DESIGN.md section 6)"}
+
+
 def train_bench(args, world, rank, local_rank, use_dist):
     """BASELINE config 5: config/h36m_351_pt.json train step on synthetic AMASS-shaped sequences."""
     import numpy as np
@@ -228,7 +296,8 @@ def quick_train_bench(steps=50, warmup=10, batch=64):
 def secondary_benchmarks(args):
     """The other claims of DESIGN.md in the same driver-run JSON line: ~20 steps each."""
     out = {}
-    jobs = [("latency_one_batch_in_flight", lambda: quick_forward_bench(args.config, args.batch, streams=1, graph=True)),
+    jobs = [("steady_state_200_steps", lambda: quick_forward_bench(args.config, args.batch, streams=max(1, args.streams_used), graph=True, steps=200, warmup=20)),
+            ("latency_one_batch_in_flight", lambda: quick_forward_bench(args.config, args.batch, streams=1, graph=True)),
             ("eager_one_batch_in_flight", lambda: quick_forward_bench(args.config, args.batch, streams=1, graph=False)),
             ("eager_pipelined", lambda: quick_forward_bench(args.config, args.batch, streams=max(2, args.streams_used), graph=False)),
             ("h36m_81_batch256", lambda: quick_forward_bench("h36m_81", 256, streams=max(1, args.streams_used))),
@@ -328,6 +397,7 @@ def main():
     ap.add_argument("--halves", action="store_true", help="two concurrent half-batch chains on two streams instead of one chain of kernels per batch")
     ap.add_argument("--no-halves", action="store_true", help="(default since the row-panel GEMM; accepted for older scripts)")
     ap.add_argument("--force-dist", action="store_true", help="initialise the process group even at world size 1 (exercises the RCCL path)")
+    ap.add_argument("--gather", default="end", choices=["end", "step"], help="N > 1: all-gather of the per-sequence error blocks -- end = one collective of every step's block behind the loop's last result (default), step = one per step on the caller's stream")
     ap.add_argument("--spawn-check", action="store_true", help="ranks print their rank / world size and exit (no GPU): checks the self-spawn path")
     args = ap.parse_args()
 
@@ -374,7 +444,7 @@ def main():
     m = torch.from_numpy(m_np).cuda()
     gt = torch.from_numpy(gt_np).cuda()
     err = torch.empty((B, J), dtype=torch.float64, device="cuda")
-    gathered = torch.empty((world * B, J), dtype=torch.float64, device="cuda") if use_dist else None
+    gather = ErrorGather(args.gather, args.steps, B, J, world, "cuda", use_dist)
     from uplift_upsample_3dhpe_amd.harness import per_joint_error
 
     def sync_all():
@@ -411,10 +481,11 @@ def main():
             run_compute = g.replay
 
         def run_steps(n):
+            gather.reset()
             for _ in range(n):
                 run_compute()
-                if use_dist:
-                    dist.all_gather_into_tensor(gathered, err)
+                gather.step(err)
+            gather.finish()
     else:
         try:
             if auto:                                    # one slot per HIP hardware queue (pipeline.distinct_queue_streams finds which streams share one)
@@ -434,18 +505,7 @@ def main():
         pipe.preload(x, m)
 
         def run_steps(n):
-            tickets = []
-
-            def consume(t):
-                e = pipe.result(t)[2]
-                if use_dist:
-                    dist.all_gather_into_tensor(gathered, e)
-            for _ in range(n):
-                tickets.append(pipe.launch())
-                if len(tickets) == S:
-                    consume(tickets.pop(0))
-            for t in tickets:
-                consume(t)
+            run_pipelined_steps(pipe, n, S, gather)
 
     run_steps(args.warmup)
     sync_all()
@@ -457,6 +517,13 @@ def main():
         t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+
+    # ---- what the timed path produced for the resident batch (parity block of the JSON line; outside the timed region) ----
+    hip_full = hip_central = None
+    if pipe is not None and rank == 0:
+        f_, c_, _ = pipe.result(pipe.launch())
+        torch.cuda.synchronize()
+        hip_full, hip_central = (f_.cpu().numpy() if f_ is not None else None), c_.cpu().numpy()
 
     # ---- per-kernel timing with HIP events on the launch stream (outside the timed region) ----
     model.set_profiling(True)
@@ -517,6 +584,7 @@ def main():
                          "note": ("algorithmic 2*M*N*K FLOPs (mlp_fused: both Dense layers of the MLP, 4*M*d*h); the f16x3 kernels issue 3 f16 "
                                   "MFMA passes per product, so the matrix pipe does 3x this work (frac of pipe = 3 * frac)") if args.precision == "f16x3" else
                                  "exact f32-input MFMA",
+                         "traffic_note": "`traffic` is read from the committed counter run of this workload (profiles/, separate --pmc passes, ONE batch in flight, launched eagerly) -- not measured in this process, which runs several hipGraphs in flight",
                          "avg_launch_ms": round(dom["ms"] / dom["n"], 5),
                          "attention": attention_roofline(agg, N, "synthetic dense-351 (NOT a shipped config)" if args.config == "dense_351" else f"config/{args.config}.json"),
                          # the four largest GEMM launch classes (the first two are within a microsecond per launch of each
@@ -535,6 +603,16 @@ def main():
             out["cpu_baseline"] = cpu_baseline(cfg, arch, weights, x_np, m_np)
         else:
             out["cpu_baseline"] = None
+        if not args.no_cpu_baseline and hip_central is not None:
+            try:
+                out["parity"] = parity_vs_oracle(cfg, arch, weights, x_np, m_np, hip_full, hip_central, gt_np)
+            except Exception as e:  # pragma: no cover
+                out["parity"] = {"error": f"{type(e).__name__}: {e}"}
+        else:
+            out["parity"] = None
+        if world > 1:
+            out["config"]["gather"] = ("one all-gather of every step's (B_local, J) f64 error block behind the loop's last result, inside the timed region" if args.gather == "end"
+                                       else "one all-gather per step on the caller's stream")
         if world == 1 and not args.no_secondary and args.config == "h36m_351":
             pipe = None
             args.streams_used = S

@@ -141,3 +141,73 @@ def test_bench_starts_its_own_ranks():
                        capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stderr[-2000:]
     assert "rank 0/2" in r.stdout and "rank 1/2" in r.stdout
+
+
+class _StubPipe:
+    """The surface of pipeline.ForwardPipeline that bench.run_pipelined_steps drives, with a forward that costs nothing: launch() -> ticket,
+    result(ticket) -> (full, central, err); the error block of step k on rank r is a known table."""
+
+    def __init__(self, rank, B, J, depth):
+        self.rank, self.B, self.J, self.depth, self.n = rank, B, J, depth, 0
+        self.live = {}
+
+    @staticmethod
+    def block(rank, k, B, J):
+        return torch.arange(B * J, dtype=torch.float64).reshape(B, J) + 1000.0 * k + 1.0e6 * rank
+
+    def launch(self):
+        t = self.n
+        self.n += 1
+        assert len(self.live) < self.depth, "more batches in flight than slots"
+        self.live[t] = self.block(self.rank, t, self.B, self.J)
+        return t
+
+    def result(self, t):
+        return None, None, self.live.pop(t)
+
+
+def _bench_loop_worker(rank, world, port, mode, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import bench
+    B, J, steps, depth = 5, 17, 7, 3
+    g = bench.ErrorGather(mode, steps, B, J, world, "cpu", True)
+    pipe = _StubPipe(rank, B, J, depth)
+    bench.run_pipelined_steps(pipe, 2, depth, g)                     # "warm-up": the loop is re-entrant (reset)
+    pipe.n = 0
+    bench.run_pipelined_steps(pipe, steps, depth, g)
+    out = {"local": g.local.numpy().copy(), "k": g.k, "gathered": None if g.gathered is None or mode != "end" else g.gathered.view(world, steps, B, J).numpy().copy(),
+           "step_out": None if g.step_out is None else g.step_out.numpy().copy()}
+    q.put((rank, out))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("mode", ["end", "step"])
+def test_bench_step_loop_gathers_over_two_ranks_gloo(mode):
+    """bench.py's REAL step loop (run_pipelined_steps + ErrorGather: what `python bench.py --gpus N` times) at world size 2 over gloo
+    with a stub forward: every step's (B, J) block of every rank arrives, in rank and step order -- mode "end": one collective behind
+    the last result; mode "step": one per step (the last one is checked)."""
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_bench_loop_worker, args=(r, 2, port, mode, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=180) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    B, J, steps = 5, 17, 7
+    for rank in (0, 1):
+        o = res[rank]
+        assert o["k"] == steps
+        for k in range(steps):
+            assert np.array_equal(o["local"][k], _StubPipe.block(rank, k, B, J).numpy())
+        if mode == "end":
+            for r in (0, 1):
+                for k in range(steps):
+                    assert np.array_equal(o["gathered"][r, k], _StubPipe.block(r, k, B, J).numpy())
+        else:
+            for r in (0, 1):
+                assert np.array_equal(o["step_out"][r * B:(r + 1) * B], _StubPipe.block(r, steps - 1, B, J).numpy())

@@ -34,6 +34,7 @@
 #include "uu3d_gemm_panel8.h"
 #include "uu3d_gemm_wt.h"
 #include "uu3d_mlp_fused.h"
+#include "uu3d_tchain.h"
 #include "uu3d_tail.h"
 #include "uu3d_attn.h"
 #include "uu3d_attn_h3.h"
@@ -114,6 +115,14 @@ struct uu3d_model {
     bool throughput = false;       // uu3d_set_schedule: launches shaped for CU-microseconds (several forwards share the chip) instead of latency
     bool no_tail = true;           // UU3D_TAIL=1 (opt-in): the last strided block + head2 as ONE XCD-cooperative launch (strided_tail_kernel) instead of a chain of 9 -- measured equal for one batch at a time and 0.7 % slower with two batches in flight (its 256 spinning workgroups hold every CU), profiles/r03_tail_ab.txt
     size_t h2_pf = 0;              // fragment-ordered head2 operand (uu3d_tail.h), offset in harena, 0 = none
+    // Temporal chain (uu3d_tchain.h; throughput schedule): one launch per temporal block for its row-local stages.  Launch 0 = LayerNorm 1 + QKV of
+    // block 1; launch i (1 .. T) = projection + MLP of block i (+ LayerNorm 1 + QKV of the block behind it: temporal block i + 1, or the first strided
+    // block with its positional encoding); launch T + 1 = projection + LayerNorm 2 + fc1 of the first strided block.  Empty = not available.
+    struct TcLaunch { int flags; size_t w_off /* halfs, harena */; size_t p_off /* floats, arena */; };
+    std::vector<TcLaunch> tchain;
+    bool no_tchain = true;         // UU3D_TCHAIN=1 (opt-in): the temporal chain under the throughput schedule.  Correct (tests/test_tchain_gpu.py) and 27 % fewer
+                                   // CU-microseconds per block than the round-4 launches, but a launch is 71 workgroups x ~200 us: with four hardware queues the
+                                   // pipelined step came out 3-5 % SLOWER (profiles/r05_tchain_ab.txt) -- narrow long launches mix badly with wide short ones
     int num_cus = 256;
     bool no_planes = false;        // UU3D_NO_PLANES=1: keep the on-the-fly split GEMMs in f16x3 mode (A/B measurements, tests)
     _Float16* harena = nullptr;    // f16 hi/lo planes of every GEMM operand (f16x3 mode)
@@ -139,6 +148,11 @@ struct uu3d_model {
 };
 
 namespace {
+
+// (a property of the configuration, not of the commit state: uu3d_workspace_bytes may be asked before the weights are committed)
+inline bool tchain_possible(const uu3d_config& c) {
+    return c.precision == UU3D_PREC_F16X3 && c.d_temporal == 384 && c.h_temporal == 768 && c.num_heads == 8 && c.temporal_depth >= 1;
+}
 
 int fail(uu3d_model* m, int code, const std::string& msg) {
     if (m) m->err = msg; else g_create_error = msg;
@@ -352,6 +366,7 @@ int uu3d_create(const uu3d_config* c, int device, uu3d_model** out) {
     { const char* e = getenv("UU3D_NO_PANEL"); m->no_panel = (e != nullptr && e[0] == '1'); }
     { const char* e = getenv("UU3D_NO_PANEL_PROJ"); m->no_panel_proj = (e != nullptr && e[0] == '1'); }
     { const char* e = getenv("UU3D_TAIL"); m->no_tail = !(e != nullptr && e[0] == '1'); }
+    { const char* e = getenv("UU3D_TCHAIN"); m->no_tchain = !(e != nullptr && e[0] == '1'); }
     { hipDeviceProp_t pr; if (hipGetDeviceProperties(&pr, device) == hipSuccess && pr.multiProcessorCount > 0) m->num_cus = pr.multiProcessorCount; }
     *out = m;
     return UU3D_OK;
@@ -581,6 +596,66 @@ int uu3d_commit_weights(uu3d_model* m, void* stream_) {
     const size_t o_h2 = P.alloc_dense((size_t)Nph * Kdt), o_h2b = P.alloc(Nph);
     pack_head(o_h2, o_h2b, "strided_temporal_fc", "strided_temporal_norm");
 
+    // ---- temporal chain (uu3d_tchain.h): per launch one parameter table (floats) and one weight stream (f16 planes, built below) ----
+    // A LayerNorm's affine part is folded into the Dense layer behind it: W' = diag(gamma) W, b' = b + beta W (f64 sums).
+    struct TcStage { std::vector<float> Wk; int K, N, kofs; bool natural; };        // Keras layout [K][N]
+    struct TcBuild { int flags; size_t p_off; std::vector<TcStage> stages; };
+    std::vector<TcBuild> tcb;
+    if (tchain_possible(c)) {
+        auto block_name = [&](bool strided, int i) { return std::string(strided ? "strided_temporal_block_" : "temporal_block_") + std::to_string(i + 1); };
+        auto folded = [&](const std::vector<float>& Wk, const std::vector<float>& b, const float* g, const float* be, int K, int Nn, std::vector<float>& bout) {
+            TcStage st{std::vector<float>((size_t)K * Nn), K, Nn, 0, false};
+            bout.assign(Nn, 0.f);
+            for (int n = 0; n < Nn; ++n) { double acc = b[n]; for (int k = 0; k < K; ++k) acc += (double)be[k] * Wk[(size_t)k * Nn + n]; bout[n] = (float)acc; }
+            for (int k = 0; k < K; ++k) for (int n = 0; n < Nn; ++n) st.Wk[(size_t)k * Nn + n] = g[k] * Wk[(size_t)k * Nn + n];
+            return st;
+        };
+        auto qkv_of = [&](const std::string& p, std::vector<float>& Wk, std::vector<float>& b) {       // wq | wk | wv as one (dt, 3 dt) kernel
+            Wk.assign((size_t)dt * 3 * dt, 0.f); b.assign(3 * dt, 0.f);
+            int part = 0;
+            for (const char* nm : {"wq", "wk", "wv"}) {
+                const float* w = W(m, p + "/attn/" + nm + "/kernel"); const float* bb = W(m, p + "/attn/" + nm + "/bias");
+                for (int k = 0; k < dt; ++k) for (int n = 0; n < dt; ++n) Wk[(size_t)k * 3 * dt + part * dt + n] = w[(size_t)k * dt + n];
+                if (bb) std::copy_n(bb, dt, b.begin() + part * dt);
+                ++part;
+            }
+        };
+        auto add_qkv = [&](TcBuild& tb, const std::string& p) {
+            std::vector<float> Wk, b, bf; qkv_of(p, Wk, b);
+            tb.stages.push_back(folded(Wk, b, W(m, p + "/norm1/gamma"), W(m, p + "/norm1/beta"), dt, 3 * dt, bf));
+            std::copy_n(bf.begin(), 3 * dt, P.buf.begin() + tb.p_off + TCP_BQKV);
+        };
+        auto add_proj = [&](TcBuild& tb, const std::string& p) {
+            const float* w = W(m, p + "/attn/projection/kernel");
+            tb.stages.push_back(TcStage{std::vector<float>(w, w + (size_t)dt * dt), dt, dt, 0, true});
+            std::copy_n(W(m, p + "/attn/projection/bias"), dt, P.buf.begin() + tb.p_off + TCP_BP);
+        };
+        auto add_fc1 = [&](TcBuild& tb, const std::string& p) {
+            const float* w = W(m, p + "/mlp/fc1/kernel"); const float* b = W(m, p + "/mlp/fc1/bias");
+            std::vector<float> bf;
+            tb.stages.push_back(folded(std::vector<float>(w, w + (size_t)dt * ht), std::vector<float>(b, b + ht), W(m, p + "/norm2/gamma"), W(m, p + "/norm2/beta"), dt, ht, bf));
+            std::copy_n(bf.begin(), ht, P.buf.begin() + tb.p_off + TCP_B1);
+        };
+        auto add_fc2 = [&](TcBuild& tb, const std::string& p) {
+            const float* w = W(m, p + "/mlp/fc2/kernel");
+            for (int half = 0; half < 2; ++half) tb.stages.push_back(TcStage{std::vector<float>(w, w + (size_t)ht * dt), ht, dt, half * dt, false});
+            std::copy_n(W(m, p + "/mlp/fc2/bias"), dt, P.buf.begin() + tb.p_off + TCP_B2);
+        };
+        { TcBuild tb{TC_QKV, P.alloc(TCP_FLOATS), {}}; add_qkv(tb, block_name(false, 0)); tcb.push_back(std::move(tb)); }
+        for (int i = 0; i < c.temporal_depth; ++i) {
+            const bool last = i + 1 == c.temporal_depth;
+            TcBuild tb{TC_PROJ | TC_MLP | (last ? (c.num_strided > 0 ? TC_QKV | TC_PE : 0) : TC_QKV), P.alloc(TCP_FLOATS), {}};
+            add_proj(tb, block_name(false, i)); add_fc1(tb, block_name(false, i)); add_fc2(tb, block_name(false, i));
+            if (!last) add_qkv(tb, block_name(false, i + 1)); else if (c.num_strided > 0) add_qkv(tb, block_name(true, 0));
+            tcb.push_back(std::move(tb));
+        }
+        if (c.num_strided > 0) {
+            TcBuild tb{TC_PROJ | TC_FC1_PLANES, P.alloc(TCP_FLOATS), {}};
+            add_proj(tb, block_name(true, 0)); add_fc1(tb, block_name(true, 0));
+            tcb.push_back(std::move(tb));
+        }
+    }
+
     // ---- upload ----
     if (m->arena_floats < P.buf.size()) {
         if (m->arena) HIPCHK(m, hipFree(m->arena));
@@ -660,6 +735,25 @@ int uu3d_commit_weights(uu3d_model* m, void* stream_) {
                 add_panel(o_h2, round_up(3 * J, 32));
             }
         }
+        // temporal chain: the launches' weight streams (tchain_pack_stage: one 48 KiB chunk per 32 output channels and stage)
+        m->tchain.clear();
+        for (auto& tb : tcb) {
+            const size_t at = align_up(hb.size(), 128);
+            hb.resize(at + (size_t)tchain_chunks(tb.flags) * TC_CHUNK_HALFS);
+            size_t o = at;
+            for (auto& st : tb.stages) {
+                std::vector<_Float16> Bh((size_t)st.N * st.K), Bl((size_t)st.N * st.K);
+                for (int n = 0; n < st.N; ++n)
+                    for (int k = 0; k < st.K; ++k) {
+                        const float x = st.Wk[(size_t)k * st.N + n];
+                        const _Float16 h = h3_hi(x);
+                        Bh[(size_t)n * st.K + k] = h; Bl[(size_t)n * st.K + k] = (_Float16)((x - (float)h) * H3_SCALE);
+                    }
+                tchain_pack_stage(Bh.data(), Bl.data(), st.N, st.K, st.kofs, st.natural, hb.data() + o);
+                o += (size_t)(st.N / 32) * TC_CHUNK_HALFS;
+            }
+            m->tchain.push_back({tb.flags, at, tb.p_off});
+        }
         if (m->harena_halfs < hb.size()) {
             if (m->harena) HIPCHK(m, hipFree(m->harena));
             m->harena = nullptr;
@@ -702,6 +796,7 @@ int uu3d_commit_weights(uu3d_model* m, void* stream_) {
 namespace {
 struct Workspace {
     float *S, *X, *QKV, *O, *Hb, *XA, *XB, *slab, *mslab;
+    unsigned char* tc_scratch;     // temporal chain: lane-linear partial-result slabs, hidden fragments, trash page (tchain_scratch_bytes)
     int* frame_list;
     TailCtl* tail_ctl;
     float2* stats;
@@ -728,11 +823,13 @@ Workspace carve(const uu3d_model* m, int B, char* base) {
     const size_t oFl = take((rows + 1) * sizeof(int));
     const size_t oMs = take((size_t)MLPF_SLICES * rows * c.d_temporal * 4);      // fused MLP: fc2 partial sums of the three hidden slices
     const size_t oTc = take(sizeof(TailCtl));                                   // strided_tail_kernel: tickets / done counters / XCC stamps
+    const size_t oCh = !tchain_possible(c) ? 0 : take(tchain_scratch_bytes((int)((rows + 127) / 128)));
     w.bytes = off;
     if (base) {
         w.S = (float*)(base + oS); w.X = (float*)(base + oX); w.QKV = (float*)(base + oQ);
         w.O = (float*)(base + oO); w.Hb = (float*)(base + oH); w.XA = (float*)(base + oA);
         w.XB = (float*)(base + oB); w.stats = (float2*)(base + oT); w.slab = (float*)(base + oSl); w.frame_list = (int*)(base + oFl); w.mslab = (float*)(base + oMs); w.tail_ctl = (TailCtl*)(base + oTc);
+        w.tc_scratch = !tchain_possible(c) ? nullptr : (unsigned char*)(base + oCh);
     }
     return w;
 }
@@ -1053,6 +1150,29 @@ struct Launcher {
                            Af, m->harena + b.w1_pf, m->harena + b.w2_mf, b.b1, mslab, M, mt);
         end();
     }
+    // One launch of the temporal chain (uu3d_tchain.h): the row-local stages of a block for every 128-row tile
+    void tchain(const char* name, const uu3d_model::TcLaunch& t, int M, const _Float16* Of, float* X, float* XA, const float* pe, int period,
+                _Float16* Q, _Float16* H, unsigned char* scratch) {
+        const int mt = (M + 127) / 128;
+        TChainArgs a{};
+        a.M = M; a.m_tiles = mt; a.period = period; a.qscale = attn_qscale();
+        a.Of = Of; a.X = X; a.XA = XA; a.pe = pe; a.W = m->harena + t.w_off; a.P = m->arena + t.p_off; a.Q = Q; a.H = H; a.scratch = scratch;
+        const double cols = ((t.flags & TC_PROJ) ? 384.0 : 0.0) + ((t.flags & TC_MLP) ? 1536.0 : 0.0) + ((t.flags & TC_FC1_PLANES) ? 768.0 : 0.0) + ((t.flags & TC_QKV) ? 1152.0 : 0.0);
+        begin(name, "tchain", 2.0 * M * 384.0 * cols, 4.0 * (384.0 * cols + 2.0 * M * 384.0 + ((t.flags & TC_QKV) ? M * 1152.0 : 0.0) + ((t.flags & TC_FC1_PLANES) ? M * 768.0 : 0.0)));
+#define UU3D_TC_LAUNCH(F) case F: { auto kern = tchain_kernel<F>; \
+            static const bool once = (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)P8_LDS_TOTAL) == hipSuccess); (void)once; \
+            hipLaunchKernelGGL(kern, dim3(mt), dim3(512), P8_LDS_TOTAL, stream, a); } break;
+        switch (t.flags) {
+            UU3D_TC_LAUNCH(TC_QKV)
+            UU3D_TC_LAUNCH(TC_PROJ | TC_MLP | TC_QKV)
+            UU3D_TC_LAUNCH(TC_PROJ | TC_MLP | TC_QKV | TC_PE)
+            UU3D_TC_LAUNCH(TC_PROJ | TC_MLP)
+            UU3D_TC_LAUNCH(TC_PROJ | TC_FC1_PLANES)
+            default: status = UU3D_ERR_UNSUPPORTED; m->err = "temporal chain: unknown stage set"; break;
+        }
+#undef UU3D_TC_LAUNCH
+        end();
+    }
     // the fused MLP's combine (x += b2 + slabs; optionally xa = x + pe) + LayerNorm + split into A fragments
     void ln_res_split_frag(const char* name, float* x, int M, const float* bias2, const float* mslab, float* xa, const float* pe, int period,
                            const float* g, const float* b, _Float16* Af) {
@@ -1340,10 +1460,40 @@ int uu3d_forward_ex(uu3d_model* m, const float* kp2d, const uint8_t* mask, int32
         return nullptr;
     };
 
-    // 3. temporal blocks.  With >= 1024 token rows the MLP is one launch (uu3d_mlp_fused.h): its three partial fc2 sums are
+    // 3. temporal blocks.
+    // Throughput schedule (several forwards share the chip): the TEMPORAL CHAIN (uu3d_tchain.h, round 5) -- per block one attention launch and one
+    // launch for everything row-local (projection + residual, LayerNorm 2, fc1, ReLU, fc2 + residual, the next block's LayerNorm 1 + QKV) by
+    // workgroups that own 128 token rows: 2 T + 3 launches for T temporal blocks and the head of the first strided block instead of 5 T + 5,
+    // no partial-sum slabs, no LayerNorm passes.
+    const bool chain = Lh.throughput && planes && !m->no_tchain && !m->tchain.empty() && M >= 1024 && Lh.attn_is_h3(N, true) &&
+                       (c.num_strided == 0 || m->L[0] == N) && (double)M * 1152 * 4.0 < 4.0e9;
+    auto chain_maps = [&](const char* tag, int i, const uint8_t* kmask) {                // return_attention=True: a block's attention maps, recomputed from q | k
+        if (attn_out == nullptr || tag[0] != 't' || attn_out[i] == nullptr) return;
+        snprintf(nm, sizeof nm, "%s%d.attn_maps", tag, i + 1);
+        Lh.begin(nm, "attn_probs", 2.0 * B * (double)c.num_heads * N * N * kDH, 4.0 * B * (double)c.num_heads * N * N);
+        const size_t lds = (size_t)N * (kDH + 1) * sizeof(float);
+        static const bool once = (hipFuncSetAttribute((const void*)attn_probs_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256) == hipSuccess); (void)once;
+        const _Float16* Qh = reinterpret_cast<const _Float16*>(w.QKV);
+        hipLaunchKernelGGL(attn_probs_kernel, dim3(B * c.num_heads), dim3(256), lds, Lh.stream, (const void*)Qh, Qh + (size_t)M * 3 * dt, 3 * dt, dt, N, c.num_heads, kDH, kmask, 1.0f, 1, attn_out[i]);
+        Lh.end();
+    };
+    if (chain) {
+        _Float16* const Q = reinterpret_cast<_Float16*>(w.QKV);
+        Lh.tchain("t1.ln_qkv", m->tchain[0], M, nullptr, w.X, nullptr, nullptr, 1, Q, nullptr, w.tc_scratch);
+        for (int i = 0; i < c.temporal_depth; ++i) {
+            const bool masked = c.has_strided_input && i < c.first_strided_token_attention_layer;
+            chain_maps("t", i, masked ? mask : nullptr);
+            snprintf(nm, sizeof nm, "t%d.attn", i + 1);
+            Lh.attn(nm, w.QKV, B, N, masked ? mask : nullptr, w.O, (size_t)M * dt, true);
+            const bool to_strided = i + 1 == c.temporal_depth && c.num_strided > 0;
+            snprintf(nm, sizeof nm, "t%d.chain", i + 1);
+            Lh.tchain(nm, m->tchain[i + 1], M, Ph, w.X, to_strided ? w.XA : nullptr, to_strided ? m->sblocks[0].pe : nullptr, N, Q, nullptr, w.tc_scratch);
+        }
+    }
+    // Otherwise: with >= 1024 token rows the MLP is one launch (uu3d_mlp_fused.h): its three partial fc2 sums are
     // added to the residual stream by the NEXT block's first LayerNorm launch (`pend`).
     const BlockDev* pend = nullptr;
-    for (int i = 0; i < c.temporal_depth; ++i) {
+    for (int i = 0; i < (chain ? 0 : c.temporal_depth); ++i) {
         const BlockDev& b = m->tblocks[i];
         const bool masked = c.has_strided_input && i < c.first_strided_token_attention_layer;
         const bool last = (i + 1 == c.temporal_depth);
@@ -1411,6 +1561,11 @@ int uu3d_forward_ex(uu3d_model* m, const float* kp2d, const uint8_t* mask, int32
                                      (i + 1 < c.num_strided) ? m->sblocks[i + 1].pe : nullptr};
         // (without temporal blocks the first strided block is the one that must not attend to the upsampling tokens, u_u_t.py:372-376)
         const bool smask = c.temporal_depth == 0 && c.has_strided_input && i < c.first_strided_token_attention_layer;
+        if (chain && i == 0) {
+            // the chain's last launch left q | k | v of this block (LayerNorm 1 of xa = x + pe); its projection, LayerNorm 2 and fc1 are the next one
+            Lh.attn("s1.attn", w.QKV, B, Li, nullptr, w.O, (size_t)Mi * dt, true);
+            Lh.tchain("s1.chain", m->tchain[c.temporal_depth + 1], Mi, Ph, xa, nullptr, nullptr, 1, nullptr, Hh, w.tc_scratch);
+        } else
         block_head("s", i, b, xa, Li, smask ? mask : nullptr, i == 0 ? pend : nullptr, false);
         if (i == 0 && has_h1) {
             // 4. head1 (after strided block 1's first LayerNorm launch, which completes w.X when the last MLP was fused).  Nothing

@@ -1,0 +1,517 @@
+// uu3d_tchain.h -- every ROW-LOCAL stage of a temporal block in ONE launch (round 5; throughput schedule).
+//
+// Reference: vit.TransformerBlock.call (common/net/vision_transformer.py:176-195) minus the attention products (:117-129):
+//     x += projection(context) ; y = LayerNorm2(x) ; x += fc2(relu(fc1(y))) ; [next block:] q | k | v = wqkv(LayerNorm1(x))
+// Round 4 ran this as five chip-wide launches per block (row-panel projection, LayerNorm pass, fused MLP with three partial-sum
+// slabs, combine + LayerNorm pass, row-panel QKV); each paid ~13 us of fixed costs and moved its activations through L2 two to
+// three times.  Here one workgroup OWNS 128 token rows for the whole chain and walks a CONCATENATED weight stream
+//     Wp (12 chunks) | W1 (24) | W2[hidden 0..383] (12) | W2[hidden 384..767] (12) | Wqkv of the next block (36)      = 96 x 48 KiB
+// through the 8-wave chunk loop of uu3d_gemm_panel8.h (contraction split over wave pairs, two waves per SIMD, 3 x 48 KiB LDS ring
+// refilled in half-chunks by LDS-DMA, counted waits) -- the ring never drains at a stage boundary.
+//
+// What makes the chain cheap is the TRANSPOSED product and a k order chosen for it:
+//   * every product is C^T = W^T A^T: the weight fragment is the MFMA's A operand, the token fragment its B operand.  In the 32 x 32
+//     C/D map a lane then holds ONE token (lane & 31) and, per 32-channel chunk, the channels 8 (r >> 2) + 4 g + (r & 3) (g = lane >> 5);
+//   * wave (q, hh) of a pair finishes the 16 channels 16 hh .. 16 hh + 15 of every chunk (its partner sends the other half of its
+//     partial sums through LDS, as in the 8-wave kernel; wave group 1 reads its weight fragments with the row index flipped by 16 so that
+//     "registers 0..7" are the kept ones in both groups);
+//   * the 8 finished values of chunk c ARE the token fragment of k-slice 2 c + hh of the next stage, if that stage's weights are packed
+//     in the k order 16 s + 8 (j >> 2) + 4 g + (j & 3) and the pair splits the contraction by slice PARITY: LayerNorm output, ReLU
+//     output and residual stream never change lanes between stages.  What does not fit the 256 registers of a wave (the 96 values of the
+//     residual stream per lane next to 96 operand registers and 64 accumulators) makes a LANE-PRIVATE round trip through an L2-hot scratch
+//     slab (16-byte pieces, lane-linear: no barrier, no visibility question -- a lane reads back what it stored itself);
+//   * LayerNorm statistics are the only thing tokens need from other lanes: two sums over (lane, lane ^ 32, partner wave) through LDS;
+//   * biases that an epilogue needs inside the chunk loop (fc1, QKV) come through the SCALAR cache (s_load_dwordx16 in front of the
+//     chunk's first barrier): the loop holds no vector-memory load at all, so nothing by name crosses its back edge and the chunk loop is
+//     a real loop (peeled four chunks for the exact counts of the first waits).
+//
+// Row tiles are always whole: tokens past M read row M - 1 and store into a trash page (lane-local arithmetic: a padded lane cannot
+// disturb a live one).
+#pragma once
+#include "uu3d_gemm_panel8.h"
+
+namespace uu3d {
+
+enum : int {
+    TC_PROJ = 1,        // starts with x += context Wp + bp (context = attention output, A-fragment order, natural k)
+    TC_MLP = 2,         // LayerNorm 2, fc1, ReLU, fc2, residual
+    TC_QKV = 4,         // ends with LayerNorm 1 + QKV of the NEXT block (f16 planes for attn_h3_kernel, q pre-scaled)
+    TC_FC1_PLANES = 8,  // (instead of TC_MLP) LayerNorm 2, fc1 (Conv1D k = 1), ReLU -> row-major f16 planes: the first strided block, whose convolution is another kernel
+    TC_PE = 16,         // in front of the final LayerNorm 1: xa = x + pe[token % period] is stored and normalised (temporal stack -> strided block 1, u_u_t.py:126-128)
+};
+
+static constexpr int TC_CHUNK_HALFS = P8_CHUNK_BYTES / 2;
+__host__ __device__ inline constexpr int tchain_chunks(int flags) {
+    return ((flags & TC_PROJ) ? 12 : 0) + ((flags & TC_MLP) ? 48 : 0) + ((flags & TC_FC1_PLANES) ? 24 : 0) + ((flags & TC_QKV) ? 36 : 0);
+}
+static constexpr size_t TC_T_FLOATS_PER_TILE = 2 * 12 * 8 * 2 * 64 * 4;      // two partial-result slabs of a 128 x 384 tile, lane-linear
+static constexpr size_t TC_H_HALFS_PER_TILE = 24 * 8 * 2 * 64 * 8;           // relu(fc1) of a tile as fc2's token fragments, lane-linear
+static constexpr size_t TC_TRASH_BYTES = 16384;
+
+// Parameter table of one launch (floats, packed at commit time: ONE pointer instead of eight -- with two dozen pointers in scalar
+// registers for the whole kernel the chunk loops' bias registers went into v_writelane spills)
+// (b1 and bqkv are the FOLDED biases b + beta W of the LayerNorm in front, and their W is diag(gamma) W: see layer_norm below)
+enum : int { TCP_BP = 0, TCP_B1 = 384, TCP_B2 = 1152, TCP_BQKV = 1536, TCP_FLOATS = 2688 };
+
+struct TChainArgs {
+    int M, m_tiles, period; float qscale;
+    const _Float16* Of;          // TC_PROJ: attention output [panel][24 slices][plane][lane][8]
+    float* X;                    // residual stream [M][384]
+    float* XA; const float* pe;  // TC_PE: xa = x + pe[token % period]
+    const _Float16* W;           // the launch's weight stream (tchain_pack_stage per stage), tchain_chunks(flags) x 48 KiB
+    const float* P;              // parameter table (TCP_*)
+    _Float16* Q;                 // TC_QKV: hi plane [M][1152], lo plane M * 1152 halfs further
+    _Float16* H;                 // TC_FC1_PLANES: hi plane [M][768], lo plane M * 768 halfs further
+    unsigned char* scratch;      // tchain_scratch_bytes(m_tiles): partial-result slabs | hidden fragments | trash page
+};
+__host__ __device__ inline constexpr size_t tchain_scratch_bytes(int m_tiles) {
+    return (size_t)m_tiles * (TC_T_FLOATS_PER_TILE * 4 + TC_H_HALFS_PER_TILE * 2) + TC_TRASH_BYTES;
+}
+
+// ---- host side: one stage's chunks of the weight stream from the transposed, padded planes Bt[n][Kp] (k contiguous; lo pre-scaled) ----
+// chunk c (output channels 32 c ..), wave group hh, position kk (0..11), plane p, lane l, element j:
+//     natural order (the attention output's):  k = 16 (12 hh + kk) + 8 (l >> 5) + j
+//     lane order (everything this kernel produced itself):  k = kofs + 16 (2 kk + hh) + 8 (j >> 2) + 4 (l >> 5) + (j & 3)
+inline void tchain_pack_stage(const _Float16* Bh, const _Float16* Bl, int N, int Kp, int kofs, bool natural, _Float16* out) {
+    for (int c = 0; c < N / 32; ++c)
+        for (int hh = 0; hh < 2; ++hh)
+            for (int kk = 0; kk < 12; ++kk)
+                for (int p = 0; p < 2; ++p)
+                    for (int l = 0; l < 64; ++l)
+                        for (int j = 0; j < 8; ++j) {
+                            const int n = 32 * c + (l & 31);
+                            const int k = natural ? 16 * (12 * hh + kk) + 8 * (l >> 5) + j
+                                                  : kofs + 16 * (2 * kk + hh) + 8 * (j >> 2) + 4 * (l >> 5) + (j & 3);
+                            out[(((((size_t)c * 2 + hh) * 12 + kk) * 2 + p) * 64 + l) * 8 + j] = (p ? Bl : Bh)[(size_t)n * Kp + k];
+                        }
+}
+
+typedef float f32x16s __attribute__((ext_vector_type(16)));
+
+#ifndef UU3D_TC_LOO
+#define UU3D_TC_LOO 0          // tools/tchain_exp: leave-one-out timing builds (results wrong): 1 no refill DMA, 2 no finish, 4 no exchange, 8 no mid barrier, 16 no fragment reads, 32 no MFMA
+#endif
+#ifdef UU3D_TC_STAMP
+// tools/tchain_exp: per workgroup 16 pairs (s_memtime = shader clock ticks, s_memrealtime = 100 MHz) at the chain's stage boundaries
+__device__ unsigned long long tchain_stamps[256 * 32];
+#define TC_STAMP(i) do { if (tid == 0 && bm < 256) { tchain_stamps[bm * 32 + 2 * (i)] = __builtin_amdgcn_s_memtime(); tchain_stamps[bm * 32 + 2 * (i) + 1] = __builtin_amdgcn_s_memrealtime(); } } while (0)
+#else
+#define TC_STAMP(i)
+#endif
+
+// ---- epilogues of a stage: what happens to the 8 finished values v[j] (channels 32 c + 16 hh + 8 (j >> 2) + 4 g + (j & 3)) of a lane ----
+struct TcEpScratch {           // partial result of a residual Dense layer -> lane-linear scratch (added to x at the transition)
+    static constexpr int kStores = 2; static constexpr bool kBias = false;
+    f32x4* __restrict__ t;     // this lane's slot: + (c * 8 + wave) * 2 * 64 per chunk
+    const float* bias;
+};
+struct TcEpHidden {            // relu(v + b1) split into hi / lo = the token fragment of fc2's k-slice 2 c + hh -> lane-linear scratch
+    static constexpr int kStores = 2; static constexpr bool kBias = true;
+    h16x8* __restrict__ hs;
+    const float* bias;
+};
+struct TcEpPlanes {            // (v + bias) [* qscale for chunks < qchunks] [relu] split into row-major hi / lo planes of leading dimension ld
+    static constexpr int kStores = 4; static constexpr bool kBias = true;
+    unsigned char* __restrict__ ph; unsigned char* __restrict__ pl;     // this lane's row in the planes (or the trash page) + (16 hh + 4 g) halfs
+    const float* bias; int qchunks; float qscale; int relu;
+};
+
+template <int FLAGS>
+__global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2)))
+tchain_kernel(const TChainArgs a)
+{
+    constexpr int HS = 12;
+    constexpr int GT = tchain_chunks(FLAGS);
+    static_assert(!((FLAGS & TC_MLP) && (FLAGS & TC_FC1_PLANES)), "one MLP form per launch");
+    static_assert(GT >= 12, "at least one stage");
+    h3_flush_f16_denormals();
+    extern __shared__ __attribute__((aligned(16))) unsigned char psm[];
+
+    const int bm = blockIdx.x;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int hh = wave >> 2, q = wave & 3, g = lane >> 5;
+    const int tok = bm * 128 + q * 32 + (lane & 31);
+    const bool live = tok < a.M;
+    const int tokc = min(tok, a.M - 1);
+    const int chl = 16 * hh + 4 * g;                       // this lane's first channel inside a 32-channel chunk (second group: + 8)
+
+    // ---- weight stream -> ring: as gemm_h3_panel8_kernel (half-chunk g2 = 2 G + j: k positions [6 j, 6 j + 6) of both wave groups) ----
+    const unsigned wofs = (unsigned)(hh * HS * 2048 + q * 3072);
+    const unsigned char* const wsrc = reinterpret_cast<const unsigned char*>(a.W) + wofs;
+    const unsigned lane16 = (unsigned)lane * 16u;
+    auto dma1 = [&](int Gc, int j, int slot, int i) __attribute__((always_inline)) {
+        const unsigned char* s = wsrc + (size_t)min(Gc, GT - 1) * P8_CHUNK_BYTES + j * (6 * 2048);
+        unsigned char* d = psm + slot * P8_CHUNK_BYTES + wofs + j * (6 * 2048);
+        switch (i) {
+            case 0: __builtin_amdgcn_global_load_lds((h3_glb_void*)(s + lane16), (h3_lds_void*)d, 16, 0, 0); break;
+            case 1: __builtin_amdgcn_global_load_lds((h3_glb_void*)(s + lane16), (h3_lds_void*)d, 16, 1024, 0); break;
+            default: __builtin_amdgcn_global_load_lds((h3_glb_void*)(s + lane16), (h3_lds_void*)d, 16, 2048, 0); break;
+        }
+    };
+#pragma unroll
+    for (int g2 = 0; g2 < 5; ++g2)
+#pragma unroll
+        for (int i = 0; i < 3; ++i) dma1(g2 >> 1, g2 & 1, g2 >> 1, i);
+    int G = 0, slot = 0;                                   // next chunk of the stream to be consumed and its ring slot (G % 3)
+
+    unsigned char* const xmine = psm + P8_RING_BYTES + wave * 2048 + lane16;
+    unsigned char* const xpart = psm + P8_RING_BYTES + (wave ^ 4) * 2048 + lane16;
+    float* const stat = reinterpret_cast<float*>(psm + P8_RING_BYTES);
+    const unsigned rd0 = (unsigned)(uintptr_t)(h3_lds_void*)(psm + hh * HS * 2048 + (unsigned)(lane ^ (hh << 4)) * 16u);
+
+    h16x8 ah[HS], al[HS];                                  // the token fragments of the running stage (this wave's 12 k positions)
+    h16x8 bh[3] = {}, bl[3] = {};
+#define UU3D_TC_READ(i, sb, kk) \
+    if (!(UU3D_TC_LOO & 16)) asm volatile("ds_read_b128 %0, %2 offset:%3\n\tds_read_b128 %1, %2 offset:%4" \
+                 : "=&v"(bh[i]), "=&v"(bl[i]) : "v"(sb), "i"((kk) * 2048), "i"((kk) * 2048 + 1024))
+
+    // ---- the finished values of one chunk, half i (j = 4 i .. 4 i + 3): own partial sum + the partner's ----
+    auto combine = [&](const f32x16& p0, const f32x16& p1, const float (&rv)[8], int i) __attribute__((always_inline)) -> f32x4 {
+        f32x4 v;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = (p0[4 * i + e] + p1[4 * i + e] * (1.0f / H3_SCALE)) + rv[4 * i + e];
+        return v;
+    };
+    auto bias4 = [&](const f32x16s& sb, int i) __attribute__((always_inline)) -> f32x4 {       // scalar registers 8 i + 4 g + e
+        // (the two candidates are made opaque first: hipcc otherwise folds the select into a DYNAMIC index of the 16-vector, a chain of
+        // 16 v_cmp / v_cndmask pairs per value whose compare masks it then spilled with v_writelane -- 170 of them per chunk pair)
+        f32x4 b;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            float b0 = sb[8 * i + e], b1 = sb[8 * i + 4 + e];
+            asm("" : "+s"(b0), "+s"(b1));
+            b[e] = g ? b1 : b0;
+        }
+        return b;
+    };
+    unsigned char* const psm_dummy = a.scratch + (size_t)bm * (TC_T_FLOATS_PER_TILE * 4);
+    // finish half i of chunk cp; the 16-byte fragments of TcEpHidden need both halves: `keep` carries half 0 to half 1
+    struct Keep { h16x4 h0, l0; };
+    auto finish = [&](auto ep, int cp, int i, const f32x4 v, const f32x16s& sb, Keep& keep) __attribute__((always_inline)) {
+        using EP = decltype(ep);
+        if constexpr (std::is_same<EP, TcEpScratch>::value) {
+            ep.t[((size_t)(cp * 8 + wave) * 2 + i) * 64] = v;
+        } else if constexpr (std::is_same<EP, TcEpHidden>::value) {
+            f32x4 y = v + bias4(sb, i);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) y[e] = fmaxf(y[e], 0.f);
+            h16x4 hi, lo;
+            h3_split(y, hi, lo);
+            if (i == 0) { keep.h0 = hi; keep.l0 = lo; }
+            else {
+                h16x8 fh, fl;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { fh[e] = keep.h0[e]; fh[4 + e] = hi[e]; fl[e] = keep.l0[e]; fl[4 + e] = lo[e]; }
+                h16x8* d = ep.hs + ((size_t)(cp * 8 + wave) * 2) * 64;
+                d[0] = fh; d[64] = fl;
+            }
+        } else {
+            f32x4 y = v + bias4(sb, i);
+            if (cp < ep.qchunks) y = y * ep.qscale;
+            if (ep.relu) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) y[e] = fmaxf(y[e], 0.f);
+            }
+            h16x4 hi, lo;
+            h3_split(y, hi, lo);
+            const unsigned o = (unsigned)(32 * cp + 8 * i) * 2u;
+            if (UU3D_TC_LOO & 64) {                        // (timing: the same bytes as coalesced 512-byte runs)
+                unsigned char* d = psm_dummy + (size_t)((cp * 8 + wave) * 4 + 2 * i) * 512 + lane * 8;
+                *reinterpret_cast<h16x4*>(d) = hi; *reinterpret_cast<h16x4*>(d + 512) = lo;
+            } else {
+            *reinterpret_cast<h16x4*>(ep.ph + o) = hi;
+            *reinterpret_cast<h16x4*>(ep.pl + o) = lo;
+            }
+        }
+    };
+
+    // ---- one chunk of a stage.  CL = min(local chunk index, 3) decides the exact counts of the waits: vector-memory operations per
+    // half-interval in issue order are [first half] 3 pieces, [second half] kStores stores of chunk c - 1 (c > 0), 3 pieces; the barrier
+    // that opens a half-interval needs the pieces issued four half-intervals earlier (uu3d_gemm_panel8.h) ----
+    auto chunk = [&](auto cl_tag, auto pre_tag, auto ep, const int c, f32x16& x0, f32x16& x1, const f32x16& p0, const f32x16& p1) __attribute__((always_inline)) {
+        constexpr int CL = decltype(cl_tag)::value;
+        constexpr bool PRE_IN = (decltype(pre_tag)::value & 1) != 0, PRE_OUT = (decltype(pre_tag)::value & 2) != 0;
+        using EP = decltype(ep);
+        constexpr int NST = EP::kStores;
+        const int pslot = slot == 0 ? 2 : slot - 1;
+        const unsigned sb = rd0 + (unsigned)slot * P8_CHUNK_BYTES;
+        // ---- barrier B_c: half-chunk 2 c + 1 landed (own pieces); every LDS read of the previous chunk returned ----
+        asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" :: "i"(9 + NST * ((CL >= 2) + (CL >= 3))) : "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+        if constexpr (!PRE_IN) {                           // (else: issued by the previous chunk of this body, in front of the barrier)
+            UU3D_TC_READ(0, sb, 0);
+            UU3D_TC_READ(1, sb, 1);
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { x0[r] = 0.f; x1[r] = 0.f; }
+#pragma unroll
+        for (int kk = 0; kk < 6; ++kk) {
+            UU3D_TC_READ((kk + 2) % 3, sb, kk + 2);
+            asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(bh[kk % 3]), "+v"(bl[kk % 3]) : "i"((UU3D_TC_LOO & 20) ? 0 : CL > 0 && (kk == 2 || kk == 3) ? 6 : 4));
+            if (UU3D_TC_LOO & 32) asm volatile("" : "+v"(x0), "+v"(x1) : "v"(bh[kk % 3]), "v"(bl[kk % 3]), "v"(ah[kk]), "v"(al[kk]));
+            else {
+            x0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(bh[kk % 3], ah[kk], x0, 0, 0, 0);
+            x1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(bh[kk % 3], al[kk], x1, 0, 0, 0);
+            x1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(bl[kk % 3], ah[kk], x1, 0, 0, 0);
+            }
+            if (CL > 0 && kk == 1 && !(UU3D_TC_LOO & 4)) {                       // send the other wave's half of chunk c - 1 (its MFMAs have drained by now)
+                f32x4 s0, s1;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { s0[e] = p0[8 + e] + p1[8 + e] * (1.0f / H3_SCALE); s1[e] = p0[12 + e] + p1[12 + e] * (1.0f / H3_SCALE); }
+                asm volatile("ds_write_b128 %0, %1\n\tds_write_b128 %0, %2 offset:1024" :: "v"((unsigned)(uintptr_t)(h3_lds_void*)xmine), "v"(s0), "v"(s1) : "memory");
+            }
+            if (kk >= 3 && !(UU3D_TC_LOO & 1)) dma1(G + 2, 1, pslot, kk - 3);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        // ---- barrier B'_c: half-chunk 2 c + 2 landed; everybody read the first halves of chunk c and wrote the exchange area ----
+        // The bias of chunk c - 1 (16 channels of this wave group) is requested through the scalar cache HERE and becomes a value at the
+        // lgkmcnt(0) of k position 7: a scalar load in flight only makes the counted LDS waits in between stricter by one operation.
+        f32x16s sbias = {};
+        if constexpr (CL > 0 && EP::kBias && !(UU3D_TC_LOO & 128)) {
+            const float* bp = ep.bias + 32 * (c - 1);          // (ep.bias already points at this wave group's 16 channels)
+            asm volatile("s_load_dwordx16 %0, %1, 0x0" : "=s"(sbias) : "s"(bp) : "memory");
+        }
+        asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(4)" :: "i"(9 + NST * (CL >= 2)) : "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        if (!(UU3D_TC_LOO & 8)) __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+        f32x4 r0, r1;
+        float rv[8];
+        Keep keep;
+        if constexpr (CL > 0 && !(UU3D_TC_LOO & 4))
+            asm volatile("ds_read_b128 %0, %2\n\tds_read_b128 %1, %2 offset:1024" : "=&v"(r0), "=&v"(r1) : "v"((unsigned)(uintptr_t)(h3_lds_void*)xpart) : "memory");
+        else { r0 = f32x4{0.f, 0.f, 0.f, 0.f}; r1 = r0; }
+        // The two waves of a SIMD (hh = 0 / 1 of a pair) finish the previous chunk at DIFFERENT k positions -- 7, 8 and 10, 11 -- and
+        // issue their refill pieces at the others (9 .. 11 and 6 .. 8): finished in lockstep, the epilogue's vector instructions of both
+        // waves left the matrix pipe idle (leave-one-out builds: MFMA time, epilogue time and barrier skeleton simply added up).  The
+        // counts of the barriers' waits are the smaller ones of the two orders (stores in front of / behind the pieces).
+#pragma unroll
+        for (int kk = 6; kk < HS; ++kk) {
+            if (kk + 2 < HS) UU3D_TC_READ((kk + 2) % 3, sb, kk + 2);
+            const int young = (kk + 1 < HS ? 2 : 0) + (kk + 2 < HS ? 2 : 0);
+            if (UU3D_TC_LOO & 20) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(bh[kk % 3]), "+v"(bl[kk % 3]), "+v"(r0), "+v"(r1));
+            else if (CL > 0 && kk == 6) asm volatile("s_waitcnt lgkmcnt(6)" : "+v"(bh[kk % 3]), "+v"(bl[kk % 3]));
+            else if (CL > 0 && kk == 7) {
+                if constexpr (EP::kBias) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(bh[kk % 3]), "+v"(bl[kk % 3]), "+v"(r0), "+v"(r1), "+s"(sbias));
+                else asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(bh[kk % 3]), "+v"(bl[kk % 3]), "+v"(r0), "+v"(r1));
+            }
+            else asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(bh[kk % 3]), "+v"(bl[kk % 3]) : "i"(young));
+            if (UU3D_TC_LOO & 32) asm volatile("" : "+v"(x0), "+v"(x1) : "v"(bh[kk % 3]), "v"(bl[kk % 3]), "v"(ah[kk]), "v"(al[kk]));
+            else {
+            x0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(bh[kk % 3], ah[kk], x0, 0, 0, 0);
+            x1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(bh[kk % 3], al[kk], x1, 0, 0, 0);
+            x1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(bl[kk % 3], ah[kk], x1, 0, 0, 0);
+            }
+            if constexpr (CL > 0) {
+                if (kk == 7) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) { rv[e] = r0[e]; rv[4 + e] = r1[e]; }
+                }
+                if (!(UU3D_TC_LOO & 2)) {
+                    if (hh == 0) {
+                        if (kk == 7) finish(ep, c - 1, 0, combine(p0, p1, rv, 0), sbias, keep);
+                        if (kk == 8) finish(ep, c - 1, 1, combine(p0, p1, rv, 1), sbias, keep);
+                    } else {
+                        if (kk == 10) finish(ep, c - 1, 0, combine(p0, p1, rv, 0), sbias, keep);
+                        if (kk == 11) finish(ep, c - 1, 1, combine(p0, p1, rv, 1), sbias, keep);
+                    }
+                }
+            }
+            if (!(UU3D_TC_LOO & 1)) {
+                if (hh == 0) { if (kk >= 9) dma1(G + 3, 0, slot, kk - 9); }
+                else { if (kk <= 8) dma1(G + 3, 0, slot, kk - 6); }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        G += 1;
+        slot = slot == 2 ? 0 : slot + 1;
+        if constexpr (PRE_OUT) {                           // the next chunk's first fragments: its first half landed one barrier ago
+            const unsigned nb = rd0 + (unsigned)slot * P8_CHUNK_BYTES;
+            UU3D_TC_READ(0, nb, 0);
+            UU3D_TC_READ(1, nb, 1);
+        }
+    };
+
+    // ---- a stage of NCH chunks over the token fragments in ah / al; leaves every result finished and stored ----
+    auto stage = [&](auto nch_tag, auto ep) __attribute__((always_inline)) {
+        constexpr int NCH = decltype(nch_tag)::value;
+        using EP = decltype(ep);
+        static_assert(NCH % 4 == 0 && NCH >= 4, "bodies of four chunks");
+        f32x16 a0, a1, b0 = {}, b1 = {};
+        // (pre tag: 1 = the chunk's first two fragment reads were issued by its predecessor, 2 = it issues its successor's.  Nothing requested
+        // by name crosses the loop's back edge: the first chunk of a body reads behind its barrier.)
+        using I0 = std::integral_constant<int, 0>; using I1 = std::integral_constant<int, 1>; using I2 = std::integral_constant<int, 2>; using I3 = std::integral_constant<int, 3>;
+        chunk(I0{}, I2{}, ep, 0, a0, a1, b0, b1);
+        chunk(I1{}, I3{}, ep, 1, b0, b1, a0, a1);
+        chunk(I2{}, I3{}, ep, 2, a0, a1, b0, b1);
+        chunk(I3{}, I1{}, ep, 3, b0, b1, a0, a1);
+#pragma unroll 1
+        for (int c = 4; c < NCH; c += 4) {
+            chunk(I3{}, I2{}, ep, c, a0, a1, b0, b1);
+            chunk(I3{}, I3{}, ep, c + 1, b0, b1, a0, a1);
+            chunk(I3{}, I3{}, ep, c + 2, a0, a1, b0, b1);
+            chunk(I3{}, I1{}, ep, c + 3, b0, b1, a0, a1);
+        }
+        // ---- the last chunk (in b0 / b1): send, barrier, receive, finish ----
+        constexpr int c = NCH - 1;
+        f32x16s sbias = {};
+        if constexpr (EP::kBias) {
+            const float* bp = ep.bias + 32 * c;
+            asm volatile("s_load_dwordx16 %0, %1, 0x0" : "=s"(sbias) : "s"(bp) : "memory");
+            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" : "+s"(sbias) :: "memory");
+        } else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();                      // everybody's reads of the exchange area (chunk c - 1) returned
+        f32x4 s0, s1, r0, r1;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { s0[e] = b0[8 + e] + b1[8 + e] * (1.0f / H3_SCALE); s1[e] = b0[12 + e] + b1[12 + e] * (1.0f / H3_SCALE); }
+        asm volatile("ds_write_b128 %0, %1\n\tds_write_b128 %0, %2 offset:1024\n\ts_waitcnt lgkmcnt(0)" :: "v"((unsigned)(uintptr_t)(h3_lds_void*)xmine), "v"(s0), "v"(s1) : "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("ds_read_b128 %0, %2\n\tds_read_b128 %1, %2 offset:1024\n\ts_waitcnt lgkmcnt(0)" : "=&v"(r0), "=&v"(r1) : "v"((unsigned)(uintptr_t)(h3_lds_void*)xpart) : "memory");
+        float rv[8];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { rv[e] = r0[e]; rv[4 + e] = r1[e]; }
+        Keep keep;
+        finish(ep, c, 0, combine(b0, b1, rv, 0), sbias, keep);
+        finish(ep, c, 1, combine(b0, b1, rv, 1), sbias, keep);
+        __builtin_amdgcn_s_barrier();                      // the exchange area is free again (the transitions keep their statistics there)
+    };
+
+    // ================= transitions: everything below works on the lane's own 96 values of the residual stream =================
+    f32x4 xr[12][2];                                       // x[token][32 c + 16 hh + 8 i + 4 g + (0..3)]
+    unsigned char* const trash = a.scratch + (size_t)a.m_tiles * (TC_T_FLOATS_PER_TILE * 4 + TC_H_HALFS_PER_TILE * 2);
+    const float* const xrow = a.X + (size_t)tokc * 384 + chl;
+    float* const xst = live ? a.X + (size_t)tok * 384 + chl : reinterpret_cast<float*>(trash) + chl;
+    f32x4* const tl = reinterpret_cast<f32x4*>(a.scratch) + (size_t)bm * (TC_T_FLOATS_PER_TILE / 4) + lane;       // slab 0; slab 1: + 12 * 8 * 2 * 64
+    h16x8* const hsl = reinterpret_cast<h16x8*>(a.scratch + (size_t)a.m_tiles * (TC_T_FLOATS_PER_TILE * 4)) + (size_t)bm * (TC_H_HALFS_PER_TILE / 8) + lane;
+
+    // x += (partial slab(s) + bias), stored back.  Every load sits in front of the first store: xrow and xst are the same memory, and
+    // with a store between them hipcc kept the 24 load groups in program order -- 24 dependent L2 round trips, 42 k cycles per transition.
+    auto add_partials = [&](int slabs, const float* bias) __attribute__((always_inline)) {
+#pragma unroll
+        for (int c = 0; c < 12; ++c)
+#pragma unroll
+            for (int i = 0; i < 2; ++i) xr[c][i] = *reinterpret_cast<const f32x4*>(xrow + 32 * c + 8 * i);
+#pragma unroll
+        for (int c = 0; c < 12; ++c)
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const f32x4 bv = *reinterpret_cast<const f32x4*>(bias + 32 * c + chl + 8 * i);
+                f32x4 y = tl[((size_t)(c * 8 + wave) * 2 + i) * 64];
+                if (slabs == 2) y = y + tl[((size_t)((12 + c) * 8 + wave) * 2 + i) * 64];
+                xr[c][i] = xr[c][i] + (y + bv);
+            }
+        asm volatile("" ::: "memory");
+#pragma unroll
+        for (int c = 0; c < 12; ++c)
+#pragma unroll
+            for (int i = 0; i < 2; ++i) *reinterpret_cast<f32x4*>(xst + 32 * c + 8 * i) = xr[c][i];
+    };
+    // sum over the token's 384 channels: this lane's 96 + lane ^ 32 + the partner wave (both waves add the same two numbers)
+    auto token_sum = [&](float s, int phase) __attribute__((always_inline)) -> float {
+        s += __shfl_xor(s, 32);
+        if (g == 0) stat[phase * 256 + wave * 32 + (lane & 31)] = s;
+        __syncthreads();
+        return s + stat[phase * 256 + (wave ^ 4) * 32 + (lane & 31)];
+    };
+    // LayerNorm (two-pass, eps inside the root) of xr WITHOUT its affine part -> the next stage's token fragments.  gamma and beta are
+    // folded into the Dense layer behind it when the stream is packed (W' = diag(gamma) W, b' = b + beta W): 48 broadcast loads of 16
+    // bytes per lane and ~200 vector instructions less per transition.
+    auto layer_norm = [&]() __attribute__((always_inline)) {
+        float s = 0.f;
+#pragma unroll
+        for (int c = 0; c < 12; ++c)
+#pragma unroll
+            for (int i = 0; i < 2; ++i) s += (xr[c][i][0] + xr[c][i][1]) + (xr[c][i][2] + xr[c][i][3]);
+        const float mean = token_sum(s, 0) * (1.0f / 384.0f);
+        float v = 0.f;
+#pragma unroll
+        for (int c = 0; c < 12; ++c)
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const f32x4 d = xr[c][i] - mean;
+                v += (d[0] * d[0] + d[1] * d[1]) + (d[2] * d[2] + d[3] * d[3]);
+            }
+        const float rstd = 1.0f / sqrtf(token_sum(v, 1) * (1.0f / 384.0f) + 1e-5f);
+#pragma unroll
+        for (int c = 0; c < 12; ++c) {
+            h16x4 hi[2], lo[2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) h3_split((xr[c][i] - mean) * rstd, hi[i], lo[i]);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { ah[c][e] = hi[0][e]; ah[c][4 + e] = hi[1][e]; al[c][e] = lo[0][e]; al[c][4 + e] = lo[1][e]; }
+        }
+    };
+
+    // ================= the chain =================
+    TC_STAMP(0);
+    if constexpr ((FLAGS & TC_PROJ) != 0) {
+        const int panel = min(bm * 128 + q * 32, a.M - 1) >> 5;
+        const h16x8* ap = reinterpret_cast<const h16x8*>(a.Of) + (size_t)panel * 24 * 2 * 64 + lane;
+#pragma unroll
+        for (int s = 0; s < HS; ++s) { ah[s] = ap[((HS * hh + s) * 2 + 0) * 64]; al[s] = ap[((HS * hh + s) * 2 + 1) * 64]; }
+        TC_STAMP(1);
+        stage(std::integral_constant<int, 12>{}, TcEpScratch{tl, nullptr});
+        TC_STAMP(2);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        add_partials(1, a.P + TCP_BP);
+    } else {
+#pragma unroll
+        for (int c = 0; c < 12; ++c)
+#pragma unroll
+            for (int i = 0; i < 2; ++i) xr[c][i] = *reinterpret_cast<const f32x4*>(xrow + 32 * c + 8 * i);
+    }
+    if constexpr ((FLAGS & (TC_MLP | TC_FC1_PLANES)) != 0) {
+        TC_STAMP(3);
+        layer_norm();
+        TC_STAMP(4);
+        if constexpr ((FLAGS & TC_FC1_PLANES) != 0) {
+            unsigned char* ph = live ? reinterpret_cast<unsigned char*>(a.H + (size_t)tok * 768 + chl) : trash;
+            unsigned char* pl = live ? reinterpret_cast<unsigned char*>(a.H + ((size_t)a.M + tok) * 768 + chl) : trash + 4096;
+            stage(std::integral_constant<int, 24>{}, TcEpPlanes{ph, pl, a.P + TCP_B1 + 16 * hh, 0, 1.0f, 1});
+        } else {
+            stage(std::integral_constant<int, 24>{}, TcEpHidden{hsl, a.P + TCP_B1 + 16 * hh});
+            TC_STAMP(5);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll 1
+            for (int half = 0; half < 2; ++half) {
+#pragma unroll
+                for (int s = 0; s < HS; ++s) {
+                    const h16x8* d = hsl + ((size_t)((12 * half + s) * 8 + wave) * 2) * 64;
+                    ah[s] = d[0]; al[s] = d[64];
+                }
+                stage(std::integral_constant<int, 12>{}, TcEpScratch{tl + (size_t)half * (12 * 8 * 2 * 64), nullptr});
+            }
+            TC_STAMP(6);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            add_partials(2, a.P + TCP_B2);
+            TC_STAMP(7);
+        }
+    }
+    if constexpr ((FLAGS & TC_QKV) != 0) {
+        if constexpr ((FLAGS & TC_PE) != 0) {
+            const float* pr = a.pe + (size_t)(tokc % a.period) * 384 + chl;
+            float* const xast = live ? a.XA + (size_t)tok * 384 + chl : reinterpret_cast<float*>(trash) + chl;
+#pragma unroll
+            for (int c = 0; c < 12; ++c)
+#pragma unroll
+                for (int i = 0; i < 2; ++i) xr[c][i] = xr[c][i] + *reinterpret_cast<const f32x4*>(pr + 32 * c + 8 * i);
+            asm volatile("" ::: "memory");
+#pragma unroll
+            for (int c = 0; c < 12; ++c)
+#pragma unroll
+                for (int i = 0; i < 2; ++i) *reinterpret_cast<f32x4*>(xast + 32 * c + 8 * i) = xr[c][i];
+        }
+        layer_norm();
+        TC_STAMP(8);
+        unsigned char* ph = live ? reinterpret_cast<unsigned char*>(a.Q + (size_t)tok * 1152 + chl) : trash;
+        unsigned char* pl = live ? reinterpret_cast<unsigned char*>(a.Q + ((size_t)a.M + tok) * 1152 + chl) : trash + 4096;
+        stage(std::integral_constant<int, 36>{}, TcEpPlanes{ph, pl, a.P + TCP_BQKV + 16 * hh, 12, a.qscale, 0});
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // (the clamped tail pieces must not outlive the LDS allocation)
+    TC_STAMP(9);
+#undef UU3D_TC_READ
+}
+
+}  // namespace uu3d

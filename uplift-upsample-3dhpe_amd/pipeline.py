@@ -21,6 +21,7 @@ with a spin kernel and timing a tiny kernel on the other with HIP events (~50 ms
 Results are bit-identical to ``model(...)``: the same launches on the same data, only on another
 stream.  Latency of ONE batch does not improve (0.9 ms); use ``model(...)`` for that.
 """
+import os
 import ctypes as C
 
 
@@ -86,7 +87,7 @@ class ForwardPipeline(object):
         if depth is not None and depth < 1:
             raise ValueError("depth >= 1")
         if streams is None and (depth is None or depth > 1):
-            q = distinct_queue_streams(model.device)
+            q = distinct_queue_streams(model.device, want=int(os.environ.get("UU3D_PIPE_QUEUES", "4")))
             if depth is None:
                 depth = len(q)
             if depth <= len(q):
