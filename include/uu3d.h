@@ -39,7 +39,9 @@ typedef enum uu3d_status {
     UU3D_ERR_NOT_READY = 4,        /* forward before every weight was set and committed       */
     UU3D_ERR_WORKSPACE = 5,        /* workspace too small / misaligned                        */
     UU3D_ERR_HIP = 6,              /* a HIP runtime call failed (see uu3d_last_error)          */
-    UU3D_ERR_NO_DEVICE = 7         /* no usable gfx950 device                                 */
+    UU3D_ERR_NO_DEVICE = 7,        /* no usable gfx950 device                                 */
+    UU3D_ERR_RANGE = 8             /* uu3d_range_status: a forward produced non-finite outputs -- activations left the f16 range of the
+                                      f16x3 products (|x| >= 65504), or its inputs were not finite                                    */
 } uu3d_status;
 
 /* Arithmetic the GEMM-shaped work is carried out in. */
@@ -212,6 +214,23 @@ int uu3d_world_to_cam_2d(const float* world_dev, const float* cams_dev, int32_t 
  */
 #define UU3D_SCHEDULE_LATENCY 0
 #define UU3D_SCHEDULE_THROUGHPUT 1
+/*
+ * RANGE CONTRACT of precision f16x3 (round 5).  The reference computes in float32 end to end; the f16x3 products split
+ * every operand into two f16 planes, so an ACTIVATION of magnitude >= 65504 (LayerNorm outputs, q | k | v, attention context, ReLU(fc1),
+ * the residual stream in front of the full-sequence head, the spatial stack's operands) becomes Inf in its hi plane and the sequence it
+ * belongs to comes out NaN.  (Weights are checked when they are committed: uu3d_commit_weights fails with UU3D_ERR_RANGE.)  Keras-default
+ * and trained weights keep activations at O(10); nothing in the format guarantees it.  Therefore:
+ *   - every f16x3 forward ends with a check of its outputs (one small launch): non-finite values set a STICKY device word of the model;
+ *   - uu3d_range_status(model, stream, &flag) synchronises `stream`, returns the word (flag 0 / 1; may be NULL) and clears it; its return
+ *     value is UU3D_ERR_RANGE when the word was set, UU3D_OK otherwise -- the forward itself stays asynchronous and keeps returning
+ *     launch errors only;
+ *   - OR-ing UU3D_SCHEDULE_EXACT_F32 into `schedule` runs THIS call on the exact-f32 kernels whatever the handle's precision (f32-input
+ *     MFMA: the whole float32 range; sequences of <= 128 tokens): the fallback for a batch that overflowed.
+ * The Python model(...) does all three: it checks after the call and repeats an overflowed batch in exact f32 (or raises Uu3dRangeError
+ * where that path does not exist); pipelines check once, at ForwardPipeline.check_range() / the end of run_eval.
+ */
+#define UU3D_SCHEDULE_EXACT_F32 0x100
+int uu3d_range_status(uu3d_model* model, void* stream, int32_t* out_flag);
 int uu3d_forward_ex(uu3d_model* model, const float* kp2d_dev, const uint8_t* stride_mask_dev, int32_t batch, float* full_out_dev,
                     float* central_out_dev, float* const* attention_out, void* workspace_dev, size_t workspace_bytes,
                     int32_t schedule, void* stream);

@@ -14,13 +14,14 @@ UU3D_PREC_F32 = 0
 UU3D_PREC_F16X3 = 1
 
 (UU3D_OK, UU3D_ERR_INVALID_ARGUMENT, UU3D_ERR_UNSUPPORTED, UU3D_ERR_SHAPE, UU3D_ERR_NOT_READY,
- UU3D_ERR_WORKSPACE, UU3D_ERR_HIP, UU3D_ERR_NO_DEVICE) = range(8)
+ UU3D_ERR_WORKSPACE, UU3D_ERR_HIP, UU3D_ERR_NO_DEVICE, UU3D_ERR_RANGE) = range(9)
+UU3D_SCHEDULE_LATENCY, UU3D_SCHEDULE_THROUGHPUT, UU3D_SCHEDULE_EXACT_F32 = 0, 1, 0x100
 
 # every symbol include/uu3d.h declares
 EXPORTED_SYMBOLS = (
     "uu3d_version", "uu3d_status_string", "uu3d_last_error", "uu3d_create", "uu3d_destroy",
     "uu3d_num_weights", "uu3d_weight_info", "uu3d_set_weight", "uu3d_get_weight",
-    "uu3d_commit_weights", "uu3d_workspace_bytes", "uu3d_forward", "uu3d_forward_attention", "uu3d_forward_ex", "uu3d_mpjpe", "uu3d_tail_status",
+    "uu3d_commit_weights", "uu3d_workspace_bytes", "uu3d_forward", "uu3d_forward_attention", "uu3d_forward_ex", "uu3d_range_status", "uu3d_mpjpe", "uu3d_tail_status",
     "uu3d_set_schedule", "uu3d_set_profiling", "uu3d_profile_read", "uu3d_gather_windows", "uu3d_world_to_cam_2d",
     "uu3d_mpjpe_loss", "uu3d_adamw_update", "uu3d_adamw_update_guarded", "uu3d_train_nonfinite_flag", "uu3d_train_nonfinite", "uu3d_ema_update",
     "uu3d_num_params", "uu3d_train_init", "uu3d_train_repack", "uu3d_train_export",
@@ -42,6 +43,10 @@ class Uu3dError(RuntimeError):
     def __init__(self, status, message):
         super().__init__(f"uu3d status {status}: {message}")
         self.status = status
+
+
+class Uu3dRangeError(Uu3dError):
+    """A forward produced non-finite outputs: activations left the f16 range of the f16x3 products (include/uu3d.h, RANGE CONTRACT)."""
 
 
 class Uu3dConfig(C.Structure):
@@ -114,6 +119,8 @@ def load_library(path=None):
     lib.uu3d_forward_attention.argtypes = [vp, vp, vp, i32, vp, vp, C.POINTER(vp), vp, sz, vp]
     lib.uu3d_forward_ex.restype = C.c_int
     lib.uu3d_forward_ex.argtypes = [vp, vp, vp, i32, vp, vp, C.POINTER(vp), vp, sz, i32, vp]
+    lib.uu3d_range_status.restype = C.c_int
+    lib.uu3d_range_status.argtypes = [vp, vp, C.POINTER(i32)]
     lib.uu3d_mpjpe.restype = C.c_int
     lib.uu3d_mpjpe.argtypes = [vp, vp, i32, i32, i32, vp, vp]
     lib.uu3d_tail_status.restype = C.c_int

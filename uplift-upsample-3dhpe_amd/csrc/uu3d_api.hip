@@ -124,6 +124,7 @@ struct uu3d_model {
                                    // CU-microseconds per block than the round-4 launches, but a launch is 71 workgroups x ~200 us: with four hardware queues the
                                    // pipelined step came out 3-5 % SLOWER (profiles/r05_tchain_ab.txt) -- narrow long launches mix badly with wide short ones
     int num_cus = 256;
+    int* d_range = nullptr;        // sticky device word of the range guard (include/uu3d.h: uu3d_range_status)
     bool no_planes = false;        // UU3D_NO_PLANES=1: keep the on-the-fly split GEMMs in f16x3 mode (A/B measurements, tests)
     _Float16* harena = nullptr;    // f16 hi/lo planes of every GEMM operand (f16x3 mode)
     size_t harena_halfs = 0;
@@ -281,6 +282,7 @@ const char* uu3d_status_string(int s) {
         case UU3D_ERR_WORKSPACE: return "workspace too small or misaligned";
         case UU3D_ERR_HIP: return "HIP runtime error";
         case UU3D_ERR_NO_DEVICE: return "no usable device";
+        case UU3D_ERR_RANGE: return "values beyond the f16 range of the f16x3 products (or non-finite inputs)";
         default: return "unknown status";
     }
 }
@@ -368,6 +370,10 @@ int uu3d_create(const uu3d_config* c, int device, uu3d_model** out) {
     { const char* e = getenv("UU3D_TAIL"); m->no_tail = !(e != nullptr && e[0] == '1'); }
     { const char* e = getenv("UU3D_TCHAIN"); m->no_tchain = !(e != nullptr && e[0] == '1'); }
     { hipDeviceProp_t pr; if (hipGetDeviceProperties(&pr, device) == hipSuccess && pr.multiProcessorCount > 0) m->num_cus = pr.multiProcessorCount; }
+    if (hipMalloc((void**)&m->d_range, sizeof(int)) != hipSuccess || hipMemset(m->d_range, 0, sizeof(int)) != hipSuccess) {
+        delete m;
+        return fail(nullptr, UU3D_ERR_HIP, "hipMalloc of the range-guard word failed");
+    }
     *out = m;
     return UU3D_OK;
 }
@@ -382,6 +388,7 @@ void uu3d_destroy(uu3d_model* m) {
     if (m->gparams) (void)hipFree(m->gparams);
     if (m->arena) (void)hipFree(m->arena);
     if (m->harena) (void)hipFree(m->harena);
+    if (m->d_range) (void)hipFree(m->d_range);
     for (auto& r : m->prof) { (void)hipEventDestroy(r.e0); (void)hipEventDestroy(r.e1); }
     delete m;
 }
@@ -674,6 +681,8 @@ int uu3d_commit_weights(uu3d_model* m, void* stream_) {
             const size_t lo = align_up(hb.size(), 64); hb.resize(lo + d.second);
             for (size_t i = 0; i < d.second; ++i) {
                 const float x = P.buf[d.first + i];
+                if (!(std::fabs(x) < 65504.0f))            // (include/uu3d.h, RANGE CONTRACT: the hi plane of such a weight is Inf)
+                    return fail(m, UU3D_ERR_RANGE, "a Dense / Conv1D kernel holds a value of magnitude >= 65504 (or a non-finite one): not representable by the f16x3 operand planes; build the model with precision f32");
                 const _Float16 h = h3_hi(x);
                 hb[hi + i] = h; hb[lo + i] = (_Float16)((x - (float)h) * H3_SCALE);
             }
@@ -746,6 +755,7 @@ int uu3d_commit_weights(uu3d_model* m, void* stream_) {
                 for (int n = 0; n < st.N; ++n)
                     for (int k = 0; k < st.K; ++k) {
                         const float x = st.Wk[(size_t)k * st.N + n];
+                        if (!(std::fabs(x) < 65504.0f)) return fail(m, UU3D_ERR_RANGE, "a LayerNorm-folded kernel of the temporal chain leaves the f16 range; build the model with precision f32");
                         const _Float16 h = h3_hi(x);
                         Bh[(size_t)n * st.K + k] = h; Bl[(size_t)n * st.K + k] = (_Float16)((x - (float)h) * H3_SCALE);
                     }
@@ -870,6 +880,7 @@ struct Launcher {
     float* slab = nullptr;          // split-K partial sums
     size_t slab_floats = 0;
     bool throughput = false;        // this CALL's schedule (uu3d_forward_ex): launches shaped for CU-microseconds instead of latency
+    int precision = UU3D_PREC_F16X3;   // this CALL's arithmetic: the handle's, or UU3D_PREC_F32 with UU3D_SCHEDULE_EXACT_F32
     int status = UU3D_OK;
 
     void begin(const char* name, const char* kernel, double flops, double bytes) {
@@ -1107,7 +1118,7 @@ struct Launcher {
         slices = (KT + kps - 1) / kps;
         const int ldslab = round_up(N, 4);
         if (slices > 1 && (size_t)slices * M * ldslab > slab_floats) { slices = 1; kps = KT; }
-        const bool h3 = (m->cfg.precision == UU3D_PREC_F16X3);
+        const bool h3 = (precision == UU3D_PREC_F16X3);
         begin(name, h3 ? "gemm_h3" : "gemm_f32", 2.0 * M * (double)N * K, 4.0 * ((double)M * K + (double)N * K + (double)M * N) + extra_bytes);
         if (h3) {
             const auto it = m->hplanes.find((size_t)(Bt - m->arena));
@@ -1185,7 +1196,7 @@ struct Launcher {
     // Few rows (strided blocks 2-3, the heads): one workgroup per 32 x 32 tile, split-K over its waves, LayerNorm in the loader
     // (uu3d_gemm_wt.h) -- one launch where the tiled path needs row_stats + split-K GEMM + splitk_reduce.
     bool wt_ok(const float* Bt, int K) const {
-        return m->cfg.precision == UU3D_PREC_F16X3 && !m->no_wt && (K % 16) == 0 && m->hplanes.count((size_t)(Bt - m->arena)) != 0;
+        return precision == UU3D_PREC_F16X3 && !m->no_wt && (K % 16) == 0 && m->hplanes.count((size_t)(Bt - m->arena)) != 0;
     }
     template <class AL, class EP>
     void gemm_wt(const char* name, const AL& al, const float* Bt, int M, int N, int K, const EP& ep, double extra_bytes = 0) {
@@ -1291,10 +1302,18 @@ int uu3d_forward_attention(uu3d_model* m, const float* kp2d, const uint8_t* mask
 int uu3d_forward_ex(uu3d_model* m, const float* kp2d, const uint8_t* mask, int32_t B, float* full_out,
                     float* central_out, float* const* attn_out, void* workspace, size_t workspace_bytes, int32_t schedule, void* stream_) {
     if (!m) return UU3D_ERR_INVALID_ARGUMENT;
+    const bool exact_f32 = (schedule & UU3D_SCHEDULE_EXACT_F32) != 0;
+    schedule &= ~UU3D_SCHEDULE_EXACT_F32;
     if (schedule != UU3D_SCHEDULE_LATENCY && schedule != UU3D_SCHEDULE_THROUGHPUT) return fail(m, UU3D_ERR_INVALID_ARGUMENT, "schedule must be UU3D_SCHEDULE_LATENCY or UU3D_SCHEDULE_THROUGHPUT");
     if (!m->committed) return fail(m, UU3D_ERR_NOT_READY, "uu3d_commit_weights has not been called");
     if (!kp2d || !central_out || !workspace || B < 1) return fail(m, UU3D_ERR_INVALID_ARGUMENT, "null buffer or batch < 1");
-    const uu3d_config& c = m->cfg;
+    uu3d_config c = m->cfg;                                // (a copy: UU3D_SCHEDULE_EXACT_F32 changes THIS call's arithmetic, not the handle's)
+    if (exact_f32) {
+        if (m->generic) return fail(m, UU3D_ERR_UNSUPPORTED, "UU3D_SCHEDULE_EXACT_F32: handles with generic dims have no exact-f32 forward");
+        int Lmax = c.num_frames;
+        if (Lmax > 128) return fail(m, UU3D_ERR_UNSUPPORTED, "UU3D_SCHEDULE_EXACT_F32: the exact-f32 attention holds sequences of <= 128 tokens");
+        c.precision = UU3D_PREC_F32;
+    }
     if ((c.has_strided_input != 0) != (mask != nullptr))
         return fail(m, UU3D_ERR_INVALID_ARGUMENT, "stride_mask must be given iff the model has strided input");
     const bool has_h1 = c.full_output && c.temporal_depth > 0;
@@ -1303,14 +1322,20 @@ int uu3d_forward_ex(uu3d_model* m, const float* kp2d, const uint8_t* mask, int32
     if (m->generic) {
         // dims other than the compiled ones: the training-mode chain, forward only, with every stochastic layer off (no DropPath draws, no token
         // mask, Dropout rates 0): vit / u_u_t in inference mode
-        return generic_forward(m, kp2d, mask, B, full_out, central_out, attn_out, workspace, workspace_bytes, stream_);
+        const int r = generic_forward(m, kp2d, mask, B, full_out, central_out, attn_out, workspace, workspace_bytes, stream_);
+        if (r == UU3D_OK && c.precision == UU3D_PREC_F16X3) {
+            const bool has_full = c.full_output && c.temporal_depth > 0 && full_out != nullptr;
+            hipLaunchKernelGGL(range_check_kernel, dim3(256), dim3(256), 0, (hipStream_t)stream_, has_full ? full_out : central_out,
+                               has_full ? (long)B * c.num_frames * c.num_keypoints * 3 : 0L, central_out, (long)B * c.num_keypoints * 3, m->d_range);
+        }
+        return r;
     }
     Workspace w = carve(m, B, (char*)workspace);
     if (workspace_bytes < w.bytes) return fail(m, UU3D_ERR_WORKSPACE, "workspace smaller than uu3d_workspace_bytes(batch)");
     if ((long)B * c.num_frames * c.num_keypoints > (1L << 30)) return fail(m, UU3D_ERR_INVALID_ARGUMENT, "batch too large");
 
     HIPCHK(m, hipSetDevice(m->device));
-    Launcher Lh{m, (hipStream_t)stream_, w.slab, w.slab_floats, schedule == UU3D_SCHEDULE_THROUGHPUT};
+    Launcher Lh{m, (hipStream_t)stream_, w.slab, w.slab_floats, schedule == UU3D_SCHEDULE_THROUGHPUT, c.precision};
     m->prof_used = 0;
     const int N = c.num_frames, J = c.num_keypoints, ds = c.d_spatial, dt = c.d_temporal, ht = c.h_temporal;
     const int M = B * N;
@@ -1589,7 +1614,27 @@ int uu3d_forward_ex(uu3d_model* m, const float* kp2d, const uint8_t* mask, int32
         EpBias ep{central_out, m->h2_b, 3 * J};
         Lh.gemm("head2", al, m->h2_wt, B, 3 * J, dt, ep);
     }
+    // range guard (include/uu3d.h): non-finite outputs of an f16x3 forward set the model's sticky word
+    if (c.precision == UU3D_PREC_F16X3) {
+        Lh.begin("range_check", "range_check", 0.0, 4.0 * ((has_h1 ? (double)M * 3 * J : 0.0) + (double)B * 3 * J));
+        hipLaunchKernelGGL(range_check_kernel, dim3(256), dim3(256), 0, Lh.stream, has_h1 ? full_out : central_out, has_h1 ? (long)M * 3 * J : 0L,
+                           central_out, (long)B * 3 * J, m->d_range);
+        Lh.end();
+    }
     if (Lh.status != UU3D_OK) return Lh.status;
+    return UU3D_OK;
+}
+
+int uu3d_range_status(uu3d_model* m, void* stream, int32_t* out_flag) {
+    if (!m) return UU3D_ERR_INVALID_ARGUMENT;
+    HIPCHK(m, hipSetDevice(m->device));
+    int h = 0;
+    HIPCHK(m, hipMemcpyAsync(&h, m->d_range, sizeof(int), hipMemcpyDeviceToHost, (hipStream_t)stream));
+    HIPCHK(m, hipMemsetAsync(m->d_range, 0, sizeof(int), (hipStream_t)stream));
+    HIPCHK(m, hipStreamSynchronize((hipStream_t)stream));
+    if (out_flag) *out_flag = h != 0;
+    if (h != 0) return fail(m, UU3D_ERR_RANGE, "non-finite values in a forward's outputs: activations beyond the f16 range (65504) of the f16x3 products, or non-finite inputs "
+                                               "(repeat the batch with UU3D_SCHEDULE_EXACT_F32 or build the model with precision f32)");
     return UU3D_OK;
 }
 

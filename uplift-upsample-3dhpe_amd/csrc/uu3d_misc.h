@@ -322,4 +322,23 @@ inline int create_streams_on_other_queues(hipStream_t main, int n, hipStream_t* 
     return distinct;
 }
 
+// Range guard of the f16x3 forward (include/uu3d.h, "RANGE CONTRACT"): any non-finite value in the outputs sets the model's sticky word.
+// An activation beyond the f16 range becomes Inf in its hi plane and NaN one product later; LayerNorm and attention spread it over its whole
+// sequence, so both outputs are looked at: `full` catches the residual stream overflowing in front of the full-sequence head alone.
+static __global__ void __launch_bounds__(256)
+range_check_kernel(const float* __restrict__ a, const long na, const float* __restrict__ b, const long nb, int* __restrict__ flag)
+{
+    const long stride = (long)gridDim.x * blockDim.x * 4;
+    bool bad = false;
+    for (long i = ((long)blockIdx.x * blockDim.x + threadIdx.x) * 4; i < na + nb; i += stride) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const long j = i + e;
+            const float v = j < na ? a[j] : (j < na + nb ? b[j - na] : 0.f);
+            bad |= !(fabsf(v) <= 3.0e38f);
+        }
+    }
+    if (__any(bad) && (threadIdx.x & 63) == 0) atomicOr(flag, 1);
+}
+
 }  // namespace uu3d

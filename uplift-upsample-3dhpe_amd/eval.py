@@ -96,7 +96,10 @@ def predict_windows(model, generator, descriptors, config, batch_size, flip=True
         finish(plo, pn, pipe.result(t)[1])
     if pipe is not None:
         torch.cuda.current_stream(dev).synchronize()               # the slots' buffers go away with the pipeline
-        pipe.close()
+        try:
+            pipe.check_range()                                     # f16x3 range guard (include/uu3d.h): once per evaluation, never per batch
+        finally:
+            pipe.close()
     if not flip:
         return raw[0]
     order = torch.as_tensor(np.asarray(config.AUGM_FLIP_KEYPOINT_ORDER), dtype=torch.long, device=dev)

@@ -55,7 +55,7 @@ class UpliftUpsampleTransformer(object):
     SPLIT_MIN_BATCH = 64
 
     def __init__(self, arch: UpliftArch, device=None, seed=0, weights=None, return_attention=False, precision="f16x3",
-                 concurrent_halves=False):
+                 concurrent_halves=False, range_guard=True):
         import torch
         # return_attention=True (u_u_t.py:176,418-419; never used by the reference's scripts): model(...) returns (full, central, att_list),
         # att_list = the (B, heads, N, N) softmax weights of every temporal block, recomputed by a separate kernel (uu3d_forward_attention)
@@ -94,6 +94,10 @@ class UpliftUpsampleTransformer(object):
         if precision not in ("f32", "f16x3"):
             raise ValueError("precision must be 'f32' or 'f16x3'")
         self.precision = precision
+        # range_guard (precision f16x3): model(...) checks its outputs after the call (one stream synchronisation) and repeats a batch whose
+        # activations left the f16 range on the exact-f32 kernels -- include/uu3d.h, RANGE CONTRACT; False: the caller checks (check_range())
+        self.range_guard = bool(range_guard)
+        self._range_warned = False
         cfg.precision = _capi.UU3D_PREC_F16X3 if precision == "f16x3" else _capi.UU3D_PREC_F32
         handle = C.c_void_p()
         st = self._lib.uu3d_create(C.byref(cfg), self.device.index or 0, C.byref(handle))
@@ -242,8 +246,11 @@ class UpliftUpsampleTransformer(object):
             self._ws[slot] = ws
         return ws
 
-    def _forward(self, x, stride_mask, full, central, slot, stream, attn=None, schedule=0):
-        """One uu3d_forward_ex call.  ``schedule`` (include/uu3d.h: 0 = latency, 1 = throughput) is an argument of THIS call."""
+    def _forward(self, x, stride_mask, full, central, slot, stream, attn=None, schedule=0, exact_f32=False):
+        """One uu3d_forward_ex call.  ``schedule`` (include/uu3d.h: 0 = latency, 1 = throughput) is an argument of THIS call;
+        ``exact_f32``: this call on the exact-f32 kernels whatever the model's precision (UU3D_SCHEDULE_EXACT_F32)."""
+        if exact_f32:
+            schedule = int(schedule) | _capi.UU3D_SCHEDULE_EXACT_F32
         B = x.shape[0]
         ws = self._workspace(B, slot)
         ptrs = None
@@ -255,6 +262,23 @@ class UpliftUpsampleTransformer(object):
                                        C.c_void_p(central.data_ptr()), ptrs, C.c_void_p(ws.data_ptr()),
                                        C.c_size_t(ws.numel()), int(schedule), C.c_void_p(stream.cuda_stream))
         _capi.check(self._lib, st, self._h)
+
+    # ---- range guard of precision f16x3 (include/uu3d.h, RANGE CONTRACT) -------------------------
+    def check_range(self, stream=None, raise_error=True):
+        """Synchronises ``stream`` (default: the current one) and reports whether any f16x3 forward since the last check produced non-finite
+        outputs (activations beyond the f16 range 65504, or non-finite inputs): raises ``Uu3dRangeError`` / returns True.  Clears the flag."""
+        torch = self._torch
+        s = stream if stream is not None else torch.cuda.current_stream(self.device)
+        flag = C.c_int32(0)
+        st = self._lib.uu3d_range_status(self._h, C.c_void_p(s.cuda_stream), C.byref(flag))
+        if st not in (_capi.UU3D_OK, _capi.UU3D_ERR_RANGE):
+            _capi.check(self._lib, st, self._h)
+        if flag.value and raise_error:
+            raise _capi.Uu3dRangeError(_capi.UU3D_ERR_RANGE, self._lib.uu3d_last_error(self._h).decode())
+        return bool(flag.value)
+
+    def _exact_f32_available(self):
+        return bool(self.arch.compiled_dims) and self.arch.num_frames <= 128
 
     def _mask_u8(self, stride_mask):
         """(B, N) bool / uint8 mask as uint8 bytes on the model's device.  A bool tensor is reinterpreted (torch bools are
@@ -348,13 +372,33 @@ class UpliftUpsampleTransformer(object):
             return full, central
         self._sync_from_trainer()
         main = torch.cuda.current_stream(self.device)
+        # Range guard (include/uu3d.h): the f16x3 products cannot represent activations of magnitude >= 65504 (the reference is float32 end to
+        # end).  A direct call checks its own result -- one stream synchronisation, skipped inside a stream capture and with range_guard=False --
+        # and repeats an overflowed batch on the exact-f32 kernels; where those do not exist it raises.  Pipelines check once (check_range()).
+        guard = self.range_guard and self.precision == "f16x3" and not torch.cuda.is_current_stream_capturing()
+
+        def guarded(run):
+            run(False)
+            if guard and self.check_range(main, raise_error=False):
+                if not self._exact_f32_available():
+                    raise _capi.Uu3dRangeError(_capi.UU3D_ERR_RANGE, "activations beyond the f16 range of the f16x3 products (or non-finite inputs), and "
+                                               "this model has no exact-f32 forward to fall back to (generic dims or > 128 tokens)")
+                if not self._range_warned:
+                    self._range_warned = True
+                    import warnings
+                    warnings.warn("uu3d: a batch left the f16 range of the f16x3 products (|activation| >= 65504) and was repeated on the exact-f32 "
+                                  "kernels; build the model with precision='f32' if this is the rule for these weights", RuntimeWarning)
+                run(True)
+                torch.cuda.current_stream(self.device).synchronize()
+                if not bool(torch.isfinite(central).all()) or (full is not None and not bool(torch.isfinite(full).all())):
+                    raise _capi.Uu3dRangeError(_capi.UU3D_ERR_RANGE, "non-finite outputs even in exact f32: the inputs or weights are not finite")
         if self.return_attention:
             att = [torch.empty((B, a.num_heads, a.num_frames, a.num_frames), dtype=torch.float32, device=self.device)
                    for _ in range(a.temporal_depth)]
-            self._forward(x, stride_mask, full, central, 0, main, attn=att)
+            guarded(lambda f32: self._forward(x, stride_mask, full, central, 0, main, attn=att, exact_f32=f32))
             return full, central, att
         if not (self._halves and B >= self.SPLIT_MIN_BATCH and not self._profiling):
-            self._forward(x, stride_mask, full, central, 0, main)
+            guarded(lambda f32: self._forward(x, stride_mask, full, central, 0, main, exact_f32=f32))
             return full, central
         # Sequences are independent, so the batch runs as two chains of kernels that the GPU interleaves: the
         # ramp-up and tail of one chain's (short, 10-50 us) kernels overlap the other chain's work.  Measured

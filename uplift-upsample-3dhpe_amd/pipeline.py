@@ -220,6 +220,14 @@ class ForwardPipeline(object):
                 mb.copy_(mu, non_blocking=True)
         return self.launch(n)
 
+    def check_range(self):
+        """Range guard of precision f16x3 (include/uu3d.h, RANGE CONTRACT) for everything submitted so far: waits for every slot, then raises
+        ``Uu3dRangeError`` if a forward produced non-finite outputs (activations beyond the f16 range, or non-finite inputs).  Pipelines do
+        not check per batch (that would be a host synchronisation per batch); callers check once -- ``eval.predict_windows`` at its end."""
+        for s in self._slots:
+            s.stream.synchronize()
+        return self.model.check_range()
+
     def result(self, ticket):
         """(full, central[, post's value]) of a submitted batch; the caller's current stream waits for it.  The tensors are the
         slot's static buffers: valid until ``depth`` more batches have been submitted."""
