@@ -13,6 +13,7 @@ from oracle import uplift_oracle as O
 from oracle import uplift_oracle_np as ON
 from tests import util
 from tests.golden.make_golden import weights_checksum
+from uplift_upsample_3dhpe_amd.weights import weight_spec
 
 GOLDEN = sorted(glob.glob(os.path.join(util.ROOT, "tests", "golden", "*_seed*.npz")))
 
@@ -161,3 +162,48 @@ def test_mpjpe_and_flip_protocol():
     s2, c2 = O.test_step(hp, w, xf, m, torch.float64)
     c2 = np.concatenate([-c2[..., :1], c2[..., 1:]], -1)[:, order]
     assert np.allclose(cen, (c1 + c2) / 2, atol=1e-12)
+
+
+# ---- wiring pin against the REFERENCE's own model classes (tests/golden/make_model_wiring_golden.py) -------------------------------
+_WIRING = os.path.join(util.ROOT, "tests", "golden", "model_wiring_expected.npz")
+
+
+def _wiring_cases():
+    g = np.load(_WIRING)
+    return sorted({k.split("/")[0] for k in g.files})
+
+
+@pytest.mark.parametrize("case", _wiring_cases())
+def test_oracle_wiring_matches_the_reference_classes(case):
+    """The reference's OWN MLP / MHA / TransformerBlock / StridedMLP / StridedTransformerBlock / UpliftUpsampleTransformer and constructor
+    (common/net/vision_transformer.py:46-195, uplift_upsample_transformer.py:21-421, ..._constructor.py:14-50), executed from their ASTs in
+    the build container with float64 numpy stand-ins for the Keras / TensorFlow ops they call, against the oracle in float64 on the same
+    seeded weights and inputs: control flow, masks, positional encodings, head layout, residual trims, padding / pooling rules -- and the
+    order of `model.weights` (Keras attribute tracking: what the by-name .h5 loader relies on, common/utils/weight_io.py:172-201,235)
+    against weights.weight_spec.  Pins the WIRING; TensorFlow's float32 kernels stay unpinned (the stand-ins are numpy)."""
+    import ast
+    g = np.load(_WIRING)
+    cfg = util.load_config(str(g[f"{case}/config"]).replace(".json", ""))
+    for k, v in ast.literal_eval(str(g[f"{case}/overrides"])):
+        setattr(cfg, k, v)
+    arch = pkg.arch_from_config(cfg)
+    w = pkg.init_weights(arch, seed=int(g[f"{case}/seed"]), perturb=0.1)
+    # 1. the order of model.weights and the top-level layer names
+    assert [n for n, _ in weight_spec(arch)] == [str(s) for s in g[f"{case}/weights_order"]]
+    tops = [str(s) for s in g[f"{case}/top_level_layers"]]
+    assert set(n.split("/")[0] for n, _ in weight_spec(arch)) <= set(tops)
+    # 2. the outputs, float64 against float64
+    x = g[f"{case}/x"]
+    m = g[f"{case}/mask"] if f"{case}/mask" in g.files else None
+    has_att = f"{case}/attention_0" in g.files
+    res = O.forward(util.hp_from_arch(arch), w, x, m, torch.float64, return_attention=has_att)
+    full, central = res[0], res[1]
+    err = np.abs(central - g[f"{case}/central"]).max()
+    assert (full is None) == (f"{case}/full" not in g.files)
+    if full is not None:
+        err = max(err, np.abs(full - g[f"{case}/full"]).max())
+    print(f"{case}: oracle f64 vs the reference's classes {err:.3e}")
+    assert err <= 1e-9
+    if has_att:
+        for i, a in enumerate(res[2]):
+            assert np.abs(a - g[f"{case}/attention_{i}"]).max() <= 1e-6
