@@ -196,7 +196,7 @@ def train_bench(args, world, rank, local_rank, use_dist):
 
 
 
-def quick_forward_bench(cfgname, batch, s_in=None, streams=1, graph=True, steps=40, warmup=10, precision="f16x3", attention=False):
+def quick_forward_bench(cfgname, batch, s_in=None, streams=1, graph=True, steps=40, warmup=10, precision="f16x3", attention=False, copy_inputs=False):
     """A short timing of another workload for the `secondary` block of the bench line (same process, same GPU): sequences/s and
     ms per step of the forward + error kernel, `streams` batches in flight; attention=True adds the temporal-attention launch's
     HIP-event time and its fraction of the MFMA peak."""
@@ -222,7 +222,9 @@ def quick_forward_bench(cfgname, batch, s_in=None, streams=1, graph=True, steps=
     def run(n):
         tickets = []
         for _ in range(n):
-            tickets.append(pipe.launch())
+            # copy_inputs: the batch is copied into the slot's input buffers every step (pipe.submit: the rounds-1-3 methodology, and what a
+            # caller without a device-side producer pays); else it is resident (pipe.launch: the headline's methodology since round 4)
+            tickets.append(pipe.submit(x, m) if copy_inputs else pipe.launch())
             if len(tickets) == streams:
                 pipe.result(tickets.pop(0))
         for t in tickets:
@@ -235,7 +237,7 @@ def quick_forward_bench(cfgname, batch, s_in=None, streams=1, graph=True, steps=
     dt = time.perf_counter() - t0
     out = {"workload": f"config/{cfgname}.json, batch {batch}, s_in {s_in}" if cfgname != "dense_351" else f"synthetic dense-351 (NOT a shipped config), batch {batch}",
            "value": round(batch * steps / dt, 1), "unit": "pose-sequences/s", "ms_per_step": round(1e3 * dt / steps, 4), "steps": steps,
-           "batches_in_flight": streams, "hipgraph": bool(graph)}
+           "batches_in_flight": streams, "hipgraph": bool(graph), "input": "copied into the slot every step (submit)" if copy_inputs else "resident in the slots (preload + launch)"}
     if attention:
         model.set_profiling(True)
         agg = {}
@@ -297,6 +299,7 @@ def secondary_benchmarks(args):
     """The other claims of DESIGN.md in the same driver-run JSON line: ~20 steps each."""
     out = {}
     jobs = [("steady_state_200_steps", lambda: quick_forward_bench(args.config, args.batch, streams=max(1, args.streams_used), graph=True, steps=200, warmup=20)),
+            ("with_input_copy_per_step", lambda: quick_forward_bench(args.config, args.batch, streams=max(1, args.streams_used), graph=True, copy_inputs=True)),
             ("latency_one_batch_in_flight", lambda: quick_forward_bench(args.config, args.batch, streams=1, graph=True)),
             ("eager_one_batch_in_flight", lambda: quick_forward_bench(args.config, args.batch, streams=1, graph=False)),
             ("eager_pipelined", lambda: quick_forward_bench(args.config, args.batch, streams=max(2, args.streams_used), graph=False)),
@@ -544,7 +547,7 @@ def main():
         total_ms = sum(a["ms"] for a in agg.values()) / reps
         # GEMM kernels by SYMBOL (the profile records carry the distinguishing part of the symbol: "gemm_panel8<BiasSplitQ>", "mlp_fused", ...):
         # the dominant kernel is the symbol with the most time per forward, whatever labels its launches carry
-        is_gemm = (lambda k: k.startswith(("gemm_h3", "gemm_panel", "mlp_fused", "gemm_wt"))) if args.precision == "f16x3" else (lambda k: k.startswith("gemm_f32"))
+        is_gemm = (lambda k: k.startswith(("gemm_h3", "gemm_panel", "mlp_fused", "gemm_wt", "tchain"))) if args.precision == "f16x3" else (lambda k: k.startswith("gemm_f32"))
         peak = PEAK_F16_MFMA_TFLOPS if args.precision == "f16x3" else PEAK_F32_MFMA_TFLOPS
         by_sym = {}
         for k, a in agg.items():

@@ -103,7 +103,9 @@ const char* uu3d_last_error(const uu3d_model* model);
  * The specialised kernels are compiled for J = 17, SPATIAL_EMBED_DIM 32, TEMPORAL_EMBED_DIM 384, NUM_HEADS 8, MLP_RATIO 2 (every
  * shipped config).  Other dims the constructor accepts (:26-32) give a handle whose forward (uu3d_forward_ex) and training step run on
  * generic, untuned kernels: embed dims and MLP widths multiples of 4, head dims in {2, 4, 8, 12, 16, 24, 32, 48, 64}, <= 128 keypoints, <= 128 frames, >= 1 temporal and strided
- * block, the full-sequence head.  Outside that: UU3D_ERR_UNSUPPORTED.
+ * block, the full-sequence head.  The generic attention keeps a head in LDS: the FORWARD holds 2 L (d_h + 4) floats (fits every legal shape), the training
+ * step's BACKWARD 4 L (d_h + 4) + 2 L (L + 1) floats <= 160 KiB -- i.e. up to 128 frames only for head dims <= 8 (and 48, which has an MFMA backward;
+ * 96 with ATTENTION_DROP_RATE > 0), 127 at 12, 124 at 16, 117 at 24, 111 at 32, 90 at 64; uu3d_train_forward_backward refuses longer sequences up front.  Outside that: UU3D_ERR_UNSUPPORTED.
  */
 int uu3d_create(const uu3d_config* config, int device, uu3d_model** out_model);
 void uu3d_destroy(uu3d_model* model);

@@ -350,3 +350,72 @@ def test_generic_dims_gradients_match_autograd(name):
                   drop_path_uniform=None if u is None else torch.from_numpy(u).cuda(), token_mask_uniform=None if tmu is None else torch.from_numpy(tmu).cuda())
     torch.cuda.synchronize()
     assert tr.global_step == 1 and not torch.equal(tr.params, p0) and bool(torch.isfinite(tr.params).all())
+
+
+def test_generic_dims_ema_export_does_not_disturb_the_next_step():
+    """on a generic-dims handle the model's inference forward and the Trainer's step share the operand packs.
+    Trainer.export_to_model(use_ema=True) commits the EMA weights (which repacks from the model's own buffer); the next
+    forward_backward has to see the TRAINED kernels again, not EMA-valued kernels under trained biases: its gradients equal the ones
+    computed before the export bit for bit, and an export between forward_backward and apply_gradients keeps the step's skip flag."""
+    from uplift_upsample_3dhpe_amd.trainer import Trainer
+    J, d_s, d_t, heads, n, strides, ratio, ms = CASES["wide_mlp"]
+    cfg = _config(J, d_s, d_t, heads, n, strides, ratio, mask_stride=ms)
+    cfg.BATCH_SIZE, cfg.DROP_PATH_RATE = 4, [0.0, 0.0, 0.0]
+    cfg.EMA_ENABLED, cfg.EMA_DECAY = True, 0.5
+    arch = pkg.arch_from_config(cfg)
+    model = pkg.build_uplift_upsample_transformer(cfg, weights=pkg.init_weights(arch, seed=3, perturb=0.1))
+    B = 4
+    rng = np.random.default_rng(1)
+    x = torch.from_numpy(rng.uniform(-1, 1, size=(B, n, J, 2)).astype(np.float32)).cuda()
+    gt = torch.from_numpy(rng.normal(0, 0.3, size=(B, n, J, 3)).astype(np.float32)).cuda()
+    m = torch.from_numpy(np.stack([util.eval_stride_mask(n, cfg.SEQUENCE_STRIDE, ms[b % 2], 0) for b in range(B)])).cuda()
+    tr = Trainer(model, cfg)
+    for _ in range(3):                                               # the EMA weights move away from the trained ones
+        tr.train_step(x, gt, m)
+    assert tr.ema is not None and not torch.equal(tr.ema, tr.params)
+    loss0, _, _ = tr.forward_backward(x, gt, m, drop_path_uniform=None)
+    g0 = tr.grads.clone()
+    tr.export_to_model(use_ema=True)                                 # commit: the packs now come from the EMA values
+    f_ema, c_ema = model([x * m[:, :, None, None], m], training=False)
+    loss1, _, _ = tr.forward_backward(x, gt, m, drop_path_uniform=None)
+    torch.cuda.synchronize()
+    assert torch.equal(loss0, loss1) and torch.equal(tr.grads, g0), "the step after an EMA export ran on EMA-valued operand packs"
+    # the exported model really holds the EMA weights (its forward differs from the trained model's)
+    tr.export_to_model(use_ema=False)
+    f_tr, c_tr = model([x * m[:, :, None, None], m], training=False)
+    assert (c_ema - c_tr).abs().max() > 1e-6
+    # a non-finite step stays skipped although an export sits between its backward pass and its update
+    xbad = x.clone(); xbad[0, int(torch.nonzero(m[0])[0]), 0, 0] = float("inf")
+    before = tr.params.clone()
+    tr.forward_backward(xbad, gt, m, drop_path_uniform=None)
+    tr.export_to_model(use_ema=True)
+    tr.apply_gradients()
+    torch.cuda.synchronize()
+    assert torch.equal(tr.params, before), "the EMA export erased the non-finite flag of the pending step"
+
+
+def test_generic_dims_training_refuses_oversized_attention_up_front():
+    """the generic attention backward keeps P and dS of a head in LDS; 124 tokens is the limit at head dim 16.
+    A longer sequence is refused by uu3d_train_forward_backward BEFORE anything is enqueued, with the numbers in the message; the
+    forward of the same model still runs (include/uu3d.h states both limits)."""
+    from uplift_upsample_3dhpe_amd.trainer import Trainer
+    from uplift_upsample_3dhpe_amd import _capi
+    for n, ok in ((123, True), (125, False)):
+        cfg = _config(17, 16, 64, 4, n, [n], 2.0)                    # head dims 4 / 16; one strided block that takes the whole sequence
+        cfg.PADDINGS = [[0, 0]]
+        cfg.BATCH_SIZE, cfg.DROP_PATH_RATE = 2, [0.0, 0.0, 0.0]
+        arch = pkg.arch_from_config(cfg)
+        model = pkg.build_uplift_upsample_transformer(cfg, weights=pkg.init_weights(arch, seed=1, perturb=0.1))
+        rng = np.random.default_rng(0)
+        x = torch.from_numpy(rng.uniform(-1, 1, size=(2, n, 17, 2)).astype(np.float32)).cuda()
+        gt = torch.from_numpy(rng.normal(0, 0.3, size=(2, n, 17, 3)).astype(np.float32)).cuda()
+        full, cen = model(x, training=False)
+        assert torch.isfinite(cen).all()
+        tr = Trainer(model, cfg)
+        if ok:
+            loss, _, _ = tr.forward_backward(x, gt, None, drop_path_uniform=None)
+            assert torch.isfinite(loss).all() and torch.isfinite(tr.grads).all()
+        else:
+            with pytest.raises(_capi.Uu3dError) as ei:
+                tr.forward_backward(x, gt, None, drop_path_uniform=None)
+            assert ei.value.status == _capi.UU3D_ERR_UNSUPPORTED and "LDS" in str(ei.value) and "125" in str(ei.value)

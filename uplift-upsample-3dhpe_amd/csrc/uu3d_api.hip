@@ -31,6 +31,7 @@
 #include "uu3d_gemm.h"
 #include "uu3d_gemm_h3.h"
 #include "uu3d_gemm_panel.h"
+#include <mutex>
 #include "uu3d_gemm_panel8.h"
 #include "uu3d_gemm_wt.h"
 #include "uu3d_mlp_fused.h"
@@ -124,6 +125,8 @@ struct uu3d_model {
                                    // CU-microseconds per block than the round-4 launches, but a launch is 71 workgroups x ~200 us: with four hardware queues the
                                    // pipelined step came out 3-5 % SLOWER (profiles/r05_tchain_ab.txt) -- narrow long launches mix badly with wide short ones
     int num_cus = 256;
+    std::recursive_mutex train_mu; // the training-mode chain keeps per-call options in the handle's training state (uu3d_train_step.inc): one call at a time
+    bool in_commit = false;        // uu3d_commit_weights is calling uu3d_train_init (generic dims): the training step's skip flag is not its to clear
     int* d_range = nullptr;        // sticky device word of the range guard (include/uu3d.h: uu3d_range_status)
     bool no_planes = false;        // UU3D_NO_PLANES=1: keep the on-the-fly split GEMMs in f16x3 mode (A/B measurements, tests)
     _Float16* harena = nullptr;    // f16 hi/lo planes of every GEMM operand (f16x3 mode)
@@ -444,7 +447,9 @@ int uu3d_commit_weights(uu3d_model* m, void* stream_) {
             for (auto& r : m->weights) n += r.numel;
             HIPCHK(m, hipMalloc((void**)&m->gparams, (size_t)n * sizeof(float)));
         }
+        m->in_commit = true;
         const int r = uu3d_train_init(m, m->gparams, stream_);
+        m->in_commit = false;
         if (r != UU3D_OK) return r;
         HIPCHK(m, hipStreamSynchronize(stream));
         m->committed = true;

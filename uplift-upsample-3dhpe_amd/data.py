@@ -156,8 +156,9 @@ class SequenceGenerator(object):
         out = {"kp2d": kp2d, "stride_mask": smask, "mask": pmask, "subjects": t.subjects[desc[:, 0]],
                "actions": t.actions[desc[:, 0]], "index": desc[:, 1].copy()}
         if with_3d and t.kp3d is not None:
-            kp3d = torch.empty((B, N, J, 3), dtype=torch.float32, device=t.device)
-            dummy = torch.empty((B, N), dtype=torch.uint8, device=t.device)
+            with torch.cuda.stream(tstream):                            # (allocated under the stream that writes them: ADVICE round 4)
+                kp3d = torch.empty((B, N, J, 3), dtype=torch.float32, device=t.device)
+                dummy = torch.empty((B, N), dtype=torch.uint8, device=t.device)
             st = lib.uu3d_gather_windows(C.c_void_p(t.kp3d.data_ptr()), C.c_void_p(t.d_starts.data_ptr()), C.c_void_p(t.d_lens.data_ptr()),
                                          C.c_void_p(d_desc.data_ptr()), fl, B, N, J, 3, int(self.pad_edge), 0,
                                          C.c_void_p(kp3d.data_ptr()), C.c_void_p(dummy.data_ptr()), None, C.c_void_p(stream))
