@@ -1,4 +1,4 @@
-"""Experiment: replay uu3d_train_forward_backward (both streams) from a hipGraph instead of ~570 eager launches.
+"""Experiment (round 1; re-run in round 5 on the three-stream step): replay uu3d_train_forward_backward from a hipGraph instead of ~400 eager launches.
    python tools/train_graph_exp.py [steps]"""
 import sys, time, os
 import numpy as np, torch
@@ -42,7 +42,9 @@ torch.cuda.synchronize()
 g = torch.cuda.CUDAGraph()
 with torch.cuda.graph(g):
     tr.forward_backward(x, gt, m, drop_path_uniform=u)
+ustatic = u
 def graphed():
+    ustatic.uniform_()                       # fresh DropPath draws into the captured buffer (what a graphed Trainer would do)
     g.replay(); tr.apply_gradients()
 for _ in range(10): graphed()
 torch.cuda.synchronize()
@@ -50,3 +52,23 @@ t0 = time.perf_counter()
 for _ in range(steps): graphed()
 torch.cuda.synchronize()
 print(f"graph replay of forward_backward + eager optimizer: {(time.perf_counter() - t0) / steps * 1e3:.3f} ms per step")
+
+g2 = tr.grads.clone()
+print("gradients of a replay == eager (same draws):", end=" ")
+ustatic.copy_(torch.rand(tr.drop_path_size(B), device="cuda", generator=torch.Generator(device="cuda").manual_seed(1)))
+uu = ustatic.clone()
+g.replay(); torch.cuda.synchronize(); a = tr.grads.clone()
+tr.forward_backward(x, gt, m, drop_path_uniform=uu); torch.cuda.synchronize()
+print(bool(torch.equal(a, tr.grads)))
+t0 = time.perf_counter()
+for _ in range(steps): g.replay()
+torch.cuda.synchronize()
+print(f"graph replay of forward_backward alone: {(time.perf_counter() - t0) / steps * 1e3:.3f} ms per step")
+t0 = time.perf_counter()
+for _ in range(steps): tr.forward_backward(x, gt, m, drop_path_uniform=u)
+torch.cuda.synchronize()
+print(f"eager forward_backward alone: {(time.perf_counter() - t0) / steps * 1e3:.3f} ms per step")
+t0 = time.perf_counter()
+for _ in range(steps): tr.apply_gradients()
+torch.cuda.synchronize()
+print(f"apply_gradients alone: {(time.perf_counter() - t0) / steps * 1e3:.3f} ms per step")

@@ -1630,6 +1630,18 @@ int uu3d_forward_ex(uu3d_model* m, const float* kp2d, const uint8_t* mask, int32
     return UU3D_OK;
 }
 
+#ifdef UU3D_TC_STAMP
+// measurement builds only (build.py extra_flags -DUU3D_TC_STAMP): the temporal chain's per-workgroup stage stamps of its LAST launch
+extern "C" int uu3d_debug_tchain_stamps(unsigned long long* out, int n) {
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(uu3d::tchain_stamps), (size_t)std::min(n, 256 * 32) * 8) == hipSuccess ? 0 : 1;
+}
+extern "C" int uu3d_debug_tchain_acc(unsigned long long* out, int reset) {      // out[32 * 4]; reset != 0: clear afterwards
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(uu3d::tchain_acc), 32 * 4 * 8) != hipSuccess) return 1;
+    if (reset) { static const unsigned long long z[32 * 4] = {}; if (hipMemcpyToSymbol(HIP_SYMBOL(uu3d::tchain_acc), z, sizeof z) != hipSuccess) return 1; }
+    return 0;
+}
+#endif
+
 int uu3d_range_status(uu3d_model* m, void* stream, int32_t* out_flag) {
     if (!m) return UU3D_ERR_INVALID_ARGUMENT;
     HIPCHK(m, hipSetDevice(m->device));

@@ -94,6 +94,7 @@ typedef float f32x16s __attribute__((ext_vector_type(16)));
 #ifdef UU3D_TC_STAMP
 // tools/tchain_exp: per workgroup 16 pairs (s_memtime = shader clock ticks, s_memrealtime = 100 MHz) at the chain's stage boundaries
 __device__ unsigned long long tchain_stamps[256 * 32];
+__device__ unsigned long long tchain_acc[32 * 4];      // per stage set (FLAGS): sum of workgroup cycles, sum of 100 MHz ticks, workgroups, -
 #define TC_STAMP(i) do { if (tid == 0 && bm < 256) { tchain_stamps[bm * 32 + 2 * (i)] = __builtin_amdgcn_s_memtime(); tchain_stamps[bm * 32 + 2 * (i) + 1] = __builtin_amdgcn_s_memrealtime(); } } while (0)
 #else
 #define TC_STAMP(i)
@@ -511,6 +512,13 @@ tchain_kernel(const TChainArgs a)
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // (the clamped tail pieces must not outlive the LDS allocation)
     TC_STAMP(9);
+#ifdef UU3D_TC_STAMP
+    if (tid == 0 && bm < 256) {
+        atomicAdd(&tchain_acc[(FLAGS & 31) * 4 + 0], tchain_stamps[bm * 32 + 18] - tchain_stamps[bm * 32 + 0]);
+        atomicAdd(&tchain_acc[(FLAGS & 31) * 4 + 1], tchain_stamps[bm * 32 + 19] - tchain_stamps[bm * 32 + 1]);
+        atomicAdd(&tchain_acc[(FLAGS & 31) * 4 + 2], 1ull);
+    }
+#endif
 #undef UU3D_TC_READ
 }
 
