@@ -295,10 +295,26 @@ def quick_train_bench(steps=50, warmup=10, batch=64):
     return out
 
 
+def _with_env(key, value, fn):
+    old = os.environ.get(key)
+    os.environ[key] = value
+    try:
+        return fn()
+    finally:
+        if old is None:
+            del os.environ[key]
+        else:
+            os.environ[key] = old
+
+
 def secondary_benchmarks(args):
     """The other claims of DESIGN.md in the same driver-run JSON line: ~20 steps each."""
     out = {}
     jobs = [("steady_state_200_steps", lambda: quick_forward_bench(args.config, args.batch, streams=max(1, args.streams_used), graph=True, steps=200, warmup=20)),
+            # the reference's own evaluation batch (config BATCH_SIZE 512 windows per forward, eval.py:147-152): launches of 284 row tiles, where the
+            # temporal chain (csrc/uu3d_tchain.h) is chosen by size -- against the same batch with the chain switched off
+            ("eval_batch_512", lambda: quick_forward_bench(args.config, 512, streams=max(1, args.streams_used), graph=True, steps=24, warmup=6)),
+            ("eval_batch_512_no_tchain", lambda: _with_env("UU3D_TCHAIN", "0", lambda: quick_forward_bench(args.config, 512, streams=max(1, args.streams_used), graph=True, steps=24, warmup=6))),
             ("with_input_copy_per_step", lambda: quick_forward_bench(args.config, args.batch, streams=max(1, args.streams_used), graph=True, copy_inputs=True)),
             ("latency_one_batch_in_flight", lambda: quick_forward_bench(args.config, args.batch, streams=1, graph=True)),
             ("eager_one_batch_in_flight", lambda: quick_forward_bench(args.config, args.batch, streams=1, graph=False)),

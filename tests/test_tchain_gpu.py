@@ -133,3 +133,32 @@ def test_chain_structural_variants(variant):
         e = max(e, np.abs(full[:6] - f32).max())
     print(f"{variant}: chain vs oracle {e:.3e}")
     assert e <= util.TOL_MAX_ABS
+
+
+def test_chain_is_chosen_by_size_without_the_switch():
+    """Default (no UU3D_TCHAIN in the environment): the chain runs under the throughput schedule once a launch has >= 256 row tiles
+    (464 sequences of 71 tokens: 258 tiles; the reference's own eval BATCH_SIZE of 512 windows is beyond that) and not at the
+    benchmark's batch of 128 (71 tiles), where it measured slower; the latency schedule never takes it."""
+    from oracle import uplift_oracle as O
+    cfg = util.load_config("h36m_351")
+    arch = pkg.arch_from_config(cfg)
+    w = pkg.init_weights(arch, seed=3, perturb=0.1)
+    old = os.environ.pop("UU3D_TCHAIN", None)
+    try:
+        model = pkg.build_uplift_upsample_transformer(cfg, weights=w)
+    finally:
+        if old is not None:
+            os.environ["UU3D_TCHAIN"] = old
+    x, m = util.synthetic_batch(cfg, batch=464, seed=1)
+    xm = x * m[:, :, None, None].astype(np.float32)
+    assert _kernels(model, arch, xm, m, 1).count("tchain") == arch.temporal_depth + 2
+    assert "tchain" not in _kernels(model, arch, xm, m, 0)
+    assert "tchain" not in _kernels(model, arch, xm[:128], m[:128], 1)
+    full, cen, _ = _forward(model, arch, xm, m, 1)
+    full_l, cen_l, _ = _forward(model, arch, xm, m, 0)
+    idx = [0, 1, 127, 128, 300, 463]                                 # sequences from the first, a middle and the last (ragged) row tiles
+    f32, c32 = O.forward(util.hp_from_arch(arch), w, xm[idx], m[idx], torch.float32)
+    e = max(np.abs(full[idx] - f32).max(), np.abs(cen[idx] - c32).max())
+    d = max(np.abs(full - full_l).max(), np.abs(cen - cen_l).max())
+    print(f"batch 464: chain (chosen by size) vs oracle {e:.3e}, vs launch chain {d:.3e}")
+    assert e <= util.TOL_MAX_ABS and d <= 3e-5

@@ -121,9 +121,12 @@ struct uu3d_model {
     // block with its positional encoding); launch T + 1 = projection + LayerNorm 2 + fc1 of the first strided block.  Empty = not available.
     struct TcLaunch { int flags; size_t w_off /* halfs, harena */; size_t p_off /* floats, arena */; };
     std::vector<TcLaunch> tchain;
-    bool no_tchain = true;         // UU3D_TCHAIN=1 (opt-in): the temporal chain under the throughput schedule.  Correct (tests/test_tchain_gpu.py) and 27 % fewer
-                                   // CU-microseconds per block than the round-4 launches, but a launch is 71 workgroups x ~200 us: with four hardware queues the
-                                   // pipelined step came out 3-5 % SLOWER (profiles/r05_tchain_ab.txt) -- narrow long launches mix badly with wide short ones
+    // When the chain runs (throughput schedule): a chain launch is one workgroup per 128 token rows, ~200 us each.  With >= 256 row tiles it fills
+    // the chip by itself and wins (batch 512, the reference's own eval BATCH_SIZE: 187.6 k against 179.1 k sequences/s); at the benchmark's batch of
+    // 128 it is 71 workgroups, and narrow long launches mix badly with the wide short ones of the other forwards in flight (162-170 k against
+    // 171-175 k, profiles/r05_tchain_ab.txt).  tchain_mode: -1 = by size (default), 1 = always (UU3D_TCHAIN=1), 0 = never (UU3D_TCHAIN=0).
+    int tchain_mode = -1;
+    int tchain_min_tiles = 256;    // UU3D_TCHAIN_MIN_TILES
     int num_cus = 256;
     std::recursive_mutex train_mu; // the training-mode chain keeps per-call options in the handle's training state (uu3d_train_step.inc): one call at a time
     bool in_commit = false;        // uu3d_commit_weights is calling uu3d_train_init (generic dims): the training step's skip flag is not its to clear
@@ -371,7 +374,8 @@ int uu3d_create(const uu3d_config* c, int device, uu3d_model** out) {
     { const char* e = getenv("UU3D_NO_PANEL"); m->no_panel = (e != nullptr && e[0] == '1'); }
     { const char* e = getenv("UU3D_NO_PANEL_PROJ"); m->no_panel_proj = (e != nullptr && e[0] == '1'); }
     { const char* e = getenv("UU3D_TAIL"); m->no_tail = !(e != nullptr && e[0] == '1'); }
-    { const char* e = getenv("UU3D_TCHAIN"); m->no_tchain = !(e != nullptr && e[0] == '1'); }
+    { const char* e = getenv("UU3D_TCHAIN"); if (e != nullptr && (e[0] == '0' || e[0] == '1')) m->tchain_mode = e[0] - '0'; }
+    { const char* e = getenv("UU3D_TCHAIN_MIN_TILES"); if (e != nullptr && atoi(e) > 0) m->tchain_min_tiles = atoi(e); }
     { hipDeviceProp_t pr; if (hipGetDeviceProperties(&pr, device) == hipSuccess && pr.multiProcessorCount > 0) m->num_cus = pr.multiProcessorCount; }
     if (hipMalloc((void**)&m->d_range, sizeof(int)) != hipSuccess || hipMemset(m->d_range, 0, sizeof(int)) != hipSuccess) {
         delete m;
@@ -1495,7 +1499,7 @@ int uu3d_forward_ex(uu3d_model* m, const float* kp2d, const uint8_t* mask, int32
     // launch for everything row-local (projection + residual, LayerNorm 2, fc1, ReLU, fc2 + residual, the next block's LayerNorm 1 + QKV) by
     // workgroups that own 128 token rows: 2 T + 3 launches for T temporal blocks and the head of the first strided block instead of 5 T + 5,
     // no partial-sum slabs, no LayerNorm passes.
-    const bool chain = Lh.throughput && planes && !m->no_tchain && !m->tchain.empty() && M >= 1024 && Lh.attn_is_h3(N, true) &&
+    const bool chain = Lh.throughput && planes && m->tchain_mode != 0 && (m->tchain_mode == 1 || (M + 127) / 128 >= m->tchain_min_tiles) && !m->tchain.empty() && M >= 1024 && Lh.attn_is_h3(N, true) &&
                        (c.num_strided == 0 || m->L[0] == N) && (double)M * 1152 * 4.0 < 4.0e9;
     auto chain_maps = [&](const char* tag, int i, const uint8_t* kmask) {                // return_attention=True: a block's attention maps, recomputed from q | k
         if (attn_out == nullptr || tag[0] != 't' || attn_out[i] == nullptr) return;
