@@ -20,6 +20,7 @@ SRC = r'''
 #include "uu3d_gemm_h3.h"
 #include "uu3d_gemm_panel.h"
 #include "uu3d_gemm_panel8.h"
+#include "uu3d_tchain.h"
 #include "uu3d_attn.h"
 #include "uu3d_attn_h3.h"
 #include "uu3d_bwd.h"
@@ -39,6 +40,9 @@ template __global__ void uu3d::gemm_h3_panel_kernel<24, PanelEpBiasResidual, 4>(
 template __global__ void uu3d::gemm_h3_panel8_kernel<PanelEpBiasSplitQ, 12, 3>(const _Float16*, const _Float16*, const float*, int, int, int, const PanelEpBiasSplitQ);
 template __global__ void uu3d::gemm_h3_panel8_kernel<PanelEpBiasResidual, 4, 3>(const _Float16*, const _Float16*, const float*, int, int, int, const PanelEpBiasResidual);
 template __global__ void uu3d::gemm_h3_panel8_kernel<PanelEpBiasResidualLn, 12, 3>(const _Float16*, const _Float16*, const float*, int, int, int, const PanelEpBiasResidualLn);
+template __global__ void uu3d::tchain_kernel<TC_PROJ | TC_MLP | TC_QKV>(const TChainArgs);
+template __global__ void uu3d::tchain_kernel<TC_QKV>(const TChainArgs);
+template __global__ void uu3d::tchain_kernel<TC_PROJ | TC_FC1_PLANES>(const TChainArgs);
 template __global__ void uu3d::ln_split_frag_kernel<24, 8>(const float*, int, int, float, const float*, const float*, _Float16*);
 template __global__ void uu3d::gemm_h3g_kernel<1, 1, GLoadConv3, EpSlab, 3>(const GLoadConv3, const _Float16*, const _Float16*, int, int, int, int, int, int, const EpSlab);
 template __global__ void uu3d::gemm_h3g_kernel<1, 2, GLoadPlain, EpBiasResidual, 3>(const GLoadPlain, const _Float16*, const _Float16*, int, int, int, int, int, int, const EpBiasResidual);
@@ -139,6 +143,57 @@ def test_eight_wave_row_panel_gemm_code_shape(asm):
         d = asm[asm.index(".amdhsa_kernel " + name):]
         d = d[:d.index(".end_amdhsa_kernel")]
         assert int(re.search(r"\.amdhsa_next_free_vgpr (\d+)", d).group(1)) <= 256, name
+
+
+def _loops(body):
+    """{header block: text of every basic block of that INNERMOST loop} from hipcc's block comments ("=>This Inner Loop Header", "in Loop: Header=BBn_m"):
+    a loop's blocks are not contiguous in the text (the compiler rotates and sinks them), so label-to-branch ranges miss pieces."""
+    blocks, cur, head = [], None, None
+    for line in body.split("\n"):
+        m = re.match(r"^\.(LBB\d+_\d+):\s*;?(.*)$", line)
+        if m:
+            cur = [m.group(1), m.group(2), []]
+            blocks.append(cur)
+        elif cur is not None:
+            cur[2].append(line)
+    inner = {name for name, comment, _ in blocks if "Inner Loop Header" in comment}          # innermost loops only
+    loops = {}
+    for name, comment, lines in blocks:
+        m = re.search(r"in Loop: Header=(BB\d+_\d+)", comment)
+        hdr = "L" + m.group(1) if m else name
+        if hdr in inner:
+            loops.setdefault(hdr, []).extend(lines)
+    return {k: "\n".join(v) for k, v in loops.items()}
+
+
+def test_temporal_chain_code_shape(asm):
+    """uu3d_tchain.h (round 5): the chunk loop of a stage is a REAL loop of four-chunk bodies.  What it relies on: nothing inside a loop is a
+    vector-memory LOAD (a load in flight across the back edge, or one hipcc can see beside the LDS-DMAs, brings a vmcnt(0) that drains the
+    ring: the biases come through the scalar cache), every wait inside a loop is one of the hand-written counted ones (14 per chunk),
+    per chunk 36 MFMAs, 6 LDS-DMA pieces (the refill position depends on the wave group: both branches are in the text) and two barriers,
+    no scratch inside a loop, 256 registers = two waves per SIMD, all of the LDS."""
+    ks = _kernels(asm)
+    chains = {k: v for k, v in ks.items() if "tchain_kernel" in k}
+    assert len(chains) == 3
+    for name, body in chains.items():
+        loops = [t for t in _loops(body).values() if "v_mfma_f32_32x32x16_f16" in t]
+        assert loops, name
+        inner = [t for t in loops if t.count("v_mfma_f32_32x32x16_f16") == 4 * 36]
+        assert inner, (name, [t.count("v_mfma_f32_32x32x16_f16") for t in loops])
+        for t in inner:
+            assert "scratch_" not in t and "v_readlane" not in t and "v_writelane" not in t, name
+            assert not re.search(r"\b(global|buffer|flat)_load_(dword|ubyte|ushort|short)", t), name           # LDS-DMA (global_load_lds_*) only
+            assert t.count("s_barrier") == 4 * 2, name
+            in_asm = sum(blk.count("s_waitcnt") for blk in re.findall(r";;#ASMSTART(.*?);;#ASMEND", t, re.S))
+            assert in_asm >= 4 * 14 and t.count("s_waitcnt") == in_asm, (name, in_asm, t.count("s_waitcnt"))     # every wait is a hand-written counted one (the wave-group branches duplicate a few); hipcc added none
+            assert not re.search(r"s_waitcnt vmcnt\(0\)", t), name
+            # first-half refills: 3 per chunk; second-half refills: 3 per chunk in EACH of the two wave-group branches
+            assert t.count("global_load_lds_dwordx4") == 4 * (3 + 2 * 3), (name, t.count("global_load_lds_dwordx4"))
+            assert t.count("s_load_dwordx16") in (0, 4), name                                                 # stages with a bias: one scalar load per chunk
+        d = asm[asm.index(".amdhsa_kernel " + name):]
+        d = d[:d.index(".end_amdhsa_kernel")]
+        assert int(re.search(r"\.amdhsa_next_free_vgpr (\d+)", d).group(1)) <= 256, name
+        assert "v_pk_mul_f32" not in body and "v_pk_fma_f32" not in body and "v_pk_add_f32" not in body, name
 
 
 def test_no_packed_fp32_valu_ops(asm):

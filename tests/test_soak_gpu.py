@@ -81,3 +81,39 @@ def test_pipelined_forwards_stay_bitwise_right_over_many_batches():
         n += 1
     assert n == 1200
     pipe.close()
+
+
+def test_pipelined_temporal_chain_stays_bitwise_right_over_many_batches(monkeypatch):
+    """The temporal chain (csrc/uu3d_tchain.h; forced on at this batch, UU3D_TCHAIN=1) through the four-queue pipeline: 600 batches cycling
+    through six inputs, every result equal to what a quiet throughput-schedule forward returned for that input -- the chain's lane-private
+    scratch slabs belong to a slot's workspace, its ring and counted waits are hand-scheduled: a slot reading another slot's scratch, or a
+    wait that counts one operation too few, shows up here as a rare mismatch."""
+    monkeypatch.setenv("UU3D_TCHAIN", "1")
+    cfg = util.load_config("h36m_351")
+    arch = pkg.arch_from_config(cfg)
+    model = pkg.build_uplift_upsample_transformer(cfg, weights=pkg.init_weights(arch, seed=0, perturb=0.1), device="cuda:0")
+    B = 128
+    inputs, want = [], []
+    for k in range(6):
+        x, m = util.synthetic_batch(cfg, batch=B, seed=60 + k)
+        xt = torch.from_numpy(x * m[:, :, None, None].astype(np.float32)).cuda(); mt = torch.from_numpy(m).cuda()
+        inputs.append((xt, mt))
+        full = torch.empty((B, arch.num_frames, arch.num_keypoints, 3), dtype=torch.float32, device="cuda")
+        cen = torch.empty((B, arch.num_keypoints, 3), dtype=torch.float32, device="cuda")
+        model._forward(xt, model._mask_u8(mt), full, cen, 0, torch.cuda.current_stream(), schedule=1)
+        torch.cuda.synchronize()
+        want.append((full, cen))
+    model.set_profiling(True)
+    model._forward(inputs[0][0], model._mask_u8(inputs[0][1]), full.clone(), cen.clone(), 0, torch.cuda.current_stream(), schedule=1)
+    assert any(e["kernel"] == "tchain" for e in model.read_profile())
+    model.set_profiling(False)
+    pipe = model.pipeline(B)
+    assert pipe.depth >= 2
+    n = 0
+    for full, cen in pipe.run(inputs[i % 6] for i in range(600)):
+        fw, cw = want[n % 6]
+        assert torch.equal(full, fw) and torch.equal(cen, cw), f"batch {n} differs"
+        n += 1
+    assert n == 600
+    pipe.check_range()
+    pipe.close()

@@ -87,16 +87,33 @@ template <int FLAGS> void run(const char* tag, int M, int iters) {
     a.W = dev(W); a.P = dev(P);
     a.Q = devz<_Float16>((size_t)M * 3 * D * 2);
     a.H = devz<_Float16>((size_t)M * Hd * 2);
-    a.scratch = devz<unsigned char>(tchain_scratch_bytes(mt));
+    // scratch = hidden fragments | xs | xas | trash; the launches that add into the residual stream find it there in lane-linear order
+    std::vector<unsigned char> scr(tchain_scratch_bytes(mt), 0);
+    float* xs_h = reinterpret_cast<float*>(scr.data() + (size_t)mt * TC_H_HALFS_PER_TILE * 2);
+    float* xas_h = xs_h + (size_t)mt * TC_X_FLOATS_PER_TILE;
+    for (int r = 0; r < M; ++r) for (int k = 0; k < D; ++k) { xs_h[tchain_xs_index(r, k)] = X[(size_t)r * D + k]; xas_h[tchain_xs_index(r, k)] = X[(size_t)r * D + k]; }
+    a.scratch = dev(scr);
+    unsigned char* scratch0 = dev(scr);
     auto kern = tchain_kernel<FLAGS>;
     CK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)P8_LDS_TOTAL));
     float* Xin = dev(X);
     auto launch = [&]() { hipLaunchKernelGGL(kern, dim3(mt), dim3(512), P8_LDS_TOTAL, 0, a); };
     launch(); CK(hipDeviceSynchronize());
+    auto fetch_linear = [&](std::vector<float>& out, bool strided1) {        // the lane-linear tile copy -> row-major
+        std::vector<unsigned char> sc(scr.size());
+        CK(hipMemcpy(sc.data(), a.scratch, sc.size(), hipMemcpyDeviceToHost));
+        const float* base = reinterpret_cast<const float*>(sc.data() + (size_t)mt * TC_H_HALFS_PER_TILE * 2) + (strided1 ? (size_t)mt * TC_X_FLOATS_PER_TILE : 0);
+        for (int r = 0; r < M; ++r) for (int k = 0; k < D; ++k) out[(size_t)r * D + k] = base[tchain_xs_index(r, k)];
+    };
 
     std::vector<float> Xo((size_t)M * D), XAo((size_t)M * D); std::vector<_Float16> Q((size_t)M * 3 * D * 2), Hp((size_t)M * Hd * 2);
     CK(hipMemcpy(Xo.data(), a.X, Xo.size() * 4, hipMemcpyDeviceToHost)); CK(hipMemcpy(XAo.data(), a.XA, XAo.size() * 4, hipMemcpyDeviceToHost));
     CK(hipMemcpy(Q.data(), a.Q, Q.size() * 2, hipMemcpyDeviceToHost)); CK(hipMemcpy(Hp.data(), a.H, Hp.size() * 2, hipMemcpyDeviceToHost));
+    // where the launch leaves the residual stream: row-major x only when it ends the temporal stack (no QKV, or + pe); else the lane-linear tile;
+    // the first strided block's launch: row-major xa
+    if (FLAGS & TC_FC1_PLANES) Xo = XAo;
+    else if ((FLAGS & TC_QKV) && !(FLAGS & TC_PE)) fetch_linear(Xo, false);
+    if (FLAGS & TC_PE) fetch_linear(XAo, true);
     double ex = 0, exa = 0, eq = 0, eh = 0, sx = 0, sq = 0, sh = 0; size_t nan = 0; int rows = 0;
     for (int r = 0; r < M; r += (r < 160 || r > M - 160) ? 1 : 53) {
         ++rows;
@@ -120,9 +137,10 @@ template <int FLAGS> void run(const char* tag, int M, int iters) {
 
     // determinism + time (x is updated in place: restore it in front of every launch that is checked, not in the timed ones)
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
-    CK(hipMemcpy(a.X, Xin, Xo.size() * 4, hipMemcpyDeviceToDevice)); launch(); CK(hipDeviceSynchronize());
+    CK(hipMemcpy(a.X, Xin, Xo.size() * 4, hipMemcpyDeviceToDevice)); CK(hipMemcpy(a.scratch, scratch0, scr.size(), hipMemcpyDeviceToDevice)); launch(); CK(hipDeviceSynchronize());
     std::vector<float> X2((size_t)M * D); std::vector<_Float16> Q2(Q.size());
-    CK(hipMemcpy(X2.data(), a.X, X2.size() * 4, hipMemcpyDeviceToHost)); CK(hipMemcpy(Q2.data(), a.Q, Q2.size() * 2, hipMemcpyDeviceToHost));
+    CK(hipMemcpy(X2.data(), (FLAGS & TC_FC1_PLANES) ? a.XA : a.X, X2.size() * 4, hipMemcpyDeviceToHost)); CK(hipMemcpy(Q2.data(), a.Q, Q2.size() * 2, hipMemcpyDeviceToHost));
+    if (!(FLAGS & TC_FC1_PLANES) && (FLAGS & TC_QKV) && !(FLAGS & TC_PE)) fetch_linear(X2, false);
     size_t diff = 0; for (size_t i = 0; i < X2.size(); ++i) diff += (X2[i] != Xo[i]); for (size_t i = 0; i < Q2.size(); ++i) diff += ((float)Q2[i] != (float)Q[i]);
     printf("    second run: %zu differing values\n", diff);
     for (int i = 0; i < warm; ++i) launch();

@@ -1005,7 +1005,7 @@ struct Launcher {
     // the caller has to launch the 4-wave kernel.
     static bool panel8_ok(int cpw) {
         static const bool off = getenv("UU3D_PANEL4") != nullptr && atoi(getenv("UU3D_PANEL4")) != 0;
-        return !off && (cpw == 4 || cpw == 6 || cpw == 8 || cpw == 12);
+        return !off && (cpw == 4 || cpw == 6 || cpw == 8 || cpw == 9 || cpw == 12);      // (9: QKV at 284 row tiles = batch 512, four column ranges)
     }
     // the profile records' kernel name = the kernel SYMBOL's distinguishing part (bench.py picks the dominant kernel by it)
     template <class EP> static const char* panel_symbol(bool eight) {
@@ -1027,6 +1027,7 @@ struct Launcher {
             case 4: UU3D_P8_LAUNCH(4)
             case 6: UU3D_P8_LAUNCH(6)
             case 8: UU3D_P8_LAUNCH(8)
+            case 9: UU3D_P8_LAUNCH(9)
             case 12: UU3D_P8_LAUNCH(12)
             default: return false;
         }
@@ -1598,7 +1599,7 @@ int uu3d_forward_ex(uu3d_model* m, const float* kp2d, const uint8_t* mask, int32
         if (chain && i == 0) {
             // the chain's last launch left q | k | v of this block (LayerNorm 1 of xa = x + pe); its projection, LayerNorm 2 and fc1 are the next one
             Lh.attn("s1.attn", w.QKV, B, Li, nullptr, w.O, (size_t)Mi * dt, true);
-            Lh.tchain("s1.chain", m->tchain[c.temporal_depth + 1], Mi, Ph, xa, nullptr, nullptr, 1, nullptr, Hh, w.tc_scratch);
+            Lh.tchain("s1.chain", m->tchain[c.temporal_depth + 1], Mi, Ph, nullptr, xa, nullptr, 1, nullptr, Hh, w.tc_scratch);      // (its stream: xa, lane-linear in the scratch since the last temporal launch; row-major xa written here for the convolution's residual rows)
         } else
         block_head("s", i, b, xa, Li, smask ? mask : nullptr, i == 0 ? pend : nullptr, false);
         if (i == 0 && has_h1) {

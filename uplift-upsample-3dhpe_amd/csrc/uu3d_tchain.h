@@ -44,8 +44,8 @@ static constexpr int TC_CHUNK_HALFS = P8_CHUNK_BYTES / 2;
 __host__ __device__ inline constexpr int tchain_chunks(int flags) {
     return ((flags & TC_PROJ) ? 12 : 0) + ((flags & TC_MLP) ? 48 : 0) + ((flags & TC_FC1_PLANES) ? 24 : 0) + ((flags & TC_QKV) ? 36 : 0);
 }
-static constexpr size_t TC_T_FLOATS_PER_TILE = 2 * 12 * 8 * 2 * 64 * 4;      // two partial-result slabs of a 128 x 384 tile, lane-linear
 static constexpr size_t TC_H_HALFS_PER_TILE = 24 * 8 * 2 * 64 * 8;           // relu(fc1) of a tile as fc2's token fragments, lane-linear
+static constexpr size_t TC_X_FLOATS_PER_TILE = 128 * 384;                    // a tile of the residual stream, lane-linear (tchain_xs_index)
 static constexpr size_t TC_TRASH_BYTES = 16384;
 
 // Parameter table of one launch (floats, packed at commit time: ONE pointer instead of eight -- with two dozen pointers in scalar
@@ -62,10 +62,20 @@ struct TChainArgs {
     const float* P;              // parameter table (TCP_*)
     _Float16* Q;                 // TC_QKV: hi plane [M][1152], lo plane M * 1152 halfs further
     _Float16* H;                 // TC_FC1_PLANES: hi plane [M][768], lo plane M * 768 halfs further
-    unsigned char* scratch;      // tchain_scratch_bytes(m_tiles): partial-result slabs | hidden fragments | trash page
+    unsigned char* scratch;      // tchain_scratch_bytes(m_tiles): hidden fragments | residual stream (lane-linear) | the same of the first strided block (x + pe) | trash page
 };
 __host__ __device__ inline constexpr size_t tchain_scratch_bytes(int m_tiles) {
-    return (size_t)m_tiles * (TC_T_FLOATS_PER_TILE * 4 + TC_H_HALFS_PER_TILE * 2) + TC_TRASH_BYTES;
+    return (size_t)m_tiles * (TC_H_HALFS_PER_TILE * 2 + 2 * TC_X_FLOATS_PER_TILE * 4) + TC_TRASH_BYTES;
+}
+
+// Lane-linear order of the residual stream INSIDE the chain (row-major only at its boundaries): element (row, channel) of a 128-row tile sits where
+// the lane that owns it in the transposed accumulator map stores 256 contiguous bytes per wave instruction -- [chunk c][wave = 4 hh + q][i][e][lane = t + 32 g]
+// with channel = 32 c + 16 hh + 8 i + 4 g + e and row = 32 q + t.  An atomic instruction of a wave then touches 2 cache lines instead of the 32 of a
+// row-major tile (measured: 21 k cycles per chunk with row-major atomics, the whole gain gone).
+__host__ __device__ inline size_t tchain_xs_index(int row, int ch) {
+    const int tile = row >> 7, q = (row >> 5) & 3, t = row & 31;
+    const int c = ch >> 5, hh = (ch >> 4) & 1, i = (ch >> 3) & 1, g = (ch >> 2) & 1, e = ch & 3;
+    return (size_t)tile * TC_X_FLOATS_PER_TILE + ((((size_t)(c * 8 + 4 * hh + q) * 2 + i) * 4 + e) * 64 + t + 32 * g);
 }
 
 // ---- host side: one stage's chunks of the weight stream from the transposed, padded planes Bt[n][Kp] (k contiguous; lo pre-scaled) ----
@@ -89,7 +99,7 @@ inline void tchain_pack_stage(const _Float16* Bh, const _Float16* Bl, int N, int
 typedef float f32x16s __attribute__((ext_vector_type(16)));
 
 #ifndef UU3D_TC_LOO
-#define UU3D_TC_LOO 0          // tools/tchain_exp: leave-one-out timing builds (results wrong): 1 no refill DMA, 2 no finish, 4 no exchange, 8 no mid barrier, 16 no fragment reads, 32 no MFMA
+#define UU3D_TC_LOO 0          // tools/tchain_exp: leave-one-out timing builds (results wrong): 1 no refill DMA, 2 no finish, 4 no exchange, 8 no mid barrier, 16 no fragment reads, 32 no MFMA, 64 plane stores coalesced, 128 no bias load, 256 transitions without memory traffic
 #endif
 #ifdef UU3D_TC_STAMP
 // tools/tchain_exp: per workgroup 16 pairs (s_memtime = shader clock ticks, s_memrealtime = 100 MHz) at the chain's stage boundaries
@@ -101,9 +111,15 @@ __device__ unsigned long long tchain_acc[32 * 4];      // per stage set (FLAGS):
 #endif
 
 // ---- epilogues of a stage: what happens to the 8 finished values v[j] (channels 32 c + 16 hh + 8 (j >> 2) + 4 g + (j & 3)) of a lane ----
-struct TcEpScratch {           // partial result of a residual Dense layer -> lane-linear scratch (added to x at the transition)
-    static constexpr int kStores = 2; static constexpr bool kBias = false;
-    f32x4* __restrict__ t;     // this lane's slot: + (c * 8 + wave) * 2 * 64 per chunk
+// x[token][channel] += v (+ bias): the residual Dense layers (projection, the two K halves of fc2) add into the residual stream IN MEMORY with
+// no-return float atomics -- fire-and-forget like stores (nothing comes back into a register, so nothing by name crosses the loop), executed at
+// L2; every element is touched by exactly ONE lane once per stage, so the sum has a fixed order.  Round 5's first form stored the partial result to a
+// scratch slab and added it at the stage transition: 0.6-1.2 MB of exposed memory traffic per transition and workgroup, 20-27 % of the kernel
+// (timing build without that traffic: 171 -> 182 k sequences/s at batch 128, 184 -> 208 k at batch 512).
+template <bool BIAS>
+struct TcEpResidual {
+    static constexpr int kStores = 8; static constexpr bool kBias = BIAS;
+    float* x;                  // the tile of the residual stream, lane-linear (tchain_xs_index), + wave * 512 + lane floats: (c, i, e) at + c * 4096 + i * 256 + e * 64
     const float* bias;
 };
 struct TcEpHidden {            // relu(v + b1) split into hi / lo = the token fragment of fc2's k-slice 2 c + hh -> lane-linear scratch
@@ -175,23 +191,30 @@ tchain_kernel(const TChainArgs a)
     };
     auto bias4 = [&](const f32x16s& sb, int i) __attribute__((always_inline)) -> f32x4 {       // scalar registers 8 i + 4 g + e
         // (the two candidates are made opaque first: hipcc otherwise folds the select into a DYNAMIC index of the 16-vector, a chain of
-        // 16 v_cmp / v_cndmask pairs per value whose compare masks it then spilled with v_writelane -- 170 of them per chunk pair)
+        // 16 v_cmp / v_cndmask pairs per value whose compare masks it then spilled with v_writelane -- 170 of them per chunk pair.  Opaque as
+        // VECTOR registers: behind an asm that DEFINES scalar registers hipcc assumes a scalar load in flight and puts an s_waitcnt lgkmcnt(0)
+        // in front of the next scalar operand -- four per chunk in the middle of the fragment prefetch, pinned by tests/test_isa_cpu.py)
         f32x4 b;
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
             float b0 = sb[8 * i + e], b1 = sb[8 * i + 4 + e];
-            asm("" : "+s"(b0), "+s"(b1));
+            asm("" : "+v"(b0), "+v"(b1));
             b[e] = g ? b1 : b0;
         }
         return b;
     };
-    unsigned char* const psm_dummy = a.scratch + (size_t)bm * (TC_T_FLOATS_PER_TILE * 4);
+    unsigned char* const psm_dummy = a.scratch + (size_t)bm * (TC_H_HALFS_PER_TILE * 2);
     // finish half i of chunk cp; the 16-byte fragments of TcEpHidden need both halves: `keep` carries half 0 to half 1
     struct Keep { h16x4 h0, l0; };
     auto finish = [&](auto ep, int cp, int i, const f32x4 v, const f32x16s& sb, Keep& keep) __attribute__((always_inline)) {
         using EP = decltype(ep);
-        if constexpr (std::is_same<EP, TcEpScratch>::value) {
-            ep.t[((size_t)(cp * 8 + wave) * 2 + i) * 64] = v;
+        if constexpr (std::is_same<EP, TcEpResidual<false>>::value || std::is_same<EP, TcEpResidual<true>>::value) {
+            f32x4 y = v;
+            if constexpr (EP::kBias) y = y + bias4(sb, i);
+            float* d = ep.x + cp * 4096 + i * 256;
+            asm volatile("global_atomic_add_f32 %0, %1, off\n\tglobal_atomic_add_f32 %0, %2, off offset:256\n\t"
+                         "global_atomic_add_f32 %0, %3, off offset:512\n\tglobal_atomic_add_f32 %0, %4, off offset:768"
+                         :: "v"(d), "v"(y[0]), "v"(y[1]), "v"(y[2]), "v"(y[3]) : "memory");
         } else if constexpr (std::is_same<EP, TcEpHidden>::value) {
             f32x4 y = v + bias4(sb, i);
 #pragma unroll
@@ -381,34 +404,55 @@ tchain_kernel(const TChainArgs a)
 
     // ================= transitions: everything below works on the lane's own 96 values of the residual stream =================
     f32x4 xr[12][2];                                       // x[token][32 c + 16 hh + 8 i + 4 g + (0..3)]
-    unsigned char* const trash = a.scratch + (size_t)a.m_tiles * (TC_T_FLOATS_PER_TILE * 4 + TC_H_HALFS_PER_TILE * 2);
-    const float* const xrow = a.X + (size_t)tokc * 384 + chl;
-    float* const xst = live ? a.X + (size_t)tok * 384 + chl : reinterpret_cast<float*>(trash) + chl;
-    f32x4* const tl = reinterpret_cast<f32x4*>(a.scratch) + (size_t)bm * (TC_T_FLOATS_PER_TILE / 4) + lane;       // slab 0; slab 1: + 12 * 8 * 2 * 64
-    h16x8* const hsl = reinterpret_cast<h16x8*>(a.scratch + (size_t)a.m_tiles * (TC_T_FLOATS_PER_TILE * 4)) + (size_t)bm * (TC_H_HALFS_PER_TILE / 8) + lane;
+    unsigned char* const trash = a.scratch + (size_t)a.m_tiles * (TC_H_HALFS_PER_TILE * 2 + 2 * TC_X_FLOATS_PER_TILE * 4);
+    h16x8* const hsl = reinterpret_cast<h16x8*>(a.scratch) + (size_t)bm * (TC_H_HALFS_PER_TILE / 8) + lane;
+    // the tile of the residual stream in lane-linear order (tchain_xs_index): xs = the temporal stack's, xas = the first strided block's (x + pe)
+    float* const xs = reinterpret_cast<float*>(a.scratch + (size_t)a.m_tiles * (TC_H_HALFS_PER_TILE * 2)) + (size_t)bm * TC_X_FLOATS_PER_TILE + wave * 512 + lane;
+    float* const xas = xs + (size_t)a.m_tiles * TC_X_FLOATS_PER_TILE;
+    auto row_ptr = [&](float* base) __attribute__((always_inline)) -> float* {      // this lane's 16 hh + 4 g slot of its row in a ROW-MAJOR stream (dead lanes: the trash page)
+        return live ? base + (size_t)tok * 384 + chl : reinterpret_cast<float*>(trash) + chl;
+    };
 
-    // x += (partial slab(s) + bias), stored back.  Every load sits in front of the first store: xrow and xst are the same memory, and
-    // with a store between them hipcc kept the 24 load groups in program order -- 24 dependent L2 round trips, 42 k cycles per transition.
-    auto add_partials = [&](int slabs, const float* bias) __attribute__((always_inline)) {
-#pragma unroll
-        for (int c = 0; c < 12; ++c)
-#pragma unroll
-            for (int i = 0; i < 2; ++i) xr[c][i] = *reinterpret_cast<const f32x4*>(xrow + 32 * c + 8 * i);
+    // This lane's 96 values out of a lane-linear tile AFTER the stage's atomics: every atomic of this wave has completed (vmcnt(0): atomics count like
+    // stores), and the loads bypass the CU's vector L1 (sc0 sc1), which the atomics -- executed at L2 -- never updated.
+    auto load_xs = [&](const float* t) __attribute__((always_inline)) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #pragma unroll
         for (int c = 0; c < 12; ++c)
 #pragma unroll
             for (int i = 0; i < 2; ++i) {
-                const f32x4 bv = *reinterpret_cast<const f32x4*>(bias + 32 * c + chl + 8 * i);
-                f32x4 y = tl[((size_t)(c * 8 + wave) * 2 + i) * 64];
-                if (slabs == 2) y = y + tl[((size_t)((12 + c) * 8 + wave) * 2 + i) * 64];
-                xr[c][i] = xr[c][i] + (y + bv);
+                const float* p = t + c * 4096 + i * 256;
+                asm volatile("global_load_dword %0, %4, off sc0 sc1\n\tglobal_load_dword %1, %4, off offset:256 sc0 sc1\n\t"
+                             "global_load_dword %2, %4, off offset:512 sc0 sc1\n\tglobal_load_dword %3, %4, off offset:768 sc0 sc1"
+                             : "=&v"(xr[c][i][0]), "=&v"(xr[c][i][1]), "=&v"(xr[c][i][2]), "=&v"(xr[c][i][3]) : "v"(p) : "memory");
             }
-        asm volatile("" ::: "memory");
+        asm volatile("s_waitcnt vmcnt(0)" : "+v"(xr[0][0]), "+v"(xr[0][1]), "+v"(xr[1][0]), "+v"(xr[1][1]), "+v"(xr[2][0]), "+v"(xr[2][1]), "+v"(xr[3][0]), "+v"(xr[3][1]),
+                                             "+v"(xr[4][0]), "+v"(xr[4][1]), "+v"(xr[5][0]), "+v"(xr[5][1]), "+v"(xr[6][0]), "+v"(xr[6][1]), "+v"(xr[7][0]), "+v"(xr[7][1]),
+                                             "+v"(xr[8][0]), "+v"(xr[8][1]), "+v"(xr[9][0]), "+v"(xr[9][1]), "+v"(xr[10][0]), "+v"(xr[10][1]), "+v"(xr[11][0]), "+v"(xr[11][1]) :: "memory");
+    };
+    auto store_xs = [&](float* t) __attribute__((always_inline)) {
 #pragma unroll
         for (int c = 0; c < 12; ++c)
 #pragma unroll
-            for (int i = 0; i < 2; ++i) *reinterpret_cast<f32x4*>(xst + 32 * c + 8 * i) = xr[c][i];
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) t[c * 4096 + i * 256 + e * 64] = xr[c][i][e];
     };
+    auto load_rows = [&](const float* base) __attribute__((always_inline)) {          // (rows past M: row M - 1)
+        const float* p = base + (size_t)tokc * 384 + chl;
+#pragma unroll
+        for (int c = 0; c < 12; ++c)
+#pragma unroll
+            for (int i = 0; i < 2; ++i) xr[c][i] = *reinterpret_cast<const f32x4*>(p + 32 * c + 8 * i);
+    };
+    auto store_rows = [&](float* base) __attribute__((always_inline)) {
+        float* p = row_ptr(base);
+#pragma unroll
+        for (int c = 0; c < 12; ++c)
+#pragma unroll
+            for (int i = 0; i < 2; ++i) *reinterpret_cast<f32x4*>(p + 32 * c + 8 * i) = xr[c][i];
+    };
+
     // sum over the token's 384 channels: this lane's 96 + lane ^ 32 + the partner wave (both waves add the same two numbers)
     auto token_sum = [&](float s, int phase) __attribute__((always_inline)) -> float {
         s += __shfl_xor(s, 32);
@@ -446,28 +490,30 @@ tchain_kernel(const TChainArgs a)
     };
 
     // ================= the chain =================
+    // Where the residual stream lives: ROW-MAJOR (a.X / a.XA) at the chain's boundaries -- the first launch reads what spatial_to_temporal_fc wrote,
+    // the last temporal launch writes x for the full-sequence head and xa = x + pe for the first strided block, the strided block's launch writes
+    // xa += projection for its convolution's residual rows -- and LANE-LINEAR (xs / xas in the scratch) in between, where the epilogues add into it.
     TC_STAMP(0);
+    constexpr bool kStrided1 = (FLAGS & TC_FC1_PLANES) != 0;                   // the launch of the first strided block: its stream is xa
     if constexpr ((FLAGS & TC_PROJ) != 0) {
         const int panel = min(bm * 128 + q * 32, a.M - 1) >> 5;
         const h16x8* ap = reinterpret_cast<const h16x8*>(a.Of) + (size_t)panel * 24 * 2 * 64 + lane;
 #pragma unroll
         for (int s = 0; s < HS; ++s) { ah[s] = ap[((HS * hh + s) * 2 + 0) * 64]; al[s] = ap[((HS * hh + s) * 2 + 1) * 64]; }
         TC_STAMP(1);
-        stage(std::integral_constant<int, 12>{}, TcEpScratch{tl, nullptr});
+        stage(std::integral_constant<int, 12>{}, TcEpResidual<true>{kStrided1 ? xas : xs, a.P + TCP_BP + 16 * hh});
         TC_STAMP(2);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        add_partials(1, a.P + TCP_BP);
+        load_xs(kStrided1 ? xas : xs);
+        if constexpr (kStrided1) store_rows(a.XA);                            // (the strided convolution's residual rows, EpConvResidual)
     } else {
-#pragma unroll
-        for (int c = 0; c < 12; ++c)
-#pragma unroll
-            for (int i = 0; i < 2; ++i) xr[c][i] = *reinterpret_cast<const f32x4*>(xrow + 32 * c + 8 * i);
+        load_rows(a.X);
+        store_xs(xs);
     }
     if constexpr ((FLAGS & (TC_MLP | TC_FC1_PLANES)) != 0) {
         TC_STAMP(3);
         layer_norm();
         TC_STAMP(4);
-        if constexpr ((FLAGS & TC_FC1_PLANES) != 0) {
+        if constexpr (kStrided1) {
             unsigned char* ph = live ? reinterpret_cast<unsigned char*>(a.H + (size_t)tok * 768 + chl) : trash;
             unsigned char* pl = live ? reinterpret_cast<unsigned char*>(a.H + ((size_t)a.M + tok) * 768 + chl) : trash + 4096;
             stage(std::integral_constant<int, 24>{}, TcEpPlanes{ph, pl, a.P + TCP_B1 + 16 * hh, 0, 1.0f, 1});
@@ -482,33 +528,33 @@ tchain_kernel(const TChainArgs a)
                     const h16x8* d = hsl + ((size_t)((12 * half + s) * 8 + wave) * 2) * 64;
                     ah[s] = d[0]; al[s] = d[64];
                 }
-                stage(std::integral_constant<int, 12>{}, TcEpScratch{tl + (size_t)half * (12 * 8 * 2 * 64), nullptr});
+                if (half == 0) stage(std::integral_constant<int, 12>{}, TcEpResidual<false>{xs, nullptr});
+                else stage(std::integral_constant<int, 12>{}, TcEpResidual<true>{xs, a.P + TCP_B2 + 16 * hh});
             }
             TC_STAMP(6);
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            add_partials(2, a.P + TCP_B2);
+            load_xs(xs);
             TC_STAMP(7);
+            if constexpr ((FLAGS & TC_QKV) == 0 || (FLAGS & TC_PE) != 0) store_rows(a.X);        // the temporal stack's result: head1 (and head2 without strided blocks) read it
         }
     }
     if constexpr ((FLAGS & TC_QKV) != 0) {
         if constexpr ((FLAGS & TC_PE) != 0) {
             const float* pr = a.pe + (size_t)(tokc % a.period) * 384 + chl;
-            float* const xast = live ? a.XA + (size_t)tok * 384 + chl : reinterpret_cast<float*>(trash) + chl;
 #pragma unroll
             for (int c = 0; c < 12; ++c)
 #pragma unroll
                 for (int i = 0; i < 2; ++i) xr[c][i] = xr[c][i] + *reinterpret_cast<const f32x4*>(pr + 32 * c + 8 * i);
-            asm volatile("" ::: "memory");
-#pragma unroll
-            for (int c = 0; c < 12; ++c)
-#pragma unroll
-                for (int i = 0; i < 2; ++i) *reinterpret_cast<f32x4*>(xast + 32 * c + 8 * i) = xr[c][i];
+            store_xs(xas);                                                     // the stream of the first strided block's launch
         }
         layer_norm();
         TC_STAMP(8);
+        // (q's scale in a VECTOR register: as a scalar kernel argument hipcc re-loaded it inside the chunk loop -- an s_load and an s_waitcnt lgkmcnt(0)
+        // per use, four per chunk, each of which also waits for the prefetched weight fragments)
+        float qs = a.qscale;
+        asm("" : "+v"(qs));
         unsigned char* ph = live ? reinterpret_cast<unsigned char*>(a.Q + (size_t)tok * 1152 + chl) : trash;
         unsigned char* pl = live ? reinterpret_cast<unsigned char*>(a.Q + ((size_t)a.M + tok) * 1152 + chl) : trash + 4096;
-        stage(std::integral_constant<int, 36>{}, TcEpPlanes{ph, pl, a.P + TCP_BQKV + 16 * hh, 12, a.qscale, 0});
+        stage(std::integral_constant<int, 36>{}, TcEpPlanes{ph, pl, a.P + TCP_BQKV + 16 * hh, 12, qs, 0});
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // (the clamped tail pieces must not outlive the LDS allocation)
     TC_STAMP(9);
