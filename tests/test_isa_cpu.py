@@ -28,8 +28,8 @@ SRC = r'''
 using namespace uu3d;
 template __global__ void uu3d::attn_head_wave_kernel<5, 48, true>(const float*, int, int, int, int, const uint8_t*, float*, int, size_t, int);
 template __global__ void uu3d::attn_f32_kernel<3, 48, true>(const float*, int, int, int, int, const uint8_t*, float*, int, size_t);
-template __global__ void uu3d::attn_h3_kernel<48, 3, 3, false>(const _Float16*, const _Float16*, int, int, int, int, const uint8_t*, _Float16*, size_t, int, int);
-template __global__ void uu3d::attn_h3_kernel<48, 12, 3, true>(const _Float16*, const _Float16*, int, int, int, int, const uint8_t*, _Float16*, size_t, int, int);
+template __global__ void uu3d::attn_h3_kernel<48, 3, 3, false>(const _Float16*, const _Float16*, int, int, int, int, const uint8_t*, _Float16*, size_t, int, int, int);
+template __global__ void uu3d::attn_h3_kernel<48, 12, 3, true>(const _Float16*, const _Float16*, int, int, int, int, const uint8_t*, _Float16*, size_t, int, int, int);
 template __global__ void uu3d::gemm_tn_h3_kernel<TnLoadLayerNorm, EpSlab>(const TnLoadLayerNorm, const float*, int, int, int, int, int, int, int, const EpSlab);
 template __global__ void uu3d::gemm_tn_kernel<TnLoadLayerNorm, EpSlab>(const TnLoadLayerNorm, const float*, int, int, int, int, int, int, int, const EpSlab);
 template __global__ void uu3d::spatial_stack_h3_kernel<17, 3, 1, false>(const float*, const SpatialParams, const _Float16*, float*, _Float16*, _Float16*, const SpatialTrainIO);

@@ -79,26 +79,30 @@ def test_chain_matches_oracle_and_the_launch_chain(batch, mask_specs):
         assert np.array_equal(f2, full) and np.array_equal(c2, cen)
 
 
-def test_chain_attention_maps_and_sequence_independence():
-    """return_attention=True under the chain (the maps are recomputed from the q | k planes the chain wrote), and: a sequence's
-    result does not depend on its neighbours in the row tile (lane-private arithmetic; padded lanes read row M - 1)."""
+def test_chain_sequence_independence_and_attention_maps():
+    """A sequence's result does not depend on its neighbours in the row tile (lane-private arithmetic; dead lanes of a ragged tile read row
+    M - 1); and return_attention=True keeps the round-4 launches (the maps are recomputed from row-major q | k planes, the chain writes
+    q | k | v in fragment order): the maps of a model with the switch on equal the latency schedule's."""
     cfg = util.load_config("h36m_351")
     arch = pkg.arch_from_config(cfg)
     w = pkg.init_weights(arch, seed=4, perturb=0.1)
     x, m = util.synthetic_batch(cfg, batch=20, seed=11)
     xm = x * m[:, :, None, None].astype(np.float32)
-    model = _model(cfg, w, return_attention=True)
-    full, cen, maps = _forward(model, arch, xm, m, 1, attn=True)
-    full_l, cen_l, maps_l = _forward(model, arch, xm, m, 0, attn=True)
-    for a, b in zip(maps, maps_l):
-        assert np.abs(a - b).max() <= 1e-5
-        assert np.abs(a.sum(-1) - 1.0).max() <= 1e-5
+    model = _model(cfg, w)
+    full, cen, _ = _forward(model, arch, xm, m, 1)
+    assert "tchain" in _kernels(model, arch, xm, m, 1)
     perm = np.random.default_rng(0).permutation(20)
     fp, cp, _ = _forward(model, arch, xm[perm], m[perm], 1)
     assert np.array_equal(fp, full[perm]) and np.array_equal(cp, cen[perm])
     f17, c17, _ = _forward(model, arch, xm[:17], m[:17], 1)                              # other tiles, another ragged tail
     assert np.array_equal(f17, full[:17])                                                # (everything the chain computes feeds `full`)
     assert np.abs(c17 - cen[:17]).max() <= 1e-5                                          # (the strided blocks' split-K depth depends on the row count)
+    amodel = _model(cfg, w, return_attention=True)
+    fa, ca, maps = _forward(amodel, arch, xm, m, 1, attn=True)
+    fl, cl, maps_l = _forward(amodel, arch, xm, m, 0, attn=True)
+    assert np.array_equal(fa, fl) and np.array_equal(ca, cl)                              # the same launches in both schedules
+    for a, b in zip(maps, maps_l):
+        assert np.array_equal(a, b) and np.abs(a.sum(-1) - 1.0).max() <= 1e-5
 
 
 @pytest.mark.parametrize("variant", ["no_strided", "one_temporal", "no_mask"])

@@ -62,7 +62,8 @@ template <int FLAGS> void run(const char* tag, int M, int iters) {
     for (int r = 0; r < M; ++r) { const float off = 0.3f * nd(rng), sc = 0.5f + fabsf(nd(rng)); for (int k = 0; k < D; ++k) { X[(size_t)r * D + k] = off + sc * nd(rng); O[(size_t)r * D + k] = nd(rng); } }
     const int mt = (M + 127) / 128;
     std::vector<_Float16> Of(panel_a_halfs(mt * 128, D), (_Float16)0.f);
-    for (int r = 0; r < M; ++r) for (int k = 0; k < D; ++k) { const float x = O[(size_t)r * D + k]; const _Float16 h = h3_hi(x); const size_t i = panel_a_index(r, k, D); Of[i] = h; Of[i + 512] = (_Float16)((x - (float)h) * H3_SCALE); }
+    // (the attention output arrives with the channels of a 16-slice in LANE order -- the order v had in the fragment-ordered q | k | v: tchain_qf_index)
+    for (int r = 0; r < M; ++r) for (int k = 0; k < D; ++k) { const float x = O[(size_t)r * D + k]; const _Float16 h = h3_hi(x); const int w16 = k & 15; const size_t i = panel_a_index(r, (k & ~15) + 8 * ((w16 >> 2) & 1) + (((w16 >> 3) << 2) | (w16 & 3)), D); Of[i] = h; Of[i + 512] = (_Float16)((x - (float)h) * H3_SCALE); }
     // LayerNorm's affine part folded into the Dense layer behind it: W' = diag(gamma) W, b' = b + beta W
     auto fold = [&](const Dense& d, const std::vector<float>& g, const std::vector<float>& be) {
         Dense f = d;
@@ -85,7 +86,7 @@ template <int FLAGS> void run(const char* tag, int M, int iters) {
     a.M = M; a.m_tiles = mt; a.period = period; a.qscale = 1.44269504088896341f / sqrtf(48.f);
     a.Of = dev(Of); a.X = dev(X); a.XA = devz<float>((size_t)M * D); a.pe = dev(pe);
     a.W = dev(W); a.P = dev(P);
-    a.Q = devz<_Float16>((size_t)M * 3 * D * 2);
+    a.Q = devz<_Float16>(tchain_qf_halfs(mt));
     a.H = devz<_Float16>((size_t)M * Hd * 2);
     // scratch = hidden fragments | xs | xas | trash; the launches that add into the residual stream find it there in lane-linear order
     std::vector<unsigned char> scr(tchain_scratch_bytes(mt), 0);
@@ -106,7 +107,7 @@ template <int FLAGS> void run(const char* tag, int M, int iters) {
         for (int r = 0; r < M; ++r) for (int k = 0; k < D; ++k) out[(size_t)r * D + k] = base[tchain_xs_index(r, k)];
     };
 
-    std::vector<float> Xo((size_t)M * D), XAo((size_t)M * D); std::vector<_Float16> Q((size_t)M * 3 * D * 2), Hp((size_t)M * Hd * 2);
+    std::vector<float> Xo((size_t)M * D), XAo((size_t)M * D); std::vector<_Float16> Q(tchain_qf_halfs(mt)), Hp((size_t)M * Hd * 2);
     CK(hipMemcpy(Xo.data(), a.X, Xo.size() * 4, hipMemcpyDeviceToHost)); CK(hipMemcpy(XAo.data(), a.XA, XAo.size() * 4, hipMemcpyDeviceToHost));
     CK(hipMemcpy(Q.data(), a.Q, Q.size() * 2, hipMemcpyDeviceToHost)); CK(hipMemcpy(Hp.data(), a.H, Hp.size() * 2, hipMemcpyDeviceToHost));
     // where the launch leaves the residual stream: row-major x only when it ends the temporal stack (no QKV, or + pe); else the lane-linear tile;
@@ -129,7 +130,7 @@ template <int FLAGS> void run(const char* tag, int M, int iters) {
         if (FLAGS & TC_QKV) {
             if (FLAGS & TC_PE) for (int k = 0; k < D; ++k) { x[k] += pe[(size_t)(r % period) * D + k]; const double e = fabs(x[k] - XAo[(size_t)r * D + k]); if (e != e) ++nan; exa = std::max(exa, e); }
             layer_norm(x, g1, be1, n); dense(n, wqkv, z);
-            for (int k = 0; k < 3 * D; ++k) { const double want = k < D ? z[k] * a.qscale : z[k]; const double got = (double)Q[(size_t)r * 3 * D + k] + (double)Q[(size_t)M * 3 * D + (size_t)r * 3 * D + k] / 2048.0;
+            for (int k = 0; k < 3 * D; ++k) { const double want = k < D ? z[k] * a.qscale : z[k]; const double got = (double)Q[tchain_qf_index(r, k, 0)] + (double)Q[tchain_qf_index(r, k, 1)] / 2048.0;
                 const double e = fabs(got - want); if (e != e) ++nan; eq = std::max(eq, e); sq = std::max(sq, fabs(want)); }
         }
     }

@@ -831,7 +831,7 @@ Workspace carve(const uu3d_model* m, int B, char* base) {
     Workspace w{};
     const size_t oS = take(rows * c.num_keypoints * c.d_spatial * 4);
     const size_t oX = take(rows * c.d_temporal * 4);
-    const size_t oQ = take(rows * 3 * c.d_temporal * 4);
+    const size_t oQ = take((rows + 128) * 3 * c.d_temporal * 4);   // (+ one 128-row tile: the temporal chain writes q | k | v in whole tiles, fragment ordered)
     const size_t oO = take((rows + 32) * c.d_temporal * 4);   // + one 32-row panel: the panel GEMM's A operand is allocated in whole panels
     const size_t oH = take((rows + 32) * c.h_temporal * 4);   // + one 32-row panel (fragment-ordered hidden planes)
     const size_t oA = take(rows * c.d_temporal * 4);
@@ -1236,7 +1236,8 @@ struct Launcher {
     float attn_qscale() const { return 1.44269504088896341f / sqrtf((float)kDH); }
     // split_lo_off != 0: the context rows go out as f16 planes (hi at out, lo split_lo_off halfs further)
     // frag: the context rows in the row-panel GEMM's A-fragment order instead of row-major planes (split_lo_off != 0 only)
-    void attn(const char* name, const float* qkv, int B, int L, const uint8_t* mask, float* out, size_t split_lo_off = 0, bool frag = false) {
+    // qfrag: q | k | v arrive in the temporal chain's fragment order (uu3d_tchain.h, tchain_qf_index) -- attn_h3_kernel only
+    void attn(const char* name, const float* qkv, int B, int L, const uint8_t* mask, float* out, size_t split_lo_off = 0, bool frag = false, bool qfrag = false) {
         if (skip_mask() & 16) return;
         const int D = m->cfg.d_temporal, H = m->cfg.num_heads;
         const int NT = (L + 15) / 16;
@@ -1244,6 +1245,7 @@ struct Launcher {
         begin(name, h3a ? "attn_h3" : "attn_f32", 4.0 * B * (double)H * L * L * kDH, 4.0 * 4.0 * B * (double)L * D);
         const int items = B * H;
         const dim3 grid(items);
+        if (qfrag && !h3a) { status = UU3D_ERR_UNSUPPORTED; m->err = "fragment-ordered q | k | v need attn_h3_kernel"; end(); return; }
         if (h3a) {                                                 // qkv = hi plane [B L][3 D] halfs, lo plane behind it
             const int nt = (L + 31) / 32;
             const size_t lds = attn_h3_lds_bytes(L, kDH);
@@ -1251,7 +1253,7 @@ struct Launcher {
             const _Float16* qh = reinterpret_cast<const _Float16*>(qkv); const _Float16* ql = qh + (size_t)B * L * 3 * D;
 #define UU3D_ATTN_H3(MW, WPE, MASKED, PIPE, waves) { auto k = attn_h3_kernel<kDH, MW, WPE, MASKED, PIPE>; \
                 static const bool once = (hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)attn_h3_lds_bytes(ATTN_H3_MAX_L, kDH)) == hipSuccess); (void)once; \
-                hipLaunchKernelGGL(k, grid, dim3(64 * (waves)), lds, stream, qh, ql, 3 * D, D, L, H, mask, oh, frag ? (size_t)512 : split_lo_off, D, frag ? 1 : 0); }
+                hipLaunchKernelGGL(k, grid, dim3(64 * (waves)), lds, stream, qh, ql, 3 * D, D, L, H, mask, oh, frag ? (size_t)512 : split_lo_off, D, frag ? 1 : 0, qfrag ? 1 : 0); }
             // 4 .. 12 key tiles (dense-351: 11): one wave per query tile, three per SIMD.  UU3D_ATTN_PIPE=1 (round 4, measured 4 % SLOWER: 35.6 against
             // 34.3 us at 351 tokens, batch 32): the PIPE form (operand reads by name ahead of their use, uu3d_attn_h3.h) needs ~190 registers =
             // two waves per SIMD, so 8 waves walk the query tiles -- the exposed LDS round trips of the round-3 kernel are not what it waits for
@@ -1501,25 +1503,15 @@ int uu3d_forward_ex(uu3d_model* m, const float* kp2d, const uint8_t* mask, int32
     // workgroups that own 128 token rows: 2 T + 3 launches for T temporal blocks and the head of the first strided block instead of 5 T + 5,
     // no partial-sum slabs, no LayerNorm passes.
     const bool chain = Lh.throughput && planes && m->tchain_mode != 0 && (m->tchain_mode == 1 || (M + 127) / 128 >= m->tchain_min_tiles) && !m->tchain.empty() && M >= 1024 && Lh.attn_is_h3(N, true) &&
-                       (c.num_strided == 0 || m->L[0] == N) && (double)M * 1152 * 4.0 < 4.0e9;
-    auto chain_maps = [&](const char* tag, int i, const uint8_t* kmask) {                // return_attention=True: a block's attention maps, recomputed from q | k
-        if (attn_out == nullptr || tag[0] != 't' || attn_out[i] == nullptr) return;
-        snprintf(nm, sizeof nm, "%s%d.attn_maps", tag, i + 1);
-        Lh.begin(nm, "attn_probs", 2.0 * B * (double)c.num_heads * N * N * kDH, 4.0 * B * (double)c.num_heads * N * N);
-        const size_t lds = (size_t)N * (kDH + 1) * sizeof(float);
-        static const bool once = (hipFuncSetAttribute((const void*)attn_probs_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256) == hipSuccess); (void)once;
-        const _Float16* Qh = reinterpret_cast<const _Float16*>(w.QKV);
-        hipLaunchKernelGGL(attn_probs_kernel, dim3(B * c.num_heads), dim3(256), lds, Lh.stream, (const void*)Qh, Qh + (size_t)M * 3 * dt, 3 * dt, dt, N, c.num_heads, kDH, kmask, 1.0f, 1, attn_out[i]);
-        Lh.end();
-    };
+                       (c.num_strided == 0 || m->L[0] == N) && (double)M * 1152 * 4.0 < 4.0e9 &&
+                       attn_out == nullptr;      // (return_attention=True: the maps kernel reads row-major q | k planes, the chain writes fragment order)
     if (chain) {
         _Float16* const Q = reinterpret_cast<_Float16*>(w.QKV);
         Lh.tchain("t1.ln_qkv", m->tchain[0], M, nullptr, w.X, nullptr, nullptr, 1, Q, nullptr, w.tc_scratch);
         for (int i = 0; i < c.temporal_depth; ++i) {
             const bool masked = c.has_strided_input && i < c.first_strided_token_attention_layer;
-            chain_maps("t", i, masked ? mask : nullptr);
             snprintf(nm, sizeof nm, "t%d.attn", i + 1);
-            Lh.attn(nm, w.QKV, B, N, masked ? mask : nullptr, w.O, (size_t)M * dt, true);
+            Lh.attn(nm, w.QKV, B, N, masked ? mask : nullptr, w.O, (size_t)M * dt, true, true);
             const bool to_strided = i + 1 == c.temporal_depth && c.num_strided > 0;
             snprintf(nm, sizeof nm, "t%d.chain", i + 1);
             Lh.tchain(nm, m->tchain[i + 1], M, Ph, w.X, to_strided ? w.XA : nullptr, to_strided ? m->sblocks[0].pe : nullptr, N, Q, nullptr, w.tc_scratch);
@@ -1598,7 +1590,7 @@ int uu3d_forward_ex(uu3d_model* m, const float* kp2d, const uint8_t* mask, int32
         const bool smask = c.temporal_depth == 0 && c.has_strided_input && i < c.first_strided_token_attention_layer;
         if (chain && i == 0) {
             // the chain's last launch left q | k | v of this block (LayerNorm 1 of xa = x + pe); its projection, LayerNorm 2 and fc1 are the next one
-            Lh.attn("s1.attn", w.QKV, B, Li, nullptr, w.O, (size_t)Mi * dt, true);
+            Lh.attn("s1.attn", w.QKV, B, Li, nullptr, w.O, (size_t)Mi * dt, true, true);
             Lh.tchain("s1.chain", m->tchain[c.temporal_depth + 1], Mi, Ph, nullptr, xa, nullptr, 1, nullptr, Hh, w.tc_scratch);      // (its stream: xa, lane-linear in the scratch since the last temporal launch; row-major xa written here for the convolution's residual rows)
         } else
         block_head("s", i, b, xa, Li, smask ? mask : nullptr, i == 0 ? pend : nullptr, false);

@@ -120,7 +120,8 @@ __global__ void __launch_bounds__(64 * MAXW) __attribute__((amdgpu_waves_per_eu(
 attn_h3_kernel(const _Float16* __restrict__ qkv_h, const _Float16* __restrict__ qkv_l, const int ld, const int D, const int L, const int H,
                const uint8_t* __restrict__ key_mask,   // (B, L) 1 = attend; nullptr = no mask
                _Float16* __restrict__ out, const size_t lo_off, const int ldo,
-               const int frag)                         // 1: the context rows leave in the row-panel GEMM's A-fragment order (uu3d_gemm_panel.h, K = ldo); lo_off = 512
+               const int frag,                         // 1: the context rows leave in the row-panel GEMM's A-fragment order (uu3d_gemm_panel.h, K = ldo); lo_off = 512
+               const int qfrag = 0)                    // 1 (round 5, the temporal chain): q | k | v arrive in FRAGMENT order (uu3d_tchain.h, tchain_qf_index): qkv_h = the buffer, qkv_l / ld unused
 {
     static_assert(DH == 48, "operand layouts below are written for a head dim of 48 (3 k-slices, 1.5 output row tiles)");
     constexpr int KS = DH / 16;                        // k-slices of Q K^T
@@ -140,6 +141,11 @@ attn_h3_kernel(const _Float16* __restrict__ qkv_h, const _Float16* __restrict__ 
     const size_t tok0 = (size_t)b * L;
     constexpr float LOG2E = 1.44269504088896341f;
     const int q31 = lane & 31, g = lane >> 5;
+    // fragment order: the 16-byte piece of (token, 16-channel group u, half gg, plane) -- [32-token panel][u (72)][plane][lane = token & 31 + 32 gg][8]
+    auto qf_piece = [&](size_t token, int u, int gg, int plane) -> const _Float16* {
+        return qkv_h + ((((token >> 5) * 72 + u) * 2 + plane) * 64 + (token & 31) + 32 * gg) * 8;
+    };
+    const int G = D >> 4;                                  // 16-channel groups per q / k / v block
 
     // ---- K, V of the head: global -> LDS by LDS-DMA, 12 NT instructions shared by the waves; rows past L: a copy of the last
     // row (finite; those keys get -inf / probability 0) ----
@@ -152,14 +158,16 @@ attn_h3_kernel(const _Float16* __restrict__ qkv_h, const _Float16* __restrict__ 
         const int key = min(32 * w + (lane >> 1), L - 1);
         const size_t ko = (tok0 + key) * ld + D + h * DH + 8 * (lane & 1);
 #pragma unroll
-        for (int i = 0; i < 6; ++i)
-            __builtin_amdgcn_global_load_lds((h3_glb_void*)((i >= 3 ? qkv_l : qkv_h) + ko + 16 * (i % 3)),
-                                             (h3_lds_void*)(Kp + ((size_t)i * Lpad + 32 * w) * 16), 16, 0, 0);
+        for (int i = 0; i < 6; ++i) {
+            const _Float16* src = qfrag ? qf_piece(tok0 + key, G + 3 * h + i % 3, lane & 1, i / 3) : (i >= 3 ? qkv_l : qkv_h) + ko + 16 * (i % 3);
+            __builtin_amdgcn_global_load_lds((h3_glb_void*)src, (h3_lds_void*)(Kp + ((size_t)i * Lpad + 32 * w) * 16), 16, 0, 0);
+        }
 #pragma unroll
         for (int i = 0; i < 6; ++i) {
-            const int j = w + NT * i, P = 64 * j + lane, k0 = P / 12, wi = P - 12 * k0;
-            const _Float16* vp = (wi >= 6 ? qkv_l : qkv_h) + 2 * D + h * DH + 8 * (wi >= 6 ? wi - 6 : wi);
-            __builtin_amdgcn_global_load_lds((h3_glb_void*)(vp + (tok0 + min(k0, L - 1)) * ld), (h3_lds_void*)(Vr + (size_t)64 * j * 8), 16, 0, 0);
+            const int j = w + NT * i, P = 64 * j + lane, k0 = P / 12, wi = P - 12 * k0, w6 = wi >= 6 ? wi - 6 : wi;
+            const _Float16* vp = (wi >= 6 ? qkv_l : qkv_h) + 2 * D + h * DH + 8 * w6;
+            const _Float16* src = qfrag ? qf_piece(tok0 + min(k0, L - 1), 2 * G + 3 * h + (w6 >> 1), w6 & 1, wi >= 6) : vp + (tok0 + min(k0, L - 1)) * ld;
+            __builtin_amdgcn_global_load_lds((h3_glb_void*)src, (h3_lds_void*)(Vr + (size_t)64 * j * 8), 16, 0, 0);
         }
     } else
     for (int e = w; e < 12 * NT; e += NW) {
@@ -167,11 +175,12 @@ attn_h3_kernel(const _Float16* __restrict__ qkv_h, const _Float16* __restrict__ 
         if (e < 6 * NT) {                                          // K: plane p, slice s, 32 keys kg; lane = (key, k-half)
             const int p = e / (3 * NT), r = e - p * 3 * NT, sl = r / NT, kg = r - sl * NT;
             const int key = min(32 * kg + (lane >> 1), L - 1);
-            src = (p ? qkv_l : qkv_h) + (tok0 + key) * ld + D + h * DH + 16 * sl + 8 * (lane & 1);
+            src = qfrag ? qf_piece(tok0 + key, G + 3 * h + sl, lane & 1, p) : (p ? qkv_l : qkv_h) + (tok0 + key) * ld + D + h * DH + 16 * sl + 8 * (lane & 1);
             dst = Kp + ((size_t)(p * KS + sl) * Lpad + 32 * kg) * 16;
         } else {                                                   // V: 64 consecutive 16-byte pieces of the [key][hi | lo] image
             const int i = e - 6 * NT, P = 64 * i + lane, key = min(P / 12, L - 1), wi = P % 12;
-            src = (wi >= 6 ? qkv_l : qkv_h) + (tok0 + key) * ld + 2 * D + h * DH + 8 * (wi % 6);
+            src = qfrag ? qf_piece(tok0 + key, 2 * G + 3 * h + ((wi % 6) >> 1), (wi % 6) & 1, wi >= 6)
+                        : (wi >= 6 ? qkv_l : qkv_h) + (tok0 + key) * ld + 2 * D + h * DH + 8 * (wi % 6);
             dst = Vr + (size_t)64 * i * 8;
         }
         __builtin_amdgcn_global_load_lds((h3_glb_void*)src, (h3_lds_void*)dst, 16, 0, 0);
@@ -179,9 +188,13 @@ attn_h3_kernel(const _Float16* __restrict__ qkv_h, const _Float16* __restrict__ 
     // the first query tile's fragments: lane = query, 8 consecutive k per slice, as stored
     h16x8 qh[KS], ql[KS];
     auto load_q = [&](int qt) {
-        const size_t o = (tok0 + min(32 * qt + q31, L - 1)) * ld + h * DH + g * 8;
+        const size_t qtok = tok0 + min(32 * qt + q31, L - 1);
+        const size_t o = qtok * ld + h * DH + g * 8;
 #pragma unroll
-        for (int s = 0; s < KS; ++s) { qh[s] = *reinterpret_cast<const h16x8*>(qkv_h + o + 16 * s); ql[s] = *reinterpret_cast<const h16x8*>(qkv_l + o + 16 * s); }
+        for (int s = 0; s < KS; ++s) {
+            if (qfrag) { qh[s] = *reinterpret_cast<const h16x8*>(qf_piece(qtok, 3 * h + s, g, 0)); ql[s] = *reinterpret_cast<const h16x8*>(qf_piece(qtok, 3 * h + s, g, 1)); }
+            else { qh[s] = *reinterpret_cast<const h16x8*>(qkv_h + o + 16 * s); ql[s] = *reinterpret_cast<const h16x8*>(qkv_l + o + 16 * s); }
+        }
     };
     if ((UU3D_ATTN_LOO) & 64) {
 #pragma unroll

@@ -60,7 +60,7 @@ struct TChainArgs {
     float* XA; const float* pe;  // TC_PE: xa = x + pe[token % period]
     const _Float16* W;           // the launch's weight stream (tchain_pack_stage per stage), tchain_chunks(flags) x 48 KiB
     const float* P;              // parameter table (TCP_*)
-    _Float16* Q;                 // TC_QKV: hi plane [M][1152], lo plane M * 1152 halfs further
+    _Float16* Q;                 // TC_QKV: q | k | v in FRAGMENT order (tchain_qf_index): [32-token panel][16-channel group 72][plane][lane][8], whole 128-row tiles
     _Float16* H;                 // TC_FC1_PLANES: hi plane [M][768], lo plane M * 768 halfs further
     unsigned char* scratch;      // tchain_scratch_bytes(m_tiles): hidden fragments | residual stream (lane-linear) | the same of the first strided block (x + pe) | trash page
 };
@@ -78,9 +78,21 @@ __host__ __device__ inline size_t tchain_xs_index(int row, int ch) {
     return (size_t)tile * TC_X_FLOATS_PER_TILE + ((((size_t)(c * 8 + 4 * hh + q) * 2 + i) * 4 + e) * 64 + t + 32 * g);
 }
 
+// q | k | v for attn_h3_kernel in FRAGMENT order: a lane's 8 finished values of a 16-channel group (channels 16 u + 8 (j >> 2) + 4 g + (j & 3)) are ONE 16-byte
+// piece, the pieces of a 32-token panel contiguous -- two coalesced 1 KiB stores per chunk and wave instead of four scattered 8-byte ones (QKV stage
+// 151 k -> 132 k cycles in the timing build), and the attention kernel's Q / K / V loads become contiguous pieces.  The channel permutation inside a group is
+// the same for q and k (their dot product does not see it) and reaches the attention OUTPUT through v: the projection's weights are packed in that order.
+// halfs: element (token, channel) of plane p
+__host__ __device__ inline size_t tchain_qf_index(size_t token, int ch, int plane) {
+    const int u = ch >> 4, w = ch & 15, j = ((w >> 3) << 2) | (w & 3), g = (w >> 2) & 1;
+    return ((((token >> 5) * 72 + u) * 2 + plane) * 64 + (token & 31) + 32 * g) * 8 + j;
+}
+__host__ __device__ inline constexpr size_t tchain_qf_halfs(int m_tiles) { return (size_t)m_tiles * 4 * 72 * 2 * 512; }
+
 // ---- host side: one stage's chunks of the weight stream from the transposed, padded planes Bt[n][Kp] (k contiguous; lo pre-scaled) ----
 // chunk c (output channels 32 c ..), wave group hh, position kk (0..11), plane p, lane l, element j:
-//     natural order (the attention output's):  k = 16 (12 hh + kk) + 8 (l >> 5) + j
+//     attention output (context rows in A-fragment order, channels inside a 16-slice in the order v arrived in: lane order, see tchain_qf_index):
+//                                                           k = 16 (12 hh + kk) + 8 (j >> 2) + 4 (l >> 5) + (j & 3)
 //     lane order (everything this kernel produced itself):  k = kofs + 16 (2 kk + hh) + 8 (j >> 2) + 4 (l >> 5) + (j & 3)
 inline void tchain_pack_stage(const _Float16* Bh, const _Float16* Bl, int N, int Kp, int kofs, bool natural, _Float16* out) {
     for (int c = 0; c < N / 32; ++c)
@@ -90,7 +102,7 @@ inline void tchain_pack_stage(const _Float16* Bh, const _Float16* Bl, int N, int
                     for (int l = 0; l < 64; ++l)
                         for (int j = 0; j < 8; ++j) {
                             const int n = 32 * c + (l & 31);
-                            const int k = natural ? 16 * (12 * hh + kk) + 8 * (l >> 5) + j
+                            const int k = natural ? 16 * (12 * hh + kk) + 8 * (j >> 2) + 4 * (l >> 5) + (j & 3)
                                                   : kofs + 16 * (2 * kk + hh) + 8 * (j >> 2) + 4 * (l >> 5) + (j & 3);
                             out[(((((size_t)c * 2 + hh) * 12 + kk) * 2 + p) * 64 + l) * 8 + j] = (p ? Bl : Bh)[(size_t)n * Kp + k];
                         }
@@ -126,6 +138,11 @@ struct TcEpHidden {            // relu(v + b1) split into hi / lo = the token fr
     static constexpr int kStores = 2; static constexpr bool kBias = true;
     h16x8* __restrict__ hs;
     const float* bias;
+};
+struct TcEpQkvFrag {           // (v + bias) [* qscale for chunks < 12] split into hi / lo = ONE 16-byte piece per plane of the fragment-ordered q | k | v (tchain_qf_index)
+    static constexpr int kStores = 2; static constexpr bool kBias = true;
+    h16x8* __restrict__ qf;    // this wave's panel + lane: group u = 2 c + hh at + u * 128 (hi), + 64 (lo)
+    const float* bias; float qscale;
 };
 struct TcEpPlanes {            // (v + bias) [* qscale for chunks < qchunks] [relu] split into row-major hi / lo planes of leading dimension ld
     static constexpr int kStores = 4; static constexpr bool kBias = true;
@@ -215,6 +232,19 @@ tchain_kernel(const TChainArgs a)
             asm volatile("global_atomic_add_f32 %0, %1, off\n\tglobal_atomic_add_f32 %0, %2, off offset:256\n\t"
                          "global_atomic_add_f32 %0, %3, off offset:512\n\tglobal_atomic_add_f32 %0, %4, off offset:768"
                          :: "v"(d), "v"(y[0]), "v"(y[1]), "v"(y[2]), "v"(y[3]) : "memory");
+        } else if constexpr (std::is_same<EP, TcEpQkvFrag>::value) {
+            f32x4 y = v + bias4(sb, i);
+            if (cp < 12) y = y * ep.qscale;
+            h16x4 hi, lo;
+            h3_split(y, hi, lo);
+            if (i == 0) { keep.h0 = hi; keep.l0 = lo; }
+            else {
+                h16x8 fh, fl;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { fh[e] = keep.h0[e]; fh[4 + e] = hi[e]; fl[e] = keep.l0[e]; fl[4 + e] = lo[e]; }
+                h16x8* d = ep.qf + (size_t)(2 * cp + hh) * 128;
+                d[0] = fh; d[64] = fl;
+            }
         } else if constexpr (std::is_same<EP, TcEpHidden>::value) {
             f32x4 y = v + bias4(sb, i);
 #pragma unroll
@@ -552,9 +582,8 @@ tchain_kernel(const TChainArgs a)
         // per use, four per chunk, each of which also waits for the prefetched weight fragments)
         float qs = a.qscale;
         asm("" : "+v"(qs));
-        unsigned char* ph = live ? reinterpret_cast<unsigned char*>(a.Q + (size_t)tok * 1152 + chl) : trash;
-        unsigned char* pl = live ? reinterpret_cast<unsigned char*>(a.Q + ((size_t)a.M + tok) * 1152 + chl) : trash + 4096;
-        stage(std::integral_constant<int, 36>{}, TcEpPlanes{ph, pl, a.P + TCP_BQKV + 16 * hh, 12, qs, 0});
+        h16x8* const qf = reinterpret_cast<h16x8*>(a.Q) + (size_t)(bm * 4 + q) * (72 * 2 * 64) + lane;     // (whole tiles: the buffer holds m_tiles * 128 rows)
+        stage(std::integral_constant<int, 36>{}, TcEpQkvFrag{qf, a.P + TCP_BQKV + 16 * hh, qs});
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // (the clamped tail pieces must not outlive the LDS allocation)
     TC_STAMP(9);
