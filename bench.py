@@ -105,15 +105,28 @@ class ErrorGather:
 
 def run_pipelined_steps(pipe, n, depth, gather):
     """n steps with `depth` batches in flight: launch() a slot, take the oldest result when `depth` are out, hand its error block to
-    `gather`; the collective of gather mode "end" closes the loop.  (`pipe`: launch() -> ticket, result(ticket) -> (full, central, err).)"""
+    `gather`; the collective of gather mode "end" closes the loop.  (`pipe`: launch() -> ticket, result(ticket) -> (full, central, err),
+    after(ticket, fn) -> fn(full, central, err) on the slot's stream, join().)  Gather mode "end" keeps the block with a copy ON THE SLOT'S
+    STREAM (pipe.after: no wait on the caller's stream, whose hardware queue a quarter of the slots share); the caller's stream joins the
+    slots before the collective.  Mode "step" needs the block on the caller's stream every step (pipe.result)."""
     gather.reset()
+    on_slot = gather.mode == "end"
+    keep = lambda full, central, e: gather.step(e)
     tickets = []
     for _ in range(n):
         tickets.append(pipe.launch())
         if len(tickets) == depth:
-            gather.step(pipe.result(tickets.pop(0))[2])
+            t = tickets.pop(0)
+            if on_slot:
+                pipe.after(t, keep)
+            else:
+                gather.step(pipe.result(t)[2])
     for t in tickets:
-        gather.step(pipe.result(t)[2])
+        if on_slot:
+            pipe.after(t, keep)
+        else:
+            gather.step(pipe.result(t)[2])
+    pipe.join()
     gather.finish()
 
 
@@ -480,9 +493,11 @@ def main():
     pipe = None
     auto = (S == 0)
     use_graph = not args.no_graph
-    errs = [torch.empty((B, J), dtype=torch.float64, device="cuda") for _ in range(max(S, 6))]
+    errs = {}                                           # one error block per slot (made by the slot's warm-up launch, before its capture)
 
     def post(full, central, i):
+        if i not in errs:
+            errs[i] = torch.empty((B, J), dtype=torch.float64, device="cuda")
         return per_joint_error(central, gt, cfg.ROOT_KEYTPOINT, out=errs[i])
 
     if args.halves and not args.no_halves:             # legacy option: two half-batch chains inside one call (no pipeline object)

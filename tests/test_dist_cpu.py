@@ -145,7 +145,7 @@ def test_bench_starts_its_own_ranks():
 
 class _StubPipe:
     """The surface of pipeline.ForwardPipeline that bench.run_pipelined_steps drives, with a forward that costs nothing: launch() -> ticket,
-    result(ticket) -> (full, central, err); the error block of step k on rank r is a known table."""
+    result(ticket) -> (full, central, err), after(ticket, fn), join(); the error block of step k on rank r is a known table."""
 
     def __init__(self, rank, B, J, depth):
         self.rank, self.B, self.J, self.depth, self.n = rank, B, J, depth, 0
@@ -164,6 +164,12 @@ class _StubPipe:
 
     def result(self, t):
         return None, None, self.live.pop(t)
+
+    def after(self, t, fn):                                          # (the real one runs fn with the slot's stream current)
+        return fn(None, None, self.live.pop(t))
+
+    def join(self):
+        self.joined = self.n
 
 
 def _bench_loop_worker(rank, world, port, mode, q):

@@ -46,7 +46,7 @@ def test_error_block_all_gather_and_bucketed_gradients_on_rccl(nccl_world1):
     t = pipe.submit(xm, torch.from_numpy(m).cuda())
     e = pipe.result(t)[2]
     dist.all_gather_into_tensor(gathered, e)
-    _, cen = model([xm, torch.from_numpy(m).cuda()], training=False)
+    _, cen = util.direct_forward(model, xm, torch.from_numpy(m).cuda(), 1)       # a quiet call under the slots' (throughput) schedule
     per_joint_error(cen, gt, cfg.ROOT_KEYTPOINT, out=err)
     torch.cuda.synchronize()
     assert torch.equal(gathered, err)

@@ -1,4 +1,4 @@
-"""GPU: the temporal chain (csrc/uu3d_tchain.h, opt-in UU3D_TCHAIN=1, throughput schedule) -- every row-local stage of a
+"""GPU: the temporal chain (csrc/uu3d_tchain.h; the throughput schedule's path from 1024 token rows on, UU3D_TCHAIN=0 switches it off) -- every row-local stage of a
 vit.TransformerBlock (common/net/vision_transformer.py:176-195: projection + residual, LayerNorm 2, fc1, ReLU, fc2 + residual, the next
 block's LayerNorm 1 + QKV) as ONE launch per block -- against the CPU oracle, against the launch chain it replaces, run to run, with
 whole and ragged row tiles, with and without key masks, with return_attention, and for the structural variants of the constructor
@@ -65,7 +65,7 @@ def test_chain_matches_oracle_and_the_launch_chain(batch, mask_specs):
     assert "tchain" not in _kernels(model, arch, xm, m, 0)                               # the latency schedule keeps its launches
     full_l, cen_l, _ = _forward(model, arch, xm, m, 0)
     plain = _model(cfg, w, chain=False)
-    assert "tchain" not in _kernels(plain, arch, xm, m, 1)                               # opt-in: without the switch nothing changes
+    assert "tchain" not in _kernels(plain, arch, xm, m, 1)                               # UU3D_TCHAIN=0: the round-4 launches
     n = min(batch, 8)
     f32, c32 = O.forward(util.hp_from_arch(arch), w, xm[:n], m[:n], torch.float32)
     e = max(np.abs(full[:n] - f32).max(), np.abs(cen[:n] - c32).max())
@@ -139,10 +139,10 @@ def test_chain_structural_variants(variant):
     assert e <= util.TOL_MAX_ABS
 
 
-def test_chain_is_chosen_by_size_without_the_switch():
-    """Default (no UU3D_TCHAIN in the environment): the chain runs under the throughput schedule once a launch has >= 256 row tiles
-    (464 sequences of 71 tokens: 258 tiles; the reference's own eval BATCH_SIZE of 512 windows is beyond that) and not at the
-    benchmark's batch of 128 (71 tiles), where it measured slower; the latency schedule never takes it."""
+def test_chain_is_the_default_of_the_throughput_schedule():
+    """Default (no UU3D_TCHAIN in the environment): the chain runs under the throughput schedule from 1024 token rows on (8 row tiles: below
+    that the tile's 128 rows are mostly dead lanes), at the benchmark's batch of 128 (71 tiles) and at the reference's own eval BATCH_SIZE
+    of 512 windows alike; the latency schedule never takes it, UU3D_TCHAIN_MIN_TILES moves the threshold."""
     from oracle import uplift_oracle as O
     cfg = util.load_config("h36m_351")
     arch = pkg.arch_from_config(cfg)
@@ -150,6 +150,11 @@ def test_chain_is_chosen_by_size_without_the_switch():
     old = os.environ.pop("UU3D_TCHAIN", None)
     try:
         model = pkg.build_uplift_upsample_transformer(cfg, weights=w)
+        os.environ["UU3D_TCHAIN_MIN_TILES"] = "256"
+        try:
+            late = pkg.build_uplift_upsample_transformer(cfg, weights=w)
+        finally:
+            del os.environ["UU3D_TCHAIN_MIN_TILES"]
     finally:
         if old is not None:
             os.environ["UU3D_TCHAIN"] = old
@@ -157,12 +162,16 @@ def test_chain_is_chosen_by_size_without_the_switch():
     xm = x * m[:, :, None, None].astype(np.float32)
     assert _kernels(model, arch, xm, m, 1).count("tchain") == arch.temporal_depth + 2
     assert "tchain" not in _kernels(model, arch, xm, m, 0)
-    assert "tchain" not in _kernels(model, arch, xm[:128], m[:128], 1)
+    assert _kernels(model, arch, xm[:128], m[:128], 1).count("tchain") == arch.temporal_depth + 2
+    assert _kernels(model, arch, xm[:15], m[:15], 1).count("tchain") == arch.temporal_depth + 2      # 1065 rows
+    assert "tchain" not in _kernels(model, arch, xm[:14], m[:14], 1)                                  # 994 rows
+    assert "tchain" not in _kernels(late, arch, xm[:128], m[:128], 1)                                 # 71 tiles < 256
+    assert _kernels(late, arch, xm, m, 1).count("tchain") == arch.temporal_depth + 2                  # 258 tiles
     full, cen, _ = _forward(model, arch, xm, m, 1)
     full_l, cen_l, _ = _forward(model, arch, xm, m, 0)
     idx = [0, 1, 127, 128, 300, 463]                                 # sequences from the first, a middle and the last (ragged) row tiles
     f32, c32 = O.forward(util.hp_from_arch(arch), w, xm[idx], m[idx], torch.float32)
     e = max(np.abs(full[idx] - f32).max(), np.abs(cen[idx] - c32).max())
     d = max(np.abs(full - full_l).max(), np.abs(cen - cen_l).max())
-    print(f"batch 464: chain (chosen by size) vs oracle {e:.3e}, vs launch chain {d:.3e}")
+    print(f"batch 464: chain (default) vs oracle {e:.3e}, vs launch chain {d:.3e}")
     assert e <= util.TOL_MAX_ABS and d <= 3e-5

@@ -47,6 +47,10 @@ def main():
         return not done
 
     cur = torch.cuda.current_stream(dev)
+    first = None
+    if os.environ.get("QUEUE_MAP_FIRST"):       # what a fresh process gets (bench.py): the pipeline's probe before anything else used a stream
+        from uplift_upsample_3dhpe_amd.pipeline import distinct_queue_streams as dqs
+        first = dqs(dev, want=4, per_queue=2)
     pool = [torch.cuda.Stream(device=dev) for _ in range(args.pool)]
     reps, cls = [], []
     for s in pool:
@@ -57,19 +61,26 @@ def main():
             reps.append(s); cls.append(len(reps) - 1)
     cur_cls = next((ci for ci, r in enumerate(reps) if same_queue(r, cur)), -1)
     print("queue class of pool streams:", cls, "| current stream:", cur_cls, "| classes:", len(reps))
+    if first is not None:
+        print("distinct_queue_streams(per_queue=2) called first in the process: classes by this tool's probe",
+              [next((ci for ci, r in enumerate(reps) if same_queue(r, q)), -1) for q in first])
 
     x_np, m_np = util.synthetic_batch(cfg, args.batch, seed=1000, mask_specs=[(5, 0)])
     x = torch.from_numpy(x_np * m_np[:, :, None, None].astype(np.float32)).to(dev)
     m = torch.from_numpy(m_np).to(dev)
 
+    resident = bool(os.environ.get("QUEUE_MAP_R5"))
+
     def measure(label, idx):
         pipe = ForwardPipeline(model, args.batch, depth=len(idx), streams=[pool[i] for i in idx])
         d = len(idx)
+        if resident:
+            pipe.preload(x, m)
 
         def run(n):
             t = []
             for _ in range(n):
-                t.append(pipe.submit(x, m))
+                t.append(pipe.launch() if resident else pipe.submit(x, m))
                 if len(t) == d:
                     pipe.result(t.pop(0))
             for q in t:
@@ -89,6 +100,24 @@ def main():
     for n in range(1, nq + 1):
         measure(f"{n} slots, {n} queues", pick([(c, 0) for c in range(n)]))
     if os.environ.get("QUEUE_MAP_DISTINCT_ONLY"):
+        return
+    if resident:                                # round 5: eight slots (the temporal chain's launches), inputs resident in the slots
+        from uplift_upsample_3dhpe_amd.pipeline import distinct_queue_streams
+        for pq in (1, 2, 3):
+            qs = distinct_queue_streams(dev, want=4, per_queue=pq)
+            qc = [next((ci for ci, r in enumerate(reps) if same_queue(r, q)), -1) for q in qs]
+            print(f"distinct_queue_streams(per_queue={pq}): {len(qs)} streams, classes by this tool's probe {qc}, distinct handles {len({q.cuda_stream for q in qs})}")
+            n0 = len(pool); pool.extend(qs); cls.extend(qc)
+            measure(f"{len(qs)} slots from distinct_queue_streams(per_queue={pq})", list(range(n0, n0 + len(qs))))
+        for rep in range(2):
+            measure("4 slots, 4 queues", pick([(c, 0) for c in range(4)]))
+            measure("8 slots, class-major (ABCDABCD)", pick([(c, k) for k in range(2) for c in range(4)]))
+            measure("8 slots, queue-major (AABBCCDD)", pick([(c, k) for c in range(4) for k in range(2)]))
+            measure("8 slots, pool order", list(range(8)))
+            measure("8 slots, pool order from 8", list(range(8, 16)))
+            measure("12 slots, class-major", pick([(c, k) for k in range(3) for c in range(4)]))
+            measure("12 slots, pool order", list(range(12)))
+            measure("16 slots, pool order", list(range(16)))
         return
     # patterns: (class, k-th stream of that class)
     if nq >= 2:

@@ -121,12 +121,13 @@ struct uu3d_model {
     // block with its positional encoding); launch T + 1 = projection + LayerNorm 2 + fc1 of the first strided block.  Empty = not available.
     struct TcLaunch { int flags; size_t w_off /* halfs, harena */; size_t p_off /* floats, arena */; };
     std::vector<TcLaunch> tchain;
-    // When the chain runs (throughput schedule): a chain launch is one workgroup per 128 token rows, ~200 us each.  With >= 256 row tiles it fills
-    // the chip by itself and wins (batch 512, the reference's own eval BATCH_SIZE: 187.6 k against 179.1 k sequences/s); at the benchmark's batch of
-    // 128 it is 71 workgroups, and narrow long launches mix badly with the wide short ones of the other forwards in flight (162-170 k against
-    // 171-175 k, profiles/r05_tchain_ab.txt).  tchain_mode: -1 = by size (default), 1 = always (UU3D_TCHAIN=1), 0 = never (UU3D_TCHAIN=0).
-    int tchain_mode = -1;
-    int tchain_min_tiles = 256;    // UU3D_TCHAIN_MIN_TILES
+    // When the chain runs: under the throughput schedule, whenever the shapes allow it (>= 1024 token rows, attention on attn_h3_kernel, no attention
+    // maps asked for).  UU3D_TCHAIN=0 keeps the round-4 launches (A/B measurements, tests), UU3D_TCHAIN_MIN_TILES=n asks for at least n row tiles.
+    // History of the round (profiles/r05_tchain_ab.txt): with partial-result slabs added at the stage transitions the chain lost at batch 128 (162-170 k
+    // against 171-175 k sequences/s) and tied at 512; with the residual adds as no-return atomics on a lane-linear stream and q | k | v in fragment order:
+    // 179-182 k against 171-173 k at batch 128 with four slots, 187 k with eight, 202.6 k against 180.2 k at batch 512.
+    int tchain_mode = -1;          // -1 by size (tchain_min_tiles), 0 never, 1 always
+    int tchain_min_tiles = 8;      // (= the 1024 rows the panel kernels ask for as well)
     int num_cus = 256;
     std::recursive_mutex train_mu; // the training-mode chain keeps per-call options in the handle's training state (uu3d_train_step.inc): one call at a time
     bool in_commit = false;        // uu3d_commit_weights is calling uu3d_train_init (generic dims): the training step's skip flag is not its to clear

@@ -46,7 +46,7 @@ def predict_windows(model, generator, descriptors, config, batch_size, flip=True
     """Central 3D predictions (W, J, 3) float32 on the device for the given window descriptors: batches of ``batch_size``
     windows, each forwarded together with its mirrored copy when ``flip`` (one launch chain over 2B sequences).
 
-    ``depth`` batches (None: one per HIP hardware queue, i.e. 4) are in flight at once, each on its own HIP stream and -- with ``graph`` -- replayed from its own hipGraph
+    ``depth`` batches (None: two per HIP hardware queue, i.e. 8) are in flight at once, each on its own HIP stream and -- with ``graph`` -- replayed from its own hipGraph
     (pipeline.ForwardPipeline: batch k + 1's big kernels run beside batch k's latency-bound tail; the window gather of a batch
     writes into its slot's input buffers on the slot's stream).  depth = 1, graph = False is the reference's loop: one eager call after the other.
     The predictions are bit-identical either way."""
@@ -69,6 +69,10 @@ def predict_windows(model, generator, descriptors, config, batch_size, flip=True
     def finish(lo, n, cen):
         raw[:, lo:lo + n].copy_(cen.view(raw.shape[0], n, J, 3))
 
+    def take(lo, n, ticket):
+        # the copy into `raw` goes on the slot's stream (pipe.after): the caller's stream never waits inside the loop
+        pipe.after(ticket, lambda full, cen: finish(lo, n, cen))
+
     pending = []
     for lo in range(0, W, batch_size):
         d = np.ascontiguousarray(descriptors[lo:lo + batch_size])
@@ -90,11 +94,11 @@ def predict_windows(model, generator, descriptors, config, batch_size, flip=True
         generator.gather(d, zero_masked=True, with_3d=False, out=(xb, mb), stream=sstream)
         pending.append((lo, n, pipe.launch(len(d))))
         if len(pending) == depth:
-            plo, pn, t = pending.pop(0)
-            finish(plo, pn, pipe.result(t)[1])
-    for plo, pn, t in pending:
-        finish(plo, pn, pipe.result(t)[1])
+            take(*pending.pop(0))
+    for p in pending:
+        take(*p)
     if pipe is not None:
+        pipe.join()
         torch.cuda.current_stream(dev).synchronize()               # the slots' buffers go away with the pipeline
         try:
             pipe.check_range()                                     # f16x3 range guard (include/uu3d.h): once per evaluation, never per batch

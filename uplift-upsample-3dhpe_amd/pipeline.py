@@ -28,14 +28,15 @@ import ctypes as C
 _QUEUE_STREAMS = {}
 
 
-def distinct_queue_streams(device, want=4, pool=16, spin_ms=2.0):
+def distinct_queue_streams(device, want=4, pool=16, spin_ms=2.0, per_queue=1):
     """Up to ``want`` torch streams that sit on pairwise DIFFERENT HIP hardware queues (found once per process and device).
 
     Two streams share a queue iff work on one waits for work on the other: a spin kernel of ``spin_ms`` goes to stream a, a tiny kernel to
     stream b, and HIP events tell when b's kernel ran -- behind the spin (same queue) or at once.  Streams come from torch's pool; the
-    first of every new queue class is kept."""
+    first of every new queue class is kept.  ``per_queue`` > 1 (round 5): that many streams of EVERY class, returned class-major
+    (q0 q1 q2 q3 q0 q1 q2 q3): slots dealt over them share the hardware queues evenly -- an uneven deal loses 10 % (module docstring)."""
     import torch
-    key = (str(device), want)
+    key = (str(device), want, per_queue)
     if key in _QUEUE_STREAMS:
         return list(_QUEUE_STREAMS[key])
     torch.cuda.synchronize(device)
@@ -59,16 +60,28 @@ def distinct_queue_streams(device, want=4, pool=16, spin_ms=2.0):
             ta.synchronize(); tb.synchronize()
             return t0.elapsed_time(tb) > 0.5 * t0.elapsed_time(ta)
 
-        reps = []
-        for _ in range(pool):
-            s = torch.cuda.Stream(device=device)
-            if not any(same_queue(r, s) for r in reps):
-                reps.append(s)
-                if len(reps) == want:
-                    break
+        tiny.add_(1.0)                                          # (first launch of the probe's kernel: module load, not queueing)
         torch.cuda.synchronize(device)
-    _QUEUE_STREAMS[key] = list(reps)
-    return list(reps)
+        reps, members = [], []
+        for _ in range(pool * per_queue):
+            s = torch.cuda.Stream(device=device)
+            with torch.cuda.stream(s):
+                tiny.add_(1.0)                                  # (first use of the stream: not queueing either)
+            s.synchronize()
+            # a late tiny kernel for any other reason reads as "same queue", never the other way round: a positive has to repeat
+            cls = next((i for i, r in enumerate(reps) if same_queue(r, s) and same_queue(r, s)), None)
+            if cls is None:
+                if len(reps) < want:
+                    reps.append(s); members.append([s])
+            elif len(members[cls]) < per_queue:
+                members[cls].append(s)
+            if len(reps) == want and all(len(mm) == per_queue for mm in members):
+                break
+        torch.cuda.synchronize(device)
+    n = min(len(mm) for mm in members) if members else 0                  # (a class that never got its share: fall back to what every class has)
+    out = [mm[k] for k in range(max(n, 1)) for mm in members if k < len(mm)]
+    _QUEUE_STREAMS[key] = list(out)
+    return list(out)
 
 
 class _Slot(object):
@@ -78,8 +91,10 @@ class _Slot(object):
 class ForwardPipeline(object):
 
     def __init__(self, model, batch, depth=None, graph=True, post=None, streams=None):
-        """``depth``: batches in flight; None = one per HIP hardware queue (``distinct_queue_streams``: 4), an int up to that number takes
-        that many of those streams, more than that falls back to fresh pool streams (slots then share queues).
+        """``depth``: batches in flight; None = TWO per HIP hardware queue (``distinct_queue_streams(per_queue=2)``: 8 -- round 5: with the temporal
+        chain's launches of one workgroup per 128 rows, eight forwards in flight keep the chip full where four do not: 187 k against 181 k
+        sequences/s at batch 128; the round-4 launches measure the same with four and eight), an int up to that number takes that many of
+        those streams (class-major: the first four sit on four different queues), more falls back to fresh pool streams.
         ``post(full, central, slot_index)``: optional device work appended to every forward ON THE SLOT'S STREAM (and into its
         graph), e.g. the per-joint error kernel; what it returns is handed out by ``result`` as a third element.
         ``streams``: the slots' streams (``depth`` of them), whatever queues they are on."""
@@ -87,7 +102,7 @@ class ForwardPipeline(object):
         if depth is not None and depth < 1:
             raise ValueError("depth >= 1")
         if streams is None and (depth is None or depth > 1):
-            q = distinct_queue_streams(model.device, want=int(os.environ.get("UU3D_PIPE_QUEUES", "4")))
+            q = distinct_queue_streams(model.device, want=int(os.environ.get("UU3D_PIPE_QUEUES", "4")), per_queue=2)
             if depth is None:
                 depth = len(q)
             if depth <= len(q):
@@ -241,6 +256,32 @@ class ForwardPipeline(object):
         s.busy = False
         out = (s.full[:s.n] if s.full is not None else None, s.central[:s.n])
         return out + ((s.extra,) if self.post is not None else ())
+
+    def after(self, ticket, fn):
+        """Follow-up device work for a submitted batch ON ITS SLOT'S STREAM: ``fn(full, central[, post's value])`` runs with the slot's stream
+        current, i.e. what it enqueues runs behind the slot's forward, in order, with no wait between streams -- returns fn's value and frees
+        the slot for its next submit (same stream: the next forward runs behind fn's work).  The alternative to ``result`` for consumers that
+        only move the outputs on (eval.predict_windows' copy into its result table, bench.py's copy of the error block): ``result`` makes the
+        CALLER'S stream wait for the slot, and a wait on the caller's stream is a barrier packet in the hardware queue that stream shares with
+        a quarter of the slots -- every forward queued behind it on that queue stalls (round 5, h36m_351 batch 128, eight slots: 164 k
+        sequences/s with the consumer's copy on the caller's stream, 186 k with it on the slot's).  ``join()`` before the caller's stream
+        (or the host) reads what fn wrote."""
+        torch = self._torch
+        if not (self._submitted - self.depth <= ticket < self._submitted):
+            raise ValueError("ticket is not in flight")
+        s = self._slots[ticket % self.depth]
+        if not s.busy:
+            raise RuntimeError("result already taken")
+        s.busy = False
+        out = (s.full[:s.n] if s.full is not None else None, s.central[:s.n])
+        with torch.cuda.stream(s.stream):
+            return fn(*(out + ((s.extra,) if self.post is not None else ())))
+
+    def join(self):
+        """The caller's current stream waits for everything enqueued on the slots' streams so far (forwards and ``after`` work)."""
+        cur = self._torch.cuda.current_stream(self.model.device)
+        for s in self._slots:
+            cur.wait_stream(s.stream)
 
     def close(self):
         """Wait for everything in flight and give the slots' workspaces back."""
