@@ -348,12 +348,13 @@ def secondary_benchmarks(args):
 def pmc_summary_for(config, batch):
     """The committed --pmc summary that was collected on THIS workload (config, per-GPU batch), or None: counters of another
     shape say nothing about this one."""
-    name = {("h36m_351", 128): "r04_final_pmc_summary.csv", ("dense_351", 32): "r04_final_dense351_pmc_summary.csv",
-            ("h36m_81", 256): "r04_final_h36m81_pmc_summary.csv"}.get((config, batch))
-    if name is None:
-        return None
-    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", name)
-    return path if os.path.exists(path) else None
+    names = {("h36m_351", 128): ("r05_final_pmc_summary.csv", "r04_final_pmc_summary.csv"), ("h36m_351", 512): ("r05_tchain_b512_pmc_summary.csv",),
+             ("dense_351", 32): ("r04_final_dense351_pmc_summary.csv",), ("h36m_81", 256): ("r04_final_h36m81_pmc_summary.csv",)}.get((config, batch), ())
+    for name in names:                                           # (the newest round's counters of this workload first)
+        path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", name)
+        if os.path.exists(path):
+            return path
+    return None
 
 
 # profile-record kernel name (csrc: Launcher::begin) -> substrings that pick the kernel SYMBOL out of a rocprofv3 summary
@@ -361,7 +362,7 @@ def symbol_filter(symbol):
     if symbol.startswith("gemm_panel8<") or symbol.startswith("gemm_panel<"):
         return ("gemm_h3_panel8_kernel" if symbol.startswith("gemm_panel8<") else "gemm_h3_panel_kernel",
                 "PanelEp" + symbol[symbol.index("<") + 1:-1] + "E")
-    return {"mlp_fused": ("mlp_fused_h3_kernel",), "gemm_wt": ("gemm_h3_wt_kernel",), "gemm_f32": ("gemm_f32_kernel",),
+    return {"tchain": ("tchain_kernel",), "mlp_fused": ("mlp_fused_h3_kernel",), "gemm_wt": ("gemm_h3_wt_kernel",), "gemm_f32": ("gemm_f32_kernel",),
             "gemm_h3": ("gemm_h3",)}.get(symbol)
 
 
@@ -423,7 +424,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true", help="skip the short secondary workloads (other configs, eager, train step) appended to the JSON line at N = 1")
     ap.add_argument("--no-graph", action="store_true", help="launch eagerly instead of replaying a hipGraph")
-    ap.add_argument("--streams", type=int, default=0, help="independent batches in flight (pipeline.ForwardPipeline: one HIP stream, workspace and hipGraph each); 1 = one batch after the other; 0 (default) = one per HIP hardware queue (4; pipeline.distinct_queue_streams)")
+    ap.add_argument("--streams", type=int, default=0, help="independent batches in flight (pipeline.ForwardPipeline: one HIP stream, workspace and hipGraph each); 1 = one batch after the other; 0 (default) = two per HIP hardware queue (8; pipeline.distinct_queue_streams)")
     ap.add_argument("--precision", default="f16x3", choices=["f16x3", "f32"], help="GEMM arithmetic of the forward (both hold the 1e-4 parity bar)")
     ap.add_argument("--mode", default="infer", choices=["infer", "train"], help="train = fwd + bwd + grad all-reduce + AdamW (BASELINE config 5)")
     ap.add_argument("--halves", action="store_true", help="two concurrent half-batch chains on two streams instead of one chain of kernels per batch")
@@ -522,7 +523,7 @@ def main():
             gather.finish()
     else:
         try:
-            if auto:                                    # one slot per HIP hardware queue (pipeline.distinct_queue_streams finds which streams share one)
+            if auto:                                    # two slots per HIP hardware queue (pipeline.distinct_queue_streams finds which streams share one)
                 pipe = model.pipeline(B, depth=None, graph=use_graph, post=post)
                 S = pipe.depth
             else:
@@ -563,8 +564,9 @@ def main():
     model.set_profiling(True)
     agg = {}
     reps = 5
+    prof_schedule = "throughput" if (pipe is not None and S > 1) else "latency"       # the launches the timed path ran
     for _ in range(reps):
-        model([x, m], training=False)
+        model.call_scheduled([x, m], prof_schedule)
         for e in model.read_profile():
             # temporal blocks share one shape class ("t.<op>"); strided blocks keep their index
             nm = e["name"]
@@ -608,17 +610,17 @@ def main():
                        "parallelism": f"batch-sharded x{world}", "hipgraph": bool(use_graph),
                        "concurrent_half_batches": bool(args.halves and not args.no_halves and B >= 64),
                        "batches_in_flight": S,
-                       "pipelining": (f"{S} independent batches in flight on {S} HIP streams" + (" on pairwise different hardware queues (probed)" if auto else "") +
+                       "pipelining": (f"{S} independent batches in flight on {S} HIP streams" + (" dealt evenly over the HIP hardware queues (probed)" if auto else "") +
                                       ", each replaying its own hipGraph of forward + error "
                                       "kernel with its own workspace (uplift-upsample-3dhpe_amd/pipeline.py; the same path eval.run_eval uses)") if S > 1
                                      else "one batch after the other"},
             "roofline": {"bound": "mfma", "kernel": f"{gk} [{dom_key}]",
                          "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s",
                          "frac": round(ach / peak, 4), "traffic": pmc_traffic(gk, pmc_summary_for(args.config, B)),
-                         "note": ("algorithmic 2*M*N*K FLOPs (mlp_fused: both Dense layers of the MLP, 4*M*d*h); the f16x3 kernels issue 3 f16 "
+                         "note": ("algorithmic 2*M*N*K FLOPs (tchain: every Dense layer the launch walks -- projection, fc1, fc2, the next block's QKV; mlp_fused: both Dense layers of the MLP, 4*M*d*h); the f16x3 kernels issue 3 f16 "
                                   "MFMA passes per product, so the matrix pipe does 3x this work (frac of pipe = 3 * frac)") if args.precision == "f16x3" else
                                  "exact f32-input MFMA",
-                         "traffic_note": "`traffic` is read from the committed counter run of this workload (profiles/, separate --pmc passes, ONE batch in flight, launched eagerly) -- not measured in this process, which runs several hipGraphs in flight",
+                         "traffic_note": "`traffic` is read from the committed counter run of this workload (profiles/, separate --pmc passes, launched eagerly under the same schedule) -- not measured in this process, which runs several hipGraphs in flight",
                          "avg_launch_ms": round(dom["ms"] / dom["n"], 5),
                          "attention": attention_roofline(agg, N, "synthetic dense-351 (NOT a shipped config)" if args.config == "dense_351" else f"config/{args.config}.json"),
                          # the four largest GEMM launch classes (the first two are within a microsecond per launch of each
@@ -631,6 +633,7 @@ def main():
                          "all_gemm_tflops": round(gemm_fl / (gemm_ms * 1e-3) / 1e12, 2),
                          "model_tflops": round(fl["total"] * seqs / world / elapsed / 1e12, 2)},
             "kernel_ms_per_forward": {k: round(a["ms"] / reps, 4) for k, a in sorted(agg.items(), key=lambda kv: -kv[1]["ms"])},
+            "kernel_ms_schedule": prof_schedule + " (one quiet forward per sample, HIP events around every launch: the launches the timed path ran)",
             "sum_kernel_ms": round(total_ms, 4),
         }
         if not args.no_cpu_baseline and world == 1:

@@ -202,10 +202,12 @@ int uu3d_world_to_cam_2d(const float* world_dev, const float* cams_dev, int32_t 
                          float* cam3d_dev, float* kp2d_dev, void* stream);
 
 /*
- * The schedule of a forward: what its launch shapes are chosen for.  Up to 255 row tiles of 128 tokens the results are bit-identical either
- * way (the same products per element, computed by other workgroups); from 256 tiles on the throughput schedule takes the temporal chain
+ * The schedule of a forward: what its launch shapes are chosen for.  Below 1024 token rows (B * N) the results are bit-identical either
+ * way (the same products per element, computed by other workgroups); from 1024 rows on the throughput schedule takes the temporal chain
  * (csrc/uu3d_tchain.h, round 5: one launch per temporal block for every row-local stage -- other summation orders and LayerNorm's affine part
- * folded into the next layer's weights: within 5e-6 of the latency schedule, same 1e-4 bar against the oracle).
+ * folded into the next layer's weights: within 3e-5 of the latency schedule (measured 4e-6), same 1e-4 bar against the oracle; deterministic run
+ * to run; return_attention keeps the round-4 launches.  UU3D_TCHAIN=0 in the environment of uu3d_create: never; UU3D_TCHAIN_MIN_TILES=n: from n
+ * row tiles of 128 tokens on).
  *   UU3D_SCHEDULE_LATENCY: one batch at a time -- every launch spreads over as many CUs as pays for ITS duration;
  *   UU3D_SCHEDULE_THROUGHPUT: several independent batches in flight on different streams (pipeline.ForwardPipeline) -- the chip is
  *     shared between forwards, so a launch is shaped for the fewest CU-microseconds instead: the attention projection runs as 71

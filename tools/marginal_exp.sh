@@ -6,13 +6,11 @@ run() { UU3D_SKIP=$1 python3 bench.py --steps 100 --warmup 10 --streams $2 --no-
 for st in 0 1; do
   run 0 $st "nothing"
   run 1 $st "spatial stack"
-  run 2 $st "QKV + fc1 panel GEMMs"
-  run 4 $st "projection"
-  run 8 $st "fused MLP"
+  run 128 $st "temporal chain launches (6)"
   run 16 $st "attention"
-  run 32 $st "ln_split_frag"
-  run 64 $st "ln_res_split_frag"
-  run 96 $st "both LayerNorm kernels"
-  run 14 $st "QKV + projection + MLP (every row-panel launch)"
+  run 144 $st "temporal chain + attention"
+  run 2 $st "QKV + fc1 panel GEMMs of the strided blocks"
+  run 4 $st "projections of the strided blocks"
+  run 145 $st "spatial stack + temporal chain + attention"
   run 0 $st "nothing"
 done

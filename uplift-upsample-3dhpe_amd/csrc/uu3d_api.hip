@@ -877,7 +877,7 @@ inline bool spatial_h3_pays(int frames) {
 
 // UU3D_SKIP=<bit mask> (TIMING EXPERIMENTS ONLY: the skipped launches leave garbage, results are wrong): which launch classes of the
 // forward are left out -- 1 spatial stack, 2 LayerNorm-fed panel GEMMs (QKV, fc1), 4 projection, 8 fused MLP, 16 attention, 32 ln_split_frag,
-// 64 ln_res_split_frag.  tools/marginal_exp.sh prices what each class costs the pipelined step.
+// 64 ln_res_split_frag, 128 the temporal chain launches.  tools/marginal_exp.sh prices what each class costs the pipelined step.
 inline int skip_mask() {
     static const int mask = [] { const char* e = getenv("UU3D_SKIP"); const int v = e ? atoi(e) : 0;
                                  if (v) fprintf(stderr, "[uu3d] UU3D_SKIP=%d: launches are being skipped, RESULTS ARE WRONG (timing experiment)\n", v); return v; }();
@@ -1175,6 +1175,7 @@ struct Launcher {
     // One launch of the temporal chain (uu3d_tchain.h): the row-local stages of a block for every 128-row tile
     void tchain(const char* name, const uu3d_model::TcLaunch& t, int M, const _Float16* Of, float* X, float* XA, const float* pe, int period,
                 _Float16* Q, _Float16* H, unsigned char* scratch) {
+        if (skip_mask() & 128) return;
         const int mt = (M + 127) / 128;
         TChainArgs a{};
         a.M = M; a.m_tiles = mt; a.period = period; a.qscale = attn_qscale();

@@ -60,8 +60,8 @@ def predict_windows(model, generator, descriptors, config, batch_size, flip=True
     # all windows at the end instead of five small launches per batch
     raw = torch.empty((2 if flip else 1, W, J, 3), dtype=torch.float32, device=dev)
     rows = min(batch_size, W) * (2 if flip else 1)
-    if depth is None and rows > 512:
-        depth = 2            # big batches fill the chip by themselves: two in flight measured best there (1024 sequences: 167 k vs 163 k with four)
+    if depth is None and rows > 256:
+        depth = 4            # big batches: one slot per hardware queue measured best (round 5, sequences/s with 2 / 4 / 8 in flight -- 256: 186 / 198 / 191 k, 512: 197 / 204 / 198 k, 1024: 203 / 208 / 203 k)
     pipe = model.pipeline(rows, depth=depth, graph=graph) if (depth is None or depth > 1 or graph) else None
     if pipe is not None:
         depth = pipe.depth

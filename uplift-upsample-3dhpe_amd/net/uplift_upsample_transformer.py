@@ -416,6 +416,24 @@ class UpliftUpsampleTransformer(object):
         main.wait_stream(side)
         return full, central
 
+    def call_scheduled(self, inputs, schedule):
+        """One inference call on the current stream under a NAMED launch schedule of include/uu3d.h: "latency" (what ``model(...)`` runs) or
+        "throughput" (what a pipeline's slots run: launches shaped for CU-microseconds, the temporal chain from 1024 token rows on) ->
+        (full, central).  No range guard (``check_range()`` afterwards).  For profiling and for tests that compare a pipeline with a quiet call."""
+        torch = self._torch
+        sched = {"latency": 0, "throughput": 1}[schedule]
+        x, stride_mask = (inputs[0], inputs[1]) if self.has_strided_input else (inputs, None)
+        a = self.arch
+        B = x.shape[0]
+        x = x.to(torch.float32).contiguous()
+        if stride_mask is not None:
+            stride_mask = self._mask_u8(stride_mask)
+        self._sync_from_trainer()
+        full = torch.empty((B, a.num_frames, a.num_keypoints, 3), dtype=torch.float32, device=self.device) if self._returns_full else None
+        central = torch.empty((B, a.num_keypoints, 3), dtype=torch.float32, device=self.device)
+        self._forward(x, stride_mask, full, central, 0, torch.cuda.current_stream(self.device), schedule=sched)
+        return full, central
+
     # ---- graph replay / several batches in flight ------------------------------------------------
     def pipeline(self, batch, depth=None, graph=True, post=None):
         """``depth`` independent batches in flight on ``depth`` HIP streams, each replaying its own hipGraph of the forward

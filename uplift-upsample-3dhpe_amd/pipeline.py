@@ -6,20 +6,24 @@ latency-bound kernels on a few CUs) leaves the chip almost idle; batches are ind
 temporal blocks can run beside batch k's tail.  ``ForwardPipeline`` keeps ``depth`` batches in flight, each on its own stream with
 its own workspace, static input / output buffers and (optionally) its own hipGraph of the whole forward:
 
-    pipe = ForwardPipeline(model, batch=128)                   # model.pipeline(128): one slot per hardware queue (4)
+    pipe = ForwardPipeline(model, batch=128)                   # model.pipeline(128): two slots per hardware queue (8)
     for full, central in pipe.run(batches):                    # batches: iterable of (x, stride_mask) or x
         ...                                                    # outputs are valid until `depth` more batches were submitted
 
-How many batches in flight, and on which streams: HIP deals a process's streams to 4 hardware queues (GPU_MAX_HW_QUEUES) in an order that
-is not the creation order (24 pool streams on one box: 0 1 2 2 1 0 3 2 1 0 3 2 ...), two streams on one queue run in order, and what the
-pipeline reaches depends on the number of DISTINCT queues under its slots and on nothing else (`tools/queue_map_exp.py`, h36m_351, batch
-128, one box): 1 / 2 / 3 / 4 queues = 120-126 / 157 / 165 / 172 k sequences/s; second slots on the same queues add nothing (ABAB = AB, ABCDABCD =
-ABCD), an uneven deal loses (ABCA 147 k, ABCDAB 166 k) -- which is what made plain "depth = 2 / 3 / 4 / 6" lose 10 % here and there.  Raising
-GPU_MAX_HW_QUEUES does not help: with 6 / 8 / 12 queues, 4 slots on 4 of them reach 118-121 k and 8-12 slots 145 k.  So the default
-(``depth=None``) asks ``distinct_queue_streams`` for one stream per hardware queue: it finds out which streams share a queue by blocking one
-with a spin kernel and timing a tiny kernel on the other with HIP events (~50 ms once per process).
-Results are bit-identical to ``model(...)``: the same launches on the same data, only on another
-stream.  Latency of ONE batch does not improve (0.9 ms); use ``model(...)`` for that.
+How many batches in flight, and on which streams: HIP deals a process's streams to 4 hardware queues (GPU_MAX_HW_QUEUES) at their FIRST USE, in an
+order that is not the creation order (24 pool streams on one box: 0 1 2 2 1 0 3 2 1 0 3 2 ...), two streams on one queue run in order, and what the
+pipeline reaches depends on how evenly its slots are dealt over the queues (`tools/queue_map_exp.py`, h36m_351, batch 128, one box, round 5 with the
+temporal chain): 1 / 2 / 3 / 4 slots on as many queues = 128-130 / 146-153 / 180 / 182-187 k sequences/s; eight or twelve slots dealt evenly
+(ABCDABCD) 186-192 k; the same eight in pool order (queue classes 0 1 2 2 1 0 3 2) 160 k.  Raising GPU_MAX_HW_QUEUES does not help (6 / 8 / 12 queues:
+118-145 k, round 4).  So the default (``depth=None``) asks ``distinct_queue_streams`` for two streams of every hardware queue: it finds out which
+streams share a queue by blocking one with a spin kernel and timing a tiny kernel on the other with HIP events (~100 ms once per process; the
+probe's kernel and every stream are used once BEFORE they are timed, and a positive has to repeat -- a first use looks like queueing, and one
+misfiled stream is an uneven deal).  What runs is four forwards at a time in lock step, one per queue (`tools/fill_drain_exp.py`: 20 steps = five
+rounds of ~2.7 ms), the second slot of a queue keeping it fed; the consumer's work belongs on the slot's stream (``after``), not behind a wait on
+the caller's (``result``), whose queue a quarter of the slots share.
+Results are bit-identical to ONE quiet call under the same schedule (depth 1: the latency schedule = ``model(...)``; more slots: the throughput
+schedule, ``model.call_scheduled(inputs, "throughput")`` -- from 1024 token rows on that is the temporal chain, within 3e-5 of ``model(...)``): the
+same launches on the same data, only on another stream.  Latency of ONE batch does not improve (0.9 ms); use ``model(...)`` for that.
 """
 import os
 import ctypes as C
