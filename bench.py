@@ -622,6 +622,11 @@ def main():
                                  "exact f32-input MFMA",
                          "traffic_note": "`traffic` is read from the committed counter run of this workload (profiles/, separate --pmc passes, launched eagerly under the same schedule) -- not measured in this process, which runs several hipGraphs in flight",
                          "avg_launch_ms": round(dom["ms"] / dom["n"], 5),
+                         **({"workgroups_per_launch": (B * N + 127) // 128, "cus": 256,
+                             "frac_of_occupied_cus": round(ach / (peak * min(256, (B * N + 127) // 128) / 256.0), 4),
+                             "occupancy_note": "the temporal chain runs ONE workgroup (8 waves, all of a CU's LDS) per 128 token rows: a launch of this batch occupies that many of the 256 CUs, "
+                                               "`achieved` / `frac` are the launch measured ALONE against the whole chip's peak; the timed path runs four forwards' launches side by side"}
+                            if gk == "tchain" else {}),
                          "attention": attention_roofline(agg, N, "synthetic dense-351 (NOT a shipped config)" if args.config == "dense_351" else f"config/{args.config}.json"),
                          # the four largest GEMM launch classes (the first two are within a microsecond per launch of each
                          # other, so which one is "dominant" changes from box to box)
