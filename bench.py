@@ -113,8 +113,9 @@ def run_pipelined_steps(pipe, n, depth, gather):
     on_slot = gather.mode == "end"
     keep = lambda full, central, e: gather.step(e)
     tickets = []
+    free = on_slot and not os.environ.get("UU3D_BENCH_WAIT_CALLER")      # (inputs resident in the slots, consumer on the slot's stream: nothing on the caller's stream to wait for)
     for _ in range(n):
-        tickets.append(pipe.launch())
+        tickets.append(pipe.launch(wait_caller=False) if free else pipe.launch())
         if len(tickets) == depth:
             t = tickets.pop(0)
             if on_slot:

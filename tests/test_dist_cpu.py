@@ -155,7 +155,7 @@ class _StubPipe:
     def block(rank, k, B, J):
         return torch.arange(B * J, dtype=torch.float64).reshape(B, J) + 1000.0 * k + 1.0e6 * rank
 
-    def launch(self):
+    def launch(self, wait_caller=True):
         t = self.n
         self.n += 1
         assert len(self.live) < self.depth, "more batches in flight than slots"

@@ -32,7 +32,7 @@ def main():
     need = ev.needed_windows(desc[:, 1].copy(), cfg)
     run = desc[need]
     print(f"{len(desc)} windows, {len(run)} forwarded (keyframe centres), batch {args.batch} windows = {2 * args.batch} sequences with flip")
-    for depth, graph in ((1, False), (1, True), (2, True), (3, True), (None, True)):       # None: one slot per hardware queue
+    for depth, graph in ((1, False), (1, True), (2, True), (3, True), (4, True), (8, True), (None, True)):       # None: run_eval's default (two slots per hardware queue up to 256 sequences per batch, one above)
         ev.predict_windows(model, gen, run[:args.batch * 8], cfg, args.batch, flip=True, depth=depth, graph=graph)     # warm-up
         torch.cuda.synchronize()
         t0 = time.perf_counter()

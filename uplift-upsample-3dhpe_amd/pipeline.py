@@ -165,9 +165,12 @@ class ForwardPipeline(object):
         if model._weights_dirty or getattr(model, "_pending_assigns", False):
             self.drain()
             model._sync_from_trainer()                              # (weights changed: the packs are rewritten on the caller's stream)
+            cur = self._torch.cuda.current_stream(model.device)
+            for sl in self._slots:                                  # (... which every slot waits for, whatever wait_caller says)
+                sl.stream.wait_stream(cur)
         return i, s
 
-    def acquire(self, n=None):
+    def acquire(self, n=None, wait_caller=True):
         """The next slot's STATIC input buffers, for a producer that writes the batch in place (no copy, no temporaries):
 
             x_buf, m_buf, stream = pipe.acquire(n)      # (n, N, J, 2) float32, (n, N) uint8 or None, the slot's torch stream
@@ -175,12 +178,14 @@ class ForwardPipeline(object):
             ticket = pipe.launch(n)
 
         Everything that fills the buffers must be enqueued on ``stream`` (or on a stream ``stream`` has been made to wait for) before
-        ``launch``.  ``stream`` already waits for the caller's current stream at this point.  The slot's previous forward has
+        ``launch``.  ``stream`` already waits for the caller's current stream at this point (``wait_caller=False``: it does not -- for a
+        producer whose inputs do not depend on anything the caller's stream has enqueued; see ``launch``).  The slot's previous forward has
         finished reading the buffers as far as ``stream`` is concerned (same stream: in order)."""
         torch = self._torch
         n = self.batch if n is None else int(n)
         i, s = self._next_slot(n)
-        s.stream.wait_stream(torch.cuda.current_stream(self.model.device))
+        if wait_caller:
+            s.stream.wait_stream(torch.cuda.current_stream(self.model.device))
         return s.x[:n], (s.m[:n] if s.m is not None else None), s.stream
 
     def preload(self, x, stride_mask=None):
@@ -197,13 +202,17 @@ class ForwardPipeline(object):
                     s.m[:n].copy_(self.model._mask_u8(stride_mask), non_blocking=True)
             cur.wait_stream(s.stream)                               # (the sources may be dropped / rewritten by the caller afterwards)
 
-    def launch(self, n=None):
+    def launch(self, n=None, wait_caller=True):
         """Enqueue the forward of the next slot on the buffers it holds (``acquire`` + a producer, or ``preload``): ``n`` sequences.
-        The slot's stream first waits for the caller's current stream (which may still read the slot's previous outputs).  Returns a ticket."""
+        The slot's stream first waits for the caller's current stream (which may still read the slot's previous outputs).  Returns a ticket.
+        ``wait_caller=False`` (round 5) skips that wait -- for loops whose consumer runs on the slot's stream (``after``) and whose inputs are
+        resident or written on the slot's stream: the wait is an event on the caller's stream, i.e. a marker packet in the hardware queue that
+        stream shares with a quarter of the slots, BEHIND their running forwards -- every launch then waits for that queue's current forward."""
         torch = self._torch
         n = self.batch if n is None else int(n)
         i, s = self._next_slot(n)
-        s.stream.wait_stream(torch.cuda.current_stream(self.model.device))
+        if wait_caller:
+            s.stream.wait_stream(torch.cuda.current_stream(self.model.device))
         with torch.cuda.stream(s.stream):
             if s.graph is not None and n == self.batch:
                 s.graph.replay()
@@ -304,10 +313,11 @@ class ForwardPipeline(object):
             pass
 
     def drain(self):
+        """The caller's stream waits for everything on the slots' streams (forwards and ``after`` work); unread results are dropped."""
+        cur = self._torch.cuda.current_stream(self.model.device)
         for s in self._slots:
-            if s.busy:
-                self._torch.cuda.current_stream(self.model.device).wait_event(s.done)
-                s.busy = False
+            cur.wait_stream(s.stream)
+            s.busy = False
 
     def run(self, batches):
         """Generator over the results of ``batches`` (items: ``(x, stride_mask)`` or ``x``), in order, ``depth`` in flight."""
