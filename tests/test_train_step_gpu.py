@@ -597,6 +597,44 @@ def test_pipeline_sees_the_trainers_weights():
     pipe.close()
 
 
+def test_free_running_pipeline_loop_sees_the_trainers_weights():
+    """The step loop of bench.py / eval.predict_windows (round 5): inputs resident in the slots, ``launch(wait_caller=False)``, the consumer on
+    the slot's stream (``after``), ``join`` at the end -- nothing in the loop touches the caller's stream.  A weight change between two such loops
+    still reaches every slot: the packs are rewritten on the caller's stream and every slot's stream waits for that, whatever wait_caller says;
+    ``drain`` waits for slots whose results were taken with ``after``.  Results = ``model.call_scheduled(..., "throughput")``."""
+    from uplift_upsample_3dhpe_amd.trainer import Trainer
+    cfg, arch, w, model, x, m, gt = _setup("h36m_351", 16, seed=13, batch_norm=16)
+    xm = torch.from_numpy(x * m[:, :, None, None]).cuda(); mt = torch.from_numpy(m).cuda()
+    pipe = model.pipeline(16)
+    pipe.preload(xm, mt)
+    table = torch.zeros((24, 16, arch.num_keypoints, 3), device="cuda")
+
+    def loop():
+        tickets = []
+        for k in range(24):
+            tickets.append((k, pipe.launch(wait_caller=False)))
+            if len(tickets) == pipe.depth:
+                kk, t = tickets.pop(0)
+                pipe.after(t, lambda f, c, kk=kk: table[kk].copy_(c))
+        for kk, t in tickets:
+            pipe.after(t, lambda f, c, kk=kk: table[kk].copy_(c))
+        pipe.join()
+        torch.cuda.synchronize()
+    loop()
+    want0 = model.call_scheduled([xm, mt], "throughput")[1]
+    assert all(torch.equal(table[k], want0) for k in range(24))
+    assert (want0 - model([xm, mt], training=False)[1]).abs().max() <= 3e-5          # (1136 rows: the temporal chain)
+    tr = Trainer(model, cfg, seed=2)
+    for step in range(2):
+        tr.train_step(torch.from_numpy(x).cuda(), torch.from_numpy(gt).cuda(), mt)
+        table.zero_()
+        loop()                                                                       # (no result() in between: every slot's last use was an after())
+        want = model.call_scheduled([xm, mt], "throughput")[1]
+        assert all(torch.equal(table[k], want) for k in range(24)), step
+        assert (want - want0).abs().max() > 1e-6
+    pipe.close()
+
+
 @pytest.mark.parametrize("n,strides", [(125, [5, 5, 5]), (128, [4, 4, 8])])
 def test_gradients_at_the_longest_sequences(n, strides):
     """The training step at 97 .. 128 tokens (round 4: the limit was 96, set by the Dropout path's LDS-resident attention backward; without
