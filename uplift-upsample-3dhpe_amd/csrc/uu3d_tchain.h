@@ -282,15 +282,20 @@ tchain_kernel(const TChainArgs a)
     // ---- one chunk of a stage.  CL = min(local chunk index, 3) decides the exact counts of the waits: vector-memory operations per
     // half-interval in issue order are [first half] 3 pieces, [second half] kStores stores of chunk c - 1 (c > 0), 3 pieces; the barrier
     // that opens a half-interval needs the pieces issued four half-intervals earlier (uu3d_gemm_panel8.h) ----
-    auto chunk = [&](auto cl_tag, auto pre_tag, auto ep, const int c, f32x16& x0, f32x16& x1, const f32x16& p0, const f32x16& p1) __attribute__((always_inline)) {
+    // XS (first two chunks of a stage only): vector-memory operations YOUNGER than the pieces those chunks' barriers need that may still be in flight when the
+    // stage starts -- the stores of the transition in front of it (store_xs / store_rows).  The counted waits let that many more operations stay outstanding
+    // (6-bit counter: at most 63); without it the first barrier of the stage waited for the transition's stores to COMPLETE (flags 23: 178 us against 167).
+    // A stage behind another stage starts drained (the epilogue's vmcnt(0)), so any XS is safe there; the kernel's FIRST stage needs XS <= the real count.
+    auto chunk = [&](auto cl_tag, auto pre_tag, auto xs_tag, auto ep, const int c, f32x16& x0, f32x16& x1, const f32x16& p0, const f32x16& p1) __attribute__((always_inline)) {
         constexpr int CL = decltype(cl_tag)::value;
+        constexpr int XS = CL <= 1 ? decltype(xs_tag)::value : 0;
         constexpr bool PRE_IN = (decltype(pre_tag)::value & 1) != 0, PRE_OUT = (decltype(pre_tag)::value & 2) != 0;
         using EP = decltype(ep);
         constexpr int NST = EP::kStores;
         const int pslot = slot == 0 ? 2 : slot - 1;
         const unsigned sb = rd0 + (unsigned)slot * P8_CHUNK_BYTES;
         // ---- barrier B_c: half-chunk 2 c + 1 landed (own pieces); every LDS read of the previous chunk returned ----
-        asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" :: "i"(9 + NST * ((CL >= 2) + (CL >= 3))) : "memory");
+        asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" :: "i"(9 + NST * ((CL >= 2) + (CL >= 3)) + XS > 63 ? 63 : 9 + NST * ((CL >= 2) + (CL >= 3)) + XS) : "memory");
         __builtin_amdgcn_sched_barrier(0);
         __builtin_amdgcn_s_barrier();
         __builtin_amdgcn_sched_barrier(0);
@@ -327,7 +332,7 @@ tchain_kernel(const TChainArgs a)
             const float* bp = ep.bias + 32 * (c - 1);          // (ep.bias already points at this wave group's 16 channels)
             asm volatile("s_load_dwordx16 %0, %1, 0x0" : "=s"(sbias) : "s"(bp) : "memory");
         }
-        asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(4)" :: "i"(9 + NST * (CL >= 2)) : "memory");
+        asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(4)" :: "i"(9 + NST * (CL >= 2) + XS > 63 ? 63 : 9 + NST * (CL >= 2) + XS) : "memory");
         __builtin_amdgcn_sched_barrier(0);
         if (!(UU3D_TC_LOO & 8)) __builtin_amdgcn_s_barrier();
         __builtin_amdgcn_sched_barrier(0);
@@ -389,7 +394,7 @@ tchain_kernel(const TChainArgs a)
     };
 
     // ---- a stage of NCH chunks over the token fragments in ah / al; leaves every result finished and stored ----
-    auto stage = [&](auto nch_tag, auto ep) __attribute__((always_inline)) {
+    auto stage = [&](auto nch_tag, auto ep, auto xs_tag) __attribute__((always_inline)) {
         constexpr int NCH = decltype(nch_tag)::value;
         using EP = decltype(ep);
         static_assert(NCH % 4 == 0 && NCH >= 4, "bodies of four chunks");
@@ -397,16 +402,16 @@ tchain_kernel(const TChainArgs a)
         // (pre tag: 1 = the chunk's first two fragment reads were issued by its predecessor, 2 = it issues its successor's.  Nothing requested
         // by name crosses the loop's back edge: the first chunk of a body reads behind its barrier.)
         using I0 = std::integral_constant<int, 0>; using I1 = std::integral_constant<int, 1>; using I2 = std::integral_constant<int, 2>; using I3 = std::integral_constant<int, 3>;
-        chunk(I0{}, I2{}, ep, 0, a0, a1, b0, b1);
-        chunk(I1{}, I3{}, ep, 1, b0, b1, a0, a1);
-        chunk(I2{}, I3{}, ep, 2, a0, a1, b0, b1);
-        chunk(I3{}, I1{}, ep, 3, b0, b1, a0, a1);
+        chunk(I0{}, I2{}, xs_tag, ep, 0, a0, a1, b0, b1);
+        chunk(I1{}, I3{}, xs_tag, ep, 1, b0, b1, a0, a1);
+        chunk(I2{}, I3{}, xs_tag, ep, 2, a0, a1, b0, b1);
+        chunk(I3{}, I1{}, xs_tag, ep, 3, b0, b1, a0, a1);
 #pragma unroll 1
         for (int c = 4; c < NCH; c += 4) {
-            chunk(I3{}, I2{}, ep, c, a0, a1, b0, b1);
-            chunk(I3{}, I3{}, ep, c + 1, b0, b1, a0, a1);
-            chunk(I3{}, I3{}, ep, c + 2, a0, a1, b0, b1);
-            chunk(I3{}, I1{}, ep, c + 3, b0, b1, a0, a1);
+            chunk(I3{}, I2{}, xs_tag, ep, c, a0, a1, b0, b1);
+            chunk(I3{}, I3{}, xs_tag, ep, c + 1, b0, b1, a0, a1);
+            chunk(I3{}, I3{}, xs_tag, ep, c + 2, a0, a1, b0, b1);
+            chunk(I3{}, I1{}, xs_tag, ep, c + 3, b0, b1, a0, a1);
         }
         // ---- the last chunk (in b0 / b1): send, barrier, receive, finish ----
         constexpr int c = NCH - 1;
@@ -519,6 +524,7 @@ tchain_kernel(const TChainArgs a)
         }
     };
 
+    using XS0 = std::integral_constant<int, 0>; using XSD = std::integral_constant<int, 54>;      // chunk(): XS
     // ================= the chain =================
     // Where the residual stream lives: ROW-MAJOR (a.X / a.XA) at the chain's boundaries -- the first launch reads what spatial_to_temporal_fc wrote,
     // the last temporal launch writes x for the full-sequence head and xa = x + pe for the first strided block, the strided block's launch writes
@@ -531,7 +537,7 @@ tchain_kernel(const TChainArgs a)
 #pragma unroll
         for (int s = 0; s < HS; ++s) { ah[s] = ap[((HS * hh + s) * 2 + 0) * 64]; al[s] = ap[((HS * hh + s) * 2 + 1) * 64]; }
         TC_STAMP(1);
-        stage(std::integral_constant<int, 12>{}, TcEpResidual<true>{kStrided1 ? xas : xs, a.P + TCP_BP + 16 * hh});
+        stage(std::integral_constant<int, 12>{}, TcEpResidual<true>{kStrided1 ? xas : xs, a.P + TCP_BP + 16 * hh}, XS0{});      // (the kernel's first stage; the fragment loads in front of it are its own operands)
         TC_STAMP(2);
         load_xs(kStrided1 ? xas : xs);
         if constexpr (kStrided1) store_rows(a.XA);                            // (the strided convolution's residual rows, EpConvResidual)
@@ -546,9 +552,9 @@ tchain_kernel(const TChainArgs a)
         if constexpr (kStrided1) {
             unsigned char* ph = live ? reinterpret_cast<unsigned char*>(a.H + (size_t)tok * 768 + chl) : trash;
             unsigned char* pl = live ? reinterpret_cast<unsigned char*>(a.H + ((size_t)a.M + tok) * 768 + chl) : trash + 4096;
-            stage(std::integral_constant<int, 24>{}, TcEpPlanes{ph, pl, a.P + TCP_B1 + 16 * hh, 0, 1.0f, 1});
+            stage(std::integral_constant<int, 24>{}, TcEpPlanes{ph, pl, a.P + TCP_B1 + 16 * hh, 0, 1.0f, 1}, XSD{});                 // (behind store_rows(a.XA))
         } else {
-            stage(std::integral_constant<int, 24>{}, TcEpHidden{hsl, a.P + TCP_B1 + 16 * hh});
+            stage(std::integral_constant<int, 24>{}, TcEpHidden{hsl, a.P + TCP_B1 + 16 * hh}, XSD{});
             TC_STAMP(5);
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #pragma unroll 1
@@ -558,8 +564,8 @@ tchain_kernel(const TChainArgs a)
                     const h16x8* d = hsl + ((size_t)((12 * half + s) * 8 + wave) * 2) * 64;
                     ah[s] = d[0]; al[s] = d[64];
                 }
-                if (half == 0) stage(std::integral_constant<int, 12>{}, TcEpResidual<false>{xs, nullptr});
-                else stage(std::integral_constant<int, 12>{}, TcEpResidual<true>{xs, a.P + TCP_B2 + 16 * hh});
+                if (half == 0) stage(std::integral_constant<int, 12>{}, TcEpResidual<false>{xs, nullptr}, XSD{});
+                else stage(std::integral_constant<int, 12>{}, TcEpResidual<true>{xs, a.P + TCP_B2 + 16 * hh}, XSD{});
             }
             TC_STAMP(6);
             load_xs(xs);
@@ -583,7 +589,8 @@ tchain_kernel(const TChainArgs a)
         float qs = a.qscale;
         asm("" : "+v"(qs));
         h16x8* const qf = reinterpret_cast<h16x8*>(a.Q) + (size_t)(bm * 4 + q) * (72 * 2 * 64) + lane;     // (whole tiles: the buffer holds m_tiles * 128 rows)
-        stage(std::integral_constant<int, 36>{}, TcEpQkvFrag{qf, a.P + TCP_BQKV + 16 * hh, qs});
+        // (flags = TC_QKV alone: the kernel's first stage, behind store_xs' 96 stores -- 54 of them may stay in flight; else a drained stage behind store_rows / store_xs)
+        stage(std::integral_constant<int, 36>{}, TcEpQkvFrag{qf, a.P + TCP_BQKV + 16 * hh, qs}, XSD{});
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // (the clamped tail pieces must not outlive the LDS allocation)
     TC_STAMP(9);
