@@ -492,7 +492,10 @@ tchain_kernel(const TChainArgs a)
     auto token_sum = [&](float s, int phase) __attribute__((always_inline)) -> float {
         s += __shfl_xor(s, 32);
         if (g == 0) stat[phase * 256 + wave * 32 + (lane & 31)] = s;
-        __syncthreads();
+        // (not __syncthreads(): its fence waits for vmcnt(0), i.e. for a transition's stores still in flight; the LDS write and the barrier are all this needs)
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
         return s + stat[phase * 256 + (wave ^ 4) * 32 + (lane & 31)];
     };
     // LayerNorm (two-pass, eps inside the root) of xr WITHOUT its affine part -> the next stage's token fragments.  gamma and beta are
