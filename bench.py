@@ -103,6 +103,17 @@ class ErrorGather:
         return None if self.gathered is None else self.gathered.view((self.world,) + tuple(self.local.shape))
 
 
+def emit_line(out):
+    """The ONE JSON line, as the LAST thing on stdout: RCCL prints its version banner through C stdio, which is block-buffered on a pipe and
+    would otherwise come out at process exit, behind the line."""
+    try:
+        import ctypes
+        ctypes.CDLL(None).fflush(None)
+    except Exception:  # pragma: no cover
+        pass
+    print(json.dumps(out), flush=True)
+
+
 def run_pipelined_steps(pipe, n, depth, gather):
     """n steps with `depth` batches in flight: launch() a slot, take the oldest result when `depth` are out, hand its error block to
     `gather`; the collective of gather mode "end" closes the loop.  (`pipe`: launch() -> ticket, result(ticket) -> (full, central, err),
@@ -193,7 +204,7 @@ def train_bench(args, world, rank, local_rank, use_dist):
     if rank == 0:
         fl = pkg.flops_per_sequence(arch)["total"] * 3.0       # forward + backward ~ 3x forward GEMM FLOPs
         seqs = world * B * args.steps
-        print(json.dumps({
+        emit_line({
             "metric": "train-sequences/sec", "value": round(seqs / elapsed, 2), "unit": "pose-sequences/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
@@ -203,7 +214,7 @@ def train_bench(args, world, rank, local_rank, use_dist):
             "config": {"workload": f"config/{cfgname}.json train step (fwd+bwd+AdamW), N={N}, J={J}, batch {B}/GPU, "
                                    f"per-sample mask stride from {cfg.MASK_STRIDE}, DropPath {cfg.DROP_PATH_RATE}",
                        "global_batch": world * B, "parallelism": f"data-parallel x{world}, flat f32 gradient all-reduce"},
-            "host_enqueue_ms_per_step": round(enqueue / args.steps * 1e3, 3), "model_tflops_3x_fwd": round(fl * seqs / world / elapsed / 1e12, 2), "loss": float(loss[0].item())}), flush=True)
+            "host_enqueue_ms_per_step": round(enqueue / args.steps * 1e3, 3), "model_tflops_3x_fwd": round(fl * seqs / world / elapsed / 1e12, 2), "loss": float(loss[0].item())})
     if use_dist:
         dist.destroy_process_group()
 
@@ -664,7 +675,7 @@ def main():
             pipe = None
             args.streams_used = S
             out["secondary"] = secondary_benchmarks(args)
-        print(json.dumps(out), flush=True)
+        emit_line(out)
     if use_dist:
         dist.destroy_process_group()
 
