@@ -591,6 +591,13 @@ def main():
             a["ms"] += e["ms"]; a["flops"] += e["flops"]; a["bytes"] += e["bytes"]; a["n"] += 1
     model.set_profiling(False)
 
+    if use_dist:                                         # every rank's buffered C stdio (RCCL's banner) out BEFORE rank 0's line
+        try:
+            import ctypes
+            ctypes.CDLL(None).fflush(None)
+        except Exception:  # pragma: no cover
+            pass
+        dist.barrier()
     if rank == 0:
         fl = pkg.flops_per_sequence(arch)
         total_ms = sum(a["ms"] for a in agg.values()) / reps
