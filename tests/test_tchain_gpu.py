@@ -105,6 +105,40 @@ def test_chain_sequence_independence_and_attention_maps():
         assert np.array_equal(a, b) and np.abs(a.sum(-1) - 1.0).max() <= 1e-5
 
 
+def test_chain_at_41_tokens():
+    """config/h36m_81.json (41 tokens: below the 49 from which attn_h3_kernel is the attention kernel of the other paths): the chain's fragment-ordered q | k | v
+    cost no split epilogue, so the throughput schedule takes the chain + attn_h3_kernel there too (UU3D_TCHAIN_SHORT=0: not)."""
+    from oracle import uplift_oracle as O
+    cfg = util.load_config("h36m_81")
+    arch = pkg.arch_from_config(cfg)
+    w = pkg.init_weights(arch, seed=3, perturb=0.1)
+    x, m = util.synthetic_batch(cfg, batch=40, seed=40, mask_specs=[(20, 0), (10, 5)])
+    xm = x * m[:, :, None, None].astype(np.float32)
+    model = _model(cfg, w)
+    full, cen, _ = _forward(model, arch, xm, m, 1)
+    names = _kernels(model, arch, xm, m, 1)
+    assert names.count("tchain") == arch.temporal_depth + 2 and names.count("attn_h3") == arch.temporal_depth + 1, names
+    assert "tchain" not in _kernels(model, arch, xm, m, 0)
+    old = os.environ.get("UU3D_TCHAIN_SHORT")
+    os.environ["UU3D_TCHAIN_SHORT"] = "0"
+    try:
+        plain = _model(cfg, w)
+    finally:
+        if old is None:
+            del os.environ["UU3D_TCHAIN_SHORT"]
+        else:
+            os.environ["UU3D_TCHAIN_SHORT"] = old
+    assert "tchain" not in _kernels(plain, arch, xm, m, 1)
+    full_l, cen_l, _ = _forward(model, arch, xm, m, 0)
+    f32, c32 = O.forward(util.hp_from_arch(arch), w, xm[:8], m[:8], torch.float32)
+    e = max(np.abs(full[:8] - f32).max(), np.abs(cen[:8] - c32).max())
+    d = max(np.abs(full - full_l).max(), np.abs(cen - cen_l).max())
+    print(f"h36m_81 batch 40: chain vs oracle {e:.3e}, vs launch chain {d:.3e}")
+    assert e <= util.TOL_MAX_ABS and d <= 3e-5
+    f2, c2, _ = _forward(model, arch, xm, m, 1)
+    assert np.array_equal(f2, full) and np.array_equal(c2, cen)
+
+
 @pytest.mark.parametrize("variant", ["no_strided", "one_temporal", "no_mask"])
 def test_chain_structural_variants(variant):
     """The stage sets the constructor can ask for: no strided blocks (the last temporal block ends at the residual stream),

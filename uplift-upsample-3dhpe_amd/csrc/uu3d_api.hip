@@ -128,6 +128,8 @@ struct uu3d_model {
     // 179-182 k against 171-173 k at batch 128 with four slots, 187 k with eight, 202.6 k against 180.2 k at batch 512.
     int tchain_mode = -1;          // -1 by size (tchain_min_tiles), 0 never, 1 always
     int tchain_min_tiles = 8;      // (= the 1024 rows the panel kernels ask for as well)
+    bool tchain_short = true;      // the chain (and attn_h3_kernel on its fragment-ordered q | k | v, which cost no split epilogue) also below 49 tokens: h36m_81 (41 tokens),
+                                   // batch 256: 337 k -> 361 k sequences/s; UU3D_TCHAIN_SHORT=0: only where attn_h3_kernel is the attention kernel anyway
     int num_cus = 256;
     std::recursive_mutex train_mu; // the training-mode chain keeps per-call options in the handle's training state (uu3d_train_step.inc): one call at a time
     bool in_commit = false;        // uu3d_commit_weights is calling uu3d_train_init (generic dims): the training step's skip flag is not its to clear
@@ -377,6 +379,7 @@ int uu3d_create(const uu3d_config* c, int device, uu3d_model** out) {
     { const char* e = getenv("UU3D_TAIL"); m->no_tail = !(e != nullptr && e[0] == '1'); }
     { const char* e = getenv("UU3D_TCHAIN"); if (e != nullptr && (e[0] == '0' || e[0] == '1')) m->tchain_mode = e[0] - '0'; }
     { const char* e = getenv("UU3D_TCHAIN_MIN_TILES"); if (e != nullptr && atoi(e) > 0) m->tchain_min_tiles = atoi(e); }
+    { const char* e = getenv("UU3D_TCHAIN_SHORT"); if (e != nullptr) m->tchain_short = atoi(e) != 0; }
     { hipDeviceProp_t pr; if (hipGetDeviceProperties(&pr, device) == hipSuccess && pr.multiProcessorCount > 0) m->num_cus = pr.multiProcessorCount; }
     if (hipMalloc((void**)&m->d_range, sizeof(int)) != hipSuccess || hipMemset(m->d_range, 0, sizeof(int)) != hipSuccess) {
         delete m;
@@ -1235,6 +1238,7 @@ struct Launcher {
     // (shorter sequences, h36m_81's 41 tokens: the split epilogue of the QKV projection costs more than the attention gains -- 242.1 k
     // sequences/s with the exact-f32 kernels there against 240.2 k)
     bool attn_is_h3(int L, bool planes_out) const { return planes_out && L <= ATTN_H3_MAX_L && (L > 128 || (L > 48 && !m->attn_f32)); }
+    bool attn_h3_any(int L) const { return precision == UU3D_PREC_F16X3 && L <= ATTN_H3_MAX_L && !m->attn_f32; }
     float attn_qscale() const { return 1.44269504088896341f / sqrtf((float)kDH); }
     // split_lo_off != 0: the context rows go out as f16 planes (hi at out, lo split_lo_off halfs further)
     // frag: the context rows in the row-panel GEMM's A-fragment order instead of row-major planes (split_lo_off != 0 only)
@@ -1243,7 +1247,7 @@ struct Launcher {
         if (skip_mask() & 16) return;
         const int D = m->cfg.d_temporal, H = m->cfg.num_heads;
         const int NT = (L + 15) / 16;
-        const bool h3a = attn_is_h3(L, split_lo_off != 0);
+        const bool h3a = attn_is_h3(L, split_lo_off != 0) || (qfrag && attn_h3_any(L));          // (the chain's fragment-ordered planes cost no split epilogue: attn_h3_kernel below 49 tokens too)
         begin(name, h3a ? "attn_h3" : "attn_f32", 4.0 * B * (double)H * L * L * kDH, 4.0 * 4.0 * B * (double)L * D);
         const int items = B * H;
         const dim3 grid(items);
@@ -1504,7 +1508,7 @@ int uu3d_forward_ex(uu3d_model* m, const float* kp2d, const uint8_t* mask, int32
     // launch for everything row-local (projection + residual, LayerNorm 2, fc1, ReLU, fc2 + residual, the next block's LayerNorm 1 + QKV) by
     // workgroups that own 128 token rows: 2 T + 3 launches for T temporal blocks and the head of the first strided block instead of 5 T + 5,
     // no partial-sum slabs, no LayerNorm passes.
-    const bool chain = Lh.throughput && planes && m->tchain_mode != 0 && (m->tchain_mode == 1 || (M + 127) / 128 >= m->tchain_min_tiles) && !m->tchain.empty() && M >= 1024 && Lh.attn_is_h3(N, true) &&
+    const bool chain = Lh.throughput && planes && m->tchain_mode != 0 && (m->tchain_mode == 1 || (M + 127) / 128 >= m->tchain_min_tiles) && !m->tchain.empty() && M >= 1024 && (Lh.attn_is_h3(N, true) || (m->tchain_short && Lh.attn_h3_any(N))) &&
                        (c.num_strided == 0 || m->L[0] == N) && (double)M * 1152 * 4.0 < 4.0e9 &&
                        attn_out == nullptr;      // (return_attention=True: the maps kernel reads row-major q | k planes, the chain writes fragment order)
     if (chain) {
