@@ -111,7 +111,7 @@ inline void tchain_pack_stage(const _Float16* Bh, const _Float16* Bl, int N, int
 typedef float f32x16s __attribute__((ext_vector_type(16)));
 
 #ifndef UU3D_TC_LOO
-#define UU3D_TC_LOO 0          // tools/tchain_exp: leave-one-out timing builds (results wrong): 1 no refill DMA, 2 no finish, 4 no exchange, 8 no mid barrier, 16 no fragment reads, 32 no MFMA, 64 plane stores coalesced, 128 no bias load, 256 transitions without memory traffic
+#define UU3D_TC_LOO 0          // tools/tchain_exp: leave-one-out timing builds (results wrong): 1 no refill DMA, 2 no finish, 4 no exchange, 8 no mid barrier, 16 no fragment reads, 32 no MFMA, 64 plane stores coalesced, 128 no bias load, 256 transitions without memory traffic, 512 projection and fc2's first half store into a slab instead of adding atomically
 #endif
 #ifdef UU3D_TC_STAMP
 // tools/tchain_exp: per workgroup 16 pairs (s_memtime = shader clock ticks, s_memrealtime = 100 MHz) at the chain's stage boundaries
@@ -133,6 +133,11 @@ struct TcEpResidual {
     static constexpr int kStores = 8; static constexpr bool kBias = BIAS;
     float* x;                  // the tile of the residual stream, lane-linear (tchain_xs_index), + wave * 512 + lane floats: (c, i, e) at + c * 4096 + i * 256 + e * 64
     const float* bias;
+};
+template <bool BIAS>
+struct TcEpSlabT {             // TIMING BUILDS ONLY (UU3D_TC_LOO & 512): v (+ bias) as two 16-byte stores into a slab instead of the atomics (the result is lost)
+    static constexpr int kStores = 2; static constexpr bool kBias = BIAS;
+    float* s; const float* bias;
 };
 struct TcEpHidden {            // relu(v + b1) split into hi / lo = the token fragment of fc2's k-slice 2 c + hh -> lane-linear scratch
     static constexpr int kStores = 2; static constexpr bool kBias = true;
@@ -232,6 +237,10 @@ tchain_kernel(const TChainArgs a)
             asm volatile("global_atomic_add_f32 %0, %1, off\n\tglobal_atomic_add_f32 %0, %2, off offset:256\n\t"
                          "global_atomic_add_f32 %0, %3, off offset:512\n\tglobal_atomic_add_f32 %0, %4, off offset:768"
                          :: "v"(d), "v"(y[0]), "v"(y[1]), "v"(y[2]), "v"(y[3]) : "memory");
+        } else if constexpr (std::is_same<EP, TcEpSlabT<false>>::value || std::is_same<EP, TcEpSlabT<true>>::value) {
+            f32x4 y = v;
+            if constexpr (EP::kBias) y = y + bias4(sb, i);
+            *reinterpret_cast<f32x4*>(ep.s + cp * 4096 + i * 256) = y;
         } else if constexpr (std::is_same<EP, TcEpQkvFrag>::value) {
             f32x4 y = v + bias4(sb, i);
             if (cp < 12) y = y * ep.qscale;
@@ -540,6 +549,8 @@ tchain_kernel(const TChainArgs a)
 #pragma unroll
         for (int s = 0; s < HS; ++s) { ah[s] = ap[((HS * hh + s) * 2 + 0) * 64]; al[s] = ap[((HS * hh + s) * 2 + 1) * 64]; }
         TC_STAMP(1);
+        if constexpr ((UU3D_TC_LOO & 512) != 0 && !kStrided1) stage(std::integral_constant<int, 12>{}, TcEpSlabT<true>{xas - lane + lane * 4, a.P + TCP_BP + 16 * hh}, XS0{});
+        else
         stage(std::integral_constant<int, 12>{}, TcEpResidual<true>{kStrided1 ? xas : xs, a.P + TCP_BP + 16 * hh}, XS0{});      // (the kernel's first stage; the fragment loads in front of it are its own operands)
         TC_STAMP(2);
         load_xs(kStrided1 ? xas : xs);
@@ -567,7 +578,10 @@ tchain_kernel(const TChainArgs a)
                     const h16x8* d = hsl + ((size_t)((12 * half + s) * 8 + wave) * 2) * 64;
                     ah[s] = d[0]; al[s] = d[64];
                 }
-                if (half == 0) stage(std::integral_constant<int, 12>{}, TcEpResidual<false>{xs, nullptr}, XSD{});
+                if (half == 0) {
+                    if constexpr ((UU3D_TC_LOO & 512) != 0) stage(std::integral_constant<int, 12>{}, TcEpSlabT<false>{xas - lane + lane * 4, nullptr}, XSD{});
+                    else stage(std::integral_constant<int, 12>{}, TcEpResidual<false>{xs, nullptr}, XSD{});
+                }
                 else stage(std::integral_constant<int, 12>{}, TcEpResidual<true>{xs, a.P + TCP_B2 + 16 * hh}, XSD{});
             }
             TC_STAMP(6);
