@@ -294,6 +294,15 @@ def test_throughput_schedule_matches_and_is_an_argument():
         if tchain == "1":
             assert sum(r["kernel"] == "tchain" for r in thr) == arch.temporal_depth + 2 and len(thr) < len(lat) - 15
         else:
+            # (the projection's throughput shape -- one workgroup per row tile, LayerNorm 2 inside -- from 64 row tiles on: 1207 rows keep the latency shape)
+            assert not any(r["kernel"] == "gemm_panel8<BiasResidualLn>" for r in thr) and not any(r["kernel"] == "gemm_panel8<BiasResidualLn>" for r in lat)
+            x, m = util.synthetic_batch(cfg, 128, seed=9)
+            model.set_profiling(True)
+            forward(model, x * m[:, :, None, None], m, schedule=1)
+            thr = model.read_profile()
+            forward(model, x * m[:, :, None, None], m, schedule=0)
+            lat = model.read_profile()
+            model.set_profiling(False)
             assert any(r["kernel"] == "gemm_panel8<BiasResidualLn>" for r in thr) and not any(r["kernel"] == "gemm_panel8<BiasResidualLn>" for r in lat)
             assert sum(r["name"].endswith("ln2_split") for r in thr) < sum(r["name"].endswith("ln2_split") for r in lat)
 

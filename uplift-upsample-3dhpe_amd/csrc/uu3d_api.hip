@@ -880,7 +880,7 @@ inline bool spatial_h3_pays(int frames) {
 
 // UU3D_SKIP=<bit mask> (TIMING EXPERIMENTS ONLY: the skipped launches leave garbage, results are wrong): which launch classes of the
 // forward are left out -- 1 spatial stack, 2 LayerNorm-fed panel GEMMs (QKV, fc1), 4 projection, 8 fused MLP, 16 attention, 32 ln_split_frag,
-// 64 ln_res_split_frag, 128 the temporal chain launches.  tools/marginal_exp.sh prices what each class costs the pipelined step.
+// 64 ln_res_split_frag, 128 the temporal chain launches, 256 strided blocks 2.., 512 strided block 1.  tools/marginal_exp.sh prices what each class costs the pipelined step.
 inline int skip_mask() {
     static const int mask = [] { const char* e = getenv("UU3D_SKIP"); const int v = e ? atoi(e) : 0;
                                  if (v) fprintf(stderr, "[uu3d] UU3D_SKIP=%d: launches are being skipped, RESULTS ARE WRONG (timing experiment)\n", v); return v; }();
@@ -1070,7 +1070,9 @@ struct Launcher {
         // several forwards in flight: the fewest CU-microseconds win, not the shortest launch (h36m_351 batch 128, 9088 rows: S = 3 / 2 / 1
         // = 213 / 142 / 71 workgroups, 16.3 / 18.9 / 27.5 us per launch; one batch at a time 127.7 / 126.2 / 121.2 k sequences/s, four in
         // flight 167.3 / 169.2 / 171.3 k on the same box)
-        if (throughput) S = 1;
+        // (... for launches that fill a good part of the chip.  With fewer than 64 row tiles -- strided block 2: 23 -- the launch holds few CUs either way, and what it
+        // costs the pipelined step is its DURATION on its forward's queue: 34.6 us as 23 workgroups x 12 chunks with LayerNorm 2 inside against 12.2 + 7.2 us)
+        if (throughput && mt >= 64) S = 1;
         { static const char* e = getenv("UU3D_PANEL_PROJ_S"); if (e != nullptr && e[0] >= '1' && e[0] <= '3') S = e[0] - '0'; }   // (A/B measurements)
         static const bool no_ln_tail = getenv("UU3D_NO_LN_TAIL") != nullptr;      // (A/B measurements)
         const bool ln_tail = S == 1 && ln_out != nullptr && !no_ln_tail && panel8_ok(12);
@@ -1562,6 +1564,8 @@ int uu3d_forward_ex(uu3d_model* m, const float* kp2d, const uint8_t* mask, int32
     for (int i = 0; i < c.num_strided; ++i) {
         const BlockDev& b = m->sblocks[i];
         const int Li = m->L[i], Lo = m->L[i + 1], Mi = B * Li, Mo = B * Lo;
+        if ((skip_mask() & 256) && i >= 1) continue;       // (timing experiments: the strided blocks behind the first / 512: the first)
+        if ((skip_mask() & 512) && i == 0) continue;
         // the last strided block + head2 as ONE launch of XCD-cooperative workgroups (uu3d_tail.h) when the block is small: few
         // rows make every launch of the chain a bare memory round trip (h36m_351 at batch 128: 9 launches, 76 us)
         // (never under the throughput schedule: its 256 workgroups spin on every CU while other forwards need them, and can then time out)
