@@ -895,6 +895,7 @@ struct Launcher {
     bool throughput = false;        // this CALL's schedule (uu3d_forward_ex): launches shaped for CU-microseconds instead of latency
     int precision = UU3D_PREC_F16X3;   // this CALL's arithmetic: the handle's, or UU3D_PREC_F32 with UU3D_SCHEDULE_EXACT_F32
     int status = UU3D_OK;
+    bool few_splits = false;        // this forward runs the temporal chain: its split-K GEMMs aim for splitk_target() workgroups
 
     void begin(const char* name, const char* kernel, double flops, double bytes) {
         if (!m->profiling) return;
@@ -952,6 +953,14 @@ struct Launcher {
         hipLaunchKernelGGL(kern, dim3(grid, slices), dim3(256), lds, stream, gl, Bh, Bl, M, N, Kp, mt, nt, kt_per_split, ep);
     }
 
+    // Workgroups a split-K GEMM aims for: enough to fill the chip three times over when the launch has it to itself (latency); under the throughput
+    // schedule the chip is shared and a launch costs its CU-microseconds -- hundreds of workgroups that each wait ten microseconds for a few
+    // hundred kilobytes are expensive then (round 5: strided blocks 2 and 3, 7 GFLOP, cost 9 % of the pipelined step)
+    int splitk_target() const {
+        // (h36m_351, batch 128, eight slots, ms per step by target: 768: 0.678, 384: 0.665, 192: 0.664, 96: 0.666, 48: 0.664 -- profiles/r05_tchain_ab.txt)
+        static const int thr = [] { const char* e = getenv("UU3D_THR_SPLITK_TARGET"); return e != nullptr && atoi(e) > 0 ? atoi(e) : 192; }();
+        return (throughput && few_splits) ? thr : 768;      // (only beside the temporal chain: forwards without it stay bit-identical between the schedules)
+    }
     // f16x3 GEMM whose A operand already is a pair of f16 planes (written by ln_split / attention / the ReLU
     // epilogue): LDS-DMA staged kernel, K % 32 == 0.  Same split-K policy as gemm().
     template <class GL, class EP>
@@ -961,7 +970,7 @@ struct Launcher {
         int slices = 1;
         // (>= 200 tiles with a short contraction fill the chip unsplit: strided block 2's projection, 276 tiles x 12 k-tiles,
         // 13.3 us against 12.6 + 6.5 us split three ways + reduce; the heads and the K = 2304 convolutions measured faster split)
-        if (tiles < 384 && KT >= 8 && !(tiles >= 200 && KT <= 16)) slices = std::max(1, std::min(KT / 4, (768 + tiles / 2) / tiles));
+        if (tiles < 384 && KT >= 8 && !(tiles >= 200 && KT <= 16)) slices = std::max(1, std::min(KT / 4, (splitk_target() + tiles / 2) / tiles));
         int kps = (KT + slices - 1) / slices;
         slices = (KT + kps - 1) / kps;
         const int ldslab = round_up(N, 4);
@@ -1129,7 +1138,7 @@ struct Launcher {
         int slices = 1;
         // (>= 200 tiles with a short contraction fill the chip unsplit: strided block 2's projection, 276 tiles x 12 k-tiles,
         // 13.3 us against 12.6 + 6.5 us split three ways + reduce; the heads and the K = 2304 convolutions measured faster split)
-        if (tiles < 384 && KT >= 8 && !(tiles >= 200 && KT <= 16)) slices = std::max(1, std::min(KT / 4, (768 + tiles / 2) / tiles));
+        if (tiles < 384 && KT >= 8 && !(tiles >= 200 && KT <= 16)) slices = std::max(1, std::min(KT / 4, (splitk_target() + tiles / 2) / tiles));
         int kps = (KT + slices - 1) / slices;
         slices = (KT + kps - 1) / kps;
         const int ldslab = round_up(N, 4);
@@ -1324,6 +1333,9 @@ int uu3d_forward_ex(uu3d_model* m, const float* kp2d, const uint8_t* mask, int32
     if (!m) return UU3D_ERR_INVALID_ARGUMENT;
     const bool exact_f32 = (schedule & UU3D_SCHEDULE_EXACT_F32) != 0;
     schedule &= ~UU3D_SCHEDULE_EXACT_F32;
+    // TIMING EXPERIMENT (tools/tail_branch_exp.py; results wrong): 0x200 = only the launches up to the first strided block, 0x400 = only the ones behind it
+    const bool part_body = (schedule & 0x200) != 0, part_tail = (schedule & 0x400) != 0;
+    schedule &= ~0x600;
     if (schedule != UU3D_SCHEDULE_LATENCY && schedule != UU3D_SCHEDULE_THROUGHPUT) return fail(m, UU3D_ERR_INVALID_ARGUMENT, "schedule must be UU3D_SCHEDULE_LATENCY or UU3D_SCHEDULE_THROUGHPUT");
     if (!m->committed) return fail(m, UU3D_ERR_NOT_READY, "uu3d_commit_weights has not been called");
     if (!kp2d || !central_out || !workspace || B < 1) return fail(m, UU3D_ERR_INVALID_ARGUMENT, "null buffer or batch < 1");
@@ -1365,7 +1377,7 @@ int uu3d_forward_ex(uu3d_model* m, const float* kp2d, const uint8_t* mask, int32
     // the f16x3 spatial kernel writes its output as the two f16 planes spatial_to_temporal_fc reads (LDS-DMA GEMM, no split in
     // the GEMM's loader): 32.6 -> 29.6 us for the GEMM, the spatial kernel unchanged (round 1's kernel paid 1-2 us for the split stores)
     const bool s2t_planes = !m->no_planes && c.precision == UU3D_PREC_F16X3 && !m->spatial_valu && !m->spatial_f32 && (m->spatial_h3_always || spatial_h3_pays(B * c.num_frames)) && ((c.num_keypoints * c.d_spatial) % 32 == 0);
-    {
+    if (!part_tail) {
         SpatialParams sp = m->sp;
         sp.total_frames = M;
         sp.frame_list = nullptr;
@@ -1403,7 +1415,7 @@ int uu3d_forward_ex(uu3d_model* m, const float* kp2d, const uint8_t* mask, int32
         }
     }
     // 2. spatial_to_temporal_fc + token blend + temporal PE
-    {
+    if (!part_tail) {
         EpSpatialToTemporal ep{w.X, m->s2t_b, dt, mask, m->token, m->pe_t, N};
         if (s2t_planes) {
             Lh.gemm_g("s2t", GLoadPlain{reinterpret_cast<const _Float16*>(w.S), reinterpret_cast<const _Float16*>(w.S) + (size_t)M * J * ds, J * ds, M}, m->s2t_wt, M, dt, J * ds, ep);
@@ -1513,7 +1525,8 @@ int uu3d_forward_ex(uu3d_model* m, const float* kp2d, const uint8_t* mask, int32
     const bool chain = Lh.throughput && planes && m->tchain_mode != 0 && (m->tchain_mode == 1 || (M + 127) / 128 >= m->tchain_min_tiles) && !m->tchain.empty() && M >= 1024 && (Lh.attn_is_h3(N, true) || (m->tchain_short && Lh.attn_h3_any(N))) &&
                        (c.num_strided == 0 || m->L[0] == N) && (double)M * 1152 * 4.0 < 4.0e9 &&
                        attn_out == nullptr;      // (return_attention=True: the maps kernel reads row-major q | k planes, the chain writes fragment order)
-    if (chain) {
+    Lh.few_splits = chain;
+    if (chain && !part_tail) {
         _Float16* const Q = reinterpret_cast<_Float16*>(w.QKV);
         Lh.tchain("t1.ln_qkv", m->tchain[0], M, nullptr, w.X, nullptr, nullptr, 1, Q, nullptr, w.tc_scratch);
         for (int i = 0; i < c.temporal_depth; ++i) {
@@ -1528,7 +1541,7 @@ int uu3d_forward_ex(uu3d_model* m, const float* kp2d, const uint8_t* mask, int32
     // Otherwise: with >= 1024 token rows the MLP is one launch (uu3d_mlp_fused.h): its three partial fc2 sums are
     // added to the residual stream by the NEXT block's first LayerNorm launch (`pend`).
     const BlockDev* pend = nullptr;
-    for (int i = 0; i < (chain ? 0 : c.temporal_depth); ++i) {
+    for (int i = 0; i < (chain || part_tail ? 0 : c.temporal_depth); ++i) {
         const BlockDev& b = m->tblocks[i];
         const bool masked = c.has_strided_input && i < c.first_strided_token_attention_layer;
         const bool last = (i + 1 == c.temporal_depth);
@@ -1549,7 +1562,7 @@ int uu3d_forward_ex(uu3d_model* m, const float* kp2d, const uint8_t* mask, int32
         if (planes) { GLoadPlain gl{Hh, Hh + (size_t)M * ht, ht, M}; Lh.gemm_g(nm, gl, b.w2_t, M, dt, ht, ep_fc2, 4.0 * M * dt); }
         else { ALoadPlain al{w.Hb, ht, M, ht}; Lh.gemm(nm, al, b.w2_t, M, dt, ht, ep_fc2, 4.0 * M * dt); }
     }
-    if (c.num_strided == 0 && has_h1) {                    // 4. head1 without strided blocks (otherwise launched inside strided block 1, below)
+    if (c.num_strided == 0 && has_h1 && !part_tail) {      // 4. head1 without strided blocks (otherwise launched inside strided block 1, below)
         ALoadPlain al{w.X, dt, M, dt}; EpBias ep{full_out, m->h1_b, 3 * J};
         Lh.gemm("head1", al, m->h1_wt, M, 3 * J, dt, ep);
     }
@@ -1564,8 +1577,8 @@ int uu3d_forward_ex(uu3d_model* m, const float* kp2d, const uint8_t* mask, int32
     for (int i = 0; i < c.num_strided; ++i) {
         const BlockDev& b = m->sblocks[i];
         const int Li = m->L[i], Lo = m->L[i + 1], Mi = B * Li, Mo = B * Lo;
-        if ((skip_mask() & 256) && i >= 1) continue;       // (timing experiments: the strided blocks behind the first / 512: the first)
-        if ((skip_mask() & 512) && i == 0) continue;
+        if (((skip_mask() & 256) || part_body) && i >= 1) continue;       // (timing experiments: the strided blocks behind the first / 512: the first)
+        if (((skip_mask() & 512) || part_tail) && i == 0) { std::swap(xa, xb); xb = w.XA; continue; }
         // the last strided block + head2 as ONE launch of XCD-cooperative workgroups (uu3d_tail.h) when the block is small: few
         // rows make every launch of the chain a bare memory round trip (h36m_351 at batch 128: 9 launches, 76 us)
         // (never under the throughput schedule: its 256 workgroups spin on every CU while other forwards need them, and can then time out)
@@ -1620,14 +1633,14 @@ int uu3d_forward_ex(uu3d_model* m, const float* kp2d, const uint8_t* mask, int32
         if (i == 0) xb = w.XA;   // XA (B*N rows) is free again; XB only needs B*L_1 rows
     }
     // 6. head2
-    if (!tail_done) {
+    if (!tail_done && !part_body) {
         // no strided blocks: the central token x[:, N // 2] (u_u_t.py:411-413) = row N / 2 of every sequence, leading dimension N d_t
         ALoadPlain al{c.num_strided > 0 ? xa : w.X + (size_t)(N / 2) * dt, c.num_strided > 0 ? dt : N * dt, B, dt};
         EpBias ep{central_out, m->h2_b, 3 * J};
         Lh.gemm("head2", al, m->h2_wt, B, 3 * J, dt, ep);
     }
     // range guard (include/uu3d.h): non-finite outputs of an f16x3 forward set the model's sticky word
-    if (c.precision == UU3D_PREC_F16X3) {
+    if (c.precision == UU3D_PREC_F16X3 && !part_body) {
         Lh.begin("range_check", "range_check", 0.0, 4.0 * ((has_h1 ? (double)M * 3 * J : 0.0) + (double)B * 3 * J));
         hipLaunchKernelGGL(range_check_kernel, dim3(256), dim3(256), 0, Lh.stream, has_h1 ? full_out : central_out, has_h1 ? (long)M * 3 * J : 0L,
                            central_out, (long)B * 3 * J, m->d_range);
