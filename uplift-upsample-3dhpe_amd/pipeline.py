@@ -95,7 +95,7 @@ class _Slot(object):
 class ForwardPipeline(object):
 
     def __init__(self, model, batch, depth=None, graph=True, post=None, streams=None):
-        """``depth``: batches in flight; None = TWO per HIP hardware queue (``distinct_queue_streams(per_queue=2)``: 8 -- round 5: with the temporal
+        """``depth``: batches in flight; None = TWO per HIP hardware queue for batches up to 128 sequences, one above (``distinct_queue_streams(per_queue=2)``: 8 / 4 -- round 5: with the temporal
         chain's launches of one workgroup per 128 rows, eight forwards in flight keep the chip full where four do not: 187 k against 181 k
         sequences/s at batch 128; the round-4 launches measure the same with four and eight), an int up to that number takes that many of
         those streams (class-major: the first four sit on four different queues), more falls back to fresh pool streams.
@@ -108,7 +108,9 @@ class ForwardPipeline(object):
         if streams is None and (depth is None or depth > 1):
             q = distinct_queue_streams(model.device, want=int(os.environ.get("UU3D_PIPE_QUEUES", "4")), per_queue=2)
             if depth is None:
-                depth = len(q)
+                # two slots per queue for batches up to 128 sequences, one above (forward only, 2 / 4 / 8 slots -- 256 per batch: 186 / 198 / 191 k sequences/s,
+                # 512: 197 / 204 / 198 k, 1024: 203 / 208 / 203 k; at 128 four and eight measure the same unless the consumer waits on the caller's stream)
+                depth = len(q) if int(batch) <= 128 else max(1, len(q) // 2)
             if depth <= len(q):
                 streams = q[:depth]
         if streams is not None and depth is None:
