@@ -342,13 +342,13 @@ def secondary_benchmarks(args):
     jobs = [("steady_state_200_steps", lambda: quick_forward_bench(args.config, args.batch, streams=max(1, args.streams_used), graph=True, steps=200, warmup=20)),
             # the reference's own evaluation batch (config BATCH_SIZE 512 windows per forward, eval.py:147-152): launches of 284 row tiles, where the
             # temporal chain (csrc/uu3d_tchain.h) is chosen by size -- against the same batch with the chain switched off
-            ("eval_batch_512", lambda: quick_forward_bench(args.config, 512, streams=max(1, args.streams_used), graph=True, steps=24, warmup=6)),
-            ("eval_batch_512_no_tchain", lambda: _with_env("UU3D_TCHAIN", "0", lambda: quick_forward_bench(args.config, 512, streams=max(1, args.streams_used), graph=True, steps=24, warmup=6))),
+            ("eval_batch_512", lambda: quick_forward_bench(args.config, 512, streams=4, graph=True, steps=24, warmup=6)),      # (above 128 sequences per batch: one slot per hardware queue, pipeline.py)
+            ("eval_batch_512_no_tchain", lambda: _with_env("UU3D_TCHAIN", "0", lambda: quick_forward_bench(args.config, 512, streams=4, graph=True, steps=24, warmup=6))),
             ("with_input_copy_per_step", lambda: quick_forward_bench(args.config, args.batch, streams=max(1, args.streams_used), graph=True, copy_inputs=True)),
             ("latency_one_batch_in_flight", lambda: quick_forward_bench(args.config, args.batch, streams=1, graph=True)),
             ("eager_one_batch_in_flight", lambda: quick_forward_bench(args.config, args.batch, streams=1, graph=False)),
             ("eager_pipelined", lambda: quick_forward_bench(args.config, args.batch, streams=max(2, args.streams_used), graph=False)),
-            ("h36m_81_batch256", lambda: quick_forward_bench("h36m_81", 256, streams=max(1, args.streams_used))),
+            ("h36m_81_batch256", lambda: quick_forward_bench("h36m_81", 256, streams=4)),
             ("s_in_10", lambda: quick_forward_bench(args.config, args.batch, s_in=10, streams=max(1, args.streams_used))),
             ("s_in_20", lambda: quick_forward_bench(args.config, args.batch, s_in=20, streams=max(1, args.streams_used))),
             ("dense_351_batch32", lambda: quick_forward_bench("dense_351", 32, streams=1, attention=True)),
