@@ -117,3 +117,28 @@ def test_pipelined_temporal_chain_stays_bitwise_right_over_many_batches(monkeypa
     assert n == 600
     pipe.check_range()
     pipe.close()
+
+
+def test_schedules_agree_over_random_batch_sizes_and_masks():
+    """Throughput against latency schedule (the temporal chain with its ragged last tiles, the split-K shapes beside it, attn_h3_kernel on fragment-ordered
+    q | k | v) over random batch sizes between 15 and 150 sequences and random stride masks, both shipped architectures: within 3e-5, and bitwise run to run."""
+    rng = np.random.default_rng(2025)
+    for cfgname in ("h36m_351", "h36m_81"):
+        cfg = util.load_config(cfgname)
+        arch = pkg.arch_from_config(cfg)
+        model = pkg.build_uplift_upsample_transformer(cfg, weights=pkg.init_weights(arch, seed=8, perturb=0.1))
+        worst = 0.0
+        for trial in range(10):
+            B = int(rng.integers(15, 151)) if cfgname == "h36m_351" else int(rng.integers(26, 200))
+            specs = [(int(rng.choice([4, 5, 10, 20])), int(rng.integers(0, 4))) for _ in range(int(rng.integers(1, 4)))]
+            x, m = util.synthetic_batch(cfg, B, seed=100 + trial, mask_specs=specs)
+            xt, mt = torch.from_numpy(x * m[:, :, None, None].astype(np.float32)).cuda(), torch.from_numpy(m).cuda()
+            f0, c0 = util.direct_forward(model, xt, mt, 0)
+            f1, c1 = util.direct_forward(model, xt, mt, 1)
+            f2, c2 = util.direct_forward(model, xt, mt, 1)
+            assert torch.equal(f1, f2) and torch.equal(c1, c2), (cfgname, B, specs)
+            d = max(float((f0 - f1).abs().max()), float((c0 - c1).abs().max()))
+            worst = max(worst, d)
+            assert d <= 3e-5, (cfgname, B, specs, d)
+        assert model.check_range(raise_error=False) is False
+        print(f"{cfgname}: throughput vs latency schedule over 10 random batches: max {worst:.2e}")
