@@ -5,6 +5,7 @@ graph -- beside the body of the slot's next batch -- than at the end of the forw
   (C) the body alone                          (the bound)
 replayed round robin, `depth` slots on evenly dealt hardware queues.   python tools/tail_branch_exp.py [steps]"""
 import os, sys, time
+os.environ["UU3D_TIMING_PARTS"] = "1"        # (uu3d_forward_ex accepts the 0x200 / 0x400 schedule bits only with this)
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 import uplift_upsample_3dhpe_amd as pkg

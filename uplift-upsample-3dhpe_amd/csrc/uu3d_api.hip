@@ -1334,8 +1334,10 @@ int uu3d_forward_ex(uu3d_model* m, const float* kp2d, const uint8_t* mask, int32
     const bool exact_f32 = (schedule & UU3D_SCHEDULE_EXACT_F32) != 0;
     schedule &= ~UU3D_SCHEDULE_EXACT_F32;
     // TIMING EXPERIMENT (tools/tail_branch_exp.py; results wrong): 0x200 = only the launches up to the first strided block, 0x400 = only the ones behind it
-    const bool part_body = (schedule & 0x200) != 0, part_tail = (schedule & 0x400) != 0;
-    schedule &= ~0x600;
+    // (only with UU3D_TIMING_PARTS=1 in the environment: otherwise the bits are an invalid schedule like any other unknown value)
+    static const bool parts_ok = getenv("UU3D_TIMING_PARTS") != nullptr && atoi(getenv("UU3D_TIMING_PARTS")) != 0;
+    const bool part_body = parts_ok && (schedule & 0x200) != 0, part_tail = parts_ok && (schedule & 0x400) != 0;
+    if (parts_ok) schedule &= ~0x600;
     if (schedule != UU3D_SCHEDULE_LATENCY && schedule != UU3D_SCHEDULE_THROUGHPUT) return fail(m, UU3D_ERR_INVALID_ARGUMENT, "schedule must be UU3D_SCHEDULE_LATENCY or UU3D_SCHEDULE_THROUGHPUT");
     if (!m->committed) return fail(m, UU3D_ERR_NOT_READY, "uu3d_commit_weights has not been called");
     if (!kp2d || !central_out || !workspace || B < 1) return fail(m, UU3D_ERR_INVALID_ARGUMENT, "null buffer or batch < 1");
