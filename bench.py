@@ -22,6 +22,10 @@ if ROOT not in sys.path:
 
 PEAK_F32_MFMA_TFLOPS = 157.3   # /opt/skills/guides/MI355X_MICROARCH.md "Peak FP32 (matrix)"
 PEAK_F16_MFMA_TFLOPS = 2500.0  # same table, "Peak BF16/FP16 MFMA ~2.5 PF dense"
+# What the leave-one-out builds of the dominant kernel say bounds it (profiles/): `bound` above stays the roofline the FLOPs are priced
+# against (the contract's "mfma"), this is the measured limiter.
+BOUND_MEASURED = ("bytes/latency: on a full chip the chain's launch takes the same time without its MFMAs (-3 %) and 28 % less without its epilogues' memory traffic "
+                  "(residual adds at the memory side, lane-private round trips of the hidden activations, q | k | v); its bare chunk loop runs at 0.66 of the matrix pipe")
 
 
 def cpu_baseline(cfg, arch, weights, x, m, budget_s=60.0):
@@ -103,6 +107,21 @@ class ErrorGather:
         return None if self.gathered is None else self.gathered.view((self.world,) + tuple(self.local.shape))
 
 
+# UU3D_* variables that make the library compute something else than the forward (timing experiments of tools/; they only act in
+# a -DUU3D_TIMING_BUILD library, but a bench line must not be produced under them at all)
+FORBIDDEN_ENV = ("UU3D_SKIP", "UU3D_TIMING_PARTS")
+
+
+def env_switches():
+    """Every UU3D_* variable present in this process's environment (A/B switches of the library and of this script): recorded in the
+    JSON line, so that a number measured under a switch says so; the result-changing ones are refused."""
+    present = {k: v for k, v in sorted(os.environ.items()) if k.startswith("UU3D_")}
+    bad = [k for k in present if k in FORBIDDEN_ENV]
+    if bad:
+        raise SystemExit(f"bench.py refuses to run with {', '.join(bad)} set: those switches skip launches (timing experiments, results wrong)")
+    return present
+
+
 def emit_line(out):
     """The ONE JSON line, as the LAST thing on stdout: RCCL prints its version banner through C stdio, which is block-buffered on a pipe and
     would otherwise come out at process exit, behind the line."""
@@ -142,21 +161,24 @@ def run_pipelined_steps(pipe, n, depth, gather):
     gather.finish()
 
 
-def parity_vs_oracle(cfg, arch, weights, x, m, full, central, gt, n=8):
+def parity_vs_oracle(cfg, arch, weights, x, m, full, central, gt, n=8, idx=None):
     """BASELINE's metric names "MPJPE vs ref": the HIP outputs of the bench batch (what the timed pipeline produced) against the CPU oracle on
     its first `n` sequences, OUTSIDE the timed region -- max-abs over both outputs and the difference of the two MPJPEs against the synthetic
     ground truth (mm; the north_star's budget is 0.05 mm).  The oracle is the checker here, never the thing measured."""
     import numpy as np
     import torch
     from oracle import uplift_oracle as O
-    n = min(n, x.shape[0])
-    f32, c32 = O.forward(O.hp_from_arch(arch), weights, x[:n], m[:n], torch.float32)
-    e = float(np.abs(central[:n] - c32).max())
+    if idx is None:
+        idx = list(range(min(n, x.shape[0])))
+    idx = np.asarray(idx, dtype=np.int64)
+    f32, c32 = O.forward(O.hp_from_arch(arch), weights, x[idx], m[idx], torch.float32)
+    e = float(np.abs(central[idx] - c32).max())
     if full is not None and f32 is not None:
-        e = max(e, float(np.abs(full[:n] - f32).max()))
-    _, a = O.frame_mpjpe_mm(central[:n], gt[:n, :, :3], cfg.ROOT_KEYTPOINT)
-    _, b = O.frame_mpjpe_mm(c32, gt[:n, :, :3], cfg.ROOT_KEYTPOINT)
-    return {"max_abs_vs_oracle": e, "mpjpe_delta_mm": float(abs(a - b)), "n_sequences": int(n), "tolerance_max_abs": 1e-4, "budget_mpjpe_mm": 0.05,
+        e = max(e, float(np.abs(full[idx] - f32).max()))
+    _, a = O.frame_mpjpe_mm(central[idx], gt[idx][:, :, :3], cfg.ROOT_KEYTPOINT)
+    _, b = O.frame_mpjpe_mm(c32, gt[idx][:, :, :3], cfg.ROOT_KEYTPOINT)
+    return {"max_abs_vs_oracle": e, "mpjpe_delta_mm": float(abs(a - b)), "n_sequences": int(len(idx)), "sequence_indices": [int(i) for i in idx],
+            "tolerance_max_abs": 1e-4, "budget_mpjpe_mm": 0.05,
             "reference": "oracle/uplift_oracle.py (PyTorch-CPU fp32 restatement; parity UNPINNED against TensorFlow, DESIGN.md section 6)"}
 
 
@@ -221,7 +243,7 @@ def train_bench(args, world, rank, local_rank, use_dist):
 
 
 
-def quick_forward_bench(cfgname, batch, s_in=None, streams=1, graph=True, steps=40, warmup=10, precision="f16x3", attention=False, copy_inputs=False):
+def quick_forward_bench(cfgname, batch, s_in=None, streams=1, graph=True, steps=40, warmup=10, precision="f16x3", attention=False, copy_inputs=False, parity=True):
     """A short timing of another workload for the `secondary` block of the bench line (same process, same GPU): sequences/s and
     ms per step of the forward + error kernel, `streams` batches in flight; attention=True adds the temporal-attention launch's
     HIP-event time and its fraction of the MFMA peak."""
@@ -232,7 +254,8 @@ def quick_forward_bench(cfgname, batch, s_in=None, streams=1, graph=True, steps=
     from uplift_upsample_3dhpe_amd.harness import per_joint_error
     cfg = util.load_config(cfgname)
     arch = pkg.arch_from_config(cfg)
-    model = pkg.build_uplift_upsample_transformer(cfg, weights=pkg.init_weights(arch, seed=0), precision=precision)
+    model_weights = pkg.init_weights(arch, seed=0)
+    model = pkg.build_uplift_upsample_transformer(cfg, weights=model_weights, precision=precision)
     s_in = s_in or (cfg.MASK_STRIDE[0] if isinstance(cfg.MASK_STRIDE, list) else cfg.MASK_STRIDE)
     x_np, m_np = util.synthetic_batch(cfg, batch, seed=1000, mask_specs=[(s_in, 0)])
     x = torch.from_numpy(x_np * m_np[:, :, None, None].astype(np.float32)).cuda()
@@ -267,6 +290,17 @@ def quick_forward_bench(cfgname, batch, s_in=None, streams=1, graph=True, steps=
     out = {"workload": f"config/{cfgname}.json, batch {batch}, s_in {s_in}" if cfgname != "dense_351" else f"synthetic dense-351 (NOT a shipped config), batch {batch}",
            "value": round(batch * steps / dt, 1), "unit": "pose-sequences/s", "ms_per_step": round(1e3 * dt / steps, 4), "steps": steps,
            "batches_in_flight": streams, "hipgraph": bool(graph), "input": "copied into the slot every step (submit)" if copy_inputs else "resident in the slots (preload + launch)"}
+    if parity:
+        # what THIS timed path produces for its resident batch, against the oracle on sequences of the first, a middle and the last row tile
+        try:
+            f_, c_, _ = pipe.result(pipe.submit(x, m) if copy_inputs else pipe.launch())
+            torch.cuda.synchronize()
+            idx = sorted({0, 1, batch // 2, batch - 1} if cfgname == "dense_351" else {0, 1, batch // 2 - 1, batch // 2, batch - 2, batch - 1})
+            idx = [i for i in idx if 0 <= i < batch]
+            out["parity"] = parity_vs_oracle(cfg, arch, model_weights, x_np * m_np[:, :, None, None].astype(np.float32), m_np,
+                                             f_.cpu().numpy() if f_ is not None else None, c_.cpu().numpy(), gt.cpu().numpy(), idx=idx)
+        except Exception as e:  # pragma: no cover
+            out["parity"] = {"error": f"{type(e).__name__}: {e}"}
     if attention:
         model.set_profiling(True)
         agg = {}
@@ -449,6 +483,7 @@ def main():
     ap.add_argument("--gather", default="end", choices=["end", "step"], help="N > 1: all-gather of the per-sequence error blocks -- end = one collective of every step's block behind the loop's last result (default), step = one per step on the caller's stream")
     ap.add_argument("--spawn-check", action="store_true", help="ranks print their rank / world size and exit (no GPU): checks the self-spawn path")
     args = ap.parse_args()
+    switches = env_switches()                              # (raises under UU3D_SKIP / UU3D_TIMING_PARTS)
 
     # `python bench.py --gpus N` without a launcher: start N ranks as CHILD processes here, before this process has
     # touched the GPU (no exec from a GPU-initialised process), and return their exit code.
@@ -476,8 +511,21 @@ def main():
             os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT="29533", RANK="0", WORLD_SIZE="1")
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
+    rccl = None
+    if use_dist:
+        # evidence that the collective spans the ranks the line claims: every rank contributes (rank, local device index) to one all-gather
+        ids = torch.tensor([rank, local_rank], dtype=torch.int64, device="cuda")
+        seen = torch.empty((world, 2), dtype=torch.int64, device="cuda")
+        dist.all_gather_into_tensor(seen, ids)
+        seen = seen.cpu().tolist()
+        rccl = {"backend": dist.get_backend(), "world_size": dist.get_world_size(), "ranks_seen": [int(r[0]) for r in seen],
+                "devices_seen": [int(r[1]) for r in seen]}
+        if sorted(rccl["ranks_seen"]) != list(range(world)):
+            raise SystemExit(f"the all-gather of rank ids returned {rccl['ranks_seen']} for world size {world}")
     if args.mode == "train":
         return train_bench(args, world, rank, local_rank, use_dist)
+    if "timing" in pkg.library_version():
+        raise SystemExit("bench.py refuses a timing build of the library (csrc/libuu3d_timing.so: launches can be skipped)")
     cfg = util.load_config(args.config)
     arch = pkg.arch_from_config(cfg)
     weights = pkg.init_weights(arch, seed=0)                 # replicated: same seed on every rank
@@ -589,6 +637,29 @@ def main():
             key = ("t." + nm.split(".", 1)[1]) if (nm[0] == "t" and "." in nm) else nm
             a = agg.setdefault(key, dict(ms=0.0, flops=0.0, bytes=0.0, n=0, kernel=e["kernel"]))
             a["ms"] += e["ms"]; a["flops"] += e["flops"]; a["bytes"] += e["bytes"]; a["n"] += 1
+    # ---- the temporal chain's launch when it FILLS the chip (what the timed path runs: several forwards' 71-workgroup launches side by side):
+    # one quiet forward of the batch that makes 256 row tiles, HIP events around its launches ----
+    under_load = None
+    if rank == 0 and prof_schedule == "throughput" and any(a["kernel"] == "tchain" for a in agg.values()):
+        try:
+            b_full = (256 * 128) // N
+            reps_x = (b_full + B - 1) // B
+            xl, ml = x.repeat((reps_x, 1, 1, 1))[:b_full].contiguous(), m.repeat((reps_x, 1))[:b_full].contiguous()
+            ms, fls, n = 0.0, 0.0, 0
+            for it in range(4):
+                model.call_scheduled([xl, ml], "throughput")
+                for e in model.read_profile():
+                    if it > 0 and e["kernel"] == "tchain" and e["name"][0] == "t" and e["name"].endswith(".chain"):
+                        ms += e["ms"]; fls += e["flops"]; n += 1
+            if n:
+                under_load = {"workgroups": (b_full * N + 127) // 128, "batch": b_full, "avg_launch_ms": round(ms / n, 5),
+                              "achieved": round(fls / (ms * 1e-3) / 1e12, 2), "unit": "TFLOP/s",
+                              "frac": round(fls / (ms * 1e-3) / 1e12 / PEAK_F16_MFMA_TFLOPS, 4),
+                              "note": "one temporal-block launch of the chain (projection .. next block's QKV) with one workgroup on every CU: HIP events around the launches of a quiet "
+                                      f"forward of {b_full} sequences, same kernel and schedule as the timed path"}
+            del xl, ml
+        except Exception as e:  # pragma: no cover
+            under_load = {"error": f"{type(e).__name__}: {e}"}
     model.set_profiling(False)
 
     if use_dist:                                         # every rank's buffered C stdio (RCCL's banner) out BEFORE rank 0's line
@@ -632,12 +703,12 @@ def main():
                                    f"seeded Keras-default weights", "global_batch": world * B,
                        "parallelism": f"batch-sharded x{world}", "hipgraph": bool(use_graph),
                        "concurrent_half_batches": bool(args.halves and not args.no_halves and B >= 64),
-                       "batches_in_flight": S,
+                       "batches_in_flight": S, "env_switches": switches,
                        "pipelining": (f"{S} independent batches in flight on {S} HIP streams" + (" dealt evenly over the HIP hardware queues (probed)" if auto else "") +
                                       ", each replaying its own hipGraph of forward + error "
                                       "kernel with its own workspace (uplift-upsample-3dhpe_amd/pipeline.py; the same path eval.run_eval uses)") if S > 1
                                      else "one batch after the other"},
-            "roofline": {"bound": "mfma", "kernel": f"{gk} [{dom_key}]",
+            "roofline": {"bound": "mfma", "bound_measured": BOUND_MEASURED if gk == "tchain" else None, "kernel": f"{gk} [{dom_key}]",
                          "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s",
                          "frac": round(ach / peak, 4), "traffic": pmc_traffic(gk, pmc_summary_for(args.config, B)),
                          "note": ("algorithmic 2*M*N*K FLOPs (tchain: every Dense layer the launch walks -- projection, fc1, fc2, the next block's QKV; mlp_fused: both Dense layers of the MLP, 4*M*d*h); the f16x3 kernels issue 3 f16 "
@@ -659,7 +730,10 @@ def main():
                                            "frac": round(bs["flops"] / (bs["ms"] * 1e-3) / 1e12 / peak, 4)}
                                           for k, bs in sorted(by_sym.items(), key=lambda kv: -kv[1]["ms"])[:4]],
                          "all_gemm_tflops": round(gemm_fl / (gemm_ms * 1e-3) / 1e12, 2),
-                         "model_tflops": round(fl["total"] * seqs / world / elapsed / 1e12, 2)},
+                         "under_load": under_load,
+                         "model_tflops": round(fl["total"] * seqs / world / elapsed / 1e12, 2),
+                         "model_frac": round(fl["total"] * seqs / world / elapsed / 1e12 / peak, 4),
+                         "model_frac_note": "whole-forward algorithmic FLOPs per second of the TIMED region (driver-clocked) over the dense peak of the arithmetic: the one figure of this block that no solo launch flatters"},
             "kernel_ms_per_forward": {k: round(a["ms"] / reps, 4) for k, a in sorted(agg.items(), key=lambda kv: -kv[1]["ms"])},
             "kernel_ms_schedule": prof_schedule + " (one quiet forward per sample, HIP events around every launch: the launches the timed path ran)",
             "sum_kernel_ms": round(total_ms, 4),
@@ -675,6 +749,7 @@ def main():
                 out["parity"] = {"error": f"{type(e).__name__}: {e}"}
         else:
             out["parity"] = None
+        out["rccl"] = rccl
         if world > 1:
             out["config"]["gather"] = ("one all-gather of every step's (B_local, J) f64 error block behind the loop's last result, inside the timed region" if args.gather == "end"
                                        else "one all-gather per step on the caller's stream")

@@ -21,6 +21,7 @@ SRC = r'''
 #include "uu3d_gemm_panel.h"
 #include "uu3d_gemm_panel8.h"
 #include "uu3d_tchain.h"
+#include "uu3d_tchain64.h"
 #include "uu3d_attn.h"
 #include "uu3d_attn_h3.h"
 #include "uu3d_bwd.h"
@@ -43,6 +44,11 @@ template __global__ void uu3d::gemm_h3_panel8_kernel<PanelEpBiasResidualLn, 12, 
 template __global__ void uu3d::tchain_kernel<TC_PROJ | TC_MLP | TC_QKV>(const TChainArgs);
 template __global__ void uu3d::tchain_kernel<TC_QKV>(const TChainArgs);
 template __global__ void uu3d::tchain_kernel<TC_PROJ | TC_FC1_PLANES>(const TChainArgs);
+template __global__ void uu3d::tchain64_kernel<TC_PROJ | TC_MLP | TC_QKV>(const TChainArgs);
+template __global__ void uu3d::tchain64_kernel<TC_PROJ | TC_MLP | TC_QKV | TC_PE>(const TChainArgs);
+template __global__ void uu3d::tchain64_kernel<TC_PROJ | TC_MLP>(const TChainArgs);
+template __global__ void uu3d::tchain64_kernel<TC_QKV>(const TChainArgs);
+template __global__ void uu3d::tchain64_kernel<TC_PROJ | TC_FC1_PLANES>(const TChainArgs);
 template __global__ void uu3d::ln_split_frag_kernel<24, 8>(const float*, int, int, float, const float*, const float*, _Float16*);
 template __global__ void uu3d::gemm_h3g_kernel<1, 1, GLoadConv3, EpSlab, 3>(const GLoadConv3, const _Float16*, const _Float16*, int, int, int, int, int, int, const EpSlab);
 template __global__ void uu3d::gemm_h3g_kernel<1, 2, GLoadPlain, EpBiasResidual, 3>(const GLoadPlain, const _Float16*, const _Float16*, int, int, int, int, int, int, const EpBiasResidual);
@@ -173,7 +179,7 @@ def test_temporal_chain_code_shape(asm):
     per chunk 36 MFMAs, 6 LDS-DMA pieces (the refill position depends on the wave group: both branches are in the text) and two barriers,
     no scratch inside a loop, 256 registers = two waves per SIMD, all of the LDS."""
     ks = _kernels(asm)
-    chains = {k: v for k, v in ks.items() if "tchain_kernel" in k}
+    chains = {k: v for k, v in ks.items() if "tchain_kernelILi" in k}
     assert len(chains) == 3
     for name, body in chains.items():
         loops = [t for t in _loops(body).values() if "v_mfma_f32_32x32x16_f16" in t]
@@ -194,6 +200,41 @@ def test_temporal_chain_code_shape(asm):
         d = d[:d.index(".end_amdhsa_kernel")]
         assert int(re.search(r"\.amdhsa_next_free_vgpr (\d+)", d).group(1)) <= 256, name
         assert "v_pk_mul_f32" not in body and "v_pk_fma_f32" not in body and "v_pk_add_f32" not in body, name
+
+
+def test_temporal_chain_64_row_code_shape(asm):
+    """uu3d_tchain64.h (round 6): the residual stream and relu(fc1) never leave the CU.  Pinned: NO float atomic and no scratch anywhere in the
+    kernel (round 5's residual adds were global_atomic_add_f32; a register the allocator spills may be a fragment read still in flight), every
+    stage a real loop of four-chunk bodies with 36 MFMAs, 12 LDS-DMA pieces and two barriers per chunk, no vector-memory load inside a loop,
+    every wait inside a loop one of the hand-written counted ones, one wave per SIMD (512 registers: the token fragments sit in AGPRs)."""
+    ks = _kernels(asm)
+    chains = {k: v for k, v in ks.items() if "tchain64_kernel" in k}
+    assert len(chains) == 5
+    for name, body in chains.items():
+        assert "global_atomic" not in body and "flat_atomic" not in body and "buffer_atomic" not in body, name
+        assert "scratch_" not in body, name
+        assert "v_pk_mul_f32" not in body and "v_pk_fma_f32" not in body and "v_pk_add_f32" not in body, name
+        # whole kernel: 36 MFMAs and 12 LDS-DMA pieces per chunk body in the text (+ the 30 pieces of the prologue), whatever hipcc unrolled
+        n_mfma, n_dma = body.count("v_mfma_f32_32x32x16_f16"), body.count("global_load_lds_dwordx4")
+        assert n_mfma % 36 == 0 and n_dma == 12 * (n_mfma // 36) + 30, (name, n_mfma, n_dma)
+        loops = {h: t for h, t in _loops(body).items() if t.count("v_mfma_f32_32x32x16_f16") == 4 * 36}      # the rolled loops of four-chunk bodies (QKV, the strided block's fc1)
+        assert loops or "Li3E" in name, name
+        for h, t in loops.items():
+            back = re.search(r"s_cbranch_\w+ \." + re.escape(h) + r"\b", t)
+            assert back, (name, h)
+            t = t[:back.start()]                                                 # (the loop's last block runs on into the stage tail: cut at the back edge)
+            assert "v_readlane" not in t and "v_writelane" not in t, name
+            assert not re.search(r"\b(global|buffer|flat)_load_(dword|ubyte|ushort|short)", t), name           # LDS-DMA (global_load_lds_*) only
+            assert t.count("s_barrier") == 4 * 2, name
+            in_asm = sum(blk.count("s_waitcnt") for blk in re.findall(r";;#ASMSTART(.*?);;#ASMEND", t, re.S))
+            assert in_asm >= 4 * 14 and t.count("s_waitcnt") == in_asm, (name, in_asm, t.count("s_waitcnt"))     # hipcc added no wait of its own
+            assert not re.search(r"s_waitcnt vmcnt\(0\)", t), name
+            assert t.count("global_load_lds_dwordx4") == 4 * 12, (name, t.count("global_load_lds_dwordx4"))
+        d = asm[asm.index(".amdhsa_kernel " + name):]
+        d = d[:d.index(".end_amdhsa_kernel")]
+        assert int(re.search(r"\.amdhsa_next_free_vgpr (\d+)", d).group(1)) <= 512, name
+        assert int(re.search(r"\.amdhsa_accum_offset (\d+)", d).group(1)) <= 256, name
+        assert "v_accvgpr_write_b32" in body, name                                                              # (the fragments are parked in AGPRs)
 
 
 def test_no_packed_fp32_valu_ops(asm):

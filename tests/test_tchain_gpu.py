@@ -209,3 +209,25 @@ def test_chain_is_the_default_of_the_throughput_schedule():
     d = max(np.abs(full - full_l).max(), np.abs(cen - cen_l).max())
     print(f"batch 464: chain (default) vs oracle {e:.3e}, vs launch chain {d:.3e}")
     assert e <= util.TOL_MAX_ABS and d <= 3e-5
+
+
+@pytest.mark.parametrize("cfgname,batch", [("h36m_81", 256), ("h36m_351", 512)])
+def test_timed_workloads_match_oracle_at_their_batch(cfgname, batch):
+    """The batches bench.py TIMES under the throughput schedule -- BASELINE configs[1] (config/h36m_81.json, batch 256: `secondary.h36m_81_batch256`)
+    and the reference's own eval BATCH_SIZE of 512 windows (`secondary.eval_batch_512`) -- straight against the oracle on six sequences taken from
+    the first, the middle and the last row tiles (metric: common/dataset/metrics.py:13-37 on what these forwards return)."""
+    from oracle import uplift_oracle as O
+    cfg = util.load_config(cfgname)
+    arch = pkg.arch_from_config(cfg)
+    w = pkg.init_weights(arch, seed=3, perturb=0.1)
+    x, m = util.synthetic_batch(cfg, batch=batch, seed=batch, mask_specs=None)                  # (the default cycle: keyframe-aligned, centre-masked and all-masked rows)
+    xm = x * m[:, :, None, None].astype(np.float32)
+    model = _model(cfg, w)
+    full, cen, _ = _forward(model, arch, xm, m, 1)
+    assert _kernels(model, arch, xm, m, 1).count("tchain") == arch.temporal_depth + 2
+    idx = [0, 1, batch // 2 - 1, batch // 2, batch - 2, batch - 1]
+    f32, c32 = O.forward(util.hp_from_arch(arch), w, xm[idx], m[idx], torch.float32)
+    e = max(np.abs(full[idx] - f32).max(), np.abs(cen[idx] - c32).max())
+    print(f"{cfgname} batch {batch}: throughput schedule vs oracle {e:.3e}")
+    assert np.isfinite(full).all() and np.isfinite(cen).all()
+    assert e <= util.TOL_MAX_ABS

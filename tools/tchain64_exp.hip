@@ -1,6 +1,6 @@
-// Round 5: the row-local chain of a temporal block in one launch (csrc/uu3d_tchain.h) against float64, and its time.
-//   hipcc -O3 -std=c++17 --offload-arch=gfx950 -Xclang -target-feature -Xclang -packed-fp32-ops -o tools/tchain_exp tools/tchain_exp.hip
-//   tools/tchain_exp [M] [iters]
+// Round 6: the temporal chain on 64-row tiles, everything on chip (csrc/uu3d_tchain64.h), against float64, and its time.
+//   hipcc -O3 -std=c++17 --offload-arch=gfx950 -Xclang -target-feature -Xclang -packed-fp32-ops -o tools/tchain64_exp tools/tchain64_exp.hip
+//   tools/tchain64_exp [M] [iters] [warm-up launches]
 #define UU3D_TC_STAMP 1
 #include <hip/hip_runtime.h>
 #include <cstdio>
@@ -15,6 +15,7 @@
 #include "../uplift-upsample-3dhpe_amd/csrc/uu3d_gemm_panel.h"
 #include "../uplift-upsample-3dhpe_amd/csrc/uu3d_gemm_panel8.h"
 #include "../uplift-upsample-3dhpe_amd/csrc/uu3d_tchain.h"
+#include "../uplift-upsample-3dhpe_amd/csrc/uu3d_tchain64.h"
 using namespace uu3d;
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %s:%d\n", hipGetErrorString(e), __FILE__, __LINE__); exit(1);} } while (0)
 
@@ -61,8 +62,8 @@ template <int FLAGS> void run(const char* tag, int M, int iters) {
     for (auto& v : pe) v = 0.02f * nd(rng);
     std::vector<float> X((size_t)M * D), O((size_t)M * D);
     for (int r = 0; r < M; ++r) { const float off = 0.3f * nd(rng), sc = 0.5f + fabsf(nd(rng)); for (int k = 0; k < D; ++k) { X[(size_t)r * D + k] = off + sc * nd(rng); O[(size_t)r * D + k] = nd(rng); } }
-    const int mt = (M + 127) / 128;
-    std::vector<_Float16> Of(panel_a_halfs(mt * 128, D), (_Float16)0.f);
+    const int mt = (M + 63) / 64;
+    std::vector<_Float16> Of(panel_a_halfs(mt * 64, D), (_Float16)0.f);
     // (the attention output arrives with the channels of a 16-slice in LANE order -- the order v had in the fragment-ordered q | k | v: tchain_qf_index)
     for (int r = 0; r < M; ++r) for (int k = 0; k < D; ++k) { const float x = O[(size_t)r * D + k]; const _Float16 h = h3_hi(x); const int w16 = k & 15; const size_t i = panel_a_index(r, (k & ~15) + 8 * ((w16 >> 2) & 1) + (((w16 >> 3) << 2) | (w16 & 3)), D); Of[i] = h; Of[i + 512] = (_Float16)((x - (float)h) * H3_SCALE); }
     // LayerNorm's affine part folded into the Dense layer behind it: W' = diag(gamma) W, b' = b + beta W
@@ -72,11 +73,19 @@ template <int FLAGS> void run(const char* tag, int M, int iters) {
         for (int k = 0; k < d.K; ++k) for (int n = 0; n < d.N; ++n) f.W[(size_t)k * d.N + n] = g[k] * d.W[(size_t)k * d.N + n];
         return f;
     };
-    const Dense w1f = fold(w1, g2, be2), wqkvf = fold(wqkv, g1, be1);
+    Dense w1f = fold(w1, g2, be2), wqkvf = fold(wqkv, g1, be1);
+    const float qscale = 1.44269504088896341f / sqrtf(48.f);
+    for (int k = 0; k < D; ++k) for (int n = 0; n < D; ++n) wqkvf.W[(size_t)k * 3 * D + n] *= qscale;     // (the 64-row kernel: q's scale folded into wq, bq)
+    for (int n = 0; n < D; ++n) wqkvf.b[n] *= qscale;
     std::vector<_Float16> W;
     if (FLAGS & TC_PROJ) wp.pack(W, 0, D, true);
     if (FLAGS & (TC_MLP | TC_FC1_PLANES)) w1f.pack(W, 0, D, false);
-    if (FLAGS & TC_MLP) { w2.pack(W, 0, D, false); w2.pack(W, D, D, false); }
+    if (FLAGS & TC_MLP) {
+        w2.pack(W, 0, D, false); w2.pack(W, D, D, false);
+        const size_t at = W.size() - (size_t)48 * TC_CHUNK_HALFS;          // W1 (24) | W2 half 0 | W2 half 1  ->  W1[0..11] | W2 half 0 | W1[12..23] | W2 half 1
+        std::vector<_Float16> tmp(W.begin() + at, W.end());
+        tchain64_reorder_mlp(tmp.data(), W.data() + at);
+    }
     if (FLAGS & TC_QKV) wqkvf.pack(W, 0, D, false);
     if (W.size() != (size_t)tchain_chunks(FLAGS) * TC_CHUNK_HALFS) { printf("stream size mismatch\n"); exit(1); }
 
@@ -87,28 +96,28 @@ template <int FLAGS> void run(const char* tag, int M, int iters) {
     a.M = M; a.m_tiles = mt; a.period = period; a.qscale = 1.44269504088896341f / sqrtf(48.f);
     a.Of = dev(Of); a.X = dev(X); a.XA = devz<float>((size_t)M * D); a.pe = dev(pe);
     a.W = dev(W); a.P = dev(P);
-    a.Q = devz<_Float16>(tchain_qf_halfs(mt));
+    a.Q = devz<_Float16>((size_t)mt * 2 * 72 * 2 * 512);
     a.H = devz<_Float16>((size_t)M * Hd * 2);
     // scratch = hidden fragments | xs | xas | trash; the launches that add into the residual stream find it there in lane-linear order
-    std::vector<unsigned char> scr(tchain_scratch_bytes(mt), 0);
-    float* xs_h = reinterpret_cast<float*>(scr.data() + (size_t)mt * TC_H_HALFS_PER_TILE * 2);
-    float* xas_h = xs_h + (size_t)mt * TC_X_FLOATS_PER_TILE;
-    for (int r = 0; r < M; ++r) for (int k = 0; k < D; ++k) { xs_h[tchain_xs_index(r, k)] = X[(size_t)r * D + k]; xas_h[tchain_xs_index(r, k)] = X[(size_t)r * D + k]; }
+    std::vector<unsigned char> scr(tchain64_scratch_bytes(mt), 0);
+    float* xs_h = reinterpret_cast<float*>(scr.data());
+    float* xas_h = xs_h + (size_t)mt * T64_X_FLOATS_PER_TILE;
+    for (int r = 0; r < M; ++r) for (int k = 0; k < D; ++k) { xs_h[tchain64_xs_index(r, k)] = X[(size_t)r * D + k]; xas_h[tchain64_xs_index(r, k)] = X[(size_t)r * D + k]; }
     a.scratch = dev(scr);
     unsigned char* scratch0 = dev(scr);
-    auto kern = tchain_kernel<FLAGS>;
-    CK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)P8_LDS_TOTAL));
+    auto kern = tchain64_kernel<FLAGS>;
+    CK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)T64_LDS_TOTAL));
     float* Xin = dev(X);
-    auto launch = [&]() { hipLaunchKernelGGL(kern, dim3(mt), dim3(512), P8_LDS_TOTAL, 0, a); };
+    auto launch = [&]() { hipLaunchKernelGGL(kern, dim3(mt), dim3(256), T64_LDS_TOTAL, 0, a); };
     launch(); CK(hipDeviceSynchronize());
     auto fetch_linear = [&](std::vector<float>& out, bool strided1) {        // the lane-linear tile copy -> row-major
         std::vector<unsigned char> sc(scr.size());
         CK(hipMemcpy(sc.data(), a.scratch, sc.size(), hipMemcpyDeviceToHost));
-        const float* base = reinterpret_cast<const float*>(sc.data() + (size_t)mt * TC_H_HALFS_PER_TILE * 2) + (strided1 ? (size_t)mt * TC_X_FLOATS_PER_TILE : 0);
-        for (int r = 0; r < M; ++r) for (int k = 0; k < D; ++k) out[(size_t)r * D + k] = base[tchain_xs_index(r, k)];
+        const float* base = reinterpret_cast<const float*>(sc.data()) + (strided1 ? (size_t)mt * T64_X_FLOATS_PER_TILE : 0);
+        for (int r = 0; r < M; ++r) for (int k = 0; k < D; ++k) out[(size_t)r * D + k] = base[tchain64_xs_index(r, k)];
     };
 
-    std::vector<float> Xo((size_t)M * D), XAo((size_t)M * D); std::vector<_Float16> Q(tchain_qf_halfs(mt)), Hp((size_t)M * Hd * 2);
+    std::vector<float> Xo((size_t)M * D), XAo((size_t)M * D); std::vector<_Float16> Q((size_t)mt * 2 * 72 * 2 * 512), Hp((size_t)M * Hd * 2);
     CK(hipMemcpy(Xo.data(), a.X, Xo.size() * 4, hipMemcpyDeviceToHost)); CK(hipMemcpy(XAo.data(), a.XA, XAo.size() * 4, hipMemcpyDeviceToHost));
     CK(hipMemcpy(Q.data(), a.Q, Q.size() * 2, hipMemcpyDeviceToHost)); CK(hipMemcpy(Hp.data(), a.H, Hp.size() * 2, hipMemcpyDeviceToHost));
     // where the launch leaves the residual stream: row-major x only when it ends the temporal stack (no QKV, or + pe); else the lane-linear tile;
@@ -127,7 +136,8 @@ template <int FLAGS> void run(const char* tag, int M, int iters) {
             if (FLAGS & TC_FC1_PLANES) for (int k = 0; k < Hd; ++k) { const double got = (double)Hp[(size_t)r * Hd + k] + (double)Hp[(size_t)M * Hd + (size_t)r * Hd + k] / 2048.0; const double e = fabs(got - hd[k]); if (e != e) ++nan; eh = std::max(eh, e); sh = std::max(sh, fabs(hd[k])); }
             else { dense(hd, w2, z); for (int k = 0; k < D; ++k) x[k] += z[k]; }
         }
-        for (int k = 0; k < D; ++k) { const double e = fabs(x[k] - Xo[(size_t)r * D + k]); if (e != e) ++nan; ex = std::max(ex, e); sx = std::max(sx, fabs(x[k])); }
+        for (int k = 0; k < D; ++k) { const double e = fabs(x[k] - Xo[(size_t)r * D + k]); if (e != e) ++nan; ex = std::max(ex, e); sx = std::max(sx, fabs(x[k]));
+            if (e > 2e-5 && getenv("DEBUG_X")) { static int shown = 0; if (shown++ < 40) printf("      x[%d][%d] got %.6f want %.6f (err %.2e)\n", r, k, Xo[(size_t)r * D + k], x[k], e); } }
         if (FLAGS & TC_QKV) {
             if (FLAGS & TC_PE) for (int k = 0; k < D; ++k) { x[k] += pe[(size_t)(r % period) * D + k]; const double e = fabs(x[k] - XAo[(size_t)r * D + k]); if (e != e) ++nan; exa = std::max(exa, e); }
             layer_norm(x, g1, be1, n); dense(n, wqkv, z);
@@ -161,7 +171,7 @@ template <int FLAGS> void run(const char* tag, int M, int iters) {
         }
         CK(hipDeviceSynchronize());
         auto t0 = std::chrono::steady_clock::now();
-        for (int it = 0; it < iters; ++it) for (int i = 0; i < nmix; ++i) hipLaunchKernelGGL(kern, dim3(mt), dim3(512), P8_LDS_TOTAL, st[i], as[i]);
+        for (int it = 0; it < iters; ++it) for (int i = 0; i < nmix; ++i) hipLaunchKernelGGL(kern, dim3(mt), dim3(256), T64_LDS_TOTAL, st[i], as[i]);
         CK(hipDeviceSynchronize());
         const double us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count();
         printf("    MIX %d streams x %d launches of %d workgroups, own weights each: %.2f us per launch-equivalent (%.2f us per %d launches side by side)\n", nmix, iters, mt, us / (iters * nmix), us / iters, nmix);
@@ -176,6 +186,9 @@ template <int FLAGS> void run(const char* tag, int M, int iters) {
             int prev = 0;
             for (int i = 1; i < 10; ++i) { if (o[2 * i] == 0 || o[2 * i] < o[2 * prev]) continue; printf(" [%d->%d] %llu", prev, i, o[2 * i] - o[2 * prev]); prev = i; }
             printf(" cycles\n");
+#ifdef UU3D_T64_CHUNK_STAMPS
+            if (o[20]) printf("            chunk 9 of QKV: wait+B %llu | first half %llu | wait+B' %llu | second half %llu   (next chunk's B entry would follow)\n", o[22] - o[20], o[24] - o[22], o[26] - o[24], o[28] - o[26]);
+#endif
         }
         std::fill(st.begin(), st.end(), 0ull); CK(hipMemcpyToSymbol(HIP_SYMBOL(tchain_stamps), st.data(), st.size() * 8));
     }

@@ -16,3 +16,9 @@ from .weights import weight_spec, init_weights, count_params  # noqa: F401
 def build_uplift_upsample_transformer(config, **kwargs):
     from .net.uplift_upsample_transformer_constructor import build_uplift_upsample_transformer as _b
     return _b(config, **kwargs)
+
+
+def library_version():
+    """``uu3d_version()`` of the loaded HIP library (a timing build, csrc/libuu3d_timing.so through UU3D_LIB, says so: bench.py refuses it)."""
+    from . import _capi
+    return _capi.load_library().uu3d_version().decode()

@@ -7,7 +7,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libuu3d.so")
+# (UU3D_LIB: another build of the same library, e.g. csrc/libuu3d_timing.so of `build.py --timing` for the marginal-cost experiments of tools/)
+LIB_PATH = os.environ.get("UU3D_LIB") or os.path.join(_HERE, "csrc", "libuu3d.so")
 
 UU3D_MAX_STRIDED = 8
 UU3D_PREC_F32 = 0

@@ -36,6 +36,7 @@
 #include "uu3d_gemm_wt.h"
 #include "uu3d_mlp_fused.h"
 #include "uu3d_tchain.h"
+#include "uu3d_tchain64.h"
 #include "uu3d_tail.h"
 #include "uu3d_attn.h"
 #include "uu3d_attn_h3.h"
@@ -128,6 +129,8 @@ struct uu3d_model {
     // 179-182 k against 171-173 k at batch 128 with four slots, 187 k with eight, 202.6 k against 180.2 k at batch 512.
     int tchain_mode = -1;          // -1 by size (tchain_min_tiles), 0 never, 1 always
     int tchain_min_tiles = 8;      // (= the 1024 rows the panel kernels ask for as well)
+    bool tchain64 = true;          // round 6: the chain on 64-row tiles with the residual stream and relu(fc1) on chip (uu3d_tchain64.h); UU3D_TCHAIN64=0: the round-5 kernel (128-row
+                                   // tiles, residual adds as float atomics) for A/B runs -- read at uu3d_create, decides the order the launches' weight streams are packed in
     bool tchain_short = true;      // the chain (and attn_h3_kernel on its fragment-ordered q | k | v, which cost no split epilogue) also below 49 tokens: h36m_81 (41 tokens),
                                    // batch 256: 337 k -> 361 k sequences/s; UU3D_TCHAIN_SHORT=0: only where attn_h3_kernel is the attention kernel anyway
     int num_cus = 256;
@@ -279,7 +282,11 @@ void pack_dense_t(std::vector<float>& buf, size_t off, const float* w, int K, in
 // =========================================================================================
 // Definitions below take C linkage from their extern "C" declarations in include/uu3d.h.
 
-const char* uu3d_version(void) { return "uu3d 0.2.0 gfx950 f16x3+f32-mfma"; }
+#ifdef UU3D_TIMING_BUILD
+const char* uu3d_version(void) { return "uu3d 0.3.0 gfx950 f16x3+f32-mfma timing-build (UU3D_SKIP / UU3D_TIMING_PARTS honoured: results can be wrong)"; }
+#else
+const char* uu3d_version(void) { return "uu3d 0.3.0 gfx950 f16x3+f32-mfma"; }
+#endif
 
 const char* uu3d_status_string(int s) {
     switch (s) {
@@ -380,7 +387,13 @@ int uu3d_create(const uu3d_config* c, int device, uu3d_model** out) {
     { const char* e = getenv("UU3D_TCHAIN"); if (e != nullptr && (e[0] == '0' || e[0] == '1')) m->tchain_mode = e[0] - '0'; }
     { const char* e = getenv("UU3D_TCHAIN_MIN_TILES"); if (e != nullptr && atoi(e) > 0) m->tchain_min_tiles = atoi(e); }
     { const char* e = getenv("UU3D_TCHAIN_SHORT"); if (e != nullptr) m->tchain_short = atoi(e) != 0; }
+    { const char* e = getenv("UU3D_TCHAIN64"); if (e != nullptr) m->tchain64 = atoi(e) != 0; }
     { hipDeviceProp_t pr; if (hipGetDeviceProperties(&pr, device) == hipSuccess && pr.multiProcessorCount > 0) m->num_cus = pr.multiProcessorCount; }
+    // (the handle's device, not the caller's current one: every later call of the library sets it as well)
+    if (hipSetDevice(device) != hipSuccess) {
+        delete m;
+        return fail(nullptr, UU3D_ERR_HIP, "hipSetDevice failed");
+    }
     if (hipMalloc((void**)&m->d_range, sizeof(int)) != hipSuccess || hipMemset(m->d_range, 0, sizeof(int)) != hipSuccess) {
         delete m;
         return fail(nullptr, UU3D_ERR_HIP, "hipMalloc of the range-guard word failed");
@@ -618,6 +631,7 @@ int uu3d_commit_weights(uu3d_model* m, void* stream_) {
 
     // ---- temporal chain (uu3d_tchain.h): per launch one parameter table (floats) and one weight stream (f16 planes, built below) ----
     // A LayerNorm's affine part is folded into the Dense layer behind it: W' = diag(gamma) W, b' = b + beta W (f64 sums).
+    const float tc_qscale = 1.44269504088896341f / sqrtf((float)(dt / std::max(1, c.num_heads)));      // = Launcher::attn_qscale(): log2(e) / sqrt(d_h)
     struct TcStage { std::vector<float> Wk; int K, N, kofs; bool natural; };        // Keras layout [K][N]
     struct TcBuild { int flags; size_t p_off; std::vector<TcStage> stages; };
     std::vector<TcBuild> tcb;
@@ -643,6 +657,7 @@ int uu3d_commit_weights(uu3d_model* m, void* stream_) {
         auto add_qkv = [&](TcBuild& tb, const std::string& p) {
             std::vector<float> Wk, b, bf; qkv_of(p, Wk, b);
             tb.stages.push_back(folded(Wk, b, W(m, p + "/norm1/gamma"), W(m, p + "/norm1/beta"), dt, 3 * dt, bf));
+            if (m->tchain64) for (int n = 0; n < dt; ++n) bf[n] *= tc_qscale;          // (the 64-row kernel: q's scale folded into wq and bq)
             std::copy_n(bf.begin(), 3 * dt, P.buf.begin() + tb.p_off + TCP_BQKV);
         };
         auto add_proj = [&](TcBuild& tb, const std::string& p) {
@@ -765,15 +780,21 @@ int uu3d_commit_weights(uu3d_model* m, void* stream_) {
             size_t o = at;
             for (auto& st : tb.stages) {
                 std::vector<_Float16> Bh((size_t)st.N * st.K), Bl((size_t)st.N * st.K);
+                const bool qkv_stage = m->tchain64 && st.N == 3 * dt;                 // (the 64-row kernel: q's scale lives in wq and bq, below)
                 for (int n = 0; n < st.N; ++n)
                     for (int k = 0; k < st.K; ++k) {
-                        const float x = st.Wk[(size_t)k * st.N + n];
+                        const float x = st.Wk[(size_t)k * st.N + n] * (qkv_stage && n < dt ? tc_qscale : 1.0f);
                         if (!(std::fabs(x) < 65504.0f)) return fail(m, UU3D_ERR_RANGE, "a LayerNorm-folded kernel of the temporal chain leaves the f16 range; build the model with precision f32");
                         const _Float16 h = h3_hi(x);
                         Bh[(size_t)n * st.K + k] = h; Bl[(size_t)n * st.K + k] = (_Float16)((x - (float)h) * H3_SCALE);
                     }
                 tchain_pack_stage(Bh.data(), Bl.data(), st.N, st.K, st.kofs, st.natural, hb.data() + o);
                 o += (size_t)(st.N / 32) * TC_CHUNK_HALFS;
+            }
+            if (m->tchain64 && (tb.flags & TC_MLP)) {                                // W1 (24 chunks) | W2 half 0 | W2 half 1  ->  W1[0..11] | W2 half 0 | W1[12..23] | W2 half 1
+                _Float16* mlp = hb.data() + at + (size_t)((tb.flags & TC_PROJ) ? 12 : 0) * TC_CHUNK_HALFS;
+                const std::vector<_Float16> tmp(mlp, mlp + (size_t)48 * TC_CHUNK_HALFS);
+                tchain64_reorder_mlp(tmp.data(), mlp);
             }
             m->tchain.push_back({tb.flags, at, tb.p_off});
         }
@@ -846,7 +867,7 @@ Workspace carve(const uu3d_model* m, int B, char* base) {
     const size_t oFl = take((rows + 1) * sizeof(int));
     const size_t oMs = take((size_t)MLPF_SLICES * rows * c.d_temporal * 4);      // fused MLP: fc2 partial sums of the three hidden slices
     const size_t oTc = take(sizeof(TailCtl));                                   // strided_tail_kernel: tickets / done counters / XCC stamps
-    const size_t oCh = !tchain_possible(c) ? 0 : take(tchain_scratch_bytes((int)((rows + 127) / 128)));
+    const size_t oCh = !tchain_possible(c) ? 0 : take(m->tchain64 ? tchain64_scratch_bytes((int)((rows + 63) / 64)) : tchain_scratch_bytes((int)((rows + 127) / 128)));
     w.bytes = off;
     if (base) {
         w.S = (float*)(base + oS); w.X = (float*)(base + oX); w.QKV = (float*)(base + oQ);
@@ -881,11 +902,17 @@ inline bool spatial_h3_pays(int frames) {
 // UU3D_SKIP=<bit mask> (TIMING EXPERIMENTS ONLY: the skipped launches leave garbage, results are wrong): which launch classes of the
 // forward are left out -- 1 spatial stack, 2 LayerNorm-fed panel GEMMs (QKV, fc1), 4 projection, 8 fused MLP, 16 attention, 32 ln_split_frag,
 // 64 ln_res_split_frag, 128 the temporal chain launches, 256 strided blocks 2.., 512 strided block 1.  tools/marginal_exp.sh prices what each class costs the pipelined step.
+// The hooks exist only in TIMING BUILDS (-DUU3D_TIMING_BUILD: `python uplift-upsample-3dhpe_amd/build.py --timing` writes csrc/libuu3d_timing.so,
+// whose uu3d_version() says so); the product library compiles them out: no environment variable can make it skip a launch.
+#ifdef UU3D_TIMING_BUILD
 inline int skip_mask() {
     static const int mask = [] { const char* e = getenv("UU3D_SKIP"); const int v = e ? atoi(e) : 0;
                                  if (v) fprintf(stderr, "[uu3d] UU3D_SKIP=%d: launches are being skipped, RESULTS ARE WRONG (timing experiment)\n", v); return v; }();
     return mask;
 }
+#else
+inline constexpr int skip_mask() { return 0; }
+#endif
 
 struct Launcher {
     uu3d_model* m;
@@ -1190,7 +1217,7 @@ struct Launcher {
     void tchain(const char* name, const uu3d_model::TcLaunch& t, int M, const _Float16* Of, float* X, float* XA, const float* pe, int period,
                 _Float16* Q, _Float16* H, unsigned char* scratch) {
         if (skip_mask() & 128) return;
-        const int mt = (M + 127) / 128;
+        const int mt = m->tchain64 ? (M + 63) / 64 : (M + 127) / 128;
         TChainArgs a{};
         a.M = M; a.m_tiles = mt; a.period = period; a.qscale = attn_qscale();
         a.Of = Of; a.X = X; a.XA = XA; a.pe = pe; a.W = m->harena + t.w_off; a.P = m->arena + t.p_off; a.Q = Q; a.H = H; a.scratch = scratch;
@@ -1199,6 +1226,18 @@ struct Launcher {
 #define UU3D_TC_LAUNCH(F) case F: { auto kern = tchain_kernel<F>; \
             static const bool once = (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)P8_LDS_TOTAL) == hipSuccess); (void)once; \
             hipLaunchKernelGGL(kern, dim3(mt), dim3(512), P8_LDS_TOTAL, stream, a); } break;
+#define UU3D_T64_LAUNCH(F) case F: { auto kern = tchain64_kernel<F>; \
+            static const bool once = (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)T64_LDS_TOTAL) == hipSuccess); (void)once; \
+            hipLaunchKernelGGL(kern, dim3(mt), dim3(256), T64_LDS_TOTAL, stream, a); } break;
+        if (m->tchain64) switch (t.flags) {
+            UU3D_T64_LAUNCH(TC_QKV)
+            UU3D_T64_LAUNCH(TC_PROJ | TC_MLP | TC_QKV)
+            UU3D_T64_LAUNCH(TC_PROJ | TC_MLP | TC_QKV | TC_PE)
+            UU3D_T64_LAUNCH(TC_PROJ | TC_MLP)
+            UU3D_T64_LAUNCH(TC_PROJ | TC_FC1_PLANES)
+            default: status = UU3D_ERR_UNSUPPORTED; m->err = "temporal chain: unknown stage set"; break;
+        }
+        else
         switch (t.flags) {
             UU3D_TC_LAUNCH(TC_QKV)
             UU3D_TC_LAUNCH(TC_PROJ | TC_MLP | TC_QKV)
@@ -1208,6 +1247,7 @@ struct Launcher {
             default: status = UU3D_ERR_UNSUPPORTED; m->err = "temporal chain: unknown stage set"; break;
         }
 #undef UU3D_TC_LAUNCH
+#undef UU3D_T64_LAUNCH
         end();
     }
     // the fused MLP's combine (x += b2 + slabs; optionally xa = x + pe) + LayerNorm + split into A fragments
@@ -1335,7 +1375,11 @@ int uu3d_forward_ex(uu3d_model* m, const float* kp2d, const uint8_t* mask, int32
     schedule &= ~UU3D_SCHEDULE_EXACT_F32;
     // TIMING EXPERIMENT (tools/tail_branch_exp.py; results wrong): 0x200 = only the launches up to the first strided block, 0x400 = only the ones behind it
     // (only with UU3D_TIMING_PARTS=1 in the environment: otherwise the bits are an invalid schedule like any other unknown value)
+#ifdef UU3D_TIMING_BUILD
     static const bool parts_ok = getenv("UU3D_TIMING_PARTS") != nullptr && atoi(getenv("UU3D_TIMING_PARTS")) != 0;
+#else
+    constexpr bool parts_ok = false;
+#endif
     const bool part_body = parts_ok && (schedule & 0x200) != 0, part_tail = parts_ok && (schedule & 0x400) != 0;
     if (parts_ok) schedule &= ~0x600;
     if (schedule != UU3D_SCHEDULE_LATENCY && schedule != UU3D_SCHEDULE_THROUGHPUT) return fail(m, UU3D_ERR_INVALID_ARGUMENT, "schedule must be UU3D_SCHEDULE_LATENCY or UU3D_SCHEDULE_THROUGHPUT");

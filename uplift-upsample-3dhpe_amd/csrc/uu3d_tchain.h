@@ -111,7 +111,7 @@ inline void tchain_pack_stage(const _Float16* Bh, const _Float16* Bl, int N, int
 typedef float f32x16s __attribute__((ext_vector_type(16)));
 
 #ifndef UU3D_TC_LOO
-#define UU3D_TC_LOO 0          // tools/tchain_exp: leave-one-out timing builds (results wrong): 1 no refill DMA, 2 no finish, 4 no exchange, 8 no mid barrier, 16 no fragment reads, 32 no MFMA, 64 plane stores coalesced, 128 no bias load, 256 transitions without memory traffic, 512 projection and fc2's first half store into a slab instead of adding atomically
+#define UU3D_TC_LOO 0          // tools/tchain_exp: leave-one-out timing builds (results wrong): 1 no refill DMA, 2 no finish, 4 no exchange, 8 no mid barrier, 16 no fragment reads, 32 no MFMA, 64 plane stores coalesced, 128 no bias load, 256 transitions without memory traffic, 512 projection and fc2's first half store into a slab instead of adding atomically, 1024 the waves of token panels 2 and 3 only refill the ring and keep the barriers (a 64-row tile's arithmetic and traffic on the 128-row skeleton)
 #endif
 #ifdef UU3D_TC_STAMP
 // tools/tchain_exp: per workgroup 16 pairs (s_memtime = shader clock ticks, s_memrealtime = 100 MHz) at the chain's stage boundaries
@@ -173,6 +173,7 @@ tchain_kernel(const TChainArgs a)
     const bool live = tok < a.M;
     const int tokc = min(tok, a.M - 1);
     const int chl = 16 * hh + 4 * g;                       // this lane's first channel inside a 32-channel chunk (second group: + 8)
+    const bool dead = (UU3D_TC_LOO & 1024) != 0 && q >= 2; // (timing builds)
 
     // ---- weight stream -> ring: as gemm_h3_panel8_kernel (half-chunk g2 = 2 G + j: k positions [6 j, 6 j + 6) of both wave groups) ----
     const unsigned wofs = (unsigned)(hh * HS * 2048 + q * 3072);
@@ -201,7 +202,7 @@ tchain_kernel(const TChainArgs a)
     h16x8 ah[HS], al[HS];                                  // the token fragments of the running stage (this wave's 12 k positions)
     h16x8 bh[3] = {}, bl[3] = {};
 #define UU3D_TC_READ(i, sb, kk) \
-    if (!(UU3D_TC_LOO & 16)) asm volatile("ds_read_b128 %0, %2 offset:%3\n\tds_read_b128 %1, %2 offset:%4" \
+    if (!(UU3D_TC_LOO & 16) && !dead) asm volatile("ds_read_b128 %0, %2 offset:%3\n\tds_read_b128 %1, %2 offset:%4" \
                  : "=&v"(bh[i]), "=&v"(bl[i]) : "v"(sb), "i"((kk) * 2048), "i"((kk) * 2048 + 1024))
 
     // ---- the finished values of one chunk, half i (j = 4 i .. 4 i + 3): own partial sum + the partner's ----
@@ -318,13 +319,13 @@ tchain_kernel(const TChainArgs a)
         for (int kk = 0; kk < 6; ++kk) {
             UU3D_TC_READ((kk + 2) % 3, sb, kk + 2);
             asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(bh[kk % 3]), "+v"(bl[kk % 3]) : "i"((UU3D_TC_LOO & 20) ? 0 : CL > 0 && (kk == 2 || kk == 3) ? 6 : 4));
-            if (UU3D_TC_LOO & 32) asm volatile("" : "+v"(x0), "+v"(x1) : "v"(bh[kk % 3]), "v"(bl[kk % 3]), "v"(ah[kk]), "v"(al[kk]));
+            if ((UU3D_TC_LOO & 32) || dead) asm volatile("" : "+v"(x0), "+v"(x1) : "v"(bh[kk % 3]), "v"(bl[kk % 3]), "v"(ah[kk]), "v"(al[kk]));
             else {
             x0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(bh[kk % 3], ah[kk], x0, 0, 0, 0);
             x1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(bh[kk % 3], al[kk], x1, 0, 0, 0);
             x1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(bl[kk % 3], ah[kk], x1, 0, 0, 0);
             }
-            if (CL > 0 && kk == 1 && !(UU3D_TC_LOO & 4)) {                       // send the other wave's half of chunk c - 1 (its MFMAs have drained by now)
+            if (CL > 0 && kk == 1 && !(UU3D_TC_LOO & 4) && !dead) {                       // send the other wave's half of chunk c - 1 (its MFMAs have drained by now)
                 f32x4 s0, s1;
 #pragma unroll
                 for (int e = 0; e < 4; ++e) { s0[e] = p0[8 + e] + p1[8 + e] * (1.0f / H3_SCALE); s1[e] = p0[12 + e] + p1[12 + e] * (1.0f / H3_SCALE); }
@@ -348,7 +349,7 @@ tchain_kernel(const TChainArgs a)
         f32x4 r0, r1;
         float rv[8];
         Keep keep;
-        if constexpr (CL > 0 && !(UU3D_TC_LOO & 4))
+        if (CL > 0 && !(UU3D_TC_LOO & 4) && !dead)
             asm volatile("ds_read_b128 %0, %2\n\tds_read_b128 %1, %2 offset:1024" : "=&v"(r0), "=&v"(r1) : "v"((unsigned)(uintptr_t)(h3_lds_void*)xpart) : "memory");
         else { r0 = f32x4{0.f, 0.f, 0.f, 0.f}; r1 = r0; }
         // The two waves of a SIMD (hh = 0 / 1 of a pair) finish the previous chunk at DIFFERENT k positions -- 7, 8 and 10, 11 -- and
@@ -366,7 +367,7 @@ tchain_kernel(const TChainArgs a)
                 else asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(bh[kk % 3]), "+v"(bl[kk % 3]), "+v"(r0), "+v"(r1));
             }
             else asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(bh[kk % 3]), "+v"(bl[kk % 3]) : "i"(young));
-            if (UU3D_TC_LOO & 32) asm volatile("" : "+v"(x0), "+v"(x1) : "v"(bh[kk % 3]), "v"(bl[kk % 3]), "v"(ah[kk]), "v"(al[kk]));
+            if ((UU3D_TC_LOO & 32) || dead) asm volatile("" : "+v"(x0), "+v"(x1) : "v"(bh[kk % 3]), "v"(bl[kk % 3]), "v"(ah[kk]), "v"(al[kk]));
             else {
             x0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(bh[kk % 3], ah[kk], x0, 0, 0, 0);
             x1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(bh[kk % 3], al[kk], x1, 0, 0, 0);
@@ -377,7 +378,7 @@ tchain_kernel(const TChainArgs a)
 #pragma unroll
                     for (int e = 0; e < 4; ++e) { rv[e] = r0[e]; rv[4 + e] = r1[e]; }
                 }
-                if (!(UU3D_TC_LOO & 2)) {
+                if (!(UU3D_TC_LOO & 2) && !dead) {
                     if (hh == 0) {
                         if (kk == 7) finish(ep, c - 1, 0, combine(p0, p1, rv, 0), sbias, keep);
                         if (kk == 8) finish(ep, c - 1, 1, combine(p0, p1, rv, 1), sbias, keep);
@@ -441,8 +442,10 @@ tchain_kernel(const TChainArgs a)
 #pragma unroll
         for (int e = 0; e < 4; ++e) { rv[e] = r0[e]; rv[4 + e] = r1[e]; }
         Keep keep;
+        if (!dead) {
         finish(ep, c, 0, combine(b0, b1, rv, 0), sbias, keep);
         finish(ep, c, 1, combine(b0, b1, rv, 1), sbias, keep);
+        }
         __builtin_amdgcn_s_barrier();                      // the exchange area is free again (the transitions keep their statistics there)
     };
 
@@ -461,6 +464,7 @@ tchain_kernel(const TChainArgs a)
     // stores), and the loads bypass the CU's vector L1 (sc0 sc1), which the atomics -- executed at L2 -- never updated.
     auto load_xs = [&](const float* t) __attribute__((always_inline)) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (dead) return;
 #pragma unroll
         for (int c = 0; c < 12; ++c)
 #pragma unroll
@@ -475,6 +479,7 @@ tchain_kernel(const TChainArgs a)
                                              "+v"(xr[8][0]), "+v"(xr[8][1]), "+v"(xr[9][0]), "+v"(xr[9][1]), "+v"(xr[10][0]), "+v"(xr[10][1]), "+v"(xr[11][0]), "+v"(xr[11][1]) :: "memory");
     };
     auto store_xs = [&](float* t) __attribute__((always_inline)) {
+        if (dead) return;
 #pragma unroll
         for (int c = 0; c < 12; ++c)
 #pragma unroll
@@ -483,6 +488,7 @@ tchain_kernel(const TChainArgs a)
                 for (int e = 0; e < 4; ++e) t[c * 4096 + i * 256 + e * 64] = xr[c][i][e];
     };
     auto load_rows = [&](const float* base) __attribute__((always_inline)) {          // (rows past M: row M - 1)
+        if (dead) return;
         const float* p = base + (size_t)tokc * 384 + chl;
 #pragma unroll
         for (int c = 0; c < 12; ++c)
@@ -490,6 +496,7 @@ tchain_kernel(const TChainArgs a)
             for (int i = 0; i < 2; ++i) xr[c][i] = *reinterpret_cast<const f32x4*>(p + 32 * c + 8 * i);
     };
     auto store_rows = [&](float* base) __attribute__((always_inline)) {
+        if (dead) return;
         float* p = row_ptr(base);
 #pragma unroll
         for (int c = 0; c < 12; ++c)
@@ -546,8 +553,10 @@ tchain_kernel(const TChainArgs a)
     if constexpr ((FLAGS & TC_PROJ) != 0) {
         const int panel = min(bm * 128 + q * 32, a.M - 1) >> 5;
         const h16x8* ap = reinterpret_cast<const h16x8*>(a.Of) + (size_t)panel * 24 * 2 * 64 + lane;
+        if (!dead) {
 #pragma unroll
         for (int s = 0; s < HS; ++s) { ah[s] = ap[((HS * hh + s) * 2 + 0) * 64]; al[s] = ap[((HS * hh + s) * 2 + 1) * 64]; }
+        }
         TC_STAMP(1);
         if constexpr ((UU3D_TC_LOO & 512) != 0 && !kStrided1) stage(std::integral_constant<int, 12>{}, TcEpSlabT<true>{xas - lane + lane * 4, a.P + TCP_BP + 16 * hh}, XS0{});
         else
@@ -573,10 +582,12 @@ tchain_kernel(const TChainArgs a)
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #pragma unroll 1
             for (int half = 0; half < 2; ++half) {
+                if (!dead) {
 #pragma unroll
                 for (int s = 0; s < HS; ++s) {
                     const h16x8* d = hsl + ((size_t)((12 * half + s) * 8 + wave) * 2) * 64;
                     ah[s] = d[0]; al[s] = d[64];
+                }
                 }
                 if (half == 0) {
                     if constexpr ((UU3D_TC_LOO & 512) != 0) stage(std::integral_constant<int, 12>{}, TcEpSlabT<false>{xas - lane + lane * 4, nullptr}, XSD{});
