@@ -20,12 +20,15 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
+TC_ROWS = 64 if os.environ.get("UU3D_TCHAIN64", "1") != "0" else 128     # token rows per workgroup of the temporal chain (csrc/uu3d_tchain64.h; UU3D_TCHAIN64=0: the round-5 kernel)
 PEAK_F32_MFMA_TFLOPS = 157.3   # /opt/skills/guides/MI355X_MICROARCH.md "Peak FP32 (matrix)"
 PEAK_F16_MFMA_TFLOPS = 2500.0  # same table, "Peak BF16/FP16 MFMA ~2.5 PF dense"
 # What the leave-one-out builds of the dominant kernel say bounds it (profiles/): `bound` above stays the roofline the FLOPs are priced
 # against (the contract's "mfma"), this is the measured limiter.
-BOUND_MEASURED = ("bytes/latency: on a full chip the chain's launch takes the same time without its MFMAs (-3 %) and 28 % less without its epilogues' memory traffic "
-                  "(residual adds at the memory side, lane-private round trips of the hidden activations, q | k | v); its bare chunk loop runs at 0.66 of the matrix pipe")
+BOUND_MEASURED = ("instruction issue of ONE wave per SIMD, and the clock the chip holds under load: leave-one-out builds of the 64-row chain with every CU busy "
+                  "(profiles/r06_tchain64.txt) -- complete 272 us, without MFMAs 231, without the epilogues' vector instructions 214, without the ring's "
+                  "LDS-DMA refills 248, bare MFMA + fragment-read loop 199 (1.33 k cycles per chunk at 1.79 GHz against 2.2 k at 1.98 GHz complete: cycles saved "
+                  "come back as a lower clock); no float atomics, no lane-private round trips: 128 MB of counter traffic per launch against 119 MB algorithmic")
 
 
 def cpu_baseline(cfg, arch, weights, x, m, budget_s=60.0):
@@ -398,7 +401,7 @@ def secondary_benchmarks(args):
 def pmc_summary_for(config, batch):
     """The committed --pmc summary that was collected on THIS workload (config, per-GPU batch), or None: counters of another
     shape say nothing about this one."""
-    names = {("h36m_351", 128): ("r05_final_pmc_summary.csv", "r04_final_pmc_summary.csv"), ("h36m_351", 512): ("r05_tchain_b512_pmc_summary.csv",),
+    names = {("h36m_351", 128): ("r06_final_pmc_summary.csv", "r06_mid_pmc_summary.csv", "r05_final_pmc_summary.csv", "r04_final_pmc_summary.csv"), ("h36m_351", 512): ("r06_b512_pmc_summary.csv", "r05_tchain_b512_pmc_summary.csv"),
              ("dense_351", 32): ("r04_final_dense351_pmc_summary.csv",), ("h36m_81", 256): ("r04_final_h36m81_pmc_summary.csv",)}.get((config, batch), ())
     for name in names:                                           # (the newest round's counters of this workload first)
         path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", name)
@@ -412,7 +415,7 @@ def symbol_filter(symbol):
     if symbol.startswith("gemm_panel8<") or symbol.startswith("gemm_panel<"):
         return ("gemm_h3_panel8_kernel" if symbol.startswith("gemm_panel8<") else "gemm_h3_panel_kernel",
                 "PanelEp" + symbol[symbol.index("<") + 1:-1] + "E")
-    return {"tchain": ("tchain_kernel",), "mlp_fused": ("mlp_fused_h3_kernel",), "gemm_wt": ("gemm_h3_wt_kernel",), "gemm_f32": ("gemm_f32_kernel",),
+    return {"tchain": ("tchain64_kernel",) if os.environ.get("UU3D_TCHAIN64", "1") != "0" else ("tchain_kernel",), "mlp_fused": ("mlp_fused_h3_kernel",), "gemm_wt": ("gemm_h3_wt_kernel",), "gemm_f32": ("gemm_f32_kernel",),
             "gemm_h3": ("gemm_h3",)}.get(symbol)
 
 
@@ -652,11 +655,11 @@ def main():
                     if it > 0 and e["kernel"] == "tchain" and e["name"][0] == "t" and e["name"].endswith(".chain"):
                         ms += e["ms"]; fls += e["flops"]; n += 1
             if n:
-                under_load = {"workgroups": (b_full * N + 127) // 128, "batch": b_full, "avg_launch_ms": round(ms / n, 5),
+                under_load = {"workgroups": (b_full * N + TC_ROWS - 1) // TC_ROWS, "rows": b_full * N, "batch": b_full, "avg_launch_ms": round(ms / n, 5),
                               "achieved": round(fls / (ms * 1e-3) / 1e12, 2), "unit": "TFLOP/s",
                               "frac": round(fls / (ms * 1e-3) / 1e12 / PEAK_F16_MFMA_TFLOPS, 4),
-                              "note": "one temporal-block launch of the chain (projection .. next block's QKV) with one workgroup on every CU: HIP events around the launches of a quiet "
-                                      f"forward of {b_full} sequences, same kernel and schedule as the timed path"}
+                              "note": "one temporal-block launch of the chain (projection .. next block's QKV) over 256 x 128 token rows = every CU busy for the whole launch: HIP events around the "
+                                      f"launches of a quiet forward of {b_full} sequences, same kernel and schedule as the timed path"}
             del xl, ml
         except Exception as e:  # pragma: no cover
             under_load = {"error": f"{type(e).__name__}: {e}"}
@@ -716,10 +719,11 @@ def main():
                                  "exact f32-input MFMA",
                          "traffic_note": "`traffic` is read from the committed counter run of this workload (profiles/, separate --pmc passes, launched eagerly under the same schedule) -- not measured in this process, which runs several hipGraphs in flight",
                          "avg_launch_ms": round(dom["ms"] / dom["n"], 5),
-                         **({"workgroups_per_launch": (B * N + 127) // 128, "cus": 256,
-                             "frac_of_occupied_cus": round(ach / (peak * min(256, (B * N + 127) // 128) / 256.0), 4),
-                             "occupancy_note": "the temporal chain runs ONE workgroup (8 waves, all of a CU's LDS) per 128 token rows: a launch of this batch occupies that many of the 256 CUs, "
-                                               "`achieved` / `frac` are the launch measured ALONE against the whole chip's peak; the timed path runs four forwards' launches side by side"}
+                         **({"workgroups_per_launch": (B * N + TC_ROWS - 1) // TC_ROWS, "cus": 256,
+                             "frac_of_occupied_cus": round(ach / (peak * min(256, (B * N + TC_ROWS - 1) // TC_ROWS) / 256.0), 4),
+                             "occupancy_note": f"the temporal chain runs ONE workgroup per {TC_ROWS} token rows and CU (64 rows: four waves of 512 registers, 152 KiB of LDS): a launch of this batch occupies "
+                                               "that many of the 256 CUs, `achieved` / `frac` are the launch measured ALONE against the whole chip's peak (`under_load`: the same launch with "
+                                               "every CU busy); the timed path runs several forwards' launches side by side"}
                             if gk == "tchain" else {}),
                          "attention": attention_roofline(agg, N, "synthetic dense-351 (NOT a shipped config)" if args.config == "dense_351" else f"config/{args.config}.json"),
                          # the four largest GEMM launch classes (the first two are within a microsecond per launch of each
