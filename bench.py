@@ -115,12 +115,13 @@ class ErrorGather:
 FORBIDDEN_ENV = ("UU3D_SKIP", "UU3D_TIMING_PARTS")
 
 
-def env_switches():
+def env_switches(timing_experiment=False):
     """Every UU3D_* variable present in this process's environment (A/B switches of the library and of this script): recorded in the
-    JSON line, so that a number measured under a switch says so; the result-changing ones are refused."""
+    JSON line, so that a number measured under a switch says so; the result-changing ones are refused (except under --timing-experiment,
+    whose line is labelled as not a result)."""
     present = {k: v for k, v in sorted(os.environ.items()) if k.startswith("UU3D_")}
     bad = [k for k in present if k in FORBIDDEN_ENV]
-    if bad:
+    if bad and not timing_experiment:
         raise SystemExit(f"bench.py refuses to run with {', '.join(bad)} set: those switches skip launches (timing experiments, results wrong)")
     return present
 
@@ -321,6 +322,37 @@ def quick_forward_bench(cfgname, batch, s_in=None, streams=1, graph=True, steps=
     return out
 
 
+def quick_model_call_bench(cfgname, batch, steps=40, warmup=5):
+    """What a caller that loops over ``model([x, mask])`` pays per call (eager launches, the LATENCY schedule, default range_guard=True:
+    one stream synchronisation + a 4-byte device-to-host copy behind every call) -- and the same loop with range_guard=False."""
+    import numpy as np
+    import torch
+    import uplift_upsample_3dhpe_amd as pkg
+    from uplift_upsample_3dhpe_amd import synthetic as util
+    cfg = util.load_config(cfgname)
+    arch = pkg.arch_from_config(cfg)
+    w = pkg.init_weights(arch, seed=0)
+    s_in = cfg.MASK_STRIDE[0] if isinstance(cfg.MASK_STRIDE, list) else cfg.MASK_STRIDE
+    x_np, m_np = util.synthetic_batch(cfg, batch, seed=1000, mask_specs=[(s_in, 0)])
+    x = torch.from_numpy(x_np * m_np[:, :, None, None].astype(np.float32)).cuda()
+    m = torch.from_numpy(m_np).cuda()
+    out = {"workload": f"config/{cfgname}.json, batch {batch}: a Python loop over model([x, mask]) (eager, latency schedule)"}
+    for guard in (True, False):
+        model = pkg.build_uplift_upsample_transformer(cfg, weights=w, range_guard=guard)
+        for _ in range(warmup):
+            model([x, m], training=False)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            model([x, m], training=False)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        out["range_guard_on" if guard else "range_guard_off"] = {"value": round(batch * steps / dt, 1), "unit": "pose-sequences/s", "ms_per_call": round(1e3 * dt / steps, 4)}
+        del model
+    torch.cuda.empty_cache()
+    return out
+
+
 def quick_train_bench(steps=50, warmup=10, batch=64):
     """BASELINE config 5 (config/h36m_351_pt.json train step: fwd + bwd + AdamW) at world size 1, for the `secondary` block."""
     import numpy as np
@@ -384,6 +416,7 @@ def secondary_benchmarks(args):
             ("with_input_copy_per_step", lambda: quick_forward_bench(args.config, args.batch, streams=max(1, args.streams_used), graph=True, copy_inputs=True)),
             ("latency_one_batch_in_flight", lambda: quick_forward_bench(args.config, args.batch, streams=1, graph=True)),
             ("eager_one_batch_in_flight", lambda: quick_forward_bench(args.config, args.batch, streams=1, graph=False)),
+            ("model_call_loop", lambda: quick_model_call_bench(args.config, args.batch)),
             ("eager_pipelined", lambda: quick_forward_bench(args.config, args.batch, streams=max(2, args.streams_used), graph=False)),
             ("h36m_81_batch256", lambda: quick_forward_bench("h36m_81", 256, streams=4)),
             ("s_in_10", lambda: quick_forward_bench(args.config, args.batch, s_in=10, streams=max(1, args.streams_used))),
@@ -419,7 +452,7 @@ def symbol_filter(symbol):
             "gemm_h3": ("gemm_h3",)}.get(symbol)
 
 
-def pmc_traffic(symbol, summary=None):
+def pmc_traffic(symbol, summary=None, grid=None):
     """HBM-side bytes per launch of a kernel symbol from the committed rocprofv3 --pmc summary of THIS workload (FETCH_SIZE x2 on
     gfx950 + WRITE_SIZE, separate --pmc passes, tools/profile_r04.sh -> tools/rocpd_summary.py; one launch = the whole batch, like
     `achieved`).  None when no summary of this workload is committed or it does not hold that symbol."""
@@ -432,6 +465,8 @@ def pmc_traffic(symbol, summary=None):
         k = r["kernel"]
         if all(w in k for w in want) and r["HBM_read_bytes_avg_x2_gfx950_corrected"] and r["HBM_write_bytes_avg"]:
             t = float(r["HBM_read_bytes_avg_x2_gfx950_corrected"]) + float(r["HBM_write_bytes_avg"])
+            if grid is not None and int(r["grid_size"]) != grid:    # (the counter run also holds the `under_load` forward's launches: another grid)
+                continue
             key = (int(r["grid_size"]), int(r["launches"]))         # the temporal-block launches: largest grid, then most launches
             if best is None or key > best[0]:
                 best = (key, t)
@@ -484,9 +519,10 @@ def main():
     ap.add_argument("--no-halves", action="store_true", help="(default since the row-panel GEMM; accepted for older scripts)")
     ap.add_argument("--force-dist", action="store_true", help="initialise the process group even at world size 1 (exercises the RCCL path)")
     ap.add_argument("--gather", default="end", choices=["end", "step"], help="N > 1: all-gather of the per-sequence error blocks -- end = one collective of every step's block behind the loop's last result (default), step = one per step on the caller's stream")
+    ap.add_argument("--timing-experiment", action="store_true", help="tools/ only: accept a timing build of the library (UU3D_LIB=.../libuu3d_timing.so) and UU3D_SKIP; the line is labelled INVALID (launches skipped, results wrong)")
     ap.add_argument("--spawn-check", action="store_true", help="ranks print their rank / world size and exit (no GPU): checks the self-spawn path")
     args = ap.parse_args()
-    switches = env_switches()                              # (raises under UU3D_SKIP / UU3D_TIMING_PARTS)
+    switches = env_switches(args.timing_experiment)        # (raises under UU3D_SKIP / UU3D_TIMING_PARTS)
 
     # `python bench.py --gpus N` without a launcher: start N ranks as CHILD processes here, before this process has
     # touched the GPU (no exec from a GPU-initialised process), and return their exit code.
@@ -527,7 +563,7 @@ def main():
             raise SystemExit(f"the all-gather of rank ids returned {rccl['ranks_seen']} for world size {world}")
     if args.mode == "train":
         return train_bench(args, world, rank, local_rank, use_dist)
-    if "timing" in pkg.library_version():
+    if "timing" in pkg.library_version() and not args.timing_experiment:
         raise SystemExit("bench.py refuses a timing build of the library (csrc/libuu3d_timing.so: launches can be skipped)")
     cfg = util.load_config(args.config)
     arch = pkg.arch_from_config(cfg)
@@ -619,6 +655,23 @@ def main():
         t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+
+    # ---- N > 1: the same loop once more with the OTHER gather mode (one all-gather per step on the caller's stream, what rounds 1-4 timed), so that
+    # scaling numbers stay comparable across rounds: reported beside the headline, never instead of it ----
+    other_gather = None
+    if use_dist and world > 1 and pipe is not None:
+        other_mode = "step" if args.gather == "end" else "end"
+        g2 = ErrorGather(other_mode, args.steps, B, J, world, "cuda", use_dist)
+        run_pipelined_steps(pipe, args.warmup, S, g2)
+        sync_all()
+        t1 = time.perf_counter()
+        run_pipelined_steps(pipe, args.steps, S, g2)
+        sync_all()
+        e2 = time.perf_counter() - t1
+        t = torch.tensor([e2], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        e2 = float(t.item())
+        other_gather = {"mode": other_mode, "value": round(world * B * args.steps / e2, 2), "unit": "pose-sequences/s", "ms_per_step": round(e2 / args.steps * 1e3, 4)}
 
     # ---- what the timed path produced for the resident batch (parity block of the JSON line; outside the timed region) ----
     hip_full = hip_central = None
@@ -713,7 +766,7 @@ def main():
                                      else "one batch after the other"},
             "roofline": {"bound": "mfma", "bound_measured": BOUND_MEASURED if gk == "tchain" else None, "kernel": f"{gk} [{dom_key}]",
                          "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s",
-                         "frac": round(ach / peak, 4), "traffic": pmc_traffic(gk, pmc_summary_for(args.config, B)),
+                         "frac": round(ach / peak, 4), "traffic": pmc_traffic(gk, pmc_summary_for(args.config, B), grid=((B * N + TC_ROWS - 1) // TC_ROWS) * (256 if TC_ROWS == 64 else 512) if gk == "tchain" else None),
                          "note": ("algorithmic 2*M*N*K FLOPs (tchain: every Dense layer the launch walks -- projection, fc1, fc2, the next block's QKV; mlp_fused: both Dense layers of the MLP, 4*M*d*h); the f16x3 kernels issue 3 f16 "
                                   "MFMA passes per product, so the matrix pipe does 3x this work (frac of pipe = 3 * frac)") if args.precision == "f16x3" else
                                  "exact f32-input MFMA",
@@ -754,9 +807,13 @@ def main():
         else:
             out["parity"] = None
         out["rccl"] = rccl
+        if args.timing_experiment:
+            out["metric"] = "TIMING EXPERIMENT, NOT A RESULT (launches may be skipped)"
+            out["INVALID_timing_experiment"] = True
         if world > 1:
             out["config"]["gather"] = ("one all-gather of every step's (B_local, J) f64 error block behind the loop's last result, inside the timed region" if args.gather == "end"
                                        else "one all-gather per step on the caller's stream")
+            out["other_gather_mode"] = other_gather           # (the same loop with the other mode: rounds 1-4 timed "step")
         if world == 1 and not args.no_secondary and args.config == "h36m_351":
             pipe = None
             args.streams_used = S

@@ -394,7 +394,7 @@ int uu3d_create(const uu3d_config* c, int device, uu3d_model** out) {
         delete m;
         return fail(nullptr, UU3D_ERR_HIP, "hipSetDevice failed");
     }
-    if (hipMalloc((void**)&m->d_range, sizeof(int)) != hipSuccess || hipMemset(m->d_range, 0, sizeof(int)) != hipSuccess) {
+    if (hipMalloc((void**)&m->d_range, 2 * sizeof(int)) != hipSuccess || hipMemset(m->d_range, 0, 2 * sizeof(int)) != hipSuccess) {      // [0] the sticky word, [1] what uu3d_range_status took
         delete m;
         return fail(nullptr, UU3D_ERR_HIP, "hipMalloc of the range-guard word failed");
     }
@@ -1712,8 +1712,8 @@ int uu3d_range_status(uu3d_model* m, void* stream, int32_t* out_flag) {
     if (!m) return UU3D_ERR_INVALID_ARGUMENT;
     HIPCHK(m, hipSetDevice(m->device));
     int h = 0;
-    HIPCHK(m, hipMemcpyAsync(&h, m->d_range, sizeof(int), hipMemcpyDeviceToHost, (hipStream_t)stream));
-    HIPCHK(m, hipMemsetAsync(m->d_range, 0, sizeof(int), (hipStream_t)stream));
+    hipLaunchKernelGGL(range_take_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, m->d_range, m->d_range + 1);      // read and clear: ONE atomic exchange
+    HIPCHK(m, hipMemcpyAsync(&h, m->d_range + 1, sizeof(int), hipMemcpyDeviceToHost, (hipStream_t)stream));
     HIPCHK(m, hipStreamSynchronize((hipStream_t)stream));
     if (out_flag) *out_flag = h != 0;
     if (h != 0) return fail(m, UU3D_ERR_RANGE, "non-finite values in a forward's outputs: activations beyond the f16 range (65504) of the f16x3 products, or non-finite inputs "

@@ -340,5 +340,7 @@ range_check_kernel(const float* __restrict__ a, const long na, const float* __re
     }
     if (__any(bad) && (threadIdx.x & 63) == 0) atomicOr(flag, 1);
 }
+// uu3d_range_status: read AND clear the sticky word in one atomic (a flag raised by another stream between a separate copy and a memset would be lost)
+static __global__ void range_take_kernel(int* __restrict__ flag, int* __restrict__ taken) { *taken = atomicExch(flag, 0); }
 
 }  // namespace uu3d

@@ -94,6 +94,8 @@ class UpliftUpsampleTransformer(object):
         if precision not in ("f32", "f16x3"):
             raise ValueError("precision must be 'f32' or 'f16x3'")
         self.precision = precision
+        # (The sticky range word is ONE per model: a guarded model(...) call must not run concurrently with a pipeline or another thread's call on
+        # the same handle -- it would take, and clear, their flag.  uu3d_range_status reads and clears it in one atomic exchange.)
         # range_guard (precision f16x3): model(...) checks its outputs after the call (one stream synchronisation) and repeats a batch whose
         # activations left the f16 range on the exact-f32 kernels -- include/uu3d.h, RANGE CONTRACT; False: the caller checks (check_range())
         self.range_guard = bool(range_guard)
@@ -408,12 +410,15 @@ class UpliftUpsampleTransformer(object):
             self._side_stream = torch.cuda.Stream(device=self.device)
         side = self._side_stream
         h = (B + 1) // 2
-        side.wait_stream(main)
-        self._forward(x[:h], stride_mask[:h] if stride_mask is not None else None,
-                      full[:h] if full is not None else None, central[:h], 0, main)
-        self._forward(x[h:], stride_mask[h:] if stride_mask is not None else None,
-                      full[h:] if full is not None else None, central[h:], 1, side)
-        main.wait_stream(side)
+
+        def run_halves(f32):
+            side.wait_stream(main)
+            self._forward(x[:h], stride_mask[:h] if stride_mask is not None else None,
+                          full[:h] if full is not None else None, central[:h], 0, main, exact_f32=f32)
+            self._forward(x[h:], stride_mask[h:] if stride_mask is not None else None,
+                          full[h:] if full is not None else None, central[h:], 1, side, exact_f32=f32)
+            main.wait_stream(side)
+        guarded(run_halves)                                # (the range guard covers both halves: the sticky word is the model's)
         return full, central
 
     def call_scheduled(self, inputs, schedule):
