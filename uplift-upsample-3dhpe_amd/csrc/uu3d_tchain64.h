@@ -216,14 +216,17 @@ tchain64_kernel(const TChainArgs a)
         } else {
             if constexpr (std::is_same<EP, T64EpHidden>::value) y = fmaxf(y, 0.f);
             if constexpr (std::is_same<EP, TcEpPlanes>::value) { if (ep.relu) y = fmaxf(y, 0.f); }
-            f.y[j] = y;
-            f.vh[j] = h3_hi(y);
+            // hi = f16(y) (v_cvt_f16_f32 by name: flushes denormal results, see h3_hi) and its float value, one asm statement (no s_nop between the two)
+            _Float16 h; float hf;
+            asm("v_cvt_f16_f32 %0, %2\n\tv_cvt_f32_f16 %1, %0" : "=&v"(h), "=v"(hf) : "v"(y));
+            f.y[j] = y - hf;
+            f.vh[j] = h;
         }
     };
     auto fin_b = [&](auto ep, const int j, Fin& f) __attribute__((always_inline)) {
         using EP = decltype(ep);
         if constexpr (!(std::is_same<EP, T64EpResidual<false>>::value || std::is_same<EP, T64EpResidual<true>>::value))
-            f.vl[j] = (_Float16)((f.y[j] - (float)f.vh[j]) * H3_SCALE);
+            f.vl[j] = (_Float16)(f.y[j] * H3_SCALE);
     };
     auto fin_store = [&](auto ep, const int cp, auto fin_tag, Fin& f) __attribute__((always_inline)) {
         using EP = decltype(ep);
@@ -263,9 +266,10 @@ tchain64_kernel(const TChainArgs a)
         // one finished value of the previous chunk: x0[k] + x1[k] / 2048, its two accumulator registers read HERE (by name: hipcc otherwise copies all 32 registers
         // of the finished accumulators into vector registers in front of the chunk's first barrier and keeps them there for half a chunk)
         auto acc = [&](const int k) __attribute__((always_inline)) -> float {
-            float a, b;
-            asm volatile("v_accvgpr_read_b32 %0, %2\n\tv_accvgpr_read_b32 %1, %3" : "=v"(a), "=v"(b) : "a"(p0[k]), "a"(p1[k]));
-            return a + b * (1.0f / H3_SCALE);
+            float a, b;                                    // (the multiply-add inside the asm: hipcc puts an s_nop behind every asm statement whose result the next instruction reads)
+            asm volatile("v_accvgpr_read_b32 %0, %2\n\tv_accvgpr_read_b32 %1, %3\n\tv_fmac_f32 %0, 0x3a000000, %1" : "=&v"(a), "=&v"(b) : "a"(p0[k]), "a"(p1[k]));
+            static_assert(H3_SCALE == 2048.0f, "0x3a000000 = 1 / 2048");
+            return a;
         };
         auto gapwork = [&](const int gp) __attribute__((always_inline)) {
             if constexpr (CL > 0 && (UU3D_T64_LOO & 2) != 0) { if (gp == 3) asm volatile("" :: "a"(p0), "a"(p1)); }      // (timing builds: the previous chunk's MFMAs stay alive)
