@@ -165,14 +165,6 @@ int uu3d_forward_attention(uu3d_model* model, const float* kp2d_dev, const uint8
 int uu3d_mpjpe(const float* pred_dev, const float* gt_dev, int32_t batch, int32_t num_keypoints,
                int32_t root_index, double* out_dev, void* stream);
 
-/* Diagnostics of the XCD-cooperative tail kernel (csrc/uu3d_tail.h; replaces the launch chain of the reference's last
- * StridedTransformerBlock + strided_temporal_fc, common/net/uplift_upsample_transformer.py:93-160,414-416) after the last
- * uu3d_forward on this workspace: synchronises the device, then returns the kernel's error word (bit 0: a bounded spin gave
- * up, bit 1: a workgroup observed data stamped by a foreign XCC id -- both must be 0), which XCC id (+1) worked on each
- * sequence group (0: the kernel did not run / the group was empty) and how many workgroups reported each XCC id. */
-int uu3d_tail_status(const uu3d_model* model, const void* workspace, int32_t batch, uint32_t* out_err,
-                     uint32_t out_owner[8], uint32_t out_census[8]);
-
 /*
  * "Next" row 3 of the scope table: the window / stride-mask generator as a gather over a RESIDENT pose table.
  * Replaces the per-sample slicing, padding, stride mask and flip of H36mSequenceGenerator
@@ -212,7 +204,7 @@ int uu3d_world_to_cam_2d(const float* world_dev, const float* cams_dev, int32_t 
  *   UU3D_SCHEDULE_THROUGHPUT: several independent batches in flight on different streams (pipeline.ForwardPipeline) -- the chip is
  *     shared between forwards, so a launch is shaped for the fewest CU-microseconds instead: the attention projection runs as 71
  *     workgroups x 12 column chunks instead of 213 x 4 (27 instead of 16 us alone, +2.4 % sequences/s with four batches in flight;
- *     DESIGN.md section 7a).
+ *     DESIGN.md section 5).
  * uu3d_forward_ex takes it as an ARGUMENT of the call (round 4): it is a property of the enqueued / captured forward, not of the
  * model, so a model(...) call on one thread and a pipeline on another never see each other's choice.  attention_out as in
  * uu3d_forward_attention (NULL: none).  uu3d_forward / uu3d_forward_attention = uu3d_forward_ex with the model's DEFAULT schedule,

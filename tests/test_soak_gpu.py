@@ -1,8 +1,8 @@
 """Soak tests of the hand-scheduled pieces: the same work many times over, every result bitwise equal to the first.
 
 * forward: the spatial stack's packed-f32 arithmetic by name relies on hand-placed hazard fences (MFMA and transcendental
-  results read by inline asm) -- a missing one reads a stale register only when the timing lines up;
-* training step: three parameter-gradient streams with event marks (DESIGN.md section 10) -- a missing cross-stream
+  results read by inline asm, docs/HISTORY.md E.12) -- a missing one reads a stale register only when the timing lines up;
+* training step: three parameter-gradient streams with event marks (DESIGN.md section 9) -- a missing cross-stream
   dependency shows up as a rare mismatch in the gradient buffer.
 The long versions are tools/soak_determinism.py (50 000 forwards: 0 mismatches), tools/soak_train_determinism.py (2 000 passes: 0) and
 tools/soak_pipeline.py (20 000 batches through the four-queue pipeline: 0; profiles/r03_soak.txt)."""

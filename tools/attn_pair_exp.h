@@ -1,7 +1,7 @@
 // tools/attn_pair_exp.h -- EXPERIMENT, not part of the library (round 3): csrc/uu3d_attn_h3.h with its per-query-tile body factored into
 // attn_h3_query_tile and attn_h3_pair_kernel added -- two heads per workgroup, the second head's K / V / Q requested before the first is
 // computed (counted vmcnt, query fragments by name into accumulation registers, raw barriers).  Correct (parity suite green when wired into
-// Launcher::attn for three key tiles), measured SLOWER: 21.5 against 18.9 us per launch at 71 tokens -- DESIGN.md section 11.
+// Launcher::attn for three key tiles), measured SLOWER: 21.5 against 18.9 us per launch at 71 tokens -- docs/HISTORY.md E.11.
 // uu3d_attn_h3.h -- temporal self-attention with f16x3 products and an online softmax over key tiles: sequences of up
 // to 416 tokens (SURVEY 8(d)'s "synthetic dense-351": 351 -> 117 -> 13 -> 1), and the shipped 71-token ones.
 //

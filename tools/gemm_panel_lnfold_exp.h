@@ -1,4 +1,4 @@
-// tools/gemm_panel_lnfold_exp.h -- EXPERIMENT RECORD: the first form of the row-panel GEMM, with the
+// tools/gemm_panel_lnfold_exp.h -- EXPERIMENT RECORD (docs/HISTORY.md E.11): the first form of the row-panel GEMM, with the
 // LayerNorm statistics + split in its own prologue (LayerNorm folded into the operand).  Superseded by
 // csrc/uu3d_gemm_panel.h + ln_split_frag_kernel; kept because the numbers quoted in DESIGN.md come from it.
 //   hipcc -O3 -std=c++17 --offload-arch=gfx950 -Xclang -target-feature -Xclang -packed-fp32-ops [-DSTAMP] [-DUU3D_PANEL_LOADALL] -o tools/gemm_panel_lnfold_exp tools/gemm_panel_lnfold_exp.hip

@@ -1,4 +1,4 @@
-// Attempt at a standalone reproducer of the packed-fp32 hazard of DESIGN.md section 12: v_pk_mul_f32 / v_pk_fma_f32 with
+// Attempt at a standalone reproducer of the packed-fp32 hazard of docs/HISTORY.md E.12: v_pk_mul_f32 / v_pk_fma_f32 with
 // op_sel broadcasts from a VGPR pair that a global_load_dwordx2 has just written, next to waves that keep the MFMA pipe and
 // the LDS busy (the situation of the f16x3 GEMM prologue).  Every lane checks the packed results against scalar arithmetic.
 #include <hip/hip_runtime.h>

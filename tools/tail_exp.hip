@@ -8,7 +8,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <vector>
-#include "uu3d_tail.h"
+#include "uu3d_tail.h"   // (moved from csrc/ to tools/ in round 6: no longer part of the library)
 
 using namespace uu3d;
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { fprintf(stderr, "%s: %s\n", #x, hipGetErrorString(e_)); exit(1); } } while (0)

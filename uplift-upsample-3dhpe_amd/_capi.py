@@ -22,7 +22,7 @@ UU3D_SCHEDULE_LATENCY, UU3D_SCHEDULE_THROUGHPUT, UU3D_SCHEDULE_EXACT_F32 = 0, 1,
 EXPORTED_SYMBOLS = (
     "uu3d_version", "uu3d_status_string", "uu3d_last_error", "uu3d_create", "uu3d_destroy",
     "uu3d_num_weights", "uu3d_weight_info", "uu3d_set_weight", "uu3d_get_weight",
-    "uu3d_commit_weights", "uu3d_workspace_bytes", "uu3d_forward", "uu3d_forward_attention", "uu3d_forward_ex", "uu3d_range_status", "uu3d_mpjpe", "uu3d_tail_status",
+    "uu3d_commit_weights", "uu3d_workspace_bytes", "uu3d_forward", "uu3d_forward_attention", "uu3d_forward_ex", "uu3d_range_status", "uu3d_mpjpe",
     "uu3d_set_schedule", "uu3d_set_profiling", "uu3d_profile_read", "uu3d_gather_windows", "uu3d_world_to_cam_2d",
     "uu3d_mpjpe_loss", "uu3d_adamw_update", "uu3d_adamw_update_guarded", "uu3d_train_nonfinite_flag", "uu3d_train_nonfinite", "uu3d_ema_update",
     "uu3d_num_params", "uu3d_train_init", "uu3d_train_repack", "uu3d_train_export",
@@ -124,8 +124,6 @@ def load_library(path=None):
     lib.uu3d_range_status.argtypes = [vp, vp, C.POINTER(i32)]
     lib.uu3d_mpjpe.restype = C.c_int
     lib.uu3d_mpjpe.argtypes = [vp, vp, i32, i32, i32, vp, vp]
-    lib.uu3d_tail_status.restype = C.c_int
-    lib.uu3d_tail_status.argtypes = [vp, vp, i32, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32 * 8), C.POINTER(C.c_uint32 * 8)]
     lib.uu3d_gather_windows.restype = C.c_int
     lib.uu3d_gather_windows.argtypes = [vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, vp, vp, vp, vp]
     lib.uu3d_world_to_cam_2d.restype = C.c_int

@@ -10,7 +10,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(CSRC, "libuu3d.so")
 SOURCES = ["uu3d_api.hip", "uu3d_ops.hip"]
-HEADERS = ["uu3d_tchain.h", "uu3d_tchain64.h", "uu3d_gemm.h", "uu3d_gemm_h3.h", "uu3d_gemm_panel.h", "uu3d_gemm_panel8.h", "uu3d_gemm_wt.h", "uu3d_mlp_fused.h", "uu3d_tail.h", "uu3d_attn.h", "uu3d_attn_h3.h", "uu3d_spatial.h", "uu3d_spatial_h3.h", "uu3d_pk.h", "uu3d_misc.h", "uu3d_train.h", "uu3d_bwd.h", "uu3d_launch.h", "uu3d_train_kernels.h", "uu3d_dropout.h", "uu3d_train_step.inc", os.path.join("..", "..", "include", "uu3d_ops.h"), os.path.join("..", "..", "include", "uu3d.h")]
+HEADERS = ["uu3d_tchain.h", "uu3d_tchain64.h", "uu3d_gemm.h", "uu3d_gemm_h3.h", "uu3d_gemm_panel.h", "uu3d_gemm_panel8.h", "uu3d_gemm_wt.h", "uu3d_mlp_fused.h", "uu3d_attn.h", "uu3d_attn_h3.h", "uu3d_spatial.h", "uu3d_spatial_h3.h", "uu3d_pk.h", "uu3d_misc.h", "uu3d_train.h", "uu3d_bwd.h", "uu3d_launch.h", "uu3d_train_kernels.h", "uu3d_dropout.h", "uu3d_train_step.inc", os.path.join("..", "..", "include", "uu3d_ops.h"), os.path.join("..", "..", "include", "uu3d.h")]
 
 
 def _fingerprint(extra_flags=()):
@@ -37,7 +37,7 @@ def _stale(lib, extra_flags=()):
 
 
 # Packed fp32 VALU ops (v_pk_mul_f32 / v_pk_fma_f32 / v_pk_add_f32) are turned OFF for the device code.
-# Measured on MI355X with ROCm 7.2: with them on, the LayerNorm prologue of the f16x3
+# Measured on MI355X with ROCm 7.2 (docs/HISTORY.md E.12): with them on, the LayerNorm prologue of the f16x3
 # GEMM came out as v_pk_mul_f32 / v_pk_fma_f32 with op_sel broadcasts from a VGPR pair, and the low half of
 # the result was intermittently 0 in lanes 48-63 -- whole output rows wrong by O(1), different on every run.
 # Without the feature the same source is bit-reproducible (tools/gemm_bench DET=1: 0 mismatches in 32 of 32

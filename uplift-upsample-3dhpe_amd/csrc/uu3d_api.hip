@@ -37,7 +37,6 @@
 #include "uu3d_mlp_fused.h"
 #include "uu3d_tchain.h"
 #include "uu3d_tchain64.h"
-#include "uu3d_tail.h"
 #include "uu3d_attn.h"
 #include "uu3d_attn_h3.h"
 #include "uu3d_spatial.h"
@@ -81,7 +80,7 @@ struct BlockDev {
     // fragment-ordered f16 planes of wqkv / w1 for the row-panel GEMM (uu3d_gemm_panel.h); offsets in harena, 0 = none
     size_t wqkv_pf = 0, w1_pf = 0;
     size_t w2_mf = 0;                  // fc2 fragments of the fused MLP kernel (uu3d_mlp_fused.h, temporal blocks), offset in harena, 0 = none
-    size_t wp_pf = 0, wc_pf = 0;       // strided blocks: fragment-ordered projection / strided-convolution operands (uu3d_tail.h), 0 = none
+    size_t wp_pf = 0;                  // fragment-ordered projection operand (row-panel GEMM), 0 = none
 };
 
 struct ProfRec {
@@ -115,8 +114,6 @@ struct uu3d_model {
     bool no_panel = false;         // UU3D_NO_PANEL=1: LayerNorm-fed GEMMs stay on the tiled kernels (A/B measurements, tests)
     bool no_panel_proj = false;    // UU3D_NO_PANEL_PROJ=1: the attention projection stays on the tiled LDS-DMA kernel
     bool throughput = false;       // uu3d_set_schedule: launches shaped for CU-microseconds (several forwards share the chip) instead of latency
-    bool no_tail = true;           // UU3D_TAIL=1 (opt-in): the last strided block + head2 as ONE XCD-cooperative launch (strided_tail_kernel) instead of a chain of 9 -- measured equal for one batch at a time and 0.7 % slower with two batches in flight (its 256 spinning workgroups hold every CU), profiles/r03_tail_ab.txt
-    size_t h2_pf = 0;              // fragment-ordered head2 operand (uu3d_tail.h), offset in harena, 0 = none
     // Temporal chain (uu3d_tchain.h; throughput schedule): one launch per temporal block for its row-local stages.  Launch 0 = LayerNorm 1 + QKV of
     // block 1; launch i (1 .. T) = projection + MLP of block i (+ LayerNorm 1 + QKV of the block behind it: temporal block i + 1, or the first strided
     // block with its positional encoding); launch T + 1 = projection + LayerNorm 2 + fc1 of the first strided block.  Empty = not available.
@@ -383,7 +380,6 @@ int uu3d_create(const uu3d_config* c, int device, uu3d_model** out) {
     { const char* e = getenv("UU3D_ATTN_F32"); m->attn_f32 = (e != nullptr && e[0] == '1'); }
     { const char* e = getenv("UU3D_NO_PANEL"); m->no_panel = (e != nullptr && e[0] == '1'); }
     { const char* e = getenv("UU3D_NO_PANEL_PROJ"); m->no_panel_proj = (e != nullptr && e[0] == '1'); }
-    { const char* e = getenv("UU3D_TAIL"); m->no_tail = !(e != nullptr && e[0] == '1'); }
     { const char* e = getenv("UU3D_TCHAIN"); if (e != nullptr && (e[0] == '0' || e[0] == '1')) m->tchain_mode = e[0] - '0'; }
     { const char* e = getenv("UU3D_TCHAIN_MIN_TILES"); if (e != nullptr && atoi(e) > 0) m->tchain_min_tiles = atoi(e); }
     { const char* e = getenv("UU3D_TCHAIN_SHORT"); if (e != nullptr) m->tchain_short = atoi(e) != 0; }
@@ -766,11 +762,6 @@ int uu3d_commit_weights(uu3d_model* m, void* stream_) {
                     m->mlpf_off[o.w2] = at;
                 }
             for (auto& o : soff) { add_panel(o.wqkv, 3 * dt); add_panel(o.w1, ht); add_panel(o.wp, dt); }
-            // the cooperative tail kernel (uu3d_tail.h) reads every operand of the last strided block and of head2 in fragment order
-            if (!soff.empty() && ht == 2 * dt) {
-                add_panel(soff.back().w2, dt, 3 * ht, round_up(3 * ht, 32));
-                add_panel(o_h2, round_up(3 * J, 32));
-            }
         }
         // temporal chain: the launches' weight streams (tchain_pack_stage: one 48 KiB chunk per 32 output channels and stage)
         m->tchain.clear();
@@ -823,7 +814,6 @@ int uu3d_commit_weights(uu3d_model* m, void* stream_) {
         { const auto it = m->panel_off.find(o.w1); b.w1_pf = (it != m->panel_off.end()) ? it->second : 0; }
         { const auto it = m->mlpf_off.find(o.w2); b.w2_mf = (!strided && it != m->mlpf_off.end()) ? it->second : 0; }
         { const auto it = m->panel_off.find(o.wp); b.wp_pf = (it != m->panel_off.end()) ? it->second : 0; }
-        { const auto it = m->panel_off.find(o.w2); b.wc_pf = (strided && it != m->panel_off.end()) ? it->second : 0; }
         return b;
     };
     m->tblocks.clear(); m->sblocks.clear();
@@ -831,7 +821,6 @@ int uu3d_commit_weights(uu3d_model* m, void* stream_) {
     for (auto& o : soff) m->sblocks.push_back(view(o, true));
     m->h1_wt = has_h1 ? A + o_h1 : nullptr; m->h1_b = has_h1 ? A + o_h1b : nullptr;
     m->h2_wt = A + o_h2; m->h2_b = A + o_h2b;
-    { const auto it = m->panel_off.find(o_h2); m->h2_pf = (it != m->panel_off.end()) ? it->second : 0; }
     m->committed = true;
     return UU3D_OK;
 }
@@ -842,7 +831,6 @@ struct Workspace {
     float *S, *X, *QKV, *O, *Hb, *XA, *XB, *slab, *mslab;
     unsigned char* tc_scratch;     // temporal chain: lane-linear partial-result slabs, hidden fragments, trash page (tchain_scratch_bytes)
     int* frame_list;
-    TailCtl* tail_ctl;
     float2* stats;
     size_t slab_floats;
     size_t bytes;
@@ -866,13 +854,12 @@ Workspace carve(const uu3d_model* m, int B, char* base) {
     const size_t oSl = take(w.slab_floats * 4);
     const size_t oFl = take((rows + 1) * sizeof(int));
     const size_t oMs = take((size_t)MLPF_SLICES * rows * c.d_temporal * 4);      // fused MLP: fc2 partial sums of the three hidden slices
-    const size_t oTc = take(sizeof(TailCtl));                                   // strided_tail_kernel: tickets / done counters / XCC stamps
     const size_t oCh = !tchain_possible(c) ? 0 : take(m->tchain64 ? tchain64_scratch_bytes((int)((rows + 63) / 64)) : tchain_scratch_bytes((int)((rows + 127) / 128)));
     w.bytes = off;
     if (base) {
         w.S = (float*)(base + oS); w.X = (float*)(base + oX); w.QKV = (float*)(base + oQ);
         w.O = (float*)(base + oO); w.Hb = (float*)(base + oH); w.XA = (float*)(base + oA);
-        w.XB = (float*)(base + oB); w.stats = (float2*)(base + oT); w.slab = (float*)(base + oSl); w.frame_list = (int*)(base + oFl); w.mslab = (float*)(base + oMs); w.tail_ctl = (TailCtl*)(base + oTc);
+        w.XB = (float*)(base + oB); w.stats = (float2*)(base + oT); w.slab = (float*)(base + oSl); w.frame_list = (int*)(base + oFl); w.mslab = (float*)(base + oMs);
         w.tc_scratch = !tchain_possible(c) ? nullptr : (unsigned char*)(base + oCh);
     }
     return w;
@@ -901,7 +888,7 @@ inline bool spatial_h3_pays(int frames) {
 
 // UU3D_SKIP=<bit mask> (TIMING EXPERIMENTS ONLY: the skipped launches leave garbage, results are wrong): which launch classes of the
 // forward are left out -- 1 spatial stack, 2 LayerNorm-fed panel GEMMs (QKV, fc1), 4 projection, 8 fused MLP, 16 attention, 32 ln_split_frag,
-// 64 ln_res_split_frag, 128 the temporal chain launches, 256 strided blocks 2.., 512 strided block 1.  tools/marginal_exp.sh prices what each class costs the pipelined step (DESIGN.md section 7a).
+// 64 ln_res_split_frag, 128 the temporal chain launches, 256 strided blocks 2.., 512 strided block 1.  tools/marginal_exp.sh prices what each class costs the pipelined step (DESIGN.md section 5).
 // The hooks exist only in TIMING BUILDS (-DUU3D_TIMING_BUILD: `python uplift-upsample-3dhpe_amd/build.py --timing` writes csrc/libuu3d_timing.so,
 // whose uu3d_version() says so); the product library compiles them out: no environment variable can make it skip a launch.
 #ifdef UU3D_TIMING_BUILD
@@ -1614,7 +1601,6 @@ int uu3d_forward_ex(uu3d_model* m, const float* kp2d, const uint8_t* mask, int32
     }
     // 5. strided blocks
     float* xa = w.XA; float* xb = w.XB;
-    bool tail_done = false;
     if (c.temporal_depth == 0 && c.num_strided > 0) {      // no temporal block whose epilogue adds the first strided PE (u_u_t.py:382-383)
         Lh.begin("s1.add_pe", "add_pe", 0.0, 12.0 * M * dt);
         hipLaunchKernelGGL(add_period_kernel, dim3((unsigned)(((size_t)M * dt / 4 + 255) / 256)), dim3(256), 0, Lh.stream, w.X, m->sblocks[0].pe, M, dt, N, w.XA);
@@ -1625,32 +1611,6 @@ int uu3d_forward_ex(uu3d_model* m, const float* kp2d, const uint8_t* mask, int32
         const int Li = m->L[i], Lo = m->L[i + 1], Mi = B * Li, Mo = B * Lo;
         if (((skip_mask() & 256) || part_body) && i >= 1) continue;       // (timing experiments: the strided blocks behind the first / 512: the first)
         if (((skip_mask() & 512) || part_tail) && i == 0) { std::swap(xa, xb); xb = w.XA; continue; }
-        // the last strided block + head2 as ONE launch of XCD-cooperative workgroups (uu3d_tail.h) when the block is small: few
-        // rows make every launch of the chain a bare memory round trip (h36m_351 at batch 128: 9 launches, 76 us)
-        // (never under the throughput schedule: its 256 workgroups spin on every CU while other forwards need them, and can then time out)
-        if (i >= 1 && i + 1 == c.num_strided && planes && !m->no_tail && !Lh.throughput && dt == 384 && ht == 768 && Li <= tail::MAX_L && Mi <= 1024 &&
-            b.wqkv_pf != 0 && b.w1_pf != 0 && b.wp_pf != 0 && b.wc_pf != 0 && m->h2_pf != 0) {
-            TailParams tp{};
-            tp.B = B; tp.G = (B + TAIL_GROUPS - 1) / TAIL_GROUPS;
-            tp.L_in = Li; tp.L_out = Lo; tp.stride = c.strides[i]; tp.pad_left = c.pad_left[i];
-            tp.res_lo = (c.strides[i] > 1 && c.pad_left[i] == 0) ? 1 : 0;
-            tp.n_out = 3 * J;
-            tp.x = xa; tp.qkv = w.QKV; tp.o = w.O; tp.hb = w.Hb; tp.part = w.slab; tp.out = central_out;
-            tp.ln1_g = b.ln1_g; tp.ln1_b = b.ln1_b; tp.bqkv = b.bqkv; tp.bp = b.bp; tp.ln2_g = b.ln2_g; tp.ln2_b = b.ln2_b;
-            tp.b1 = b.b1; tp.b2 = b.b2; tp.bh = m->h2_b;
-            tp.wqkv_f = m->harena + b.wqkv_pf; tp.wp_f = m->harena + b.wp_pf; tp.w1_f = m->harena + b.w1_pf;
-            tp.wc_f = m->harena + b.wc_pf; tp.wh_f = m->harena + m->h2_pf;
-            tp.ctl = w.tail_ctl;
-            const double fl = 2.0 * Mi * (double)dt * (3 * dt + dt + ht) + 4.0 * B * (double)c.num_heads * Li * Li * kDH + 2.0 * Mo * (double)dt * 3 * ht + 2.0 * Mo * (double)dt * 3 * J;
-            snprintf(nm, sizeof nm, "s%d.tail_head2", i + 1);
-            Lh.begin(nm, "strided_tail", fl, 4.0 * ((double)dt * (3 * dt + dt + ht + 3 * ht + 3 * J) + (double)Mi * dt));
-            (void)hipMemsetAsync(w.tail_ctl, 0, sizeof(TailCtl), Lh.stream);
-            { static const bool once = (hipFuncSetAttribute((const void*)strided_tail_kernel_t<false>, hipFuncAttributeMaxDynamicSharedMemorySize, tail::LDS_BYTES) == hipSuccess); (void)once; }
-            hipLaunchKernelGGL(strided_tail_kernel_t<false>, dim3(m->num_cus), dim3(256), tail::LDS_BYTES, Lh.stream, tp);
-            Lh.end();
-            tail_done = true;
-            break;
-        }
         // MaxPool1D(pool 1, stride s) on the trimmed sequence; stride 1 keeps x untrimmed (u_u_t.py:138-154)
         const int lo = (c.strides[i] > 1 && c.pad_left[i] == 0) ? 1 : 0;
         const EpConvResidual ep_conv{xb, b.b2, dt, xa, Li, Lo, c.strides[i], lo,
@@ -1679,7 +1639,7 @@ int uu3d_forward_ex(uu3d_model* m, const float* kp2d, const uint8_t* mask, int32
         if (i == 0) xb = w.XA;   // XA (B*N rows) is free again; XB only needs B*L_1 rows
     }
     // 6. head2
-    if (!tail_done && !part_body) {
+    if (!part_body) {
         // no strided blocks: the central token x[:, N // 2] (u_u_t.py:411-413) = row N / 2 of every sequence, leading dimension N d_t
         ALoadPlain al{c.num_strided > 0 ? xa : w.X + (size_t)(N / 2) * dt, c.num_strided > 0 ? dt : N * dt, B, dt};
         EpBias ep{central_out, m->h2_b, 3 * J};
@@ -1725,16 +1685,6 @@ int uu3d_mpjpe(const float* pred, const float* gt, int32_t B, int32_t J, int32_t
     if (!pred || !gt || !out || B < 1 || J < 1 || root < 0 || root >= J) return UU3D_ERR_INVALID_ARGUMENT;
     hipLaunchKernelGGL(mpjpe_kernel, dim3((B * J + 255) / 256), dim3(256), 0, (hipStream_t)stream, pred, gt, B, J, root, out);
     return hipGetLastError() == hipSuccess ? UU3D_OK : UU3D_ERR_HIP;
-}
-
-int uu3d_tail_status(const uu3d_model* m, const void* workspace, int32_t batch, uint32_t* err, uint32_t owner[8], uint32_t census[8]) {
-    if (!m || !workspace || batch < 1) return UU3D_ERR_INVALID_ARGUMENT;
-    const Workspace w = carve(m, batch, (char*)const_cast<void*>(workspace));
-    TailCtl h;
-    if (hipDeviceSynchronize() != hipSuccess || hipMemcpy(&h, w.tail_ctl, sizeof h, hipMemcpyDeviceToHost) != hipSuccess) return UU3D_ERR_HIP;
-    if (err) *err = h.err;
-    for (int i = 0; i < 8; ++i) { if (owner) owner[i] = h.owner[i]; if (census) census[i] = h.census[i]; }
-    return UU3D_OK;
 }
 
 int uu3d_gather_windows(const float* poses, const int64_t* video_start, const int32_t* video_len, const uu3d_window* windows,

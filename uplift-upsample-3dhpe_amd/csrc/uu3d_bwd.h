@@ -789,7 +789,7 @@ attn_generic_bwd_kernel(const float* __restrict__ qkv, const float* __restrict__
 // The spatial stack's attention backward: L = 17 joints, head dim 4, no key mask -- attn_generic_bwd_kernel<4> with every
 // loop unrolled over a compile-time L, the probability / dS rows of a query in REGISTERS, K / V / Q / dO rows read as 16-byte
 // LDS broadcasts in batches, and P^T / dS^T written to LDS once for the per-key pass.  Same arithmetic order as the generic
-// kernel (bitwise equal results); 45.8 -> see DESIGN.md section 10.  `pack` (sequence, head) pairs per workgroup of 128 threads.
+// kernel (bitwise equal results); 45.8 -> see DESIGN.md section 9.  `pack` (sequence, head) pairs per workgroup of 128 threads.
 template <int L>
 __host__ __device__ inline constexpr size_t attn_small_bwd_lds_bytes() { return (size_t)(4 * L * 4 + 2 * L * ((L + 3) / 4 * 4)) * sizeof(float); }
 template <int L>

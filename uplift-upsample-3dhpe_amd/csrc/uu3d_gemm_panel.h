@@ -24,7 +24,7 @@
 // Grid: (M / 128) row tiles x S column ranges of N / (32 S) chunks each, launched as (8 S, ceil(ceil(items / 8) / S)).  Measured (tools/gemm_panel_exp): see DESIGN.md.
 // Forms that measured slower and live in tools/ now: LayerNorm statistics + split in the kernel's own prologue
 // (tools/gemm_panel_lnfold_exp.h), LayerNorm folded into the operand with producer-side fragment stores ("LNF") and the
-// accumulating variant for the residual Dense layers (git history of round 1).
+// accumulating variant for the residual Dense layers (git history of round 1; docs/HISTORY.md E.11).
 #pragma once
 #include "uu3d_gemm_h3.h"
 #include <type_traits>

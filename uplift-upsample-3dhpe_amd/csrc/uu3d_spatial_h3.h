@@ -34,7 +34,7 @@
 //     - attention pairs KEYS instead: K and V sit in LDS as [frame][key pair][channel][2], so (logit j, logit j + 1) =
 //       sum_c (q_c, q_c) * (k_jc, k_j+1,c) and the P V sums run over even / odd keys in the two halves;
 //     - none of these instructions carries op_sel / op_sel_hi: the form that loses an operand next to a busy matrix pipe
-//        reads the OTHER half of a register pair, which only those modifiers do.  hipcc itself
+//       (docs/HISTORY.md E.12) reads the OTHER half of a register pair, which only those modifiers do.  hipcc itself
 //       still never emits packed f32 (target feature off); tests/test_isa_cpu.py pins both facts.
 #pragma once
 #include <hip/hip_runtime.h>
@@ -165,7 +165,7 @@ __device__ __forceinline__ void mm(const WFrag<NT, KK>& w, const _Float16* Bh, c
 // v[l] + v[l ^ 32] with v = p.x + p.y, in every lane: one v_permlane32_swap (lanes 32..63 of the first operand <-> lanes 0..31 of the second)
 // instead of a ds_bpermute round trip through LDS
 // The pair's own two halves are added by name: left to hipcc, "p.x + p.y, twice" (the swap consumes two copies) becomes ONE
-// v_pk_add_f32 with op_sel:[0,1] op_sel_hi:[1,0] -- the cross-half form this kernel must not contain.
+// v_pk_add_f32 with op_sel:[0,1] op_sel_hi:[1,0] -- the cross-half form this kernel must not contain (docs/HISTORY.md E.12).
 __device__ __forceinline__ float sum_halves(const f32x2 p) {
     typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
     float v;

@@ -457,19 +457,6 @@ class UpliftUpsampleTransformer(object):
         replay.pipeline = pipe
         return replay
 
-    def tail_status(self, batch, slot=0):
-        """Diagnostics of the XCD-cooperative tail kernel after the last forward of ``batch`` sequences (uu3d_tail_status):
-        dict(err, owner[8], census[8]); err must be 0 (bit 0: spin timeout, bit 1: foreign XCC id observed)."""
-        ws = self._ws.get(slot)
-        if ws is None:
-            raise RuntimeError("no forward has run on this workspace slot")
-        err = C.c_uint32()
-        owner, census = (C.c_uint32 * 8)(), (C.c_uint32 * 8)()
-        _capi.check(self._lib, self._lib.uu3d_tail_status(self._h, C.c_void_p(ws.data_ptr()), int(batch), C.byref(err),
-                                                          C.byref(owner), C.byref(census)), self._h)
-        return dict(err=int(err.value), owner=[int(v) for v in owner], census=[int(v) for v in census])
-
-    # ---- profiling -------------------------------------------------------------------------
     def set_profiling(self, enabled):
         self._profiling = bool(enabled)          # per-launch events time one chain, so the batch is not split
         _capi.check(self._lib, self._lib.uu3d_set_profiling(self._h, int(bool(enabled))), self._h)
