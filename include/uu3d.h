@@ -196,7 +196,7 @@ int uu3d_world_to_cam_2d(const float* world_dev, const float* cams_dev, int32_t 
 /*
  * The schedule of a forward: what its launch shapes are chosen for.  Below 1024 token rows (B * N) the results are bit-identical either
  * way (the same products per element, computed by other workgroups); from 1024 rows on the throughput schedule takes the temporal chain
- * (csrc/uu3d_tchain.h, round 5: one launch per temporal block for every row-local stage -- other summation orders and LayerNorm's affine part
+ * (csrc/uu3d_tchain64.h, rounds 5-6: one launch per temporal block for every row-local stage, residual stream and relu(fc1) on chip -- other summation orders and LayerNorm's affine part
  * folded into the next layer's weights: within 3e-5 of the latency schedule (measured 4e-6), same 1e-4 bar against the oracle; deterministic run
  * to run; return_attention keeps the round-4 launches.  UU3D_TCHAIN=0 in the environment of uu3d_create: never; UU3D_TCHAIN_MIN_TILES=n: from n
  * row tiles of 128 tokens on).

@@ -194,7 +194,7 @@ def test_concurrent_half_batches_option(cfgname, batch):
     assert np.abs(f1 - f2).max() <= 2e-5 and np.abs(c1 - c2).max() <= 2e-5
 
 
-@pytest.mark.parametrize("env", ["UU3D_NO_PANEL", "UU3D_NO_PLANES", "UU3D_ATTN_WG", "UU3D_NO_WT", "UU3D_ATTN_F32", "UU3D_NO_MLPF", "UU3D_TAIL", "UU3D_NO_PANEL_PROJ"])
+@pytest.mark.parametrize("env", ["UU3D_NO_PANEL", "UU3D_NO_PLANES", "UU3D_ATTN_WG", "UU3D_NO_WT", "UU3D_ATTN_F32", "UU3D_NO_MLPF", "UU3D_NO_PANEL_PROJ"])
 def test_optional_kernel_paths_agree(env, monkeypatch):
     """The opt-out switches kept for A/B measurements at the full h36m_351 batch, where every one of them
     changes the kernels that run: same results as the product path to rounding.  (The round-1 experiments that measured
