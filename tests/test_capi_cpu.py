@@ -60,3 +60,35 @@ def test_missing_library_fails_loudly(tmp_path):
     from uplift_upsample_3dhpe_amd import _capi
     with pytest.raises(_capi.Uu3dLibraryError):
         _capi.load_library(str(tmp_path / "nope.so"))
+
+
+def test_product_library_has_no_timing_hooks_and_the_bench_refuses_them(lib, monkeypatch):
+    """Round 6: UU3D_SKIP / UU3D_TIMING_PARTS (launches left out, results wrong) exist only in a -DUU3D_TIMING_BUILD library whose version
+    string says so; the product library does not even contain the variable names, and bench.py refuses to produce a line under them."""
+    import bench
+    from uplift_upsample_3dhpe_amd import _capi
+    assert "timing" not in lib.uu3d_version().decode()
+    blob = open(_capi.LIB_PATH, "rb").read()
+    assert b"UU3D_SKIP" not in blob and b"UU3D_TIMING_PARTS" not in blob
+    monkeypatch.setenv("UU3D_TCHAIN64", "0")
+    assert bench.env_switches() == {"UU3D_TCHAIN64": "0"}                      # A/B switches are recorded ...
+    monkeypatch.setenv("UU3D_SKIP", "128")
+    with pytest.raises(SystemExit):                                            # ... result-changing ones refused
+        bench.env_switches()
+    assert "UU3D_SKIP" in bench.env_switches(timing_experiment=True)           # (tools/marginal_r06.sh: the line is labelled INVALID)
+
+
+def test_build_is_keyed_by_content_not_by_file_times(tmp_path):
+    """build.py rebuilds unless the fingerprint next to the library matches the sources (sha256 over sources, headers, flags, hipcc version)."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("uu3d_build_t", os.path.join(util.ROOT, "uplift-upsample-3dhpe_amd", "build.py"))
+    b = importlib.util.module_from_spec(spec); spec.loader.exec_module(b)
+    assert not b._stale(b.LIB)                                                 # (the fixture built it)
+    assert b._fingerprint() != b._fingerprint(("-DUU3D_TIMING_BUILD",))
+    stamp = b.LIB + ".sha256"
+    good = open(stamp).read()
+    try:
+        open(stamp, "w").write("0" * 64 + "\n")
+        assert b._stale(b.LIB)                                                 # a binary of other sources passes for stale whatever its mtime
+    finally:
+        open(stamp, "w").write(good)
