@@ -1,0 +1,18 @@
+#!/bin/bash
+# gpurun -- 'bash tools/ab_tchain16.sh': the pipelined bench with the three forms of the temporal chain, alternating on one box:
+# 16 = eight waves on 16-token panels (default), 64 = four waves of 512 registers (UU3D_TCHAIN16=0), 128 = the round-5 kernel (UU3D_TCHAIN64=0)
+run() { python bench.py --no-cpu-baseline --no-secondary --steps ${STEPS:-200} --warmup 20 "$@" 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.readlines()[-1]); print('%.1f k seq/s  %.4f ms/step' % (d['value']/1e3, d['ms_per_step']))"; }
+for rep in 1 2 3; do
+  echo "8 waves x 16 tokens : $(run)"
+  echo "4 waves x 32 tokens : $(UU3D_TCHAIN16=0 run)"
+  echo "128-row (round 5)   : $(UU3D_TCHAIN64=0 run)"
+done
+for rep in 1 2; do
+  echo "8 waves x 16 tokens , 20 steps: $(STEPS=20 run --warmup 5)"
+  echo "4 waves x 32 tokens , 20 steps: $(STEPS=20 UU3D_TCHAIN16=0 run --warmup 5)"
+  echo "128-row (round 5)   , 20 steps: $(STEPS=20 UU3D_TCHAIN64=0 run --warmup 5)"
+done
+echo "8 waves x 16 tokens , batch 512 x 4: $(run --batch 512 --streams 4 --steps 50)"
+echo "128-row (round 5)   , batch 512 x 4: $(UU3D_TCHAIN64=0 run --batch 512 --streams 4 --steps 50)"
+echo "8 waves x 16 tokens , h36m_81 b256 x 4: $(run --config h36m_81 --batch 256 --streams 4)"
+echo "128-row (round 5)   , h36m_81 b256 x 4: $(UU3D_TCHAIN64=0 run --config h36m_81 --batch 256 --streams 4)"

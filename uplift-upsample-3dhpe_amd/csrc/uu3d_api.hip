@@ -37,6 +37,7 @@
 #include "uu3d_mlp_fused.h"
 #include "uu3d_tchain.h"
 #include "uu3d_tchain64.h"
+#include "uu3d_tchain16.h"
 #include "uu3d_attn.h"
 #include "uu3d_attn_h3.h"
 #include "uu3d_spatial.h"
@@ -128,6 +129,8 @@ struct uu3d_model {
     int tchain_min_tiles = 8;      // (= the 1024 rows the panel kernels ask for as well)
     bool tchain64 = true;          // round 6: the chain on 64-row tiles with the residual stream and relu(fc1) on chip (uu3d_tchain64.h); UU3D_TCHAIN64=0: the round-5 kernel (128-row
                                    // tiles, residual adds as float atomics) for A/B runs -- read at uu3d_create, decides the order the launches' weight streams are packed in
+    bool tchain16 = true;          // the 64-row chain as EIGHT waves on 16-token panels (uu3d_tchain16.h: v_mfma_f32_16x16x32_f16, two waves per SIMD); UU3D_TCHAIN16=0: four waves of
+                                   // 512 registers on 32-token panels (uu3d_tchain64.h) -- read at uu3d_create: the two forms pack the weight stream differently
     bool tchain_short = true;      // the chain (and attn_h3_kernel on its fragment-ordered q | k | v, which cost no split epilogue) also below 49 tokens: h36m_81 (41 tokens),
                                    // batch 256: 337 k -> 361 k sequences/s; UU3D_TCHAIN_SHORT=0: only where attn_h3_kernel is the attention kernel anyway
     int num_cus = 256;
@@ -384,6 +387,8 @@ int uu3d_create(const uu3d_config* c, int device, uu3d_model** out) {
     { const char* e = getenv("UU3D_TCHAIN_MIN_TILES"); if (e != nullptr && atoi(e) > 0) m->tchain_min_tiles = atoi(e); }
     { const char* e = getenv("UU3D_TCHAIN_SHORT"); if (e != nullptr) m->tchain_short = atoi(e) != 0; }
     { const char* e = getenv("UU3D_TCHAIN64"); if (e != nullptr) m->tchain64 = atoi(e) != 0; }
+    { const char* e = getenv("UU3D_TCHAIN16"); if (e != nullptr) m->tchain16 = atoi(e) != 0; }
+    if (!m->tchain64) m->tchain16 = false;
     { hipDeviceProp_t pr; if (hipGetDeviceProperties(&pr, device) == hipSuccess && pr.multiProcessorCount > 0) m->num_cus = pr.multiProcessorCount; }
     // (the handle's device, not the caller's current one: every later call of the library sets it as well)
     if (hipSetDevice(device) != hipSuccess) {
@@ -779,7 +784,8 @@ int uu3d_commit_weights(uu3d_model* m, void* stream_) {
                         const _Float16 h = h3_hi(x);
                         Bh[(size_t)n * st.K + k] = h; Bl[(size_t)n * st.K + k] = (_Float16)((x - (float)h) * H3_SCALE);
                     }
-                tchain_pack_stage(Bh.data(), Bl.data(), st.N, st.K, st.kofs, st.natural, hb.data() + o);
+                if (m->tchain16) tchain16_pack_stage(Bh.data(), Bl.data(), st.N, st.K, st.kofs, st.natural, hb.data() + o);
+                else tchain_pack_stage(Bh.data(), Bl.data(), st.N, st.K, st.kofs, st.natural, hb.data() + o);
                 o += (size_t)(st.N / 32) * TC_CHUNK_HALFS;
             }
             if (m->tchain64 && (tb.flags & TC_MLP)) {                                // W1 (24 chunks) | W2 half 0 | W2 half 1  ->  W1[0..11] | W2 half 0 | W1[12..23] | W2 half 1
@@ -1216,7 +1222,18 @@ struct Launcher {
 #define UU3D_T64_LAUNCH(F) case F: { auto kern = tchain64_kernel<F>; \
             static const bool once = (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)T64_LDS_TOTAL) == hipSuccess); (void)once; \
             hipLaunchKernelGGL(kern, dim3(mt), dim3(256), T64_LDS_TOTAL, stream, a); } break;
-        if (m->tchain64) switch (t.flags) {
+#define UU3D_T16_LAUNCH(F) case F: { auto kern = tchain16_kernel<F>; \
+            static const bool once = (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)T16_LDS_TOTAL) == hipSuccess); (void)once; \
+            hipLaunchKernelGGL(kern, dim3(mt), dim3(512), T16_LDS_TOTAL, stream, a); } break;
+        if (m->tchain16) switch (t.flags) {
+            UU3D_T16_LAUNCH(TC_QKV)
+            UU3D_T16_LAUNCH(TC_PROJ | TC_MLP | TC_QKV)
+            UU3D_T16_LAUNCH(TC_PROJ | TC_MLP | TC_QKV | TC_PE)
+            UU3D_T16_LAUNCH(TC_PROJ | TC_MLP)
+            UU3D_T16_LAUNCH(TC_PROJ | TC_FC1_PLANES)
+            default: status = UU3D_ERR_UNSUPPORTED; m->err = "temporal chain: unknown stage set"; break;
+        }
+        else if (m->tchain64) switch (t.flags) {
             UU3D_T64_LAUNCH(TC_QKV)
             UU3D_T64_LAUNCH(TC_PROJ | TC_MLP | TC_QKV)
             UU3D_T64_LAUNCH(TC_PROJ | TC_MLP | TC_QKV | TC_PE)
@@ -1235,6 +1252,7 @@ struct Launcher {
         }
 #undef UU3D_TC_LAUNCH
 #undef UU3D_T64_LAUNCH
+#undef UU3D_T16_LAUNCH
         end();
     }
     // the fused MLP's combine (x += b2 + slabs; optionally xa = x + pe) + LayerNorm + split into A fragments
