@@ -20,7 +20,10 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
-TC_ROWS = 64 if os.environ.get("UU3D_TCHAIN64", "1") != "0" else 128     # token rows per workgroup of the temporal chain (csrc/uu3d_tchain64.h; UU3D_TCHAIN64=0: the round-5 kernel)
+# The temporal chain's kernel: token rows and threads per workgroup (csrc/uu3d_tchain16.h: 64 rows on eight waves; UU3D_TCHAIN16=0: uu3d_tchain64.h, four waves;
+# UU3D_TCHAIN64=0: the round-5 kernel, 128 rows on eight waves)
+TC_ROWS, TC_THREADS, TC_KERNEL = ((128, 512, "tchain_kernel") if os.environ.get("UU3D_TCHAIN64", "1") == "0" else
+                                   (64, 256, "tchain64_kernel") if os.environ.get("UU3D_TCHAIN16", "1") == "0" else (64, 512, "tchain16_kernel"))
 PEAK_F32_MFMA_TFLOPS = 157.3   # /opt/skills/guides/MI355X_MICROARCH.md "Peak FP32 (matrix)"
 PEAK_F16_MFMA_TFLOPS = 2500.0  # same table, "Peak BF16/FP16 MFMA ~2.5 PF dense"
 # What the leave-one-out builds of the dominant kernel say bounds it (profiles/): `bound` above stays the roofline the FLOPs are priced
@@ -448,7 +451,7 @@ def symbol_filter(symbol):
     if symbol.startswith("gemm_panel8<") or symbol.startswith("gemm_panel<"):
         return ("gemm_h3_panel8_kernel" if symbol.startswith("gemm_panel8<") else "gemm_h3_panel_kernel",
                 "PanelEp" + symbol[symbol.index("<") + 1:-1] + "E")
-    return {"tchain": ("tchain64_kernel",) if os.environ.get("UU3D_TCHAIN64", "1") != "0" else ("tchain_kernel",), "mlp_fused": ("mlp_fused_h3_kernel",), "gemm_wt": ("gemm_h3_wt_kernel",), "gemm_f32": ("gemm_f32_kernel",),
+    return {"tchain": (TC_KERNEL,), "mlp_fused": ("mlp_fused_h3_kernel",), "gemm_wt": ("gemm_h3_wt_kernel",), "gemm_f32": ("gemm_f32_kernel",),
             "gemm_h3": ("gemm_h3",)}.get(symbol)
 
 
@@ -766,7 +769,7 @@ def main():
                                      else "one batch after the other"},
             "roofline": {"bound": "mfma", "bound_measured": BOUND_MEASURED if gk == "tchain" else None, "kernel": f"{gk} [{dom_key}]",
                          "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s",
-                         "frac": round(ach / peak, 4), "traffic": pmc_traffic(gk, pmc_summary_for(args.config, B), grid=((B * N + TC_ROWS - 1) // TC_ROWS) * (256 if TC_ROWS == 64 else 512) if gk == "tchain" else None),
+                         "frac": round(ach / peak, 4), "traffic": pmc_traffic(gk, pmc_summary_for(args.config, B), grid=((B * N + TC_ROWS - 1) // TC_ROWS) * TC_THREADS if gk == "tchain" else None),
                          "note": ("algorithmic 2*M*N*K FLOPs (tchain: every Dense layer the launch walks -- projection, fc1, fc2, the next block's QKV; mlp_fused: both Dense layers of the MLP, 4*M*d*h); the f16x3 kernels issue 3 f16 "
                                   "MFMA passes per product, so the matrix pipe does 3x this work (frac of pipe = 3 * frac)") if args.precision == "f16x3" else
                                  "exact f32-input MFMA",
@@ -774,7 +777,7 @@ def main():
                          "avg_launch_ms": round(dom["ms"] / dom["n"], 5),
                          **({"workgroups_per_launch": (B * N + TC_ROWS - 1) // TC_ROWS, "cus": 256,
                              "frac_of_occupied_cus": round(ach / (peak * min(256, (B * N + TC_ROWS - 1) // TC_ROWS) / 256.0), 4),
-                             "occupancy_note": f"the temporal chain runs ONE workgroup per {TC_ROWS} token rows and CU (64 rows: four waves of 512 registers, 152 KiB of LDS): a launch of this batch occupies "
+                             "occupancy_note": f"the temporal chain runs ONE workgroup per {TC_ROWS} token rows and CU (64 rows: eight waves on 16-token panels, 157 KiB of LDS): a launch of this batch occupies "
                                                "that many of the 256 CUs, `achieved` / `frac` are the launch measured ALONE against the whole chip's peak (`under_load`: the same launch with "
                                                "every CU busy); the timed path runs several forwards' launches side by side"}
                             if gk == "tchain" else {}),

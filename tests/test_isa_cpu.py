@@ -22,6 +22,7 @@ SRC = r'''
 #include "uu3d_gemm_panel8.h"
 #include "uu3d_tchain.h"
 #include "uu3d_tchain64.h"
+#include "uu3d_tchain16.h"
 #include "uu3d_attn.h"
 #include "uu3d_attn_h3.h"
 #include "uu3d_bwd.h"
@@ -44,6 +45,11 @@ template __global__ void uu3d::gemm_h3_panel8_kernel<PanelEpBiasResidualLn, 12, 
 template __global__ void uu3d::tchain_kernel<TC_PROJ | TC_MLP | TC_QKV>(const TChainArgs);
 template __global__ void uu3d::tchain_kernel<TC_QKV>(const TChainArgs);
 template __global__ void uu3d::tchain_kernel<TC_PROJ | TC_FC1_PLANES>(const TChainArgs);
+template __global__ void uu3d::tchain16_kernel<TC_PROJ | TC_MLP | TC_QKV>(const TChainArgs);
+template __global__ void uu3d::tchain16_kernel<TC_PROJ | TC_MLP | TC_QKV | TC_PE>(const TChainArgs);
+template __global__ void uu3d::tchain16_kernel<TC_PROJ | TC_MLP>(const TChainArgs);
+template __global__ void uu3d::tchain16_kernel<TC_QKV>(const TChainArgs);
+template __global__ void uu3d::tchain16_kernel<TC_PROJ | TC_FC1_PLANES>(const TChainArgs);
 template __global__ void uu3d::tchain64_kernel<TC_PROJ | TC_MLP | TC_QKV>(const TChainArgs);
 template __global__ void uu3d::tchain64_kernel<TC_PROJ | TC_MLP | TC_QKV | TC_PE>(const TChainArgs);
 template __global__ void uu3d::tchain64_kernel<TC_PROJ | TC_MLP>(const TChainArgs);
@@ -235,6 +241,38 @@ def test_temporal_chain_64_row_code_shape(asm):
         assert int(re.search(r"\.amdhsa_next_free_vgpr (\d+)", d).group(1)) <= 512, name
         assert int(re.search(r"\.amdhsa_accum_offset (\d+)", d).group(1)) <= 256, name
         assert "v_accvgpr_write_b32" in body, name                                                              # (the fragments are parked in AGPRs)
+
+
+def test_temporal_chain_16_token_panels_code_shape(asm):
+    """uu3d_tchain16.h (round 6, the default chain): 64 rows per workgroup on eight waves (16-token panels, v_mfma_f32_16x16x32_f16), everything of a
+    temporal block's row-local stages on chip.  Pinned: no float atomic, no scratch, 256 registers = two waves per SIMD, per chunk body 36 MFMAs, 6 LDS-DMA
+    pieces and two barriers, no vector-memory load inside a rolled loop, every wait inside it one of the hand-written counted ones."""
+    ks = _kernels(asm)
+    chains = {k: v for k, v in ks.items() if "tchain16_kernel" in k}
+    assert len(chains) == 5
+    for name, body in chains.items():
+        assert "global_atomic" not in body and "flat_atomic" not in body and "buffer_atomic" not in body, name
+        assert "scratch_" not in body, name
+        assert "v_pk_mul_f32" not in body and "v_pk_fma_f32" not in body and "v_pk_add_f32" not in body, name
+        assert "v_mfma_f32_32x32x16_f16" not in body, name
+        n_mfma, n_dma = body.count("v_mfma_f32_16x16x32_f16"), body.count("global_load_lds_dwordx4")
+        assert n_mfma % 36 == 0 and n_dma == 6 * (n_mfma // 36) + 15, (name, n_mfma, n_dma)
+        loops = {h: t for h, t in _loops(body).items() if t.count("v_mfma_f32_16x16x32_f16") == 4 * 36}
+        assert loops or "Li3E" in name, name
+        for h, t in loops.items():
+            back = re.search(r"s_cbranch_\w+ \." + re.escape(h) + r"\b", t)
+            assert back, (name, h)
+            t = t[:back.start()]
+            assert "v_readlane" not in t and "v_writelane" not in t, name
+            assert not re.search(r"\b(global|buffer|flat)_load_(dword|ubyte|ushort|short)", t), name
+            assert t.count("s_barrier") == 4 * 2, name
+            in_asm = sum(blk.count("s_waitcnt") for blk in re.findall(r";;#ASMSTART(.*?);;#ASMEND", t, re.S))
+            assert in_asm >= 4 * 14 and t.count("s_waitcnt") == in_asm, (name, in_asm, t.count("s_waitcnt"))
+            assert not re.search(r"s_waitcnt vmcnt\(0\)", t), name
+            assert t.count("global_load_lds_dwordx4") == 4 * 6, (name, t.count("global_load_lds_dwordx4"))
+        d = asm[asm.index(".amdhsa_kernel " + name):]
+        d = d[:d.index(".end_amdhsa_kernel")]
+        assert int(re.search(r"\.amdhsa_next_free_vgpr (\d+)", d).group(1)) <= 256, name
 
 
 def test_no_packed_fp32_valu_ops(asm):

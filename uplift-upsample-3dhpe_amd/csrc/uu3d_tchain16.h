@@ -63,6 +63,9 @@ struct T16EpHidden { static constexpr int kStores = 0; static constexpr bool kBi
 struct T16EpQkv { static constexpr int kStores = 2; static constexpr bool kBias = true; h16x4* __restrict__ qf; const float* bias; int nbias; };
 struct T16EpPlanes { static constexpr int kStores = 2; static constexpr bool kBias = true; unsigned char* __restrict__ ph; unsigned char* __restrict__ pl; const float* bias; int nbias; };
 
+#ifndef UU3D_T16_DEPTH
+#define UU3D_T16_DEPTH 2       // weight fragments are requested this many positions kk ahead of the MFMAs that use them (a ring of DEPTH + 1 register pairs)
+#endif
 #ifndef UU3D_T16_LOO
 #define UU3D_T16_LOO 0         // tools/tchain16_exp: leave-one-out timing builds (results wrong): 1 no refill DMA, 2 no finish
 #endif
@@ -105,7 +108,8 @@ tchain16_kernel(const TChainArgs a)
     f32x4 xr[12];                                          // residual stream: x[token][32 c + 16 hh + 4 g + (0..3)]
     h16x8 ah[KS], al[KS];                                  // token fragments of the running stage, one per k-step
     h16x8 fh[KS], fl[KS];                                  // one half of relu(fc1) as fc2's token fragments
-    h16x8 bh[3] = {}, bl[3] = {};                          // weight fragments (hi / lo plane) of three consecutive positions kk
+    constexpr int DP = UU3D_T16_DEPTH, RB = DP + 1;
+    h16x8 bh[RB] = {}, bl[RB] = {};                        // weight fragments (hi / lo plane) of DP + 1 consecutive positions kk
 
     auto late = [&](int v) __attribute__((always_inline)) -> int { asm volatile("" : "+s"(v)); return v; };      // (uu3d_tchain64.h)
     const unsigned xoff = (unsigned)(wave * 256 + lane * 4);
@@ -232,6 +236,7 @@ tchain16_kernel(const TChainArgs a)
         const unsigned sb = rd0 + (unsigned)slot * P8_CHUNK_BYTES;
         Fin f;
         auto gapwork = [&](const int gp) __attribute__((always_inline)) {
+            if constexpr (CL > 0 && (UU3D_T16_LOO & 2) != 0) { if (gp == 3) asm volatile("" :: "v"(p.a0[0]), "v"(p.a0[1]), "v"(p.a1[0]), "v"(p.a1[1])); }      // (timing builds: the previous chunk's MFMAs stay alive)
             if constexpr (FIN) {
                 if (gp == 3 || gp == 4) {
 #pragma unroll
@@ -251,29 +256,29 @@ tchain16_kernel(const TChainArgs a)
         __builtin_amdgcn_s_barrier();
         __builtin_amdgcn_sched_barrier(0);
         if constexpr (!PRE_IN) {
-            UU3D_T16_READ(0, sb, 0);
-            UU3D_T16_READ(1, sb, 1);
+#pragma unroll
+            for (int d = 0; d < DP; ++d) UU3D_T16_READ(d, sb, d);
         }
 #pragma unroll
         for (int m = 0; m < 2; ++m) { x.a0[m] = f32x4{0.f, 0.f, 0.f, 0.f}; x.a1[m] = f32x4{0.f, 0.f, 0.f, 0.f}; }
 #define UU3D_T16_KK(kk) \
-            x.a0[(kk) & 1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bh[(kk) % 3], Ah[(kk) >> 1], x.a0[(kk) & 1], 0, 0, 0); \
+            x.a0[(kk) & 1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bh[(kk) % RB], Ah[(kk) >> 1], x.a0[(kk) & 1], 0, 0, 0); \
             __builtin_amdgcn_sched_barrier(0); gapwork(3 * (kk)); __builtin_amdgcn_sched_barrier(0); \
-            x.a1[(kk) & 1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bh[(kk) % 3], Al[(kk) >> 1], x.a1[(kk) & 1], 0, 0, 0); \
+            x.a1[(kk) & 1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bh[(kk) % RB], Al[(kk) >> 1], x.a1[(kk) & 1], 0, 0, 0); \
             __builtin_amdgcn_sched_barrier(0); gapwork(3 * (kk) + 1); __builtin_amdgcn_sched_barrier(0); \
-            x.a1[(kk) & 1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bl[(kk) % 3], Ah[(kk) >> 1], x.a1[(kk) & 1], 0, 0, 0); \
+            x.a1[(kk) & 1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bl[(kk) % RB], Ah[(kk) >> 1], x.a1[(kk) & 1], 0, 0, 0); \
             __builtin_amdgcn_sched_barrier(0); gapwork(3 * (kk) + 2); __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int kk = 0; kk < 6; ++kk) {
-            UU3D_T16_READ((kk + 2) % 3, sb, kk + 2);
-            // younger than pair kk: pairs kk + 1, kk + 2, and the send (one write, behind position 1) while pair kk was requested in front of it (kk = 2, 3)
-            asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(bh[kk % 3]), "+v"(bl[kk % 3]) : "i"(4 + (FIN && (kk == 2 || kk == 3) ? 1 : 0)));
+            UU3D_T16_READ((kk + DP) % RB, sb, kk + DP);
+            // younger than pair kk: pairs kk + 1 .. kk + DP, and the send (one write, behind position 1) while pair kk was requested in front of it (2 <= kk <= 1 + DP)
+            asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(bh[kk % RB]), "+v"(bl[kk % RB]) : "i"(2 * DP + (FIN && kk >= 2 && kk <= 1 + DP ? 1 : 0)));
             UU3D_T16_KK(kk)
             if ((kk & 1) == 0) dma1(G + 2, 1, pslot, kk >> 1);
             __builtin_amdgcn_sched_barrier(0);
         }
         // ---- barrier B'_c: half-chunk 2 c + 2 landed; everybody read the first halves of chunk c and wrote the exchange area ----
-        asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(4)" :: "i"(9 + NST * (CL >= 2)) : "memory");      // (pairs 6 and 7 stay in flight; the send is older)
+        asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(%1)" :: "i"(9 + NST * (CL >= 2)), "i"(2 * DP) : "memory");      // (pairs 6 .. 5 + DP stay in flight; the send is older)
         __builtin_amdgcn_sched_barrier(0);
         __builtin_amdgcn_s_barrier();
         __builtin_amdgcn_sched_barrier(0);
@@ -284,14 +289,15 @@ tchain16_kernel(const TChainArgs a)
         }
 #pragma unroll
         for (int kk = 6; kk < HS; ++kk) {
-            if (kk + 2 < HS) UU3D_T16_READ((kk + 2) % 3, sb, kk + 2);
-            const int ahead = 2 * ((kk + 2 < HS ? kk + 2 : HS - 1) - kk);
-            if (FIN && kk == 6) asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(bh[kk % 3]), "+v"(bl[kk % 3]) : "i"(ahead + NRB));
-            else if (FIN && kk == 7) {                     // the finish starts behind this wait: the receive and the bias must be there (pairs 8 and 9 are younger)
-                if constexpr (EP::kBias) asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(bh[kk % 3]), "+v"(bl[kk % 3]), "+v"(f.r), "+v"(f.b));
-                else asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(bh[kk % 3]), "+v"(bl[kk % 3]), "+v"(f.r));
+            if (kk + DP < HS) UU3D_T16_READ((kk + DP) % RB, sb, kk + DP);
+            // younger than pair kk: the pairs kk + 1 .. min(kk + DP, 11), and the NRB reads behind B'_c while pair kk was requested in front of it (kk <= 5 + DP)
+            const int ahead = 2 * ((kk + DP < HS ? kk + DP : HS - 1) - kk);
+            if (FIN && kk == 7) {                          // the finish starts behind this wait: the receive and the bias must be there; younger than them: the pairs requested behind B'_c
+                const int behind = 6 + DP < HS ? 2 * ((7 + DP < HS ? 7 + DP : HS - 1) - (6 + DP) + 1) : 0;
+                if constexpr (EP::kBias) asm volatile("s_waitcnt lgkmcnt(%4)" : "+v"(bh[kk % RB]), "+v"(bl[kk % RB]), "+v"(f.r), "+v"(f.b) : "i"(behind < ahead ? behind : ahead));
+                else asm volatile("s_waitcnt lgkmcnt(%3)" : "+v"(bh[kk % RB]), "+v"(bl[kk % RB]), "+v"(f.r) : "i"(behind < ahead ? behind : ahead));
             }
-            else asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(bh[kk % 3]), "+v"(bl[kk % 3]) : "i"(ahead));
+            else asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(bh[kk % RB]), "+v"(bl[kk % RB]) : "i"(ahead + (FIN && kk == 6 ? NRB : 0)));
             UU3D_T16_KK(kk)
             if ((kk & 1) == 0) dma1(G + 3, 0, slot, (kk - 6) >> 1);
             __builtin_amdgcn_sched_barrier(0);
@@ -301,8 +307,8 @@ tchain16_kernel(const TChainArgs a)
         slot = slot == 2 ? 0 : slot + 1;
         if constexpr (PRE_OUT) {                           // the next chunk's first fragments: its first half landed one barrier ago
             const unsigned nb = rd0 + (unsigned)slot * P8_CHUNK_BYTES;
-            UU3D_T16_READ(0, nb, 0);
-            UU3D_T16_READ(1, nb, 1);
+#pragma unroll
+            for (int d = 0; d < DP; ++d) UU3D_T16_READ(d, nb, d);
         }
     };
 
