@@ -28,10 +28,10 @@ PEAK_F32_MFMA_TFLOPS = 157.3   # /opt/skills/guides/MI355X_MICROARCH.md "Peak FP
 PEAK_F16_MFMA_TFLOPS = 2500.0  # same table, "Peak BF16/FP16 MFMA ~2.5 PF dense"
 # What the leave-one-out builds of the dominant kernel say bounds it (profiles/): `bound` above stays the roofline the FLOPs are priced
 # against (the contract's "mfma"), this is the measured limiter.
-BOUND_MEASURED = ("instruction issue of ONE wave per SIMD, and the clock the chip holds under load: leave-one-out builds of the 64-row chain with every CU busy "
-                  "(profiles/r06_tchain64.txt) -- complete 272 us, without MFMAs 231, without the epilogues' vector instructions 214, without the ring's "
-                  "LDS-DMA refills 248, bare MFMA + fragment-read loop 199 (1.33 k cycles per chunk at 1.79 GHz against 2.2 k at 1.98 GHz complete: cycles saved "
-                  "come back as a lower clock); no float atomics, no lane-private round trips: 128 MB of counter traffic per launch against 119 MB algorithmic")
+BOUND_MEASURED = ("LDS fragment reads, two lock-step barriers per chunk and the clock the chip holds under load: leave-one-out builds of the chain (eight waves on "
+                  "16-token panels, csrc/uu3d_tchain16.h) with every CU busy / one launch alone (profiles/r06_ab_tchain16.txt) -- complete 253 / 103 us, without the "
+                  "ring's LDS-DMA refills 222 / 92, without the epilogues 202 / 84, neither 178 / 72: the bare loop runs at ~1.55 k cycles per chunk for 1.15 k of MFMA; "
+                  "no float atomics, no lane-private round trips: 122 MB of counter traffic per launch against 119 MB algorithmic")
 
 
 def cpu_baseline(cfg, arch, weights, x, m, budget_s=60.0):
