@@ -20,15 +20,13 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
-# The temporal chain's kernel: token rows and threads per workgroup (csrc/uu3d_tchain16.h: 64 rows on eight waves; UU3D_TCHAIN16=0: uu3d_tchain64.h, four waves;
-# UU3D_TCHAIN64=0: the round-5 kernel, 128 rows on eight waves)
-TC_ROWS, TC_THREADS, TC_KERNEL = ((128, 512, "tchain_kernel") if os.environ.get("UU3D_TCHAIN64", "1") == "0" else
-                                   (64, 256, "tchain64_kernel") if os.environ.get("UU3D_TCHAIN16", "1") == "0" else (64, 512, "tchain16_kernel"))
+# The temporal chain's kernel (csrc/uu3d_tchain16.h): token rows and threads per workgroup
+TC_ROWS, TC_THREADS, TC_KERNEL = 64, 512, "tchain16_kernel"
 PEAK_F32_MFMA_TFLOPS = 157.3   # /opt/skills/guides/MI355X_MICROARCH.md "Peak FP32 (matrix)"
 PEAK_F16_MFMA_TFLOPS = 2500.0  # same table, "Peak BF16/FP16 MFMA ~2.5 PF dense"
 # What the leave-one-out builds of the dominant kernel say bounds it (profiles/): `bound` above stays the roofline the FLOPs are priced
 # against (the contract's "mfma"), this is the measured limiter.
-BOUND_MEASURED = ("LDS fragment reads, two lock-step barriers per chunk and the clock the chip holds under load: leave-one-out builds of the chain (eight waves on "
+BOUND_MEASURED = ("LDS fragment reads, two lock-step barriers per chunk and the clock the chip holds on its 1400 W power cap (2.15 GHz under the bench loop, profiles/r06_power.txt): leave-one-out builds of the chain (eight waves on "
                   "16-token panels, csrc/uu3d_tchain16.h) with every CU busy / one launch alone (profiles/r06_ab_tchain16.txt) -- complete 253 / 103 us, without the "
                   "ring's LDS-DMA refills 222 / 92, without the epilogues 202 / 84, neither 178 / 72: the bare loop runs at ~1.55 k cycles per chunk for 1.15 k of MFMA; "
                   "no float atomics, no lane-private round trips: 122 MB of counter traffic per launch against 119 MB algorithmic")

@@ -70,8 +70,8 @@ def test_product_library_has_no_timing_hooks_and_the_bench_refuses_them(lib, mon
     assert "timing" not in lib.uu3d_version().decode()
     blob = open(_capi.LIB_PATH, "rb").read()
     assert b"UU3D_SKIP" not in blob and b"UU3D_TIMING_PARTS" not in blob
-    monkeypatch.setenv("UU3D_TCHAIN64", "0")
-    assert bench.env_switches() == {"UU3D_TCHAIN64": "0"}                      # A/B switches are recorded ...
+    monkeypatch.setenv("UU3D_TCHAIN", "0")
+    assert bench.env_switches() == {"UU3D_TCHAIN": "0"}                      # A/B switches are recorded ...
     monkeypatch.setenv("UU3D_SKIP", "128")
     with pytest.raises(SystemExit):                                            # ... result-changing ones refused
         bench.env_switches()

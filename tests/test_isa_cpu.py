@@ -20,8 +20,6 @@ SRC = r'''
 #include "uu3d_gemm_h3.h"
 #include "uu3d_gemm_panel.h"
 #include "uu3d_gemm_panel8.h"
-#include "uu3d_tchain.h"
-#include "uu3d_tchain64.h"
 #include "uu3d_tchain16.h"
 #include "uu3d_attn.h"
 #include "uu3d_attn_h3.h"
@@ -42,19 +40,11 @@ template __global__ void uu3d::gemm_h3_panel_kernel<24, PanelEpBiasResidual, 4>(
 template __global__ void uu3d::gemm_h3_panel8_kernel<PanelEpBiasSplitQ, 12, 3>(const _Float16*, const _Float16*, const float*, int, int, int, const PanelEpBiasSplitQ);
 template __global__ void uu3d::gemm_h3_panel8_kernel<PanelEpBiasResidual, 4, 3>(const _Float16*, const _Float16*, const float*, int, int, int, const PanelEpBiasResidual);
 template __global__ void uu3d::gemm_h3_panel8_kernel<PanelEpBiasResidualLn, 12, 3>(const _Float16*, const _Float16*, const float*, int, int, int, const PanelEpBiasResidualLn);
-template __global__ void uu3d::tchain_kernel<TC_PROJ | TC_MLP | TC_QKV>(const TChainArgs);
-template __global__ void uu3d::tchain_kernel<TC_QKV>(const TChainArgs);
-template __global__ void uu3d::tchain_kernel<TC_PROJ | TC_FC1_PLANES>(const TChainArgs);
 template __global__ void uu3d::tchain16_kernel<TC_PROJ | TC_MLP | TC_QKV>(const TChainArgs);
 template __global__ void uu3d::tchain16_kernel<TC_PROJ | TC_MLP | TC_QKV | TC_PE>(const TChainArgs);
 template __global__ void uu3d::tchain16_kernel<TC_PROJ | TC_MLP>(const TChainArgs);
 template __global__ void uu3d::tchain16_kernel<TC_QKV>(const TChainArgs);
 template __global__ void uu3d::tchain16_kernel<TC_PROJ | TC_FC1_PLANES>(const TChainArgs);
-template __global__ void uu3d::tchain64_kernel<TC_PROJ | TC_MLP | TC_QKV>(const TChainArgs);
-template __global__ void uu3d::tchain64_kernel<TC_PROJ | TC_MLP | TC_QKV | TC_PE>(const TChainArgs);
-template __global__ void uu3d::tchain64_kernel<TC_PROJ | TC_MLP>(const TChainArgs);
-template __global__ void uu3d::tchain64_kernel<TC_QKV>(const TChainArgs);
-template __global__ void uu3d::tchain64_kernel<TC_PROJ | TC_FC1_PLANES>(const TChainArgs);
 template __global__ void uu3d::ln_split_frag_kernel<24, 8>(const float*, int, int, float, const float*, const float*, _Float16*);
 template __global__ void uu3d::gemm_h3g_kernel<1, 1, GLoadConv3, EpSlab, 3>(const GLoadConv3, const _Float16*, const _Float16*, int, int, int, int, int, int, const EpSlab);
 template __global__ void uu3d::gemm_h3g_kernel<1, 2, GLoadPlain, EpBiasResidual, 3>(const GLoadPlain, const _Float16*, const _Float16*, int, int, int, int, int, int, const EpBiasResidual);
@@ -178,73 +168,8 @@ def _loops(body):
     return {k: "\n".join(v) for k, v in loops.items()}
 
 
-def test_temporal_chain_code_shape(asm):
-    """uu3d_tchain.h (round 5): the chunk loop of a stage is a REAL loop of four-chunk bodies.  What it relies on: nothing inside a loop is a
-    vector-memory LOAD (a load in flight across the back edge, or one hipcc can see beside the LDS-DMAs, brings a vmcnt(0) that drains the
-    ring: the biases come through the scalar cache), every wait inside a loop is one of the hand-written counted ones (14 per chunk),
-    per chunk 36 MFMAs, 6 LDS-DMA pieces (the refill position depends on the wave group: both branches are in the text) and two barriers,
-    no scratch inside a loop, 256 registers = two waves per SIMD, all of the LDS."""
-    ks = _kernels(asm)
-    chains = {k: v for k, v in ks.items() if "tchain_kernelILi" in k}
-    assert len(chains) == 3
-    for name, body in chains.items():
-        loops = [t for t in _loops(body).values() if "v_mfma_f32_32x32x16_f16" in t]
-        assert loops, name
-        inner = [t for t in loops if t.count("v_mfma_f32_32x32x16_f16") == 4 * 36]
-        assert inner, (name, [t.count("v_mfma_f32_32x32x16_f16") for t in loops])
-        for t in inner:
-            assert "scratch_" not in t and "v_readlane" not in t and "v_writelane" not in t, name
-            assert not re.search(r"\b(global|buffer|flat)_load_(dword|ubyte|ushort|short)", t), name           # LDS-DMA (global_load_lds_*) only
-            assert t.count("s_barrier") == 4 * 2, name
-            in_asm = sum(blk.count("s_waitcnt") for blk in re.findall(r";;#ASMSTART(.*?);;#ASMEND", t, re.S))
-            assert in_asm >= 4 * 14 and t.count("s_waitcnt") == in_asm, (name, in_asm, t.count("s_waitcnt"))     # every wait is a hand-written counted one (the wave-group branches duplicate a few); hipcc added none
-            assert not re.search(r"s_waitcnt vmcnt\(0\)", t), name
-            # first-half refills: 3 per chunk; second-half refills: 3 per chunk in EACH of the two wave-group branches
-            assert t.count("global_load_lds_dwordx4") == 4 * (3 + 2 * 3), (name, t.count("global_load_lds_dwordx4"))
-            assert t.count("s_load_dwordx16") in (0, 4), name                                                 # stages with a bias: one scalar load per chunk
-        d = asm[asm.index(".amdhsa_kernel " + name):]
-        d = d[:d.index(".end_amdhsa_kernel")]
-        assert int(re.search(r"\.amdhsa_next_free_vgpr (\d+)", d).group(1)) <= 256, name
-        assert "v_pk_mul_f32" not in body and "v_pk_fma_f32" not in body and "v_pk_add_f32" not in body, name
-
-
-def test_temporal_chain_64_row_code_shape(asm):
-    """uu3d_tchain64.h (round 6): the residual stream and relu(fc1) never leave the CU.  Pinned: NO float atomic and no scratch anywhere in the
-    kernel (round 5's residual adds were global_atomic_add_f32; a register the allocator spills may be a fragment read still in flight), every
-    stage a real loop of four-chunk bodies with 36 MFMAs, 12 LDS-DMA pieces and two barriers per chunk, no vector-memory load inside a loop,
-    every wait inside a loop one of the hand-written counted ones, one wave per SIMD (512 registers: the token fragments sit in AGPRs)."""
-    ks = _kernels(asm)
-    chains = {k: v for k, v in ks.items() if "tchain64_kernel" in k}
-    assert len(chains) == 5
-    for name, body in chains.items():
-        assert "global_atomic" not in body and "flat_atomic" not in body and "buffer_atomic" not in body, name
-        assert "scratch_" not in body, name
-        assert "v_pk_mul_f32" not in body and "v_pk_fma_f32" not in body and "v_pk_add_f32" not in body, name
-        # whole kernel: 36 MFMAs and 12 LDS-DMA pieces per chunk body in the text (+ the 30 pieces of the prologue), whatever hipcc unrolled
-        n_mfma, n_dma = body.count("v_mfma_f32_32x32x16_f16"), body.count("global_load_lds_dwordx4")
-        assert n_mfma % 36 == 0 and n_dma == 12 * (n_mfma // 36) + 30, (name, n_mfma, n_dma)
-        loops = {h: t for h, t in _loops(body).items() if t.count("v_mfma_f32_32x32x16_f16") == 4 * 36}      # the rolled loops of four-chunk bodies (QKV, the strided block's fc1)
-        assert loops or "Li3E" in name, name
-        for h, t in loops.items():
-            back = re.search(r"s_cbranch_\w+ \." + re.escape(h) + r"\b", t)
-            assert back, (name, h)
-            t = t[:back.start()]                                                 # (the loop's last block runs on into the stage tail: cut at the back edge)
-            assert "v_readlane" not in t and "v_writelane" not in t, name
-            assert not re.search(r"\b(global|buffer|flat)_load_(dword|ubyte|ushort|short)", t), name           # LDS-DMA (global_load_lds_*) only
-            assert t.count("s_barrier") == 4 * 2, name
-            in_asm = sum(blk.count("s_waitcnt") for blk in re.findall(r";;#ASMSTART(.*?);;#ASMEND", t, re.S))
-            assert in_asm >= 4 * 14 and t.count("s_waitcnt") == in_asm, (name, in_asm, t.count("s_waitcnt"))     # hipcc added no wait of its own
-            assert not re.search(r"s_waitcnt vmcnt\(0\)", t), name
-            assert t.count("global_load_lds_dwordx4") == 4 * 12, (name, t.count("global_load_lds_dwordx4"))
-        d = asm[asm.index(".amdhsa_kernel " + name):]
-        d = d[:d.index(".end_amdhsa_kernel")]
-        assert int(re.search(r"\.amdhsa_next_free_vgpr (\d+)", d).group(1)) <= 512, name
-        assert int(re.search(r"\.amdhsa_accum_offset (\d+)", d).group(1)) <= 256, name
-        assert "v_accvgpr_write_b32" in body, name                                                              # (the fragments are parked in AGPRs)
-
-
 def test_temporal_chain_16_token_panels_code_shape(asm):
-    """uu3d_tchain16.h (round 6, the default chain): 64 rows per workgroup on eight waves (16-token panels, v_mfma_f32_16x16x32_f16), everything of a
+    """uu3d_tchain16.h (the temporal chain; round 5's form added its residuals with global_atomic_add_f32): 64 rows per workgroup on eight waves (16-token panels, v_mfma_f32_16x16x32_f16), everything of a
     temporal block's row-local stages on chip.  Pinned: no float atomic, no scratch, 256 registers = two waves per SIMD, per chunk body 36 MFMAs, 6 LDS-DMA
     pieces and two barriers, no vector-memory load inside a rolled loop, every wait inside it one of the hand-written counted ones."""
     ks = _kernels(asm)

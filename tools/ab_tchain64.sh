@@ -1,4 +1,6 @@
 #!/bin/bash
+# NOTE: the library switches UU3D_TCHAIN64 / UU3D_TCHAIN16 this script alternates existed up to commit ed9e71b; the two earlier chain kernels
+# now live under tools/ (uu3d_tchain.h, uu3d_tchain64.h) with their stand-alone harnesses.  Check that commit out to rerun this A/B.
 # gpurun -- 'bash tools/ab_tchain64.sh': the pipelined bench with the 64-row chain (default) against the round-5 kernel (UU3D_TCHAIN64=0), alternating on one box
 run() { python bench.py --no-cpu-baseline --no-secondary --steps ${STEPS:-200} --warmup 20 "$@" 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.readlines()[-1]); print('%.1f k seq/s  %.4f ms/step' % (d['value']/1e3, d['ms_per_step']))"; }
 for rep in 1 2 3; do

@@ -1,4 +1,6 @@
 #!/bin/bash
+# NOTE: the library switches UU3D_TCHAIN64 / UU3D_TCHAIN16 this script alternates existed up to commit ed9e71b; the two earlier chain kernels
+# now live under tools/ (uu3d_tchain.h, uu3d_tchain64.h) with their stand-alone harnesses.  Check that commit out to rerun this A/B.
 # gpurun --timeout 2400 -- 'bash tools/profile_r06_all.sh'  : the r06 profiles DESIGN.md / the bench line quote, reduced to gpurun_out/sum/
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 # the benchmark workload (batch 128): traced / counted under the throughput schedule (two slots: the 64-row temporal chain), as the timed path runs it

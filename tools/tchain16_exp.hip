@@ -1,7 +1,6 @@
 // Round 6: the temporal chain on 64-row tiles, eight waves on 16-token panels (csrc/uu3d_tchain16.h), against float64, and its time.
-//   hipcc -O3 -std=c++17 --offload-arch=gfx950 -Xclang -target-feature -Xclang -packed-fp32-ops -o tools/tchain16_exp tools/tchain16_exp.hip
+//   hipcc -O3 -std=c++17 --offload-arch=gfx950 -Xclang -target-feature -Xclang -packed-fp32-ops -I uplift-upsample-3dhpe_amd/csrc -o tools/tchain16_exp tools/tchain16_exp.hip
 //   tools/tchain16_exp [M] [iters] [warm-up launches]
-#define UU3D_TC_STAMP 1
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdlib>
@@ -14,8 +13,6 @@
 #include "../uplift-upsample-3dhpe_amd/csrc/uu3d_gemm_h3.h"
 #include "../uplift-upsample-3dhpe_amd/csrc/uu3d_gemm_panel.h"
 #include "../uplift-upsample-3dhpe_amd/csrc/uu3d_gemm_panel8.h"
-#include "../uplift-upsample-3dhpe_amd/csrc/uu3d_tchain.h"
-#include "../uplift-upsample-3dhpe_amd/csrc/uu3d_tchain64.h"
 #include "../uplift-upsample-3dhpe_amd/csrc/uu3d_tchain16.h"
 using namespace uu3d;
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %s:%d\n", hipGetErrorString(e), __FILE__, __LINE__); exit(1);} } while (0)
@@ -85,7 +82,7 @@ template <int FLAGS> void run(const char* tag, int M, int iters) {
         w2.pack(W, 0, D, false); w2.pack(W, D, D, false);
         const size_t at = W.size() - (size_t)48 * TC_CHUNK_HALFS;          // W1 (24) | W2 half 0 | W2 half 1  ->  W1[0..11] | W2 half 0 | W1[12..23] | W2 half 1
         std::vector<_Float16> tmp(W.begin() + at, W.end());
-        tchain64_reorder_mlp(tmp.data(), W.data() + at);
+        tchain16_reorder_mlp(tmp.data(), W.data() + at);
     }
     if (FLAGS & TC_QKV) wqkvf.pack(W, 0, D, false);
     if (W.size() != (size_t)tchain_chunks(FLAGS) * TC_CHUNK_HALFS) { printf("stream size mismatch\n"); exit(1); }
@@ -100,9 +97,9 @@ template <int FLAGS> void run(const char* tag, int M, int iters) {
     a.Q = devz<_Float16>((size_t)mt * 2 * 72 * 2 * 512);
     a.H = devz<_Float16>((size_t)M * Hd * 2);
     // scratch = hidden fragments | xs | xas | trash; the launches that add into the residual stream find it there in lane-linear order
-    std::vector<unsigned char> scr(tchain64_scratch_bytes(mt), 0);
+    std::vector<unsigned char> scr(tchain16_scratch_bytes(mt), 0);
     float* xs_h = reinterpret_cast<float*>(scr.data());
-    float* xas_h = xs_h + (size_t)mt * T64_X_FLOATS_PER_TILE;
+    float* xas_h = xs_h + (size_t)mt * T16_X_FLOATS_PER_TILE;
     for (int r = 0; r < M; ++r) for (int k = 0; k < D; ++k) { xs_h[tchain16_xs_index(r, k)] = X[(size_t)r * D + k]; xas_h[tchain16_xs_index(r, k)] = X[(size_t)r * D + k]; }
     a.scratch = dev(scr);
     unsigned char* scratch0 = dev(scr);
@@ -114,7 +111,7 @@ template <int FLAGS> void run(const char* tag, int M, int iters) {
     auto fetch_linear = [&](std::vector<float>& out, bool strided1) {        // the lane-linear tile copy -> row-major
         std::vector<unsigned char> sc(scr.size());
         CK(hipMemcpy(sc.data(), a.scratch, sc.size(), hipMemcpyDeviceToHost));
-        const float* base = reinterpret_cast<const float*>(sc.data()) + (strided1 ? (size_t)mt * T64_X_FLOATS_PER_TILE : 0);
+        const float* base = reinterpret_cast<const float*>(sc.data()) + (strided1 ? (size_t)mt * T16_X_FLOATS_PER_TILE : 0);
         for (int r = 0; r < M; ++r) for (int k = 0; k < D; ++k) out[(size_t)r * D + k] = base[tchain16_xs_index(r, k)];
     };
 
@@ -176,22 +173,6 @@ template <int FLAGS> void run(const char* tag, int M, int iters) {
         CK(hipDeviceSynchronize());
         const double us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count();
         printf("    MIX %d streams x %d launches of %d workgroups, own weights each: %.2f us per launch-equivalent (%.2f us per %d launches side by side)\n", nmix, iters, mt, us / (iters * nmix), us / iters, nmix);
-    }
-    {   // stamps of the last launch: workgroups 0, mt / 2, mt - 1
-        std::vector<unsigned long long> st(256 * 32);
-        CK(hipMemcpyFromSymbol(st.data(), HIP_SYMBOL(tchain_stamps), st.size() * 8));
-        for (int w : {0, mt / 2, mt - 1}) {
-            if (w >= 256) continue;
-            const unsigned long long* o = &st[(size_t)w * 32];
-            printf("    wg %3d: clock %.2f GHz;", w, (double)(o[18] - o[0]) / ((double)(o[19] - o[1]) * 10.0));
-            int prev = 0;
-            for (int i = 1; i < 10; ++i) { if (o[2 * i] == 0 || o[2 * i] < o[2 * prev]) continue; printf(" [%d->%d] %llu", prev, i, o[2 * i] - o[2 * prev]); prev = i; }
-            printf(" cycles\n");
-#ifdef UU3D_T64_CHUNK_STAMPS
-            if (o[20]) printf("            chunk 9 of QKV: wait+B %llu | first half %llu | wait+B' %llu | second half %llu   (next chunk's B entry would follow)\n", o[22] - o[20], o[24] - o[22], o[26] - o[24], o[28] - o[26]);
-#endif
-        }
-        std::fill(st.begin(), st.end(), 0ull); CK(hipMemcpyToSymbol(HIP_SYMBOL(tchain_stamps), st.data(), st.size() * 8));
     }
 }
 

@@ -1,5 +1,5 @@
-// Round 6: the temporal chain on 64-row tiles, everything on chip (csrc/uu3d_tchain64.h), against float64, and its time.
-//   hipcc -O3 -std=c++17 --offload-arch=gfx950 -Xclang -target-feature -Xclang -packed-fp32-ops -o tools/tchain64_exp tools/tchain64_exp.hip
+// Round 6: the temporal chain on 64-row tiles, everything on chip (tools/uu3d_tchain64.h), against float64, and its time.
+//   hipcc -O3 -std=c++17 --offload-arch=gfx950 -Xclang -target-feature -Xclang -packed-fp32-ops -I uplift-upsample-3dhpe_amd/csrc -o tools/tchain64_exp tools/tchain64_exp.hip
 //   tools/tchain64_exp [M] [iters] [warm-up launches]
 #define UU3D_TC_STAMP 1
 #include <hip/hip_runtime.h>
@@ -14,8 +14,8 @@
 #include "../uplift-upsample-3dhpe_amd/csrc/uu3d_gemm_h3.h"
 #include "../uplift-upsample-3dhpe_amd/csrc/uu3d_gemm_panel.h"
 #include "../uplift-upsample-3dhpe_amd/csrc/uu3d_gemm_panel8.h"
-#include "../uplift-upsample-3dhpe_amd/csrc/uu3d_tchain.h"
-#include "../uplift-upsample-3dhpe_amd/csrc/uu3d_tchain64.h"
+#include "uu3d_tchain.h"
+#include "uu3d_tchain64.h"
 using namespace uu3d;
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %s:%d\n", hipGetErrorString(e), __FILE__, __LINE__); exit(1);} } while (0)
 

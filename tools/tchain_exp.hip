@@ -1,5 +1,5 @@
-// Round 5: the row-local chain of a temporal block in one launch (csrc/uu3d_tchain.h) against float64, and its time.
-//   hipcc -O3 -std=c++17 --offload-arch=gfx950 -Xclang -target-feature -Xclang -packed-fp32-ops -o tools/tchain_exp tools/tchain_exp.hip
+// Round 5: the row-local chain of a temporal block in one launch (tools/uu3d_tchain.h) against float64, and its time.
+//   hipcc -O3 -std=c++17 --offload-arch=gfx950 -Xclang -target-feature -Xclang -packed-fp32-ops -I uplift-upsample-3dhpe_amd/csrc -o tools/tchain_exp tools/tchain_exp.hip
 //   tools/tchain_exp [M] [iters]
 #define UU3D_TC_STAMP 1
 #include <hip/hip_runtime.h>
@@ -14,7 +14,7 @@
 #include "../uplift-upsample-3dhpe_amd/csrc/uu3d_gemm_h3.h"
 #include "../uplift-upsample-3dhpe_amd/csrc/uu3d_gemm_panel.h"
 #include "../uplift-upsample-3dhpe_amd/csrc/uu3d_gemm_panel8.h"
-#include "../uplift-upsample-3dhpe_amd/csrc/uu3d_tchain.h"
+#include "uu3d_tchain.h"
 using namespace uu3d;
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %s:%d\n", hipGetErrorString(e), __FILE__, __LINE__); exit(1);} } while (0)
 

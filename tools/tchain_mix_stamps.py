@@ -1,4 +1,5 @@
-"""How long the temporal chain's workgroups take INSIDE the pipelined mix (library built with -DUU3D_TC_STAMP):
+"""(RECORD: needs the round-5 chain kernel in the library and its -DUU3D_TC_STAMP hooks, both removed after commit ed9e71b.)
+How long the temporal chain's workgroups take INSIDE the pipelined mix (library built with -DUU3D_TC_STAMP):
    python uplift-upsample-3dhpe_amd/build.py ... ; gpurun -- 'UU3D_TCHAIN=1 python tools/tchain_mix_stamps.py [slots]'"""
 import os, sys, ctypes as C, time
 import numpy as np, torch

@@ -1,3 +1,6 @@
+// tools/uu3d_tchain.h -- RECORD: the round-5 form of the temporal chain (128-row tiles, residual adds as float atomics), replaced by
+// csrc/uu3d_tchain16.h in round 6 and kept for tools/tchain_exp.hip (profiles/r05_tchain_ab.txt, r06_ab_tchain16.txt).  Not part of the library.
+//
 // uu3d_tchain.h -- every ROW-LOCAL stage of a temporal block in ONE launch (round 5; throughput schedule).
 //
 // Reference: vit.TransformerBlock.call (common/net/vision_transformer.py:176-195) minus the attention products (:117-129):
@@ -28,42 +31,13 @@
 // Row tiles are always whole: tokens past M read row M - 1 and store into a trash page (lane-local arithmetic: a padded lane cannot
 // disturb a live one).
 #pragma once
-#include "uu3d_gemm_panel8.h"
+#include "uu3d_tchain16.h"      // flags, TChainArgs, parameter table, tchain_qf_index (csrc/: the product kernel's header holds what the forms share)
 
 namespace uu3d {
 
-enum : int {
-    TC_PROJ = 1,        // starts with x += context Wp + bp (context = attention output, A-fragment order, natural k)
-    TC_MLP = 2,         // LayerNorm 2, fc1, ReLU, fc2, residual
-    TC_QKV = 4,         // ends with LayerNorm 1 + QKV of the NEXT block (f16 planes for attn_h3_kernel, q pre-scaled)
-    TC_FC1_PLANES = 8,  // (instead of TC_MLP) LayerNorm 2, fc1 (Conv1D k = 1), ReLU -> row-major f16 planes: the first strided block, whose convolution is another kernel
-    TC_PE = 16,         // in front of the final LayerNorm 1: xa = x + pe[token % period] is stored and normalised (temporal stack -> strided block 1, u_u_t.py:126-128)
-};
-
-static constexpr int TC_CHUNK_HALFS = P8_CHUNK_BYTES / 2;
-__host__ __device__ inline constexpr int tchain_chunks(int flags) {
-    return ((flags & TC_PROJ) ? 12 : 0) + ((flags & TC_MLP) ? 48 : 0) + ((flags & TC_FC1_PLANES) ? 24 : 0) + ((flags & TC_QKV) ? 36 : 0);
-}
 static constexpr size_t TC_H_HALFS_PER_TILE = 24 * 8 * 2 * 64 * 8;           // relu(fc1) of a tile as fc2's token fragments, lane-linear
 static constexpr size_t TC_X_FLOATS_PER_TILE = 128 * 384;                    // a tile of the residual stream, lane-linear (tchain_xs_index)
-static constexpr size_t TC_TRASH_BYTES = 16384;
 
-// Parameter table of one launch (floats, packed at commit time: ONE pointer instead of eight -- with two dozen pointers in scalar
-// registers for the whole kernel the chunk loops' bias registers went into v_writelane spills)
-// (b1 and bqkv are the FOLDED biases b + beta W of the LayerNorm in front, and their W is diag(gamma) W: see layer_norm below)
-enum : int { TCP_BP = 0, TCP_B1 = 384, TCP_B2 = 1152, TCP_BQKV = 1536, TCP_FLOATS = 2688 };
-
-struct TChainArgs {
-    int M, m_tiles, period; float qscale;
-    const _Float16* Of;          // TC_PROJ: attention output [panel][24 slices][plane][lane][8]
-    float* X;                    // residual stream [M][384]
-    float* XA; const float* pe;  // TC_PE: xa = x + pe[token % period]
-    const _Float16* W;           // the launch's weight stream (tchain_pack_stage per stage), tchain_chunks(flags) x 48 KiB
-    const float* P;              // parameter table (TCP_*)
-    _Float16* Q;                 // TC_QKV: q | k | v in FRAGMENT order (tchain_qf_index): [32-token panel][16-channel group 72][plane][lane][8], whole 128-row tiles
-    _Float16* H;                 // TC_FC1_PLANES: hi plane [M][768], lo plane M * 768 halfs further
-    unsigned char* scratch;      // tchain_scratch_bytes(m_tiles): hidden fragments | residual stream (lane-linear) | the same of the first strided block (x + pe) | trash page
-};
 __host__ __device__ inline constexpr size_t tchain_scratch_bytes(int m_tiles) {
     return (size_t)m_tiles * (TC_H_HALFS_PER_TILE * 2 + 2 * TC_X_FLOATS_PER_TILE * 4) + TC_TRASH_BYTES;
 }
@@ -77,17 +51,6 @@ __host__ __device__ inline size_t tchain_xs_index(int row, int ch) {
     const int c = ch >> 5, hh = (ch >> 4) & 1, i = (ch >> 3) & 1, g = (ch >> 2) & 1, e = ch & 3;
     return (size_t)tile * TC_X_FLOATS_PER_TILE + ((((size_t)(c * 8 + 4 * hh + q) * 2 + i) * 4 + e) * 64 + t + 32 * g);
 }
-
-// q | k | v for attn_h3_kernel in FRAGMENT order: a lane's 8 finished values of a 16-channel group (channels 16 u + 8 (j >> 2) + 4 g + (j & 3)) are ONE 16-byte
-// piece, the pieces of a 32-token panel contiguous -- two coalesced 1 KiB stores per chunk and wave instead of four scattered 8-byte ones (QKV stage
-// 151 k -> 132 k cycles in the timing build), and the attention kernel's Q / K / V loads become contiguous pieces.  The channel permutation inside a group is
-// the same for q and k (their dot product does not see it) and reaches the attention OUTPUT through v: the projection's weights are packed in that order.
-// halfs: element (token, channel) of plane p
-__host__ __device__ inline size_t tchain_qf_index(size_t token, int ch, int plane) {
-    const int u = ch >> 4, w = ch & 15, j = ((w >> 3) << 2) | (w & 3), g = (w >> 2) & 1;
-    return ((((token >> 5) * 72 + u) * 2 + plane) * 64 + (token & 31) + 32 * g) * 8 + j;
-}
-__host__ __device__ inline constexpr size_t tchain_qf_halfs(int m_tiles) { return (size_t)m_tiles * 4 * 72 * 2 * 512; }
 
 // ---- host side: one stage's chunks of the weight stream from the transposed, padded planes Bt[n][Kp] (k contiguous; lo pre-scaled) ----
 // chunk c (output channels 32 c ..), wave group hh, position kk (0..11), plane p, lane l, element j:

@@ -1,3 +1,6 @@
+// tools/uu3d_tchain64.h -- RECORD: the first 64-row form of the temporal chain (four waves of 512 registers), replaced by csrc/uu3d_tchain16.h
+// and kept for tools/tchain64_exp.hip (profiles/r06_tchain64.txt, r06_ab_tchain16.txt).  Not part of the library.
+//
 // uu3d_tchain64.h -- the temporal chain on 64-ROW tiles with the residual stream and the hidden activations ON CHIP (round 6).
 //
 // Reference: vit.TransformerBlock.call (common/net/vision_transformer.py:176-195) minus the attention products (:117-129):
@@ -30,7 +33,7 @@ namespace uu3d {
 
 static constexpr size_t T64_XCHG_BYTES = 4 * 2048;                        // 4 waves x 64 lanes x 8 floats
 static constexpr size_t T64_LDS_TOTAL = P8_RING_BYTES + T64_XCHG_BYTES;   // 155648
-static constexpr size_t T64_X_FLOATS_PER_TILE = 64 * 384;
+static constexpr size_t T64_X_FLOATS_PER_TILE = T16_X_FLOATS_PER_TILE;
 
 // Lane-linear order of a 64-row tile of the residual stream between two launches: [chunk c][wave = 2 hh + q][i][lane = t + 32 g][e] with
 // channel = 32 c + 16 hh + 8 i + 4 g + e and row = 32 q + t: one coalesced 1 KiB store / load per (chunk, i) and wave.
@@ -39,19 +42,8 @@ __host__ __device__ inline size_t tchain64_xs_index(int row, int ch) {
     const int c = ch >> 5, hh = (ch >> 4) & 1, i = (ch >> 3) & 1, g = (ch >> 2) & 1, e = ch & 3;
     return (size_t)tile * T64_X_FLOATS_PER_TILE + ((((size_t)(c * 4 + 2 * hh + q) * 2 + i) * 64 + t + 32 * g) * 4 + e);
 }
-// scratch: residual tiles (temporal stack) | residual tiles of the first strided block (x + pe) | trash page
-__host__ __device__ inline constexpr size_t tchain64_scratch_bytes(int m_tiles64) {
-    return (size_t)m_tiles64 * (2 * T64_X_FLOATS_PER_TILE * 4) + TC_TRASH_BYTES;
-}
-// The launch's weight stream: as tchain_chunks(), but the MLP's chunks in the order W1[0..11] | W2 half 0 | W1[12..23] | W2 half 1.
-// (host) `in`: the stages packed in the round-5 order (W1 24 chunks, W2 half 0, W2 half 1), `out`: the order above.
-inline void tchain64_reorder_mlp(const _Float16* in, _Float16* out) {
-    const size_t C = TC_CHUNK_HALFS;
-    std::copy(in, in + 12 * C, out);                                  // W1[0..11]
-    std::copy(in + 24 * C, in + 36 * C, out + 12 * C);                // W2 half 0
-    std::copy(in + 12 * C, in + 24 * C, out + 24 * C);                // W1[12..23]
-    std::copy(in + 36 * C, in + 48 * C, out + 36 * C);                // W2 half 1
-}
+__host__ __device__ inline constexpr size_t tchain64_scratch_bytes(int m_tiles64) { return tchain16_scratch_bytes(m_tiles64); }
+inline void tchain64_reorder_mlp(const _Float16* in, _Float16* out) { tchain16_reorder_mlp(in, out); }
 
 template <bool BIAS> struct T64EpResidual { static constexpr int kStores = 0; static constexpr bool kBias = BIAS; static constexpr int kReg = 1; const float* bias; };
 struct T64EpQkvFrag { static constexpr int kStores = 2; static constexpr bool kBias = true; h16x8* __restrict__ qf; const float* bias; };   // (TcEpQkvFrag without q's scale)

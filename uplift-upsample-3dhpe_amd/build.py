@@ -10,7 +10,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(CSRC, "libuu3d.so")
 SOURCES = ["uu3d_api.hip", "uu3d_ops.hip"]
-HEADERS = ["uu3d_tchain.h", "uu3d_tchain64.h", "uu3d_tchain16.h", "uu3d_gemm.h", "uu3d_gemm_h3.h", "uu3d_gemm_panel.h", "uu3d_gemm_panel8.h", "uu3d_gemm_wt.h", "uu3d_mlp_fused.h", "uu3d_attn.h", "uu3d_attn_h3.h", "uu3d_spatial.h", "uu3d_spatial_h3.h", "uu3d_pk.h", "uu3d_misc.h", "uu3d_train.h", "uu3d_bwd.h", "uu3d_launch.h", "uu3d_train_kernels.h", "uu3d_dropout.h", "uu3d_train_step.inc", os.path.join("..", "..", "include", "uu3d_ops.h"), os.path.join("..", "..", "include", "uu3d.h")]
+HEADERS = ["uu3d_tchain16.h", "uu3d_gemm.h", "uu3d_gemm_h3.h", "uu3d_gemm_panel.h", "uu3d_gemm_panel8.h", "uu3d_gemm_wt.h", "uu3d_mlp_fused.h", "uu3d_attn.h", "uu3d_attn_h3.h", "uu3d_spatial.h", "uu3d_spatial_h3.h", "uu3d_pk.h", "uu3d_misc.h", "uu3d_train.h", "uu3d_bwd.h", "uu3d_launch.h", "uu3d_train_kernels.h", "uu3d_dropout.h", "uu3d_train_step.inc", os.path.join("..", "..", "include", "uu3d_ops.h"), os.path.join("..", "..", "include", "uu3d.h")]
 
 
 def _fingerprint(extra_flags=()):

@@ -35,8 +35,6 @@
 #include "uu3d_gemm_panel8.h"
 #include "uu3d_gemm_wt.h"
 #include "uu3d_mlp_fused.h"
-#include "uu3d_tchain.h"
-#include "uu3d_tchain64.h"
 #include "uu3d_tchain16.h"
 #include "uu3d_attn.h"
 #include "uu3d_attn_h3.h"
@@ -115,22 +113,17 @@ struct uu3d_model {
     bool no_panel = false;         // UU3D_NO_PANEL=1: LayerNorm-fed GEMMs stay on the tiled kernels (A/B measurements, tests)
     bool no_panel_proj = false;    // UU3D_NO_PANEL_PROJ=1: the attention projection stays on the tiled LDS-DMA kernel
     bool throughput = false;       // uu3d_set_schedule: launches shaped for CU-microseconds (several forwards share the chip) instead of latency
-    // Temporal chain (uu3d_tchain.h; throughput schedule): one launch per temporal block for its row-local stages.  Launch 0 = LayerNorm 1 + QKV of
+    // Temporal chain (uu3d_tchain16.h; throughput schedule): one launch per temporal block for its row-local stages.  Launch 0 = LayerNorm 1 + QKV of
     // block 1; launch i (1 .. T) = projection + MLP of block i (+ LayerNorm 1 + QKV of the block behind it: temporal block i + 1, or the first strided
     // block with its positional encoding); launch T + 1 = projection + LayerNorm 2 + fc1 of the first strided block.  Empty = not available.
     struct TcLaunch { int flags; size_t w_off /* halfs, harena */; size_t p_off /* floats, arena */; };
     std::vector<TcLaunch> tchain;
     // When the chain runs: under the throughput schedule, whenever the shapes allow it (>= 1024 token rows, attention on attn_h3_kernel, no attention
     // maps asked for).  UU3D_TCHAIN=0 keeps the round-4 launches (A/B measurements, tests), UU3D_TCHAIN_MIN_TILES=n asks for at least n row tiles.
-    // History of the round (profiles/r05_tchain_ab.txt): with partial-result slabs added at the stage transitions the chain lost at batch 128 (162-170 k
-    // against 171-175 k sequences/s) and tied at 512; with the residual adds as no-return atomics on a lane-linear stream and q | k | v in fragment order:
-    // 179-182 k against 171-173 k at batch 128 with four slots, 187 k with eight, 202.6 k against 180.2 k at batch 512.
+    // History: round 5 (128-row tiles, residual adds as float atomics, profiles/r05_tchain_ab.txt) 179-187 k sequences/s against 171-175 k of the round-4
+    // launches at batch 128; round 6 (64-row tiles, everything on chip, profiles/r06_ab_tchain16.txt) 197-212 k on the same box as 179-201 k.
     int tchain_mode = -1;          // -1 by size (tchain_min_tiles), 0 never, 1 always
     int tchain_min_tiles = 8;      // (= the 1024 rows the panel kernels ask for as well)
-    bool tchain64 = true;          // round 6: the chain on 64-row tiles with the residual stream and relu(fc1) on chip (uu3d_tchain64.h); UU3D_TCHAIN64=0: the round-5 kernel (128-row
-                                   // tiles, residual adds as float atomics) for A/B runs -- read at uu3d_create, decides the order the launches' weight streams are packed in
-    bool tchain16 = true;          // the 64-row chain as EIGHT waves on 16-token panels (uu3d_tchain16.h: v_mfma_f32_16x16x32_f16, two waves per SIMD); UU3D_TCHAIN16=0: four waves of
-                                   // 512 registers on 32-token panels (uu3d_tchain64.h) -- read at uu3d_create: the two forms pack the weight stream differently
     bool tchain_short = true;      // the chain (and attn_h3_kernel on its fragment-ordered q | k | v, which cost no split epilogue) also below 49 tokens: h36m_81 (41 tokens),
                                    // batch 256: 337 k -> 361 k sequences/s; UU3D_TCHAIN_SHORT=0: only where attn_h3_kernel is the attention kernel anyway
     int num_cus = 256;
@@ -386,9 +379,6 @@ int uu3d_create(const uu3d_config* c, int device, uu3d_model** out) {
     { const char* e = getenv("UU3D_TCHAIN"); if (e != nullptr && (e[0] == '0' || e[0] == '1')) m->tchain_mode = e[0] - '0'; }
     { const char* e = getenv("UU3D_TCHAIN_MIN_TILES"); if (e != nullptr && atoi(e) > 0) m->tchain_min_tiles = atoi(e); }
     { const char* e = getenv("UU3D_TCHAIN_SHORT"); if (e != nullptr) m->tchain_short = atoi(e) != 0; }
-    { const char* e = getenv("UU3D_TCHAIN64"); if (e != nullptr) m->tchain64 = atoi(e) != 0; }
-    { const char* e = getenv("UU3D_TCHAIN16"); if (e != nullptr) m->tchain16 = atoi(e) != 0; }
-    if (!m->tchain64) m->tchain16 = false;
     { hipDeviceProp_t pr; if (hipGetDeviceProperties(&pr, device) == hipSuccess && pr.multiProcessorCount > 0) m->num_cus = pr.multiProcessorCount; }
     // (the handle's device, not the caller's current one: every later call of the library sets it as well)
     if (hipSetDevice(device) != hipSuccess) {
@@ -630,7 +620,7 @@ int uu3d_commit_weights(uu3d_model* m, void* stream_) {
     const size_t o_h2 = P.alloc_dense((size_t)Nph * Kdt), o_h2b = P.alloc(Nph);
     pack_head(o_h2, o_h2b, "strided_temporal_fc", "strided_temporal_norm");
 
-    // ---- temporal chain (uu3d_tchain.h): per launch one parameter table (floats) and one weight stream (f16 planes, built below) ----
+    // ---- temporal chain (uu3d_tchain16.h): per launch one parameter table (floats) and one weight stream (f16 planes, built below) ----
     // A LayerNorm's affine part is folded into the Dense layer behind it: W' = diag(gamma) W, b' = b + beta W (f64 sums).
     const float tc_qscale = 1.44269504088896341f / sqrtf((float)(dt / std::max(1, c.num_heads)));      // = Launcher::attn_qscale(): log2(e) / sqrt(d_h)
     struct TcStage { std::vector<float> Wk; int K, N, kofs; bool natural; };        // Keras layout [K][N]
@@ -658,7 +648,7 @@ int uu3d_commit_weights(uu3d_model* m, void* stream_) {
         auto add_qkv = [&](TcBuild& tb, const std::string& p) {
             std::vector<float> Wk, b, bf; qkv_of(p, Wk, b);
             tb.stages.push_back(folded(Wk, b, W(m, p + "/norm1/gamma"), W(m, p + "/norm1/beta"), dt, 3 * dt, bf));
-            if (m->tchain64) for (int n = 0; n < dt; ++n) bf[n] *= tc_qscale;          // (the 64-row kernel: q's scale folded into wq and bq)
+            for (int n = 0; n < dt; ++n) bf[n] *= tc_qscale;          // (q's scale is folded into wq and bq)
             std::copy_n(bf.begin(), 3 * dt, P.buf.begin() + tb.p_off + TCP_BQKV);
         };
         auto add_proj = [&](TcBuild& tb, const std::string& p) {
@@ -768,7 +758,7 @@ int uu3d_commit_weights(uu3d_model* m, void* stream_) {
                 }
             for (auto& o : soff) { add_panel(o.wqkv, 3 * dt); add_panel(o.w1, ht); add_panel(o.wp, dt); }
         }
-        // temporal chain: the launches' weight streams (tchain_pack_stage: one 48 KiB chunk per 32 output channels and stage)
+        // temporal chain: the launches' weight streams (tchain16_pack_stage: one 48 KiB chunk per 32 output channels and stage)
         m->tchain.clear();
         for (auto& tb : tcb) {
             const size_t at = align_up(hb.size(), 128);
@@ -776,7 +766,7 @@ int uu3d_commit_weights(uu3d_model* m, void* stream_) {
             size_t o = at;
             for (auto& st : tb.stages) {
                 std::vector<_Float16> Bh((size_t)st.N * st.K), Bl((size_t)st.N * st.K);
-                const bool qkv_stage = m->tchain64 && st.N == 3 * dt;                 // (the 64-row kernel: q's scale lives in wq and bq, below)
+                const bool qkv_stage = st.N == 3 * dt;                 // (q's scale lives in wq and bq)
                 for (int n = 0; n < st.N; ++n)
                     for (int k = 0; k < st.K; ++k) {
                         const float x = st.Wk[(size_t)k * st.N + n] * (qkv_stage && n < dt ? tc_qscale : 1.0f);
@@ -784,14 +774,13 @@ int uu3d_commit_weights(uu3d_model* m, void* stream_) {
                         const _Float16 h = h3_hi(x);
                         Bh[(size_t)n * st.K + k] = h; Bl[(size_t)n * st.K + k] = (_Float16)((x - (float)h) * H3_SCALE);
                     }
-                if (m->tchain16) tchain16_pack_stage(Bh.data(), Bl.data(), st.N, st.K, st.kofs, st.natural, hb.data() + o);
-                else tchain_pack_stage(Bh.data(), Bl.data(), st.N, st.K, st.kofs, st.natural, hb.data() + o);
+                tchain16_pack_stage(Bh.data(), Bl.data(), st.N, st.K, st.kofs, st.natural, hb.data() + o);
                 o += (size_t)(st.N / 32) * TC_CHUNK_HALFS;
             }
-            if (m->tchain64 && (tb.flags & TC_MLP)) {                                // W1 (24 chunks) | W2 half 0 | W2 half 1  ->  W1[0..11] | W2 half 0 | W1[12..23] | W2 half 1
+            if (tb.flags & TC_MLP) {                                // W1 (24 chunks) | W2 half 0 | W2 half 1  ->  W1[0..11] | W2 half 0 | W1[12..23] | W2 half 1
                 _Float16* mlp = hb.data() + at + (size_t)((tb.flags & TC_PROJ) ? 12 : 0) * TC_CHUNK_HALFS;
                 const std::vector<_Float16> tmp(mlp, mlp + (size_t)48 * TC_CHUNK_HALFS);
-                tchain64_reorder_mlp(tmp.data(), mlp);
+                tchain16_reorder_mlp(tmp.data(), mlp);
             }
             m->tchain.push_back({tb.flags, at, tb.p_off});
         }
@@ -835,7 +824,7 @@ int uu3d_commit_weights(uu3d_model* m, void* stream_) {
 namespace {
 struct Workspace {
     float *S, *X, *QKV, *O, *Hb, *XA, *XB, *slab, *mslab;
-    unsigned char* tc_scratch;     // temporal chain: lane-linear partial-result slabs, hidden fragments, trash page (tchain_scratch_bytes)
+    unsigned char* tc_scratch;     // temporal chain: the residual tiles between its launches (lane-linear), trash page (tchain16_scratch_bytes)
     int* frame_list;
     float2* stats;
     size_t slab_floats;
@@ -860,7 +849,7 @@ Workspace carve(const uu3d_model* m, int B, char* base) {
     const size_t oSl = take(w.slab_floats * 4);
     const size_t oFl = take((rows + 1) * sizeof(int));
     const size_t oMs = take((size_t)MLPF_SLICES * rows * c.d_temporal * 4);      // fused MLP: fc2 partial sums of the three hidden slices
-    const size_t oCh = !tchain_possible(c) ? 0 : take(m->tchain64 ? tchain64_scratch_bytes((int)((rows + 63) / 64)) : tchain_scratch_bytes((int)((rows + 127) / 128)));
+    const size_t oCh = !tchain_possible(c) ? 0 : take(tchain16_scratch_bytes((int)((rows + 63) / 64)));
     w.bytes = off;
     if (base) {
         w.S = (float*)(base + oS); w.X = (float*)(base + oX); w.QKV = (float*)(base + oQ);
@@ -1206,26 +1195,20 @@ struct Launcher {
                            Af, m->harena + b.w1_pf, m->harena + b.w2_mf, b.b1, mslab, M, mt);
         end();
     }
-    // One launch of the temporal chain (uu3d_tchain.h): the row-local stages of a block for every 128-row tile
+    // One launch of the temporal chain (uu3d_tchain16.h): the row-local stages of a block for every 64-row tile
     void tchain(const char* name, const uu3d_model::TcLaunch& t, int M, const _Float16* Of, float* X, float* XA, const float* pe, int period,
                 _Float16* Q, _Float16* H, unsigned char* scratch) {
         if (skip_mask() & 128) return;
-        const int mt = m->tchain64 ? (M + 63) / 64 : (M + 127) / 128;
+        const int mt = (M + 63) / 64;
         TChainArgs a{};
         a.M = M; a.m_tiles = mt; a.period = period; a.qscale = attn_qscale();
         a.Of = Of; a.X = X; a.XA = XA; a.pe = pe; a.W = m->harena + t.w_off; a.P = m->arena + t.p_off; a.Q = Q; a.H = H; a.scratch = scratch;
         const double cols = ((t.flags & TC_PROJ) ? 384.0 : 0.0) + ((t.flags & TC_MLP) ? 1536.0 : 0.0) + ((t.flags & TC_FC1_PLANES) ? 768.0 : 0.0) + ((t.flags & TC_QKV) ? 1152.0 : 0.0);
         begin(name, "tchain", 2.0 * M * 384.0 * cols, 4.0 * (384.0 * cols + 2.0 * M * 384.0 + ((t.flags & TC_QKV) ? M * 1152.0 : 0.0) + ((t.flags & TC_FC1_PLANES) ? M * 768.0 : 0.0)));
-#define UU3D_TC_LAUNCH(F) case F: { auto kern = tchain_kernel<F>; \
-            static const bool once = (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)P8_LDS_TOTAL) == hipSuccess); (void)once; \
-            hipLaunchKernelGGL(kern, dim3(mt), dim3(512), P8_LDS_TOTAL, stream, a); } break;
-#define UU3D_T64_LAUNCH(F) case F: { auto kern = tchain64_kernel<F>; \
-            static const bool once = (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)T64_LDS_TOTAL) == hipSuccess); (void)once; \
-            hipLaunchKernelGGL(kern, dim3(mt), dim3(256), T64_LDS_TOTAL, stream, a); } break;
 #define UU3D_T16_LAUNCH(F) case F: { auto kern = tchain16_kernel<F>; \
             static const bool once = (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)T16_LDS_TOTAL) == hipSuccess); (void)once; \
             hipLaunchKernelGGL(kern, dim3(mt), dim3(512), T16_LDS_TOTAL, stream, a); } break;
-        if (m->tchain16) switch (t.flags) {
+        switch (t.flags) {
             UU3D_T16_LAUNCH(TC_QKV)
             UU3D_T16_LAUNCH(TC_PROJ | TC_MLP | TC_QKV)
             UU3D_T16_LAUNCH(TC_PROJ | TC_MLP | TC_QKV | TC_PE)
@@ -1233,25 +1216,6 @@ struct Launcher {
             UU3D_T16_LAUNCH(TC_PROJ | TC_FC1_PLANES)
             default: status = UU3D_ERR_UNSUPPORTED; m->err = "temporal chain: unknown stage set"; break;
         }
-        else if (m->tchain64) switch (t.flags) {
-            UU3D_T64_LAUNCH(TC_QKV)
-            UU3D_T64_LAUNCH(TC_PROJ | TC_MLP | TC_QKV)
-            UU3D_T64_LAUNCH(TC_PROJ | TC_MLP | TC_QKV | TC_PE)
-            UU3D_T64_LAUNCH(TC_PROJ | TC_MLP)
-            UU3D_T64_LAUNCH(TC_PROJ | TC_FC1_PLANES)
-            default: status = UU3D_ERR_UNSUPPORTED; m->err = "temporal chain: unknown stage set"; break;
-        }
-        else
-        switch (t.flags) {
-            UU3D_TC_LAUNCH(TC_QKV)
-            UU3D_TC_LAUNCH(TC_PROJ | TC_MLP | TC_QKV)
-            UU3D_TC_LAUNCH(TC_PROJ | TC_MLP | TC_QKV | TC_PE)
-            UU3D_TC_LAUNCH(TC_PROJ | TC_MLP)
-            UU3D_TC_LAUNCH(TC_PROJ | TC_FC1_PLANES)
-            default: status = UU3D_ERR_UNSUPPORTED; m->err = "temporal chain: unknown stage set"; break;
-        }
-#undef UU3D_TC_LAUNCH
-#undef UU3D_T64_LAUNCH
 #undef UU3D_T16_LAUNCH
         end();
     }
@@ -1298,7 +1262,7 @@ struct Launcher {
     float attn_qscale() const { return 1.44269504088896341f / sqrtf((float)kDH); }
     // split_lo_off != 0: the context rows go out as f16 planes (hi at out, lo split_lo_off halfs further)
     // frag: the context rows in the row-panel GEMM's A-fragment order instead of row-major planes (split_lo_off != 0 only)
-    // qfrag: q | k | v arrive in the temporal chain's fragment order (uu3d_tchain.h, tchain_qf_index) -- attn_h3_kernel only
+    // qfrag: q | k | v arrive in the temporal chain's fragment order (uu3d_tchain16.h, tchain_qf_index) -- attn_h3_kernel only
     void attn(const char* name, const float* qkv, int B, int L, const uint8_t* mask, float* out, size_t split_lo_off = 0, bool frag = false, bool qfrag = false) {
         if (skip_mask() & 16) return;
         const int D = m->cfg.d_temporal, H = m->cfg.num_heads;
@@ -1569,9 +1533,9 @@ int uu3d_forward_ex(uu3d_model* m, const float* kp2d, const uint8_t* mask, int32
     };
 
     // 3. temporal blocks.
-    // Throughput schedule (several forwards share the chip): the TEMPORAL CHAIN (uu3d_tchain.h, round 5) -- per block one attention launch and one
+    // Throughput schedule (several forwards share the chip): the TEMPORAL CHAIN (uu3d_tchain16.h) -- per block one attention launch and one
     // launch for everything row-local (projection + residual, LayerNorm 2, fc1, ReLU, fc2 + residual, the next block's LayerNorm 1 + QKV) by
-    // workgroups that own 128 token rows: 2 T + 3 launches for T temporal blocks and the head of the first strided block instead of 5 T + 5,
+    // workgroups that own 64 token rows: 2 T + 3 launches for T temporal blocks and the head of the first strided block instead of 5 T + 5,
     // no partial-sum slabs, no LayerNorm passes.
     const bool chain = Lh.throughput && planes && m->tchain_mode != 0 && (m->tchain_mode == 1 || (M + 127) / 128 >= m->tchain_min_tiles) && !m->tchain.empty() && M >= 1024 && (Lh.attn_is_h3(N, true) || (m->tchain_short && Lh.attn_h3_any(N))) &&
                        (c.num_strided == 0 || m->L[0] == N) && (double)M * 1152 * 4.0 < 4.0e9 &&
@@ -1673,18 +1637,6 @@ int uu3d_forward_ex(uu3d_model* m, const float* kp2d, const uint8_t* mask, int32
     if (Lh.status != UU3D_OK) return Lh.status;
     return UU3D_OK;
 }
-
-#ifdef UU3D_TC_STAMP
-// measurement builds only (build.py extra_flags -DUU3D_TC_STAMP): the temporal chain's per-workgroup stage stamps of its LAST launch
-extern "C" int uu3d_debug_tchain_stamps(unsigned long long* out, int n) {
-    return hipMemcpyFromSymbol(out, HIP_SYMBOL(uu3d::tchain_stamps), (size_t)std::min(n, 256 * 32) * 8) == hipSuccess ? 0 : 1;
-}
-extern "C" int uu3d_debug_tchain_acc(unsigned long long* out, int reset) {      // out[32 * 4]; reset != 0: clear afterwards
-    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(uu3d::tchain_acc), 32 * 4 * 8) != hipSuccess) return 1;
-    if (reset) { static const unsigned long long z[32 * 4] = {}; if (hipMemcpyToSymbol(HIP_SYMBOL(uu3d::tchain_acc), z, sizeof z) != hipSuccess) return 1; }
-    return 0;
-}
-#endif
 
 int uu3d_range_status(uu3d_model* m, void* stream, int32_t* out_flag) {
     if (!m) return UU3D_ERR_INVALID_ARGUMENT;

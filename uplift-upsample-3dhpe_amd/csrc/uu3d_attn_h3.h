@@ -121,7 +121,7 @@ attn_h3_kernel(const _Float16* __restrict__ qkv_h, const _Float16* __restrict__ 
                const uint8_t* __restrict__ key_mask,   // (B, L) 1 = attend; nullptr = no mask
                _Float16* __restrict__ out, const size_t lo_off, const int ldo,
                const int frag,                         // 1: the context rows leave in the row-panel GEMM's A-fragment order (uu3d_gemm_panel.h, K = ldo); lo_off = 512
-               const int qfrag = 0)                    // 1 (round 5, the temporal chain): q | k | v arrive in FRAGMENT order (uu3d_tchain.h, tchain_qf_index): qkv_h = the buffer, qkv_l / ld unused
+               const int qfrag = 0)                    // 1 (round 5, the temporal chain): q | k | v arrive in FRAGMENT order (uu3d_tchain16.h, tchain_qf_index): qkv_h = the buffer, qkv_l / ld unused
 {
     static_assert(DH == 48, "operand layouts below are written for a head dim of 48 (3 k-slices, 1.5 output row tiles)");
     constexpr int KS = DH / 16;                        // k-slices of Q K^T

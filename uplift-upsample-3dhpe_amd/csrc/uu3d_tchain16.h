@@ -1,13 +1,21 @@
-// uu3d_tchain16.h -- the temporal chain on 64-row tiles, EIGHT waves per workgroup on 16-token panels (round 6, second form).
+// uu3d_tchain16.h -- every ROW-LOCAL stage of a temporal block in ONE launch: the temporal chain (throughput schedule).
 //
 // Reference: vit.TransformerBlock.call (common/net/vision_transformer.py:176-195) minus the attention products (:117-129):
 //     x += projection(context) ; y = LayerNorm2(x) ; x += fc2(relu(fc1(y))) ; [next block:] q | k | v = wqkv(LayerNorm1(x))
 //
-// uu3d_tchain64.h keeps the residual stream and relu(fc1) of 64 token rows on chip with FOUR waves of 512 registers -- one wave per SIMD,
-// and a single in-order wave is issue bound: what it issues besides its MFMAs adds to the MFMA time (2.2 k cycles per chunk for 1.15 k of
-// MFMA).  Two waves per SIMD hide that, but 8 waves x 256 registers cannot hold 64 rows on 32-token panels without every token fragment
-// twice.  v_mfma_f32_16x16x32_f16 can: a wave owns a 16-TOKEN panel (4 panels x 2 k-halves = 8 waves), per lane 48 registers of residual
-// stream, 48 of token fragments, 48 of half of relu(fc1), 32 of accumulators -- 256 registers, two waves per SIMD, nothing duplicated.
+// One workgroup OWNS 64 token rows for the whole chain and walks a CONCATENATED weight stream
+//     Wp (12 chunks) | W1[0..11] | W2[hidden 0..383] (12) | W1[12..23] | W2[hidden 384..767] (12) | Wqkv of the next block (36)   = 96 x 48 KiB
+// through a 3 x 48 KiB LDS ring refilled in half-chunks by LDS-DMA with counted waits; the ring never drains at a stage boundary.
+// The residual stream and relu(fc1) of the 64 rows never leave the CU: a CU has 512 KiB of registers and 160 KiB of LDS (144 KiB of it the
+// ring); 64 rows need 96 KiB of residual stream, 96 KiB of token fragments and -- with the MLP walked fc1[0:384] -> fc2 half 0 ->
+// fc1[384:768] -> fc2 half 1 -- 96 KiB of HALF of relu(fc1).  Nothing but the launch's input (attention output fragments, the residual
+// tile) and output (residual tile, q | k | v) touches memory: no atomics, no scratch round trips.  The price is the weight stream per
+// token row (4.6 MB per 64 rows): L2 -> LDS by LDS-DMA delivers ~100 GB/s per CU with every CU streaming (tools/wstream_exp.hip).
+//
+// Eight waves on 16-TOKEN panels (4 panels x 2 k-halves), two per SIMD: a single in-order wave per SIMD is issue bound (what it issues
+// besides its MFMAs adds to the MFMA time), and 8 waves x 256 registers cannot hold 64 rows on 32-token panels without every token
+// fragment twice; with v_mfma_f32_16x16x32_f16 they can: per lane 48 registers of residual stream, 48 of token fragments, 48 of half of
+// relu(fc1), 32 of accumulators.
 //
 // Layout of the 16 x 16 x 32 MFMA (tools/mfma16_layout.hip): A (16 x 32): lane l = row l % 16, k = 8 (l / 16) + j; B (32 x 16): lane l =
 // column l % 16, k = 8 (l / 16) + j; D (16 x 16): lane l = column l % 16, rows 4 (l / 16) + r.  Transposed product C^T = W^T A^T: A = a
@@ -18,14 +26,77 @@
 // accumulator 0 is always the kept one) and sends the partner's tile through LDS (4 floats per lane and chunk).  The 4 values a lane
 // finishes for chunk c are elements 4 (c & 1) .. + 3 of its token fragment of k-step c >> 1 of the next stage: k order
 //     k (hh; S, g, j) = 32 (2 S + (j >> 2)) + 16 hh + 4 g + (j & 3)
-// so LayerNorm output, ReLU output and residual stream never change lanes.  Everything else as uu3d_tchain64.h: 3 x 48 KiB ring refilled in
-// half-chunks by LDS-DMA with counted waits, the MLP as fc1[0:384] -> fc2 half 0 -> fc1[384:768] -> fc2 half 1, rolled loops of four-chunk
-// bodies over register arrays that ROTATE behind every body, the epilogue of chunk c - 1 sliced into the gaps behind single MFMAs of chunk c.
-// Biases come from a table in LDS (one ds_read_b128 per chunk: the lane's 4 channels), copied there when the stage starts.
+// so LayerNorm output, ReLU output and residual stream never change lanes.  LayerNorm's affine part is folded into the Dense layer behind
+// it; its statistics are the only thing tokens need from other lanes (two shuffles + LDS).  Biases come from a table in LDS (one
+// ds_read_b128 per chunk: the lane's 4 channels), copied there when the stage starts.
+// Every stage is the rolled loop of four-chunk bodies.  Results that stay in registers need STATIC register indices: a body always works
+// on the first four chunk slots of its register array and the array is ROTATED by four slots behind every body (three rotations per
+// 12-chunk stage are the identity) -- fully unrolled stages (60 bodies) sent hipcc's allocator into thousands of spills.  The epilogue of
+// chunk c - 1 is sliced into the gaps behind single MFMAs of chunk c.
+// Row tiles are always whole: tokens past M read row M - 1 and store into a trash page (lane-local arithmetic: a padded lane cannot
+// disturb a live one).
+//
+// The two earlier forms of this kernel (round 5: 128 rows, residual adds as float atomics; round 6 first form: 64 rows on four waves of
+// 512 registers) are kept with their harnesses under tools/ (uu3d_tchain.h, uu3d_tchain64.h); profiles/r06_ab_tchain16.txt is the A/B.
 #pragma once
-#include "uu3d_tchain64.h"
+#include <algorithm>
+#include "uu3d_gemm_panel8.h"
 
 namespace uu3d {
+
+enum : int {
+    TC_PROJ = 1,        // starts with x += context Wp + bp (context = attention output, A-fragment order, natural k)
+    TC_MLP = 2,         // LayerNorm 2, fc1, ReLU, fc2, residual
+    TC_QKV = 4,         // ends with LayerNorm 1 + QKV of the NEXT block (f16 planes for attn_h3_kernel, q pre-scaled)
+    TC_FC1_PLANES = 8,  // (instead of TC_MLP) LayerNorm 2, fc1 (Conv1D k = 1), ReLU -> row-major f16 planes: the first strided block, whose convolution is another kernel
+    TC_PE = 16,         // in front of the final LayerNorm 1: xa = x + pe[token % period] is stored and normalised (temporal stack -> strided block 1, u_u_t.py:126-128)
+};
+
+static constexpr int TC_CHUNK_HALFS = P8_CHUNK_BYTES / 2;
+__host__ __device__ inline constexpr int tchain_chunks(int flags) {
+    return ((flags & TC_PROJ) ? 12 : 0) + ((flags & TC_MLP) ? 48 : 0) + ((flags & TC_FC1_PLANES) ? 24 : 0) + ((flags & TC_QKV) ? 36 : 0);
+}
+static constexpr size_t TC_TRASH_BYTES = 16384;
+
+// Parameter table of one launch (floats, packed at commit time: ONE pointer instead of eight)
+// (b1 and bqkv are the FOLDED biases b + beta W of the LayerNorm in front, and their W is diag(gamma) W; q's scale is folded into wq and bq)
+enum : int { TCP_BP = 0, TCP_B1 = 384, TCP_B2 = 1152, TCP_BQKV = 1536, TCP_FLOATS = 2688 };
+
+struct TChainArgs {
+    int M, m_tiles, period; float qscale;
+    const _Float16* Of;          // TC_PROJ: attention output [panel][24 slices][plane][lane][8]
+    float* X;                    // residual stream [M][384] (row-major: read by the first launch of a forward, written by the last ones)
+    float* XA; const float* pe;  // TC_PE: xa = x + pe[token % period]
+    const _Float16* W;           // the launch's weight stream (tchain16_pack_stage per stage), tchain_chunks(flags) x 48 KiB
+    const float* P;              // parameter table (TCP_*)
+    _Float16* Q;                 // TC_QKV: q | k | v in FRAGMENT order (tchain_qf_index): [32-token panel][16-channel group 72][plane][lane][8], whole 128-row tiles
+    _Float16* H;                 // TC_FC1_PLANES: hi plane [M][768], lo plane M * 768 halfs further
+    unsigned char* scratch;      // tchain16_scratch_bytes(m_tiles): residual tiles (lane-linear) | the same of the first strided block (x + pe) | trash page
+};
+
+// q | k | v for attn_h3_kernel in FRAGMENT order: the 8 values of a 16-channel group (channels 16 u + 8 (j >> 2) + 4 g + (j & 3)) that belong to one
+// (token, g) are ONE 16-byte piece, the pieces of a 32-token panel contiguous: the attention kernel's Q / K / V loads are contiguous pieces.  The
+// channel permutation inside a group is the same for q and k (their dot product does not see it) and reaches the attention OUTPUT through v: the
+// projection's weights are packed in that order.   halfs: element (token, channel) of plane p
+__host__ __device__ inline size_t tchain_qf_index(size_t token, int ch, int plane) {
+    const int u = ch >> 4, w = ch & 15, j = ((w >> 3) << 2) | (w & 3), g = (w >> 2) & 1;
+    return ((((token >> 5) * 72 + u) * 2 + plane) * 64 + (token & 31) + 32 * g) * 8 + j;
+}
+__host__ __device__ inline constexpr size_t tchain_qf_halfs(int m_tiles) { return (size_t)m_tiles * 4 * 72 * 2 * 512; }      // m_tiles: 128-row tiles
+
+static constexpr size_t T16_X_FLOATS_PER_TILE = 64 * 384;
+// scratch: residual tiles (temporal stack) | residual tiles of the first strided block (x + pe) | trash page
+__host__ __device__ inline constexpr size_t tchain16_scratch_bytes(int m_tiles64) {
+    return (size_t)m_tiles64 * (2 * T16_X_FLOATS_PER_TILE * 4) + TC_TRASH_BYTES;
+}
+// The MLP's chunks in the order the kernel walks them.  (host) `in`: W1 (24 chunks) | W2 half 0 | W2 half 1, `out`: W1[0..11] | W2 half 0 | W1[12..23] | W2 half 1
+inline void tchain16_reorder_mlp(const _Float16* in, _Float16* out) {
+    const size_t C = TC_CHUNK_HALFS;
+    std::copy(in, in + 12 * C, out);                                  // W1[0..11]
+    std::copy(in + 24 * C, in + 36 * C, out + 12 * C);                // W2 half 0
+    std::copy(in + 12 * C, in + 24 * C, out + 24 * C);                // W1[12..23]
+    std::copy(in + 36 * C, in + 48 * C, out + 36 * C);                // W2 half 1
+}
 
 static constexpr size_t T16_XCHG_BYTES = 8 * 1024;                        // 8 waves x 64 lanes x 4 floats
 static constexpr size_t T16_BIAS_BYTES = 1152 * 4;                        // the running stage's bias vector (QKV: 1152 floats)
@@ -36,7 +107,7 @@ static constexpr size_t T16_LDS_TOTAL = P8_RING_BYTES + T16_XCHG_BYTES + T16_BIA
 __host__ __device__ inline size_t tchain16_xs_index(int row, int ch) {
     const int tile = row >> 6, q = (row >> 4) & 3, t = row & 15;
     const int c = ch >> 5, hh = (ch >> 4) & 1, g = (ch >> 2) & 3, r = ch & 3;
-    return (size_t)tile * T64_X_FLOATS_PER_TILE + (((size_t)(c * 8 + 4 * hh + q) * 64 + t + 16 * g) * 4 + r);
+    return (size_t)tile * T16_X_FLOATS_PER_TILE + (((size_t)(c * 8 + 4 * hh + q) * 64 + t + 16 * g) * 4 + r);
 }
 
 // ---- host side: one stage's chunks of the weight stream from the transposed planes Bt[n][Kp] (k contiguous; lo pre-scaled) ----
@@ -111,10 +182,10 @@ tchain16_kernel(const TChainArgs a)
     constexpr int DP = UU3D_T16_DEPTH, RB = DP + 1;
     h16x8 bh[RB] = {}, bl[RB] = {};                        // weight fragments (hi / lo plane) of DP + 1 consecutive positions kk
 
-    auto late = [&](int v) __attribute__((always_inline)) -> int { asm volatile("" : "+s"(v)); return v; };      // (uu3d_tchain64.h)
+    auto late = [&](int v) __attribute__((always_inline)) -> int { asm volatile("" : "+s"(v)); return v; };
     const unsigned xoff = (unsigned)(wave * 256 + lane * 4);
     auto xs_tile = [&](int b, bool strided1) __attribute__((always_inline)) -> float* {      // residual tiles: temporal stack | first strided block (x + pe)
-        return reinterpret_cast<float*>(a.scratch) + ((size_t)b + (strided1 ? (size_t)a.m_tiles : 0)) * T64_X_FLOATS_PER_TILE;
+        return reinterpret_cast<float*>(a.scratch) + ((size_t)b + (strided1 ? (size_t)a.m_tiles : 0)) * T16_X_FLOATS_PER_TILE;
     };
     auto load_xs = [&](const float* tl) __attribute__((always_inline)) {
 #pragma unroll
@@ -133,7 +204,7 @@ tchain16_kernel(const TChainArgs a)
     };
     auto store_rows = [&](float* base) __attribute__((always_inline)) {               // (dead lanes: the trash page)
         const int tk = late(bm) * 64 + q * 16 + t;
-        unsigned char* const tr = a.scratch + (size_t)a.m_tiles * (2 * T64_X_FLOATS_PER_TILE * 4);
+        unsigned char* const tr = a.scratch + (size_t)a.m_tiles * (2 * T16_X_FLOATS_PER_TILE * 4);
         float* p = tk < a.M ? base + (size_t)tk * 384 + chl : reinterpret_cast<float*>(tr) + chl;
 #pragma unroll
         for (int c = 0; c < 12; ++c) *reinterpret_cast<f32x4*>(p + 32 * c) = xr[c];
@@ -424,7 +495,7 @@ tchain16_kernel(const TChainArgs a)
     if constexpr ((FLAGS & (TC_MLP | TC_FC1_PLANES)) != 0) {
         layer_norm();
         if constexpr (kStrided1) {
-            unsigned char* const trash = a.scratch + (size_t)a.m_tiles * (2 * T64_X_FLOATS_PER_TILE * 4);
+            unsigned char* const trash = a.scratch + (size_t)a.m_tiles * (2 * T16_X_FLOATS_PER_TILE * 4);
             unsigned char* ph = live ? reinterpret_cast<unsigned char*>(a.H + (size_t)tok * 768 + chl) : trash;
             unsigned char* pl = live ? reinterpret_cast<unsigned char*>(a.H + ((size_t)a.M + tok) * 768 + chl) : trash + 4096;
             stage(std::integral_constant<int, 24>{}, T16EpPlanes{ph, pl, a.P + TCP_B1, 768}, ah, al, 0);
