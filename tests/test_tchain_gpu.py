@@ -211,11 +211,13 @@ def test_chain_is_the_default_of_the_throughput_schedule():
     assert e <= util.TOL_MAX_ABS and d <= 3e-5
 
 
-@pytest.mark.parametrize("cfgname,batch", [("h36m_81", 256), ("h36m_351", 512)])
+@pytest.mark.parametrize("cfgname,batch", [("h36m_81", 256), ("h36m_351", 512), ("h36m_351", 2048), ("h36m_81", 4096)])
 def test_timed_workloads_match_oracle_at_their_batch(cfgname, batch):
     """The batches bench.py TIMES under the throughput schedule -- BASELINE configs[1] (config/h36m_81.json, batch 256: `secondary.h36m_81_batch256`)
     and the reference's own eval BATCH_SIZE of 512 windows (`secondary.eval_batch_512`) -- straight against the oracle on six sequences taken from
-    the first, the middle and the last row tiles (metric: common/dataset/metrics.py:13-37 on what these forwards return)."""
+    the first, the middle and the last row tiles (metric: common/dataset/metrics.py:13-37 on what these forwards return).  The two large batches
+    (2272 and 2624 row tiles of the chain, 145 k and 168 k token rows) are the size edge: every index of the path in 64-bit range, one forward = 9 / 10 waves
+    of workgroups per chain launch."""
     from oracle import uplift_oracle as O
     cfg = util.load_config(cfgname)
     arch = pkg.arch_from_config(cfg)
