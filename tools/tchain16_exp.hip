@@ -179,6 +179,7 @@ template <int FLAGS> void run(const char* tag, int M, int iters) {
 int main(int argc, char** argv) {
     const int M = argc > 1 ? atoi(argv[1]) : 9088, iters = argc > 2 ? atoi(argv[2]) : 20;
     if (argc > 3) warm = atoi(argv[3]);
+    if (getenv("ONLY_MID")) { run<TC_PROJ | TC_MLP | TC_QKV>("mid: proj + MLP + LN1 + QKV", M, iters); return 0; }      // (tools/power_tchain16.sh: one stage set, long enough to sample power)
     run<TC_QKV>("first: LN1 + QKV", M, iters);
     run<TC_PROJ | TC_MLP | TC_QKV>("mid: proj + MLP + LN1 + QKV", M, iters);
     run<TC_PROJ | TC_MLP | TC_QKV | TC_PE>("mid -> strided 1 (pe)", M, iters);
